@@ -1,0 +1,187 @@
+"""Synthetic PSM batches for the BASELINE.json configs.
+
+A *batch* is the CSR layout the C ABI (include/pyascore_hip.h) takes:
+
+    mz, intensity : float64[total_peaks]   raw peaks of all spectra, back to back
+    peak_off      : int64[n_psm + 1]
+    pep           : uint8[total_residues]  peptide letters, back to back
+    pep_off       : int64[n_psm + 1]
+    n_of_mod      : int32[n_psm]           unlocalised mods per PSM
+    max_charge    : int32[n_psm]           max fragment charge per PSM
+    aux_pos       : uint32[total_aux]      fixed-mod positions (0 = n-term, else 1-based)
+    aux_mass      : float32[total_aux]
+    aux_off       : int64[n_psm + 1]
+
+Residue masses are the reference's table (Types.h:7-30) in float64, as section 8(d) asks.
+"""
+import numpy as np
+
+# Types.h:7-30
+RESIDUE_MASS = {
+    "G": 57.02146, "A": 71.03711, "S": 87.03203, "P": 97.05276, "V": 99.06841,
+    "T": 101.04768, "C": 103.00919, "L": 113.08406, "I": 113.08406, "N": 114.04293,
+    "D": 115.02694, "Q": 128.05858, "K": 128.09496, "E": 129.04259, "M": 131.04049,
+    "H": 137.05891, "F": 147.06841, "U": 150.95364, "R": 156.10111, "Y": 163.06333,
+    "W": 186.07931, "O": 237.14773,
+}
+BASE_ALPHABET = "ACDEFGHIKLMNPQRVW"
+PHOSPHO = 79.966331
+PROTON = 1.007825
+WATER = 18.010565
+
+_MASS_LUT = np.zeros(256)
+for _k, _v in RESIDUE_MASS.items():
+    _MASS_LUT[ord(_k)] = _v
+
+CONFIGS = {
+    # name: generator shape + scorer settings
+    "cfg1": dict(n_psm=1, L=12, n_sites=2, n_mod=1, mz_error=0.5, fragment_types="by",
+                 max_charge=1, neutral_loss=None),
+    "cfg2": dict(n_psm=100_000, L=20, n_sites=6, n_mod=3, mz_error=0.05, fragment_types="by",
+                 max_charge=1, neutral_loss=None),
+    "cfg3": dict(n_psm=1_000_000, L=None, n_sites=None, n_mod=None, mz_error=0.05,
+                 fragment_types="by", max_charge=1, neutral_loss=None),
+    "cfg4": dict(n_psm=250_000, L=20, n_sites=6, n_mod=3, mz_error=0.02, fragment_types="bycz",
+                 max_charge=4, neutral_loss=("sty", 97.9769)),
+    "cfg5": dict(n_psm=50_000, L=30, n_sites=15, n_mod=5, mz_error=0.05, fragment_types="by",
+                 max_charge=1, neutral_loss=None),
+}
+
+
+def _fixed_shape(rng, n, L, n_sites, n_mod, mz_error, n_noise=300, keep_p=0.6):
+    """n PSMs of one (L, n_sites, n_mod) shape -> (pep uint8[n,L], mz list, inten list, counts)."""
+    base = np.frombuffer(BASE_ALPHABET.encode(), dtype=np.uint8)
+    pep = base[rng.integers(0, len(base), size=(n, L))]
+    sites = np.sort(np.argsort(rng.random((n, L)), axis=1)[:, :n_sites], axis=1)
+    sty = np.frombuffer(b"STY", dtype=np.uint8)[rng.choice(3, size=(n, n_sites), p=(0.5, 0.35, 0.15))]
+    rows = np.arange(n)[:, None]
+    pep[rows, sites] = sty
+    truth = np.argsort(rng.random((n, n_sites)), axis=1)[:, :n_mod]
+    mass = _MASS_LUT[pep]
+    np.add.at(mass, (np.repeat(np.arange(n), n_mod), sites[rows, truth].ravel()), PHOSPHO)
+    fwd = np.cumsum(mass, axis=1)[:, : L - 1]
+    rev = np.cumsum(mass[:, ::-1], axis=1)[:, : L - 1]
+    sig = np.concatenate([fwd + PROTON, rev + WATER + PROTON], axis=1)
+    keep = rng.random(sig.shape) < keep_p
+    sig = sig + rng.uniform(-0.4 * mz_error, 0.4 * mz_error, size=sig.shape)
+    sig_int = rng.lognormal(6.0, 1.2, size=sig.shape)
+    noise = rng.uniform(100.0, 2000.0, size=(n, n_noise))
+    noise_int = rng.lognormal(4.5, 1.0, size=(n, n_noise))
+    mz = np.concatenate([np.where(keep, sig, np.inf), noise], axis=1)
+    inten = np.concatenate([sig_int, noise_int], axis=1)
+    order = np.argsort(mz, axis=1, kind="stable")
+    mz = np.take_along_axis(mz, order, axis=1)
+    inten = np.take_along_axis(inten, order, axis=1)
+    counts = keep.sum(axis=1) + n_noise
+    valid = np.arange(mz.shape[1])[None, :] < counts[:, None]
+    return pep, mz[valid], inten[valid], counts.astype(np.int64)
+
+
+def make_batch(config="cfg2", n_psm=None, seed=0, **override):
+    """Synthetic batch of one BASELINE config (``n_psm`` overrides the config's size)."""
+    cfg = dict(CONFIGS[config])
+    cfg.update(override)
+    n = int(n_psm if n_psm is not None else cfg["n_psm"])
+    rng = np.random.default_rng(seed)
+    err = cfg["mz_error"]
+    if cfg["L"] is not None:
+        pep, mz, inten, counts = _fixed_shape(rng, n, cfg["L"], cfg["n_sites"], cfg["n_mod"], err)
+        pep_len = np.full(n, cfg["L"], np.int64)
+        pep_flat = pep.ravel()
+        n_of_mod = np.full(n, cfg["n_mod"], np.int32)
+    else:
+        # cfg3: L ~ U{8..40}, n_mod ~ U{1..4}, n_sites ~ U{n_mod+1 .. min(12, L-1)}
+        Ls = rng.integers(8, 41, size=n)
+        ks = rng.integers(1, 5, size=n)
+        hi = np.minimum(12, Ls - 1)
+        ns = ks + 1 + (rng.random(n) * (hi - ks)).astype(np.int64)
+        ns = np.minimum(ns, hi)
+        key = (Ls * 64 + ns) * 8 + ks
+        order = np.argsort(key, kind="stable")
+        uniq, starts = np.unique(key[order], return_index=True)
+        ends = np.append(starts[1:], n)
+        peps, mzs, ints, cnts = [None] * n, [None] * n, [None] * n, np.zeros(n, np.int64)
+        for s, e in zip(starts, ends):
+            idx = order[s:e]
+            L, nsit, k = int(Ls[idx[0]]), int(ns[idx[0]]), int(ks[idx[0]])
+            p, m, it, c = _fixed_shape(rng, e - s, L, nsit, k, err)
+            off = np.concatenate([[0], np.cumsum(c)])
+            for j, i in enumerate(idx):
+                peps[i] = p[j]
+                mzs[i] = m[off[j]:off[j + 1]]
+                ints[i] = it[off[j]:off[j + 1]]
+                cnts[i] = c[j]
+        pep_flat = np.concatenate(peps)
+        mz = np.concatenate(mzs)
+        inten = np.concatenate(ints)
+        counts = cnts
+        pep_len = Ls.astype(np.int64)
+        n_of_mod = ks.astype(np.int32)
+    batch = dict(
+        n_psm=n,
+        mz=np.ascontiguousarray(mz, dtype=np.float64),
+        intensity=np.ascontiguousarray(inten, dtype=np.float64),
+        peak_off=np.concatenate([[0], np.cumsum(counts)]).astype(np.int64),
+        pep=np.ascontiguousarray(pep_flat, dtype=np.uint8),
+        pep_off=np.concatenate([[0], np.cumsum(pep_len)]).astype(np.int64),
+        n_of_mod=n_of_mod,
+        max_charge=np.full(n, cfg["max_charge"], np.int32),
+        aux_pos=np.zeros(0, np.uint32),
+        aux_mass=np.zeros(0, np.float32),
+        aux_off=np.zeros(n + 1, np.int64),
+    )
+    settings = dict(bin_size=100.0, n_top=10, mod_group="STY", mod_mass=PHOSPHO, mz_error=err,
+                    fragment_types=cfg["fragment_types"], neutral_loss=cfg["neutral_loss"])
+    return batch, settings
+
+
+def pack_batch(psms):
+    """List of dicts {mz, intensity, peptide, n_of_mod, max_charge, aux_pos, aux_mass} -> CSR."""
+    n = len(psms)
+    mz = [np.asarray(p["mz"], np.float64) for p in psms]
+    it = [np.asarray(p["intensity"], np.float64) for p in psms]
+    pep = [np.frombuffer(p["peptide"].encode(), dtype=np.uint8) for p in psms]
+    ap = [np.asarray(p.get("aux_pos", ()), np.uint32) for p in psms]
+    am = [np.asarray(p.get("aux_mass", ()), np.float32) for p in psms]
+
+    def cat(xs, dt):
+        return np.ascontiguousarray(np.concatenate(xs) if xs else np.zeros(0), dtype=dt)
+
+    def off(xs):
+        return np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.int64)
+
+    return dict(
+        n_psm=n, mz=cat(mz, np.float64), intensity=cat(it, np.float64), peak_off=off(mz),
+        pep=cat(pep, np.uint8), pep_off=off(pep),
+        n_of_mod=np.asarray([p["n_of_mod"] for p in psms], np.int32),
+        max_charge=np.asarray([p.get("max_charge", 1) for p in psms], np.int32),
+        aux_pos=cat(ap, np.uint32), aux_mass=cat(am, np.float32), aux_off=off(ap),
+    )
+
+
+def unpack_psm(batch, i):
+    """PSM ``i`` of a CSR batch as the keyword arguments of ``PyAscore.score``."""
+    a, b = batch["peak_off"][i], batch["peak_off"][i + 1]
+    c, d = batch["pep_off"][i], batch["pep_off"][i + 1]
+    e, f = batch["aux_off"][i], batch["aux_off"][i + 1]
+    out = dict(mz_arr=batch["mz"][a:b], int_arr=batch["intensity"][a:b],
+               peptide=bytes(batch["pep"][c:d]).decode(), n_of_mod=int(batch["n_of_mod"][i]),
+               max_fragment_charge=int(batch["max_charge"][i]))
+    if f > e:
+        out["aux_mod_pos"] = batch["aux_pos"][e:f]
+        out["aux_mod_mass"] = batch["aux_mass"][e:f]
+    return out
+
+
+def slice_batch(batch, lo, hi):
+    """Contiguous PSM range [lo, hi) of a CSR batch (used for sharding across ranks)."""
+    a, b = batch["peak_off"][lo], batch["peak_off"][hi]
+    c, d = batch["pep_off"][lo], batch["pep_off"][hi]
+    e, f = batch["aux_off"][lo], batch["aux_off"][hi]
+    return dict(
+        n_psm=hi - lo, mz=batch["mz"][a:b], intensity=batch["intensity"][a:b],
+        peak_off=(batch["peak_off"][lo:hi + 1] - a), pep=batch["pep"][c:d],
+        pep_off=(batch["pep_off"][lo:hi + 1] - c), n_of_mod=batch["n_of_mod"][lo:hi],
+        max_charge=batch["max_charge"][lo:hi], aux_pos=batch["aux_pos"][e:f],
+        aux_mass=batch["aux_mass"][e:f], aux_off=(batch["aux_off"][lo:hi + 1] - e),
+    )
