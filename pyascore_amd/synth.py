@@ -131,7 +131,8 @@ def make_batch(config="cfg2", n_psm=None, seed=0, **override):
         aux_off=np.zeros(n + 1, np.int64),
     )
     settings = dict(bin_size=100.0, n_top=10, mod_group="STY", mod_mass=PHOSPHO, mz_error=err,
-                    fragment_types=cfg["fragment_types"], neutral_loss=cfg["neutral_loss"])
+                    fragment_types=cfg["fragment_types"],
+                    neutral_losses=[list(cfg["neutral_loss"])] if cfg["neutral_loss"] else [])
     return batch, settings
 
 
