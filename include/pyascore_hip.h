@@ -1,0 +1,149 @@
+/*
+ * pyascore_hip.h -- C ABI of the MI355X-native Ascore scorer (libpyascore_hip.so).
+ *
+ * This is the drop-in boundary for pyAscore's ptm_scoring hot path.  Every entry point
+ * replaces a piece of the reference's Cython/C++ interface (citations are into the reference
+ * tree, pyascore/ptm_scoring/):
+ *
+ *   pya_create / pya_destroy      PyAscore.__cinit__/__dealloc__      Ascore.pyx:64-79
+ *   pya_add_neutral_loss          PyAscore.add_neutral_loss           Ascore.pyx:81-99
+ *   pya_score_batch               PyAscore.score, batched             Ascore.pyx:103-152
+ *                                 (= BinnedSpectra::consumeSpectra cpp/Spectra.cpp:43-68,
+ *                                    ModifiedPeptide::consumePeptide/consumePeak
+ *                                    cpp/ModifiedPeptide.cpp:105-142, Ascore::score
+ *                                    cpp/Ascore.cpp:256-271)
+ *   pya_results fields            best_score / ascores / alt_sites / best signature
+ *                                                                     Ascore.pyx:232-288
+ *   pya_get_pep_scores            PyAscore.pep_scores                 Ascore.pyx:241-252
+ *   pya_calculate_ambiguity       PyAscore.calculate_ambiguity        Ascore.pyx:208-230
+ *   pya_format_peptide            ModifiedPeptide::getPeptide         cpp/ModifiedPeptide.cpp:199-253
+ *   pya_plan_*                    (new) device-resident variant of pya_score_batch for callers
+ *                                 that keep spectra in HBM and own a HIP stream
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or framework types cross the boundary;
+ *   - inputs are borrowed for the duration of the call (for pya_plan_run: until the stream
+ *     has drained); outputs are caller-allocated; the library never frees caller memory;
+ *   - every function returns PYA_OK (0) or a negative status; pya_last_error() gives the
+ *     message and pya_error_index() the offending PSM (or -1);
+ *   - a handle is single-owner (one handle <-> one device); different handles may be used
+ *     from different threads;
+ *   - there is NO CPU fallback: without a HIP device pya_create fails with PYA_ERR_HIP.
+ *
+ * Signature bit sets ("sig bits"): bit j is the j-th modifiable residue counted from the
+ * N-terminus, 1 = modified.  Alternative-site masks: bit (p-1) = 1-based peptide position p.
+ */
+#ifndef PYASCORE_HIP_H
+#define PYASCORE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYA_OK 0
+#define PYA_ERR_ARG (-1)    /* invalid configuration / argument                          */
+#define PYA_ERR_HIP (-2)    /* HIP runtime failure or no device                          */
+#define PYA_ERR_PSM (-3)    /* a PSM is invalid (unknown residue, empty spectrum, ...)   */
+#define PYA_ERR_LIMIT (-4)  /* a PSM exceeds a documented limit of this implementation   */
+#define PYA_ERR_STATE (-5)  /* call sequence error (e.g. no retained batch)              */
+
+/* documented limits (DESIGN.md "Limits") */
+#define PYA_MAX_PEPTIDE_LEN 64
+#define PYA_MAX_SITES 63
+#define PYA_MAX_SIGNATURES 15000
+#define PYA_MAX_PEAKS 8192
+#define PYA_MAX_FRAGMENT_TYPES 8
+#define PYA_MAX_NL_VALUES 4
+#define PYA_N_TOP 10
+
+#define PYA_FLAG_KEEP 1u    /* retain per-signature records for pya_get_pep_scores /     */
+                            /* pya_calculate_ambiguity                                    */
+#define PYA_FLAG_TIMING 2u  /* record HIP events around every kernel of pya_plan_run     */
+
+typedef struct pya_handle pya_handle;
+typedef struct pya_plan pya_plan;
+
+typedef struct pya_config {
+    float bin_size;             /* m/z width of a peak window                            */
+    uint32_t n_top;             /* peaks retained per window; must be 10                 */
+    const char *mod_group;      /* e.g. "STY"; 'n' / 'c' allow the termini               */
+    float mod_mass;
+    float mz_error;             /* Da                                                    */
+    const char *fragment_types; /* subset of "bycz Z", e.g. "by"                         */
+    int32_t device;             /* HIP device ordinal                                    */
+} pya_config;
+
+/* host-side CSR description of a batch of PSMs (all arrays borrowed) */
+typedef struct pya_batch {
+    uint64_t n_psm;
+    const int64_t *peak_off;    /* [n_psm+1] offsets into mz / intensity                 */
+    const uint8_t *pep;         /* peptide letters of all PSMs, back to back             */
+    const int64_t *pep_off;     /* [n_psm+1]                                             */
+    const int32_t *n_of_mod;    /* [n_psm] unlocalised modifications                     */
+    const int32_t *max_charge;  /* [n_psm] max fragment charge (>= 1)                    */
+    const uint32_t *aux_pos;    /* fixed mods: 0 = n-term, else 1-based position; or NULL */
+    const float *aux_mass;
+    const int64_t *aux_off;     /* [n_psm+1] or NULL                                     */
+} pya_batch;
+
+/* caller-allocated structure-of-arrays results; host pointers for pya_score_batch,
+ * device pointers for pya_plan_run */
+typedef struct pya_results {
+    uint32_t max_k;             /* row stride of ascores / alt_mask (>= max n_of_mod)    */
+    float *best_score;          /* [n_psm]  PepScore of the best localisation, -1 if none */
+    uint64_t *best_sig;         /* [n_psm]  sig bits of the best localisation            */
+    int32_t *n_sig;             /* [n_psm]  number of localisations scored               */
+    float *ascores;             /* [n_psm * max_k]  +inf where unambiguous               */
+    uint64_t *alt_mask;         /* [n_psm * max_k]                                       */
+} pya_results;
+
+int pya_create(const pya_config *cfg, pya_handle **out);
+void pya_destroy(pya_handle *h);
+int pya_add_neutral_loss(pya_handle *h, const char *group, float mass);
+const char *pya_last_error(const pya_handle *h);
+int64_t pya_error_index(const pya_handle *h);
+
+/* host buffers in, host buffers out: H2D copy + kernels + D2H copy, synchronous */
+int pya_score_batch(pya_handle *h, const pya_batch *batch, const double *mz,
+                    const double *intensity, uint32_t flags, const pya_results *out);
+
+/* device-resident path: plan once (host pre-pass, tables, workspace), run many times */
+int pya_plan_create(pya_handle *h, const pya_batch *batch, uint32_t flags, pya_plan **out);
+int pya_plan_run(pya_plan *plan, const double *d_mz, const double *d_intensity,
+                 void *hip_stream, const pya_results *d_out);
+/* ms per kernel of the last pya_plan_run (PYA_FLAG_TIMING): bin, score, localize; syncs */
+int pya_plan_timings(pya_plan *plan, float ms[3]);
+/* waits for the stream of the last run and reports the first PSM the kernels rejected */
+int pya_plan_check(pya_plan *plan);
+uint64_t pya_plan_workspace_bytes(const pya_plan *plan);
+uint64_t pya_plan_total_signatures(const pya_plan *plan);
+void pya_plan_destroy(pya_plan *plan);
+
+/* all localisations of PSM `psm` of the last pya_score_batch(..., PYA_FLAG_KEEP, ...), in the
+ * reference's sorted order; arrays sized for `cap` records; returns the record count in *n */
+int pya_get_pep_scores(pya_handle *h, uint64_t psm, uint64_t cap, uint64_t *n, uint64_t *sig_bits,
+                       int32_t *counts /* cap x 10 */, float *scores /* cap x 10 */,
+                       float *weighted_score, int32_t *total_fragments);
+int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits,
+                            const float *ref_scores, float ref_weighted, uint64_t other_bits,
+                            const float *other_scores, float other_weighted, float *out);
+
+/* host-only helpers */
+int pya_format_peptide(const pya_handle *h, const uint8_t *pep, uint64_t pep_len, int32_t n_of_mod,
+                       const uint32_t *aux_pos, const float *aux_mass, uint64_t n_aux,
+                       uint64_t sig_bits, int32_t sig_len, char *buf, uint64_t cap);
+int pya_count_sites(const pya_handle *h, const uint8_t *pep, uint64_t pep_len, int32_t *n_sites,
+                    uint8_t *site_pos /* >= PYA_MAX_PEPTIDE_LEN, 0-based residue of each site */);
+
+/* test hook: runs the on-device emulation of the reference's std::sort (descending, keyed by
+ * weighted score) on arbitrary keys and returns the permutation */
+int pya_debug_sort(pya_handle *h, const float *keys, uint32_t n, uint32_t *perm);
+
+const char *pya_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYASCORE_HIP_H */

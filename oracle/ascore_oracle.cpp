@@ -684,7 +684,7 @@ int64_t orc_score_batch(orc_handle *h, uint64_t n_psm, const double *mz, const d
                 const SiteResult &r = h->site_results[j];
                 a = *std::min_element(r.ascores.begin(), r.ascores.end());
                 for (uint32_t s : r.positions)
-                    if (s < 64) m |= 1ull << s;
+                    if (s >= 1 && s <= 64) m |= 1ull << (s - 1);
             }
             ascores[i * max_k + j] = a;
             alt_mask[i * max_k + j] = m;
@@ -775,3 +775,17 @@ uint64_t orc_power_set_sums(const float *target, uint64_t n, uint64_t max_depth,
 }
 
 } /* extern "C" */
+
+/* The reference's sort call itself (cpp/Ascore.cpp:141-146) on caller keys: used to check the
+ * on-device emulation (pya_debug_sort).  perm[r] = original index of the r-th sorted element. */
+extern "C" void orc_std_sort(const float *keys, uint64_t n, uint32_t *perm) {
+    struct Rec {
+        float weighted_score;
+        uint32_t idx;
+    };
+    std::vector<Rec> v(n);
+    for (uint64_t i = 0; i < n; i++) v[i] = {keys[i], (uint32_t)i};
+    std::sort(v.begin(), v.end(),
+              [](const Rec &a, const Rec &b) { return a.weighted_score > b.weighted_score; });
+    for (uint64_t i = 0; i < n; i++) perm[i] = v[i].idx;
+}

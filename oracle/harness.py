@@ -39,7 +39,7 @@ def collect(scorer, batch, unpack):
         for j, alt in enumerate(scorer.alt_sites):
             m = 0
             for s in alt:
-                m |= 1 << int(s)
+                m |= 1 << (int(s) - 1)
             out["alt_mask"][i, j] = m
         if ps:
             out["best_sig"][i] = sig_bits(ps[0]["signature"])

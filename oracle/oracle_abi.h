@@ -52,7 +52,7 @@ float orc_calculate_ambiguity(orc_handle *h, const int32_t *sig_ref, const float
  * Per PSM it performs exactly one orc_score() and extracts the fixed summary:
  *   best_score[i], best_sig[i] (bit j = site j modified, N-term site = bit 0),
  *   n_sig[i] = number of pep_scores, ascores[i*max_k + j], alt_mask[i*max_k + j]
- *   (bit p = 1-based peptide position p is an alternative site; positions >= 64 dropped).
+ *   (bit p-1 = 1-based peptide position p is an alternative site; positions > 64 dropped).
  * Returns 0 or the negative (index+1) of the first PSM that threw. */
 int64_t orc_score_batch(orc_handle *h, uint64_t n_psm, const double *mz, const double *inten,
                         const int64_t *peak_off, const char *pep, const int64_t *pep_off,

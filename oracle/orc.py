@@ -67,12 +67,22 @@ def load(kind):
         "orc_power_set_sums": (_u64, [_p, _u64, _u64, _p, _u64]),
         "orc_impl_name": (C.c_char_p, []),
     }
+    if kind == "oracle":
+        sig["orc_std_sort"] = (None, [_p, _u64, _p])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     _LIBS[kind] = lib
     return lib
+
+
+def std_sort(keys):
+    """Permutation the reference's std::sort call (Ascore.cpp:141-146) applies to `keys`."""
+    keys = np.ascontiguousarray(keys, dtype=np.float32)
+    perm = np.zeros(keys.size, np.uint32)
+    load("oracle").orc_std_sort(_ptr(keys), keys.size, _ptr(perm))
+    return perm
 
 
 class OracleAscore:

@@ -205,7 +205,7 @@ int64_t orc_score_batch(orc_handle *h, uint64_t n_psm, const double *mz, const d
             uint64_t m = 0;
             if (j < a.size()) {
                 for (size_t s : h->asc->getAlternativeSites(j))
-                    if (s < 64) m |= (1ull << s);
+                    if (s >= 1 && s <= 64) m |= (1ull << (s - 1));
             }
             alt_mask[i * max_k + j] = m;
         }

@@ -1,0 +1,80 @@
+"""ctypes binding of include/pyascore_hip.h (libpyascore_hip.so, built in-tree by build.py).
+
+There is no fallback: if the library is missing or no HIP device is usable, importing the
+scorer fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyascore_hip.so")
+
+PYA_OK, PYA_ERR_ARG, PYA_ERR_HIP, PYA_ERR_PSM, PYA_ERR_LIMIT, PYA_ERR_STATE = 0, -1, -2, -3, -4, -5
+PYA_FLAG_KEEP, PYA_FLAG_TIMING = 1, 2
+PYA_MAX_PEPTIDE_LEN = 64
+
+_vp = C.c_void_p
+
+
+class Config(C.Structure):
+    _fields_ = [("bin_size", C.c_float), ("n_top", C.c_uint32), ("mod_group", C.c_char_p),
+                ("mod_mass", C.c_float), ("mz_error", C.c_float), ("fragment_types", C.c_char_p),
+                ("device", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_psm", C.c_uint64), ("peak_off", _vp), ("pep", _vp), ("pep_off", _vp),
+                ("n_of_mod", _vp), ("max_charge", _vp), ("aux_pos", _vp), ("aux_mass", _vp),
+                ("aux_off", _vp)]
+
+
+class Results(C.Structure):
+    _fields_ = [("max_k", C.c_uint32), ("best_score", _vp), ("best_sig", _vp), ("n_sig", _vp),
+                ("ascores", _vp), ("alt_mask", _vp)]
+
+
+# every symbol include/pyascore_hip.h declares
+SYMBOLS = {
+    "pya_create": (C.c_int, [C.POINTER(Config), C.POINTER(_vp)]),
+    "pya_destroy": (None, [_vp]),
+    "pya_add_neutral_loss": (C.c_int, [_vp, C.c_char_p, C.c_float]),
+    "pya_last_error": (C.c_char_p, [_vp]),
+    "pya_error_index": (C.c_int64, [_vp]),
+    "pya_score_batch": (C.c_int, [_vp, C.POINTER(Batch), _vp, _vp, C.c_uint32, C.POINTER(Results)]),
+    "pya_plan_create": (C.c_int, [_vp, C.POINTER(Batch), C.c_uint32, C.POINTER(_vp)]),
+    "pya_plan_run": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(Results)]),
+    "pya_plan_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 3)]),
+    "pya_plan_check": (C.c_int, [_vp]),
+    "pya_plan_workspace_bytes": (C.c_uint64, [_vp]),
+    "pya_plan_total_signatures": (C.c_uint64, [_vp]),
+    "pya_plan_destroy": (None, [_vp]),
+    "pya_get_pep_scores": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), _vp, _vp,
+                                     _vp, _vp, _vp]),
+    "pya_calculate_ambiguity": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_float, C.c_uint64,
+                                          _vp, C.c_float, C.POINTER(C.c_float)]),
+    "pya_format_peptide": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int32, _vp, _vp, C.c_uint64,
+                                     C.c_uint64, C.c_int32, C.c_char_p, C.c_uint64]),
+    "pya_count_sites": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_int32), _vp]),
+    "pya_debug_sort": (C.c_int, [_vp, _vp, C.c_uint32, _vp]),
+    "pya_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library (no device needed for loading; pya_create needs one)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pyascore_amd: %s is missing. Build it with `python -m pyascore_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,270 @@
+"""``PyAscore`` -- the reference's Python surface for the PTM-localisation scorer
+(pyascore/ptm_scoring/Ascore.pyx:12-288), backed by the MI355X kernels through the C ABI of
+include/pyascore_hip.h.  Same constructor, ``add_neutral_loss``, ``score``, properties and
+``calculate_ambiguity``; plus ``score_batch`` (``score`` is a batch of one).
+
+Deviations, all towards *more* defined behaviour: inputs the reference
+would abort or read out of bounds on (unknown residue, empty spectrum, ``n_top != 10``,
+``max_fragment_charge < 1``, mismatched array lengths) raise ``ValueError`` here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+def _as_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _check_f64(name, a):
+    if a is None:
+        raise TypeError("Argument '%s' must not be None" % name)
+    if not isinstance(a, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)"
+                        % (name, type(a).__name__))
+    if a.ndim != 1:
+        raise ValueError("Buffer has wrong number of dimensions (expected 1, got %d)" % a.ndim)
+    if a.dtype != np.float64:
+        raise ValueError("Buffer dtype mismatch, expected 'double' but got '%s'" % a.dtype)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("ndarray is not C-contiguous")
+    return a
+
+
+def _check_typed(name, a, dtype, cname):
+    if not isinstance(a, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)"
+                        % (name, type(a).__name__))
+    if a.ndim != 1:
+        raise ValueError("Buffer has wrong number of dimensions (expected 1, got %d)" % a.ndim)
+    if a.dtype != dtype:
+        raise ValueError("Buffer dtype mismatch, expected '%s' but got '%s'" % (cname, a.dtype))
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("ndarray is not C-contiguous")
+    return a
+
+
+class PyAscore:
+    """Scores the localization of post translational modifications (Ascore.pyx:12-59).
+
+    Parameters
+    ----------
+    bin_size : float
+        Size in MZ of each bin
+    n_top : int
+        Number of top peaks to retain in each bin (this implementation requires 10)
+    mod_group : str
+        Residues that can carry the unlocalized modification, e.g. "STY" ('n'/'c' = termini)
+    mod_mass : float
+        Mass of the unlocalized modification, e.g. 79.966331
+    mz_error : float
+        Matching tolerance in Da (default 0.5)
+    fragment_types : str
+        Ion types to score, subset of b, c, y, z, Z (default "by")
+    device : int, optional (keyword only)
+        HIP device ordinal; defaults to LOCAL_RANK or 0.
+    """
+
+    def __init__(self, bin_size, n_top, mod_group, mod_mass, mz_error=.5, fragment_types="by", *,
+                 device=None):
+        if not isinstance(mod_group, str) or not isinstance(fragment_types, str):
+            raise TypeError("mod_group and fragment_types must be str")
+        self._lib = _lib.load()
+        self._h = None
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self._mod_group = mod_group
+        self._cfg_strings = (mod_group.encode("utf8"), fragment_types.encode("utf8"))
+        cfg = _lib.Config(float(bin_size), int(n_top), self._cfg_strings[0], float(mod_mass),
+                          float(mz_error), self._cfg_strings[1], int(device))
+        h = C.c_void_p()
+        rc = self._lib.pya_create(C.byref(cfg), C.byref(h))
+        self._h = h if h.value else None
+        if rc:
+            self._raise(rc)
+        self.device = int(device)
+        self._last = None            # summary of the last score() call
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and getattr(self, "_lib", None) is not None:
+            self._lib.pya_destroy(h)
+            self._h = None
+
+    def _raise(self, rc):
+        msg = self._lib.pya_last_error(self._h).decode("utf8", "replace") if self._h else "pya_create failed"
+        if rc in (_lib.PYA_ERR_ARG, _lib.PYA_ERR_PSM, _lib.PYA_ERR_LIMIT):
+            raise ValueError(msg)
+        raise RuntimeError(msg)
+
+    # ------------------------------------------------------------------------------------------
+    def add_neutral_loss(self, group, mass):
+        """Add a neutral loss ion to any fragment containing specified amino acids
+        (Ascore.pyx:81-99).  Upper case = unmodified residue, lower case = modified residue."""
+        if not isinstance(group, str):
+            raise TypeError("Argument 'group' has incorrect type (expected str)")
+        rc = self._lib.pya_add_neutral_loss(self._h, group.encode("utf8"), float(mass))
+        if rc:
+            self._raise(rc)
+
+    def score(self, mz_arr, int_arr, peptide, n_of_mod, max_fragment_charge=1, aux_mod_pos=None,
+              aux_mod_mass=None):
+        """Consume spectra and associated peptide information and score PTM localization
+        (Ascore.pyx:103-152)."""
+        mz_arr = _check_f64("mz_arr", mz_arr)
+        int_arr = _check_f64("int_arr", int_arr)
+        if not isinstance(peptide, str):
+            raise TypeError("Argument 'peptide' has incorrect type (expected str, got %s)"
+                            % type(peptide).__name__)
+        if int_arr.size != mz_arr.size:
+            raise ValueError("mz_arr and int_arr differ in length (%d vs %d)" % (mz_arr.size, int_arr.size))
+        if int(n_of_mod) < 0 or int(max_fragment_charge) < 0:
+            raise OverflowError("can't convert negative value to size_t")
+        pep = np.frombuffer(peptide.encode("utf8"), dtype=np.uint8)
+        if aux_mod_pos is not None and aux_mod_mass is not None:
+            ap = _check_typed("aux_mod_pos", aux_mod_pos, np.uint32, "unsigned int")
+            am = _check_typed("aux_mod_mass", aux_mod_mass, np.float32, "float")
+            if ap.size != am.size:
+                raise ValueError("aux_mod_pos and aux_mod_mass differ in length")
+        else:
+            ap = np.zeros(0, np.uint32)
+            am = np.zeros(0, np.float32)
+        batch = dict(
+            n_psm=1, mz=mz_arr, intensity=int_arr, peak_off=np.array([0, mz_arr.size], np.int64),
+            pep=pep, pep_off=np.array([0, pep.size], np.int64),
+            n_of_mod=np.array([n_of_mod], np.int32), max_charge=np.array([max_fragment_charge], np.int32),
+            aux_pos=ap, aux_mass=am, aux_off=np.array([0, ap.size], np.int64))
+        res = self.score_batch(batch, keep=True)
+        self._last = dict(pep=pep, peptide=peptide, k=int(n_of_mod), aux_pos=ap.copy(), aux_mass=am.copy(),
+                          best_score=float(res["best_score"][0]), best_sig=int(res["best_sig"][0]),
+                          n_sig=int(res["n_sig"][0]), ascores=res["ascores"][0].copy(),
+                          alt_mask=res["alt_mask"][0].copy())
+
+    def score_batch(self, batch, keep=False):
+        """Scores a CSR batch (see pyascore_amd.synth) in one call.
+
+        Returns dict(best_score f32[n], best_sig u64[n], n_sig i32[n], ascores f32[n, max_k],
+        alt_mask u64[n, max_k]); row i holds what the reference's properties would hold after
+        ``score()`` of PSM i (ascores beyond n_of_mod[i] are 0)."""
+        n = int(batch["n_psm"])
+        mz = np.ascontiguousarray(batch["mz"], np.float64)
+        it = np.ascontiguousarray(batch["intensity"], np.float64)
+        arrs = dict(
+            peak_off=np.ascontiguousarray(batch["peak_off"], np.int64),
+            pep=np.ascontiguousarray(batch["pep"], np.uint8),
+            pep_off=np.ascontiguousarray(batch["pep_off"], np.int64),
+            n_of_mod=np.ascontiguousarray(batch["n_of_mod"], np.int32),
+            max_charge=np.ascontiguousarray(batch["max_charge"], np.int32),
+            aux_pos=np.ascontiguousarray(batch["aux_pos"], np.uint32),
+            aux_mass=np.ascontiguousarray(batch["aux_mass"], np.float32),
+            aux_off=np.ascontiguousarray(batch["aux_off"], np.int64))
+        if arrs["peak_off"].size != n + 1 or arrs["pep_off"].size != n + 1 or arrs["aux_off"].size != n + 1:
+            raise ValueError("offset arrays must have n_psm + 1 entries")
+        if n and (mz.size < arrs["peak_off"][-1] or it.size < arrs["peak_off"][-1]):
+            raise ValueError("peak_off runs past the end of the spectrum arrays")
+        max_k = max(1, int(arrs["n_of_mod"].max())) if n else 1
+        out = dict(best_score=np.zeros(n, np.float32), best_sig=np.zeros(n, np.uint64),
+                   n_sig=np.zeros(n, np.int32), ascores=np.zeros((n, max_k), np.float32),
+                   alt_mask=np.zeros((n, max_k), np.uint64))
+        if n == 0:
+            return out
+        b = _lib.Batch(n, _as_ptr(arrs["peak_off"]), _as_ptr(arrs["pep"]), _as_ptr(arrs["pep_off"]),
+                       _as_ptr(arrs["n_of_mod"]), _as_ptr(arrs["max_charge"]), _as_ptr(arrs["aux_pos"]),
+                       _as_ptr(arrs["aux_mass"]), _as_ptr(arrs["aux_off"]))
+        r = _lib.Results(max_k, _as_ptr(out["best_score"]), _as_ptr(out["best_sig"]), _as_ptr(out["n_sig"]),
+                         _as_ptr(out["ascores"]), _as_ptr(out["alt_mask"]))
+        rc = self._lib.pya_score_batch(self._h, C.byref(b), _as_ptr(mz), _as_ptr(it),
+                                       _lib.PYA_FLAG_KEEP if keep else 0, C.byref(r))
+        if rc:
+            self._raise(rc)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def _format(self, last, bits, sig_len):
+        buf = C.create_string_buffer(1024)
+        n = self._lib.pya_format_peptide(self._h, _as_ptr(last["pep"]), last["pep"].size, last["k"],
+                                         _as_ptr(last["aux_pos"]), _as_ptr(last["aux_mass"]),
+                                         last["aux_pos"].size, int(bits), int(sig_len), buf, 1024)
+        if n < 0:
+            self._raise(n)
+        return buf.value.decode("utf8")
+
+    def _n_sites(self, last):
+        ns = C.c_int32()
+        self._lib.pya_count_sites(self._h, _as_ptr(last["pep"]), last["pep"].size, C.byref(ns), None)
+        return ns.value
+
+    @property
+    def best_sequence(self):
+        last = self._last
+        if last is None or last["n_sig"] <= 0:
+            return ""
+        return self._format(last, last["best_sig"], self._n_sites(last))
+
+    @property
+    def best_score(self):
+        return -1.0 if self._last is None else self._last["best_score"]
+
+    @property
+    def pep_scores(self):
+        last = self._last
+        if last is None or last["n_sig"] <= 0:
+            return []
+        n = last["n_sig"]
+        ns = self._n_sites(last)
+        bits = np.zeros(n, np.uint64)
+        counts = np.zeros((n, 10), np.int32)
+        scores = np.zeros((n, 10), np.float32)
+        ws = np.zeros(n, np.float32)
+        nfrag = np.zeros(n, np.int32)
+        got = C.c_uint64()
+        rc = self._lib.pya_get_pep_scores(self._h, 0, n, C.byref(got), _as_ptr(bits), _as_ptr(counts),
+                                          _as_ptr(scores), _as_ptr(ws), _as_ptr(nfrag))
+        if rc:
+            self._raise(rc)
+        out = []
+        for i in range(int(got.value)):
+            b = int(bits[i])
+            out.append(dict(signature=np.array([(b >> j) & 1 for j in range(ns)], dtype=np.int32),
+                            counts=counts[i].copy(), scores=scores[i].copy(),
+                            weighted_score=float(ws[i]), total_fragments=int(nfrag[i]),
+                            sequence=self._format(last, b, ns)))
+        return out
+
+    @property
+    def ascores(self):
+        if self._last is None:
+            return np.zeros(0, np.float32)
+        return self._last["ascores"][: self._last["k"]].astype(np.float32)
+
+    @property
+    def alt_sites(self):
+        if self._last is None:
+            return []
+        out = []
+        for j in range(self._last["k"]):
+            m = int(self._last["alt_mask"][j])
+            out.append(np.array([p + 1 for p in range(64) if (m >> p) & 1], dtype=np.uint32))
+        return out
+
+    def calculate_ambiguity(self, ref_score, other_score):
+        """Calculate ambiguity between 2 competing localizations of the last scored PSM
+        (Ascore.pyx:208-230).  Inputs should come from ``pep_scores``."""
+        if self._last is None:
+            raise RuntimeError("calculate_ambiguity needs a scored PSM")
+        from_sig = lambda s: sum(1 << j for j, v in enumerate(s) if int(v))  # noqa: E731
+        rs = np.ascontiguousarray(ref_score["scores"], np.float32)
+        os_ = np.ascontiguousarray(other_score["scores"], np.float32)
+        if rs.size != 10 or os_.size != 10:
+            raise ValueError("score containers must hold 10 depth scores")
+        out = C.c_float()
+        rc = self._lib.pya_calculate_ambiguity(
+            self._h, 0, from_sig(ref_score["signature"]), _as_ptr(rs), float(ref_score["weighted_score"]),
+            from_sig(other_score["signature"]), _as_ptr(os_), float(other_score["weighted_score"]),
+            C.byref(out))
+        if rc:
+            self._raise(rc)
+        return float(out.value)

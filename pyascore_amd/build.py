@@ -1,0 +1,60 @@
+"""Builds pyascore_amd/libpyascore_hip.so in-tree (hipcc cross-compiles gfx950 without a GPU).
+
+    python -m pyascore_amd.build [--force]
+
+Device code (*.hip) is compiled by hipcc for gfx950 only; the host side (host.cpp,
+score_table.cpp) by g++ so the float32 score-table chain is evaluated by the same compiler
+family and libm as the reference (DESIGN.md "Exactness").  -ffp-contract=off everywhere.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpyascore_hip.so")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+
+DEVICE_SRC = ["bin_spectra.hip", "score_signatures.hip", "rank_and_localize.hip"]
+HOST_SRC = ["host.cpp", "score_table.cpp"]
+HEADERS = ["common.h", "device_common.hip.h", os.path.join("..", "..", "include", "pyascore_hip.h")]
+
+DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
+                "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+HOST_FLAGS = ["-O2", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-result",
+              "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build(force=False):
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in DEVICE_SRC:
+        s, o = os.path.join(CSRC, src), os.path.join(CSRC, src + ".o")
+        if force or _stale(o, [s] + hdrs):
+            _run([HIPCC] + DEVICE_FLAGS + ["-c", s, "-o", o])
+        objs.append(o)
+    for src in HOST_SRC:
+        s, o = os.path.join(CSRC, src), os.path.join(CSRC, src + ".o")
+        if force or _stale(o, [s] + hdrs):
+            _run(["g++"] + HOST_FLAGS + ["-c", s, "-o", o])
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

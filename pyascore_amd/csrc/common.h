@@ -1,0 +1,92 @@
+/* common.h -- structures shared by the host library and the gfx950 kernels. */
+#ifndef PYA_COMMON_H
+#define PYA_COMMON_H
+
+#include <stdint.h>
+
+#define PYA_WAVE 64
+#define PYA_NTOP 10
+#define PYA_NO_MATCH 15            /* rank value meaning "no retained peak in the window" */
+#define PYA_MAX_L 64
+#define PYA_MAX_TYPES 8
+#define PYA_MAX_NL 4               /* distinct neutral-loss masses                         */
+#define PYA_MAX_UNIQ 16            /* distinct sums of <= 2 neutral losses (incl. 0)       */
+#define PYA_MAX_LIST 2048          /* fragments of one signature and one ion type          */
+#define PYA_MAX_LUT_N 4096         /* largest trial count the score table covers           */
+#define PYA_MAX_PUSHED 1024        /* tied best competitors kept per PSM                   */
+
+/* per-PSM status written by the kernels */
+#define PYA_ST_OK 0
+#define PYA_ST_NO_BINS 1           /* min == max at a multiple of 100: reference is UB      */
+#define PYA_ST_TOO_MANY_BINS 2
+#define PYA_ST_LUT_RANGE 3         /* trial count outside the uploaded score table          */
+#define PYA_ST_PUSHED_OVERFLOW 4
+
+/* Scorer configuration as the kernels see it (one copy in device memory per handle).
+ * Residue tables are indexed by (letter - 'A') & 31.                                      */
+struct DevConfig {
+    float bin_size;
+    float mod_mass;
+    float mz_error;
+    int32_t n_types;
+    int32_t n_fwd;                  /* number of b/c entries in types[] (they come first)   */
+    uint8_t types[PYA_MAX_TYPES];   /* forward types first, then backward; order is free    */
+    uint8_t first_forward;          /* direction of fragment_types[0]                       */
+    uint8_t allow_n, allow_c;       /* 'n' / 'c' in mod_group                               */
+    uint8_t n_nl;                   /* distinct NL masses D                                 */
+    float res_mass[32];             /* Types.h:7-30, 0 = not a residue                      */
+    uint8_t res_modifiable[32];     /* letter in mod_group                                  */
+    uint8_t nl_upper[32];           /* NL class (1..D, 0 none) of the unmodified residue    */
+    uint8_t nl_lower[32];           /* NL class of the modified / aux-modified residue      */
+    int32_t n_uniq;                 /* distinct values among {0} U {t_i} U {t_i + t_j}      */
+    float uniq[PYA_MAX_UNIQ];       /* uniq[0] = 0                                          */
+    uint16_t present[256];          /* NL stack state (2 bits per class, saturating at 2)   */
+                                    /*   -> bit set of uniq[] values that exist             */
+    float weights[PYA_NTOP];        /* Ascore.cpp:16-18                                     */
+};
+
+/* device pointers + scalars of one launch family; passed by value as kernel argument */
+struct BatchDev {
+    /* inputs */
+    const double *mz;
+    const double *inten;
+    const int64_t *peak_off;
+    const uint8_t *pep;
+    const int64_t *pep_off;
+    const int32_t *n_of_mod;
+    const int32_t *max_charge;
+    const uint32_t *aux_pos;
+    const float *aux_mass;
+    const int64_t *aux_off;         /* never NULL on device (all zeros if no aux mods)      */
+    /* host pre-pass */
+    const uint8_t *n_sites;         /* [n_psm]                                              */
+    const uint32_t *n_sig;          /* [n_psm] C(n_sites, k) or 0                           */
+    const uint32_t *order_off;      /* [n_psm] offset of the PSM's shape in order_tab       */
+    const int64_t *sig_off;         /* [n_psm+1] offsets into ws / rec                      */
+    const uint64_t *order_tab;      /* pre-sort signature order per shape (sig bits)        */
+    const DevConfig *cfg;
+    const float *lut;               /* score table                                          */
+    const uint32_t *lut_off;        /* [lut_n_max+1] row offsets                            */
+    uint32_t lut_n_max;
+    /* workspace */
+    float *ret_mz;                  /* retained peaks, m/z ascending, at peak_off[psm]      */
+    uint8_t *ret_rank;
+    uint32_t *ret_n;                /* [n_psm]                                              */
+    float *ws;                      /* weighted score per signature, pre-sort order         */
+    uint32_t *rec;                  /* optional per-signature records: 6 words each         */
+    uint32_t *sorted_idx;           /* optional sorted permutation, at sig_off              */
+    int32_t *status;                /* [n_psm]                                              */
+    /* outputs */
+    float *best_score;
+    uint64_t *best_sig;
+    int32_t *n_sig_out;
+    float *ascores;
+    uint64_t *alt_mask;
+    uint32_t max_k;
+    uint32_t keep;                  /* write rec / sorted_idx                               */
+};
+
+/* per-signature record (keep mode): 10 cumulative counts as u16 + total fragments */
+#define PYA_REC_WORDS 6
+
+#endif

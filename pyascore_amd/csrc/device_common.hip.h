@@ -1,0 +1,230 @@
+/* device_common.hip.h -- gfx950 device helpers shared by the three kernels.
+ *
+ * Arithmetic contract (DESIGN.md "Exactness"): everything that decides a match is computed in
+ * the reference's own operation order and precision; this translation unit is compiled with
+ * -ffp-contract=off and without fast-math so no operation is fused, reassociated or
+ * approximated.  Wavefront = 64 lanes throughout; one PSM per wavefront.
+ */
+#ifndef PYA_DEVICE_COMMON_H
+#define PYA_DEVICE_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include "common.h"
+
+#define DEV __device__ __forceinline__
+
+DEV int lane_id() { return (int)(threadIdx.x & 63); }
+
+DEV uint64_t lanemask_lt() {
+    return (1ull << lane_id()) - 1ull;
+}
+
+template <typename T>
+DEV T wave_bcast(T v, int src) {
+    return __shfl(v, src, 64);
+}
+
+DEV int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEV uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+DEV uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+DEV uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEV double wave_min_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+DEV double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+/* exclusive prefix sum over the wave; *total receives the wave sum */
+DEV int wave_excl_scan_i32(int v, int *total) {
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o, 64);
+        if (lane_id() >= o) x += y;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+/* LDS traffic of one wave is in order, but the compiler must not move accesses across the
+ * points where lanes exchange data through LDS. */
+DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Theoretical fragment m/z.  ModifiedPeptide.cpp:570-591: float (running - loss) widened to
+ * double, ion-type offsets added one at a time in double, charge applied in double, narrowed.
+ * ------------------------------------------------------------------------------------- */
+DEV double type_offset(double m, uint8_t type) {
+    if (type == 'y') {
+        m += 18.010565;
+    } else if (type == 'z') {
+        m += 18.010565;
+        m -= 17.026549;
+    } else if (type == 'Z') {
+        m += 18.010565;
+        m -= 16.018724;
+    } else if (type == 'c') {
+        m += 17.026549;
+    }
+    return m;
+}
+DEV float charge_mz(double m, int z) {
+    if (z == 1) return (float)(m + 1.007825);             /* (m + 1*P)/1 is exact in both steps */
+    double zd = (double)z;
+    return (float)((m + zd * 1.007825) / zd);
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Match lookup = net semantics of consumePeak/hasMatch/getMatch (ModifiedPeptide.cpp:126-150):
+ *   min rank over retained peaks p with f32(f-err) < p < f32(f+err) and f >= p - 0.5.
+ * Retained peaks are staged in LDS sorted by m/z (float), `pow2` = smallest power of two >= n.
+ * ------------------------------------------------------------------------------------- */
+struct PeakTable {
+    const float *mz;        /* LDS */
+    const uint8_t *rank;    /* LDS */
+    int n;
+    int pow2;
+    float err;
+};
+
+DEV int match_rank(const PeakTable &t, float f) {
+    float lo = f - t.err;
+    float hi = f + t.err;
+    int idx = 0;                                           /* number of peaks with p <= lo */
+    for (int step = t.pow2; step > 0; step >>= 1) {
+        int probe = idx + step;
+        if (probe <= t.n && t.mz[probe - 1] <= lo) idx = probe;
+    }
+    int best = PYA_NO_MATCH;
+    while (idx < t.n) {
+        float p = t.mz[idx];
+        if (!(p < hi)) break;
+        if ((double)f >= (double)p - 0.5) {
+            int r = (int)t.rank[idx];
+            best = r < best ? r : best;
+        }
+        idx++;
+    }
+    return best;
+}
+
+/* rank histogram: 10 x 16-bit fields in three 64-bit words (ranks 0-3 | 4-7 | 8-9) */
+struct Hist {
+    uint64_t a, b, c;
+};
+DEV void hist_add(Hist &h, int rank) {
+    uint64_t inc = 1ull << ((rank & 3) * 16);
+    h.a += rank < 4 ? inc : 0ull;
+    h.b += (rank >= 4 && rank < 8) ? inc : 0ull;
+    h.c += (rank >= 8 && rank < PYA_NTOP) ? inc : 0ull;
+}
+DEV uint32_t hist_get(const Hist &h, int r) {
+    uint64_t w = r < 4 ? h.a : (r < 8 ? h.b : h.c);
+    return (uint32_t)(w >> ((r & 3) * 16)) & 0xffffu;
+}
+DEV Hist hist_wave_sum(Hist h) {
+    h.a = wave_sum_u64(h.a);
+    h.b = wave_sum_u64(h.b);
+    h.c = wave_sum_u64(h.c);
+    return h;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Per-residue data of one peptide, one residue per lane (registers, read with v_readlane).
+ * ModifiedPeptide.cpp:24-79.
+ * ------------------------------------------------------------------------------------- */
+struct Residues {
+    float m0, m1;           /* unmodified / modified mass of the lane's residue             */
+    uint32_t nl;            /* NL class unmodified | modified << 4                          */
+    uint64_t site_mask;     /* wave-uniform: bit i = residue i modifiable                   */
+    int L;
+};
+
+DEV Residues load_residues(const BatchDev &b, const DevConfig *cfg, int64_t psm) {
+    Residues r;
+    int64_t p0 = b.pep_off[psm];
+    r.L = (int)(b.pep_off[psm + 1] - p0);
+    int i = lane_id();
+    bool in = i < r.L;
+    uint32_t c = in ? (uint32_t)b.pep[p0 + i] : (uint32_t)'A';
+    uint32_t li = (c - 'A') & 31u;
+    float m0 = cfg->res_mass[li];
+    bool modifiable = in && (cfg->res_modifiable[li] || (cfg->allow_n && i == 0) ||
+                             (cfg->allow_c && i == r.L - 1));
+    float m1 = m0 + cfg->mod_mass;
+    uint32_t nl0 = cfg->nl_upper[li];
+    uint32_t nl1 = modifiable ? (uint32_t)cfg->nl_lower[li] : 0u;
+    int64_t a0 = b.aux_off[psm], a1 = b.aux_off[psm + 1];
+    for (int64_t a = a0; a < a1; a++) {                   /* ModifiedPeptide.cpp:59-79 */
+        uint32_t pos = b.aux_pos[a];
+        int idx = pos > 0 ? (int)pos - 1 : 0;
+        float am = b.aux_mass[a];
+        if (idx == i) {
+            m0 += am;
+            m1 += am;
+            if (cfg->nl_lower[li]) nl0 = cfg->nl_lower[li];
+        }
+    }
+    r.m0 = m0;
+    r.m1 = m1;
+    r.nl = nl0 | (nl1 << 4);
+    r.site_mask = __ballot(modifiable);
+    return r;
+}
+
+/* sig bits (bit j = j-th modifiable residue) -> residue mask (bit i = residue i modified) */
+DEV uint64_t deposit_sites(uint64_t bits, uint64_t site_mask) {
+    uint64_t out = 0, m = site_mask;
+    while (bits) {
+        uint64_t low = m & (0 - m);
+        if (bits & 1) out |= low;
+        m &= m - 1;
+        bits >>= 1;
+    }
+    return out;
+}
+
+DEV uint32_t nl_bump(uint32_t state, uint32_t cls) {
+    /* 2 bits per class, saturating at 2; cls in 1..4 */
+    uint32_t sh = (cls - 1) * 2;
+    uint32_t cur = (state >> sh) & 3u;
+    return cur < 2u ? state + (1u << sh) : state;
+}
+
+#endif

@@ -1,0 +1,887 @@
+/* host.cpp -- host side of libpyascore_hip.so: the C ABI of include/pyascore_hip.h.
+ *
+ * Host work is limited to what is not data-parallel arithmetic over spectra:
+ *   - validating PSMs and counting modifiable residues (one pass over the peptide letters),
+ *   - per-shape signature order tables (the iteration order of the reference's
+ *     std::unordered_map<long,...>, cpp/Ascore.cpp:54,114-120 -- reproduced with the same
+ *     libstdc++ container, it depends only on (n_sites, n_mods, direction)),
+ *   - the binomial score table (score_table.cpp),
+ *   - workspace sizing, bucketing PSMs by C(n,k) so each launch gets the LDS it needs,
+ *   - kernel launches and copies.
+ * There is no CPU scoring path here: without a HIP device every entry point fails.
+ */
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pyascore_hip.h"
+#include "common.h"
+
+void pya_score_table_extend(float mz_error, uint32_t n_top, uint32_t n_to, std::vector<float> &lut,
+                            std::vector<uint32_t> &off);
+extern "C" {
+size_t pya_bin_lds_bytes(uint32_t cap);
+size_t pya_score_lds_bytes(uint32_t cap);
+size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t list_cap);
+int pya_launch_bin(const BatchDev *b, uint32_t n_psm, uint32_t cap, hipStream_t stream);
+int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
+                     hipStream_t stream);
+int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
+                        uint32_t n_cap, uint32_t list_cap, hipStream_t stream);
+int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,
+                         uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
+                         float oth_ws, float *d_out, hipStream_t stream);
+int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream);
+}
+
+namespace {
+
+const size_t kMaxLds = 160 * 1024;
+const uint32_t kBucketLimits[] = {64, 512, 4096, PYA_MAX_SIGNATURES};
+const int kNumBuckets = 4;
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    hipError_t upload(const T *src, size_t count, hipStream_t s = nullptr) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || count == 0) return e;
+        return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+uint64_t binom(uint32_t n, uint32_t k) {
+    if (k > n) return 0;
+    if (k > n - k) k = n - k;
+    unsigned __int128 r = 1;
+    for (uint32_t i = 1; i <= k; i++) {
+        r = r * (n - k + i) / i;
+        if (r > (unsigned __int128)1 << 62) return ~0ull;
+    }
+    return (uint64_t)r;
+}
+
+bool is_forward(char t) { return t == 'b' || t == 'c'; }
+bool is_backward(char t) { return t == 'y' || t == 'z' || t == 'Z'; }
+
+float std_residue_mass(char c) {                       /* Types.h:7-30 */
+    switch (c) {
+        case 'G': return 57.02146f;   case 'A': return 71.03711f;   case 'S': return 87.03203f;
+        case 'P': return 97.05276f;   case 'V': return 99.06841f;   case 'T': return 101.04768f;
+        case 'C': return 103.00919f;  case 'L': return 113.08406f;  case 'I': return 113.08406f;
+        case 'N': return 114.04293f;  case 'D': return 115.02694f;  case 'Q': return 128.05858f;
+        case 'K': return 128.09496f;  case 'E': return 129.04259f;  case 'M': return 131.04049f;
+        case 'H': return 137.05891f;  case 'F': return 147.06841f;  case 'U': return 150.95364f;
+        case 'R': return 156.10111f;  case 'Y': return 163.06333f;  case 'W': return 186.07931f;
+        case 'O': return 237.14773f;
+    }
+    return 0.f;
+}
+
+}  // namespace
+
+struct pya_handle {
+    int device = 0;
+    float bin_size = 100.f, mod_mass = 0.f, mz_error = 0.5f;
+    std::string mod_group, fragment_types;
+    std::map<char, float> nl;                 /* letter -> neutral loss (ModifiedPeptide.h:19) */
+    DevConfig cfg;
+    bool cfg_dirty = true;
+    DevBuf<DevConfig> d_cfg;
+
+    std::vector<float> lut;
+    std::vector<uint32_t> lut_off;
+    uint32_t lut_uploaded_n = 0;              /* rows [0, lut_uploaded_n) are on the device */
+    DevBuf<float> d_lut;
+    DevBuf<uint32_t> d_lut_off;
+
+    std::map<uint32_t, uint32_t> shape_off;   /* (n << 8 | k) -> offset into order_tab */
+    std::vector<uint64_t> order_tab;
+    size_t order_uploaded = 0;
+    DevBuf<uint64_t> d_order;
+
+    std::string err;
+    int64_t err_index = -1;
+    pya_plan *kept = nullptr;                 /* plan of the last PYA_FLAG_KEEP batch */
+
+    int fail(int code, int64_t index, const char *fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        err_index = index;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char *what) {
+        return fail(PYA_ERR_HIP, -1, "HIP error in %s: %s", what, hipGetErrorString(e));
+    }
+    bool letter_modifiable(char c, size_t i, size_t L) const {
+        return mod_group.find(c) != std::string::npos ||
+               (i == 0 && mod_group.find('n') != std::string::npos) ||
+               (i + 1 == L && mod_group.find('c') != std::string::npos);
+    }
+};
+
+#define HIPCHK(h, call)                                        \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return (h)->hip_fail(e_, #call); \
+    } while (0)
+
+struct Bucket {
+    std::vector<uint32_t> ids;
+    DevBuf<uint32_t> d_ids;
+    uint32_t n_cap = 0, list_cap = 1;
+};
+
+struct pya_plan {
+    pya_handle *h = nullptr;
+    uint32_t flags = 0;
+    uint64_t n_psm = 0;
+    int64_t total_peaks = 0, total_sigs = 0;
+    uint32_t peak_cap = 64;
+    uint32_t max_k = 1;
+    /* host copies needed later */
+    std::vector<int64_t> peak_off, sig_off, pep_off, aux_off;
+    std::vector<uint32_t> n_sig, order_off;
+    std::vector<uint8_t> n_sites, pep;
+    std::vector<int32_t> n_of_mod, max_charge;
+    /* device metadata */
+    DevBuf<int64_t> d_peak_off, d_pep_off, d_aux_off, d_sig_off;
+    DevBuf<uint8_t> d_pep, d_n_sites;
+    DevBuf<int32_t> d_n_of_mod, d_max_charge, d_status;
+    DevBuf<uint32_t> d_aux_pos, d_n_sig, d_order_off, d_ret_n, d_rec, d_sorted;
+    DevBuf<float> d_aux_mass, d_ret_mz, d_ws;
+    DevBuf<uint8_t> d_ret_rank;
+    Bucket buckets[kNumBuckets];
+    /* owned copies of inputs/outputs (pya_score_batch path) */
+    DevBuf<double> d_mz, d_inten;
+    DevBuf<float> d_best_score, d_ascores;
+    DevBuf<uint64_t> d_best_sig, d_alt;
+    DevBuf<int32_t> d_n_sig_out;
+    BatchDev dev;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t last_stream = nullptr;
+    bool ran = false;
+
+    ~pya_plan() {
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    uint64_t workspace_bytes() const {
+        uint64_t b = d_peak_off.bytes() + d_pep_off.bytes() + d_aux_off.bytes() + d_sig_off.bytes() +
+                     d_pep.bytes() + d_n_sites.bytes() + d_n_of_mod.bytes() + d_max_charge.bytes() +
+                     d_status.bytes() + d_aux_pos.bytes() + d_n_sig.bytes() + d_order_off.bytes() +
+                     d_ret_n.bytes() + d_rec.bytes() + d_sorted.bytes() + d_aux_mass.bytes() +
+                     d_ret_mz.bytes() + d_ws.bytes() + d_ret_rank.bytes();
+        for (const Bucket &k : buckets) b += k.d_ids.bytes();
+        return b;
+    }
+};
+
+namespace {
+
+/* ---------------------------------------------------------------------------------------- */
+/* configuration -> DevConfig                                                               */
+/* ---------------------------------------------------------------------------------------- */
+int build_dev_config(pya_handle *h) {
+    DevConfig &c = h->cfg;
+    std::memset(&c, 0, sizeof c);
+    c.bin_size = h->bin_size;
+    c.mod_mass = h->mod_mass;
+    c.mz_error = h->mz_error;
+    int nt = 0;
+    for (char t : h->fragment_types)
+        if (is_forward(t)) c.types[nt++] = (uint8_t)t;
+    c.n_fwd = nt;
+    for (char t : h->fragment_types)
+        if (is_backward(t)) c.types[nt++] = (uint8_t)t;
+    c.n_types = nt;
+    c.first_forward = h->fragment_types.empty() ? 1 : (is_forward(h->fragment_types[0]) ? 1 : 0);
+    c.allow_n = h->mod_group.find('n') != std::string::npos;
+    c.allow_c = h->mod_group.find('c') != std::string::npos;
+    for (int l = 0; l < 26; l++) {
+        char up = (char)('A' + l), lowc = (char)('a' + l);
+        c.res_mass[l] = std_residue_mass(up);
+        c.res_modifiable[l] = h->mod_group.find(up) != std::string::npos;
+        (void)lowc;
+    }
+    /* distinct neutral-loss masses -> classes 1..D */
+    std::vector<float> vals;
+    auto cls_of = [&](float v) -> int {
+        for (size_t i = 0; i < vals.size(); i++)
+            if (vals[i] == v) return (int)i + 1;
+        vals.push_back(v);
+        return (int)vals.size();
+    };
+    for (int l = 0; l < 26; l++) {
+        auto u = h->nl.find((char)('A' + l));
+        auto lo = h->nl.find((char)('a' + l));
+        /* a zero loss is "no loss" (ModifiedPeptide.cpp:400 tests != 0) */
+        if (u != h->nl.end() && u->second != 0.f) c.nl_upper[l] = (uint8_t)cls_of(u->second);
+        if (lo != h->nl.end() && lo->second != 0.f) c.nl_lower[l] = (uint8_t)cls_of(lo->second);
+    }
+    if (vals.size() > PYA_MAX_NL)
+        return h->fail(PYA_ERR_LIMIT, -1, "more than %d distinct neutral-loss masses", PYA_MAX_NL);
+    c.n_nl = (uint8_t)vals.size();
+    /* PowerSetSum(stack, 2): {0} U singles U pair sums, exact-deduplicated (Util.cpp:95-141).
+     * Candidate = (value, requirement on the per-class counts). */
+    struct Cand {
+        float v;
+        int a, b;  /* classes (0-based); a == b means the class must occur twice; b < 0: single */
+    };
+    std::vector<Cand> cands;
+    const int D = (int)vals.size();
+    for (int a = 0; a < D; a++) cands.push_back({0.f + vals[a], a, -1});
+    for (int a = 0; a < D; a++)
+        for (int b2 = a; b2 < D; b2++) cands.push_back({(0.f + vals[a]) + vals[b2], a, b2});
+    std::vector<float> uniq{0.f};
+    std::vector<int> cand_u(cands.size());
+    for (size_t i = 0; i < cands.size(); i++) {
+        int u = -1;
+        for (size_t j = 0; j < uniq.size(); j++)
+            if (uniq[j] == cands[i].v) u = (int)j;
+        if (u < 0) {
+            uniq.push_back(cands[i].v);
+            u = (int)uniq.size() - 1;
+        }
+        cand_u[i] = u;
+    }
+    if (uniq.size() > PYA_MAX_UNIQ) return h->fail(PYA_ERR_LIMIT, -1, "too many neutral-loss sums");
+    c.n_uniq = (int32_t)uniq.size();
+    for (size_t j = 0; j < uniq.size(); j++) c.uniq[j] = uniq[j];
+    for (int st = 0; st < 256; st++) {
+        int cnt[4];
+        bool valid = true;
+        for (int a = 0; a < 4; a++) {
+            cnt[a] = (st >> (2 * a)) & 3;
+            if (cnt[a] == 3 || (a >= D && cnt[a])) valid = false;
+        }
+        uint16_t m = 1;
+        if (valid)
+            for (size_t i = 0; i < cands.size(); i++) {
+                const Cand &k = cands[i];
+                bool ok = k.b < 0 ? cnt[k.a] >= 1 : (k.a == k.b ? cnt[k.a] >= 2 : (cnt[k.a] >= 1 && cnt[k.b] >= 1));
+                if (ok) m |= (uint16_t)(1u << cand_u[i]);
+            }
+        c.present[st] = m;
+    }
+    /* Ascore.cpp:15-19 */
+    const float w[PYA_NTOP] = {0.5f, 0.75f, 1.f, 1.f, 1.f, 1.f, 0.75f, 0.5f, 0.25f, 0.25f};
+    double sum = 0.;
+    for (float x : w) sum += x;
+    float fs = (float)sum;
+    for (int i = 0; i < PYA_NTOP; i++) c.weights[i] = w[i] / fs;
+    return PYA_OK;
+}
+
+int sync_config(pya_handle *h) {
+    if (!h->cfg_dirty) return PYA_OK;
+    int rc = build_dev_config(h);
+    if (rc) return rc;
+    HIPCHK(h, h->d_cfg.upload(&h->cfg, 1));
+    HIPCHK(h, hipDeviceSynchronize());
+    h->cfg_dirty = false;
+    return PYA_OK;
+}
+
+int ensure_lut(pya_handle *h, uint32_t n_max) {
+    if (n_max > PYA_MAX_LUT_N)
+        return h->fail(PYA_ERR_LIMIT, -1, "a PSM can have up to %u theoretical fragments per site "
+                       "assignment; the score table covers %u", n_max, PYA_MAX_LUT_N);
+    if (h->lut_uploaded_n > n_max) return PYA_OK;
+    uint32_t target = std::max<uint32_t>(n_max, 128);
+    pya_score_table_extend(h->mz_error, PYA_NTOP, target, h->lut, h->lut_off);
+    HIPCHK(h, h->d_lut.upload(h->lut.data(), h->lut.size()));
+    HIPCHK(h, h->d_lut_off.upload(h->lut_off.data(), h->lut_off.size()));
+    HIPCHK(h, hipDeviceSynchronize());
+    h->lut_uploaded_n = target + 1;
+    return PYA_OK;
+}
+
+/* Pre-sort order of the signatures of a shape: keys (N-term site = MSB) are inserted into the
+ * reference's hash map in the first fragment type's traversal order and read back in the
+ * container's iteration order (cpp/Ascore.cpp:91-120, cpp/ModifiedPeptide.cpp:410-476). */
+uint32_t shape_offset(pya_handle *h, uint32_t n, uint32_t k) {
+    uint32_t key = n << 8 | k;
+    auto it = h->shape_off.find(key);
+    if (it != h->shape_off.end()) return it->second;
+    uint32_t off = (uint32_t)h->order_tab.size();
+    const bool fwd = h->cfg.first_forward;
+    std::unordered_map<long, uint64_t> order;
+    if (k <= n) {
+        std::vector<uint32_t> c(k);
+        for (uint32_t i = 0; i < k; i++) c[i] = i;
+        for (;;) {
+            uint64_t bits = 0;
+            for (uint32_t t : c) bits |= 1ull << (fwd ? t : n - 1 - t);
+            long lk = 0;
+            for (uint32_t j = 0; j < n; j++) lk = (lk << 1) | (long)(bits >> j & 1);
+            order.emplace(lk, bits);
+            int j = (int)k - 1;
+            while (j >= 0 && c[j] == n - k + (uint32_t)j) j--;
+            if (j < 0) break;
+            c[j]++;
+            for (uint32_t t = j + 1; t < k; t++) c[t] = c[t - 1] + 1;
+        }
+    }
+    for (auto &kv : order) h->order_tab.push_back(kv.second);
+    h->shape_off[key] = off;
+    return off;
+}
+
+uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+/* tables owned by the handle may have been re-uploaded (grown) since the plan was made */
+void refresh_shared(pya_plan *p) {
+    pya_handle *h = p->h;
+    BatchDev &d = p->dev;
+    d.order_tab = h->d_order.p;
+    d.cfg = h->d_cfg.p;
+    d.lut = h->d_lut.p;
+    d.lut_off = h->d_lut_off.p;
+    d.lut_n_max = h->lut_uploaded_n - 1;
+}
+
+void fill_dev(pya_plan *p) {
+    pya_handle *h = p->h;
+    BatchDev &d = p->dev;
+    std::memset(&d, 0, sizeof d);
+    d.peak_off = p->d_peak_off.p;
+    d.pep = p->d_pep.p;
+    d.pep_off = p->d_pep_off.p;
+    d.n_of_mod = p->d_n_of_mod.p;
+    d.max_charge = p->d_max_charge.p;
+    d.aux_pos = p->d_aux_pos.p;
+    d.aux_mass = p->d_aux_mass.p;
+    d.aux_off = p->d_aux_off.p;
+    d.n_sites = p->d_n_sites.p;
+    d.n_sig = p->d_n_sig.p;
+    d.order_off = p->d_order_off.p;
+    d.sig_off = p->d_sig_off.p;
+    d.order_tab = h->d_order.p;
+    d.cfg = h->d_cfg.p;
+    d.lut = h->d_lut.p;
+    d.lut_off = h->d_lut_off.p;
+    d.lut_n_max = h->lut_uploaded_n - 1;
+    d.ret_mz = p->d_ret_mz.p;
+    d.ret_rank = p->d_ret_rank.p;
+    d.ret_n = p->d_ret_n.p;
+    d.ws = p->d_ws.p;
+    d.rec = p->d_rec.p;
+    d.sorted_idx = p->d_sorted.p;
+    d.status = p->d_status.p;
+    d.max_k = p->max_k;
+    d.keep = (p->flags & PYA_FLAG_KEEP) ? 1u : 0u;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pya_version(void) { return "pyascore_hip 0.1.0 (gfx950)"; }
+
+int pya_create(const pya_config *cfg, pya_handle **out) {
+    if (!cfg || !out) return PYA_ERR_ARG;
+    *out = nullptr;
+    std::unique_ptr<pya_handle> h(new pya_handle);
+    *out = h.get();                                    /* so the caller can read the message */
+    pya_handle *hp = h.release();
+    if (!cfg->mod_group || !cfg->fragment_types) return hp->fail(PYA_ERR_ARG, -1, "NULL string in config");
+    if (cfg->n_top != PYA_NTOP)
+        return hp->fail(PYA_ERR_ARG, -1, "n_top must be %d (the PepScore weights are %d long, "
+                        "Ascore.cpp:16-18); got %u", PYA_NTOP, PYA_NTOP, cfg->n_top);
+    if (!(cfg->bin_size > 0.f)) return hp->fail(PYA_ERR_ARG, -1, "bin_size must be positive");
+    if (!(cfg->mz_error > 0.f) || !(cfg->mz_error < 50.f))
+        return hp->fail(PYA_ERR_ARG, -1, "mz_error must be in (0, 50)");
+    std::string ft = cfg->fragment_types;
+    if (ft.empty() || ft.size() > PYA_MAX_FRAGMENT_TYPES)
+        return hp->fail(PYA_ERR_ARG, -1, "fragment_types must name 1..%d ion types", PYA_MAX_FRAGMENT_TYPES);
+    for (char t : ft)
+        if (!is_forward(t) && !is_backward(t))
+            return hp->fail(PYA_ERR_ARG, -1, "unknown fragment type '%c' (b, c, y, z, Z are supported)", t);
+    hp->device = cfg->device;
+    hp->bin_size = cfg->bin_size;
+    hp->mod_mass = cfg->mod_mass;
+    hp->mz_error = cfg->mz_error;
+    hp->mod_group = cfg->mod_group;
+    hp->fragment_types = ft;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return hp->fail(PYA_ERR_HIP, -1, "no HIP device available (%s); this library has no CPU path",
+                        e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return hp->fail(PYA_ERR_ARG, -1, "device %d out of range", cfg->device);
+    HIPCHK(hp, hipSetDevice(cfg->device));
+    int rc = build_dev_config(hp);
+    if (rc) return rc;
+    return PYA_OK;
+}
+
+void pya_destroy(pya_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    delete h->kept;
+    delete h;
+}
+
+const char *pya_last_error(const pya_handle *h) { return h ? h->err.c_str() : "NULL handle"; }
+int64_t pya_error_index(const pya_handle *h) { return h ? h->err_index : -1; }
+
+int pya_add_neutral_loss(pya_handle *h, const char *group, float mass) {
+    if (!h || !group) return PYA_ERR_ARG;
+    std::map<char, float> saved = h->nl;
+    for (const char *c = group; *c; c++) h->nl[*c] = mass;     /* ModifiedPeptide.cpp:99-103 */
+    h->cfg_dirty = true;
+    int rc = build_dev_config(h);
+    if (rc) {
+        h->nl = saved;
+        build_dev_config(h);
+    }
+    return rc;
+}
+
+int pya_count_sites(const pya_handle *h, const uint8_t *pep, uint64_t L, int32_t *n_sites, uint8_t *site_pos) {
+    if (!h || !pep || !n_sites) return PYA_ERR_ARG;
+    int n = 0;
+    for (uint64_t i = 0; i < L; i++)
+        if (h->letter_modifiable((char)pep[i], i, L)) {
+            if (site_pos && n < PYA_MAX_PEPTIDE_LEN) site_pos[n] = (uint8_t)i;
+            n++;
+        }
+    *n_sites = n;
+    return PYA_OK;
+}
+
+/* ModifiedPeptide::getPeptide, cpp/ModifiedPeptide.cpp:199-253 */
+int pya_format_peptide(const pya_handle *h, const uint8_t *pep, uint64_t L, int32_t n_of_mod,
+                       const uint32_t *aux_pos, const float *aux_mass, uint64_t n_aux, uint64_t sig_bits,
+                       int32_t sig_len, char *buf, uint64_t cap) {
+    if (!h || !pep || !buf || cap == 0) return PYA_ERR_ARG;
+    std::vector<size_t> sites;
+    for (uint64_t i = 0; i < L; i++)
+        if (h->letter_modifiable((char)pep[i], i, L)) sites.push_back(i);
+    const size_t n = sites.size();
+    std::vector<float> mm(L + 2, 0.f);
+    if ((size_t)n_of_mod > n) {
+        if (h->mod_group.find('n') != std::string::npos) mm.front() += h->mod_mass;
+        else mm.back() += h->mod_mass;
+    }
+    for (int32_t j = 0; j < sig_len; j++) {
+        if (!(sig_bits >> j & 1)) continue;
+        size_t pos = (size_t)j < n ? sites[j] : L;
+        char aa = pos < L ? (char)pep[pos] : 0;
+        if (h->mod_group.find(aa) != std::string::npos) mm[pos + 1] += h->mod_mass;
+        else if (pos == 0) mm.front() += h->mod_mass;
+        else if (pos + 1 == L) mm.back() += h->mod_mass;
+    }
+    for (uint64_t a = 0; a < n_aux; a++)
+        if (aux_pos[a] < mm.size()) mm[aux_pos[a]] += aux_mass[a];
+    size_t s = 0, e = mm.size();
+    if (mm.front() == 0.f) s++;
+    if (mm.back() == 0.f) e--;
+    std::string full = "n" + std::string((const char *)pep, L) + "c", out;
+    for (size_t i = s; i < e; i++) {
+        out += full[i];
+        if (mm[i] > 0.f) {
+            char t[16];
+            std::snprintf(t, sizeof t, "[%d]", (int)std::round(mm[i]));
+            out += t;
+        }
+    }
+    size_t ncopy = std::min<size_t>(out.size(), cap - 1);
+    std::memcpy(buf, out.data(), ncopy);
+    buf[ncopy] = 0;
+    return (int)out.size();
+}
+
+int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan **out) {
+    if (!h || !b || !out) return PYA_ERR_ARG;
+    *out = nullptr;
+    h->err.clear();
+    h->err_index = -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = sync_config(h);
+    if (rc) return rc;
+    const uint64_t n = b->n_psm;
+    if (n > 0 && (!b->peak_off || !b->pep || !b->pep_off || !b->n_of_mod || !b->max_charge))
+        return h->fail(PYA_ERR_ARG, -1, "NULL array in batch");
+    if (n >= (1ull << 31)) return h->fail(PYA_ERR_LIMIT, -1, "more than 2^31 PSMs in one batch");
+    std::unique_ptr<pya_plan> p(new pya_plan);
+    p->h = h;
+    p->flags = flags;
+    p->n_psm = n;
+    p->peak_off.assign(b->peak_off, b->peak_off + n + 1);
+    p->pep_off.assign(b->pep_off, b->pep_off + n + 1);
+    p->n_of_mod.assign(b->n_of_mod, b->n_of_mod + n);
+    p->max_charge.assign(b->max_charge, b->max_charge + n);
+    const bool has_aux = b->aux_off && b->aux_pos && b->aux_mass;
+    if (has_aux) p->aux_off.assign(b->aux_off, b->aux_off + n + 1);
+    else p->aux_off.assign(n + 1, 0);
+    const int64_t peak_base = n ? p->peak_off[0] : 0, pep_base = n ? p->pep_off[0] : 0,
+                  aux_base = n ? p->aux_off[0] : 0;
+    p->total_peaks = n ? p->peak_off[n] - peak_base : 0;
+    const int64_t total_pep = n ? p->pep_off[n] - pep_base : 0;
+    const int64_t total_aux = n ? p->aux_off[n] - aux_base : 0;
+    p->pep.assign(b->pep + pep_base, b->pep + pep_base + total_pep);
+    for (uint64_t i = 0; i <= n; i++) {
+        p->peak_off[i] -= peak_base;
+        p->pep_off[i] -= pep_base;
+        p->aux_off[i] -= aux_base;
+    }
+    p->n_sites.resize(n);
+    p->n_sig.resize(n);
+    p->order_off.resize(n);
+    p->sig_off.resize(n + 1);
+    const uint32_t n_uniq = (uint32_t)h->cfg.n_uniq, n_types = (uint32_t)h->cfg.n_types;
+    uint32_t max_P = 1, lut_need = 0, max_k = 1;
+    int64_t sig_total = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const int64_t P = p->peak_off[i + 1] - p->peak_off[i];
+        const int64_t L = p->pep_off[i + 1] - p->pep_off[i];
+        const int32_t k = p->n_of_mod[i], z = p->max_charge[i];
+        if (P <= 0) return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: empty spectrum", (unsigned long long)i);
+        if (P > PYA_MAX_PEAKS)
+            return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: %lld peaks exceed the limit of %d",
+                           (unsigned long long)i, (long long)P, PYA_MAX_PEAKS);
+        if (L < 1 || L > PYA_MAX_PEPTIDE_LEN)
+            return h->fail(L < 1 ? PYA_ERR_PSM : PYA_ERR_LIMIT, (int64_t)i,
+                           "PSM %llu: peptide length %lld outside 1..%d", (unsigned long long)i, (long long)L,
+                           PYA_MAX_PEPTIDE_LEN);
+        if (k < 0) return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: negative n_of_mod", (unsigned long long)i);
+        if (z < 1 || z > 16)
+            return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: max_fragment_charge %d outside 1..16",
+                           (unsigned long long)i, z);
+        const uint8_t *s = p->pep.data() + p->pep_off[i];
+        uint32_t ns = 0;
+        for (int64_t j = 0; j < L; j++) {
+            char c = (char)s[j];
+            if (c < 'A' || c > 'Z' || std_residue_mass(c) == 0.f)
+                return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: unknown residue '%c' at position %lld",
+                               (unsigned long long)i, c, (long long)(j + 1));
+            if (h->letter_modifiable(c, (size_t)j, (size_t)L)) ns++;
+        }
+        for (int64_t a = p->aux_off[i]; has_aux && a < p->aux_off[i + 1]; a++) {
+            uint32_t pos = b->aux_pos[aux_base + a];
+            if (pos > (uint32_t)L)
+                return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: aux_mod_pos %u beyond the peptide",
+                               (unsigned long long)i, pos);
+        }
+        if (ns > PYA_MAX_SITES)
+            return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: %u modifiable residues exceed %d",
+                           (unsigned long long)i, ns, PYA_MAX_SITES);
+        uint64_t N = (uint32_t)k > ns ? 0 : binom(ns, (uint32_t)k);
+        if (N > PYA_MAX_SIGNATURES)
+            return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: C(%u,%d) site assignments exceed the limit of %d",
+                           (unsigned long long)i, ns, k, PYA_MAX_SIGNATURES);
+        p->n_sites[i] = (uint8_t)ns;
+        p->n_sig[i] = (uint32_t)N;
+        p->order_off[i] = N ? shape_offset(h, ns, (uint32_t)k) : 0;
+        p->sig_off[i] = sig_total;
+        sig_total += (int64_t)N;
+        max_P = std::max<uint32_t>(max_P, (uint32_t)P);
+        const uint32_t per_type = (uint32_t)(L - 1) * (uint32_t)z * n_uniq;
+        if (per_type > PYA_MAX_LIST)
+            return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: %u fragments per ion type exceed %d",
+                           (unsigned long long)i, per_type, PYA_MAX_LIST);
+        lut_need = std::max(lut_need, per_type * n_types);
+        if ((uint32_t)k > max_k) max_k = (uint32_t)k;
+        if (N > 0 && (uint32_t)k < ns) {
+            int bi = 0;
+            while (N > kBucketLimits[bi]) bi++;
+            Bucket &bk = p->buckets[bi];
+            bk.ids.push_back((uint32_t)i);
+            bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
+            bk.list_cap = std::max<uint32_t>(bk.list_cap, next_pow2(std::max<uint32_t>(per_type, 1)));
+        } else {
+            Bucket &bk = p->buckets[0];                 /* unambiguous / empty: cheapest launch */
+            bk.ids.push_back((uint32_t)i);
+            bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
+        }
+    }
+    p->sig_off[n] = sig_total;
+    p->total_sigs = sig_total;
+    p->max_k = max_k;
+    p->peak_cap = (max_P + 63u) & ~63u;
+    rc = ensure_lut(h, lut_need);
+    if (rc) return rc;
+    if (h->order_uploaded != h->order_tab.size() || !h->d_order.p) {
+        HIPCHK(h, h->d_order.upload(h->order_tab.data(), h->order_tab.size()));
+        h->order_uploaded = h->order_tab.size();
+    }
+    for (Bucket &bk : p->buckets) {
+        if (bk.ids.empty()) continue;
+        size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.list_cap);
+        if (need > kMaxLds)
+            return h->fail(PYA_ERR_LIMIT, (int64_t)bk.ids[0], "LDS budget exceeded (%zu bytes) for the bucket of PSM %u",
+                           need, bk.ids[0]);
+        HIPCHK(h, bk.d_ids.upload(bk.ids.data(), bk.ids.size()));
+    }
+    HIPCHK(h, p->d_peak_off.upload(p->peak_off.data(), n + 1));
+    HIPCHK(h, p->d_pep_off.upload(p->pep_off.data(), n + 1));
+    HIPCHK(h, p->d_aux_off.upload(p->aux_off.data(), n + 1));
+    HIPCHK(h, p->d_sig_off.upload(p->sig_off.data(), n + 1));
+    HIPCHK(h, p->d_pep.upload(p->pep.data(), p->pep.size()));
+    HIPCHK(h, p->d_n_sites.upload(p->n_sites.data(), n));
+    HIPCHK(h, p->d_n_of_mod.upload(p->n_of_mod.data(), n));
+    HIPCHK(h, p->d_max_charge.upload(p->max_charge.data(), n));
+    HIPCHK(h, p->d_n_sig.upload(p->n_sig.data(), n));
+    HIPCHK(h, p->d_order_off.upload(p->order_off.data(), n));
+    HIPCHK(h, p->d_aux_pos.upload(has_aux ? b->aux_pos + aux_base : nullptr, (size_t)total_aux));
+    HIPCHK(h, p->d_aux_mass.upload(has_aux ? b->aux_mass + aux_base : nullptr, (size_t)total_aux));
+    HIPCHK(h, p->d_status.alloc(n));
+    HIPCHK(h, p->d_ret_n.alloc(n));
+    HIPCHK(h, p->d_ret_mz.alloc((size_t)p->total_peaks));
+    HIPCHK(h, p->d_ret_rank.alloc((size_t)p->total_peaks));
+    HIPCHK(h, p->d_ws.alloc((size_t)sig_total));
+    if (flags & PYA_FLAG_KEEP) {
+        HIPCHK(h, p->d_rec.alloc((size_t)sig_total * PYA_REC_WORDS));
+        HIPCHK(h, p->d_sorted.alloc((size_t)sig_total));
+    }
+    if (flags & PYA_FLAG_TIMING)
+        for (auto &e : p->ev) HIPCHK(h, hipEventCreate(&e));
+    HIPCHK(h, hipDeviceSynchronize());
+    fill_dev(p.get());
+    *out = p.release();
+    return PYA_OK;
+}
+
+int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *hip_stream,
+                 const pya_results *o) {
+    if (!p || !o) return PYA_ERR_ARG;
+    pya_handle *h = p->h;
+    if (p->n_psm == 0) return PYA_OK;
+    if (!d_mz || !d_inten || !o->best_score || !o->best_sig || !o->n_sig || !o->ascores || !o->alt_mask)
+        return h->fail(PYA_ERR_ARG, -1, "NULL device pointer passed to pya_plan_run");
+    if (o->max_k < p->max_k)
+        return h->fail(PYA_ERR_ARG, -1, "results.max_k (%u) is smaller than the largest n_of_mod (%u)",
+                       o->max_k, p->max_k);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    refresh_shared(p);
+    BatchDev d = p->dev;
+    d.mz = d_mz;
+    d.inten = d_inten;
+    d.best_score = o->best_score;
+    d.best_sig = o->best_sig;
+    d.n_sig_out = o->n_sig;
+    d.ascores = o->ascores;
+    d.alt_mask = o->alt_mask;
+    d.max_k = o->max_k;
+    const bool timing = p->flags & PYA_FLAG_TIMING;
+    if (timing) HIPCHK(h, hipEventRecord(p->ev[0], st));
+    int e = pya_launch_bin(&d, (uint32_t)p->n_psm, p->peak_cap, st);
+    if (e) return h->hip_fail((hipError_t)e, "bin_spectra launch");
+    if (timing) HIPCHK(h, hipEventRecord(p->ev[1], st));
+    for (Bucket &bk : p->buckets) {
+        e = pya_launch_score(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, st);
+        if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
+    }
+    if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
+    for (Bucket &bk : p->buckets) {
+        e = pya_launch_localize(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, bk.n_cap, bk.list_cap, st);
+        if (e) return h->hip_fail((hipError_t)e, "localize launch");
+    }
+    if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
+    p->last_stream = st;
+    p->ran = true;
+    p->dev = d;
+    return PYA_OK;
+}
+
+int pya_plan_timings(pya_plan *p, float ms[3]) {
+    if (!p || !ms) return PYA_ERR_ARG;
+    pya_handle *h = p->h;
+    if (!(p->flags & PYA_FLAG_TIMING) || !p->ran) return h->fail(PYA_ERR_STATE, -1, "plan has no timing events");
+    HIPCHK(h, hipEventSynchronize(p->ev[3]));
+    for (int i = 0; i < 3; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
+    return PYA_OK;
+}
+
+int pya_plan_check(pya_plan *p) {
+    if (!p) return PYA_ERR_ARG;
+    pya_handle *h = p->h;
+    if (!p->ran || p->n_psm == 0) return PYA_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(p->last_stream));
+    std::vector<int32_t> st(p->n_psm);
+    HIPCHK(h, hipMemcpy(st.data(), p->d_status.p, p->n_psm * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < p->n_psm; i++) {
+        switch (st[i]) {
+            case PYA_ST_OK: break;
+            case PYA_ST_NO_BINS:
+                return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: all peaks sit on one multiple of 100 m/z; the "
+                               "spectrum has no windows", (unsigned long long)i);
+            case PYA_ST_TOO_MANY_BINS:
+                return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: more than 65535 m/z windows", (unsigned long long)i);
+            case PYA_ST_LUT_RANGE:
+                return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: trial count outside the score table", (unsigned long long)i);
+            case PYA_ST_PUSHED_OVERFLOW:
+                return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: more than %d tied competitors", (unsigned long long)i, PYA_MAX_PUSHED);
+            default:
+                return h->fail(PYA_ERR_HIP, (int64_t)i, "PSM %llu: unexpected kernel status %d", (unsigned long long)i, st[i]);
+        }
+    }
+    return PYA_OK;
+}
+
+uint64_t pya_plan_workspace_bytes(const pya_plan *p) { return p ? p->workspace_bytes() : 0; }
+uint64_t pya_plan_total_signatures(const pya_plan *p) { return p ? (uint64_t)p->total_sigs : 0; }
+
+void pya_plan_destroy(pya_plan *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->h->device);
+    if (p->h->kept == p) p->h->kept = nullptr;
+    delete p;
+}
+
+int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const double *inten, uint32_t flags,
+                    const pya_results *out) {
+    if (!h || !b || !out) return PYA_ERR_ARG;
+    if (b->n_psm == 0) return PYA_OK;
+    if (!mz || !inten) return h->fail(PYA_ERR_ARG, -1, "NULL spectrum arrays");
+    pya_plan *p = nullptr;
+    int rc = pya_plan_create(h, b, flags & ~PYA_FLAG_TIMING, &p);
+    if (rc) return rc;
+    std::unique_ptr<pya_plan> guard(p);
+    const uint64_t n = b->n_psm;
+    const int64_t base = b->peak_off[0];
+    const uint32_t mk = out->max_k;
+    if (mk < p->max_k) return h->fail(PYA_ERR_ARG, -1, "results.max_k too small");
+    HIPCHK(h, p->d_mz.upload(mz + base, (size_t)p->total_peaks));
+    HIPCHK(h, p->d_inten.upload(inten + base, (size_t)p->total_peaks));
+    HIPCHK(h, p->d_best_score.alloc(n));
+    HIPCHK(h, p->d_best_sig.alloc(n));
+    HIPCHK(h, p->d_n_sig_out.alloc(n));
+    HIPCHK(h, p->d_ascores.alloc(n * mk));
+    HIPCHK(h, p->d_alt.alloc(n * mk));
+    pya_results d_out = {mk, p->d_best_score.p, p->d_best_sig.p, p->d_n_sig_out.p, p->d_ascores.p, p->d_alt.p};
+    rc = pya_plan_run(p, p->d_mz.p, p->d_inten.p, nullptr, &d_out);
+    if (rc) return rc;
+    rc = pya_plan_check(p);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(out->best_score, p->d_best_score.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out->best_sig, p->d_best_sig.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out->n_sig, p->d_n_sig_out.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out->ascores, p->d_ascores.p, n * mk * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out->alt_mask, p->d_alt.p, n * mk * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (flags & PYA_FLAG_KEEP) {
+        delete h->kept;
+        h->kept = guard.release();
+    }
+    return PYA_OK;
+}
+
+int pya_get_pep_scores(pya_handle *h, uint64_t psm, uint64_t cap, uint64_t *n_out, uint64_t *sig_bits,
+                       int32_t *counts, float *scores, float *ws_out, int32_t *nfrag_out) {
+    if (!h || !n_out) return PYA_ERR_ARG;
+    pya_plan *p = h->kept;
+    if (!p) return h->fail(PYA_ERR_STATE, -1, "no batch retained: call pya_score_batch with PYA_FLAG_KEEP first");
+    if (psm >= p->n_psm) return h->fail(PYA_ERR_ARG, -1, "PSM index out of range");
+    const uint32_t N = p->n_sig[psm];
+    *n_out = N;
+    if (N == 0 || cap == 0) return PYA_OK;
+    if (cap < N) return h->fail(PYA_ERR_ARG, -1, "capacity %llu < %u records", (unsigned long long)cap, N);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t s0 = p->sig_off[psm];
+    std::vector<uint32_t> rec((size_t)N * PYA_REC_WORDS), sorted(N);
+    std::vector<float> ws(N);
+    HIPCHK(h, hipMemcpy(rec.data(), p->d_rec.p + s0 * PYA_REC_WORDS, rec.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(sorted.data(), p->d_sorted.p + s0, (size_t)N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(ws.data(), p->d_ws.p + s0, (size_t)N * 4, hipMemcpyDeviceToHost));
+    const uint64_t *order = h->order_tab.data() + p->order_off[psm];
+    for (uint32_t r = 0; r < N; r++) {
+        const uint32_t i = sorted[r];
+        if (i >= N) return h->fail(PYA_ERR_HIP, (int64_t)psm, "corrupt sort permutation");
+        const uint32_t *w = &rec[(size_t)i * PYA_REC_WORDS];
+        const uint32_t nf = w[5];
+        sig_bits[r] = order[i];
+        ws_out[r] = ws[i];
+        nfrag_out[r] = (int32_t)nf;
+        for (int d = 0; d < PYA_NTOP; d++) {
+            uint32_t c = (w[d >> 1] >> ((d & 1) * 16)) & 0xffffu;
+            counts[(size_t)r * PYA_NTOP + d] = (int32_t)c;
+            /* same table the kernels read (score_table.cpp) */
+            scores[(size_t)r * PYA_NTOP + d] =
+                nf < h->lut_off.size() ? h->lut[h->lut_off[nf] + (uint32_t)d * (nf + 1) + c] : 0.f;
+        }
+    }
+    return PYA_OK;
+}
+
+int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits, const float *ref_scores,
+                            float ref_ws, uint64_t other_bits, const float *other_scores, float other_ws,
+                            float *out) {
+    if (!h || !ref_scores || !other_scores || !out) return PYA_ERR_ARG;
+    pya_plan *p = h->kept;
+    if (!p) return h->fail(PYA_ERR_STATE, -1, "no batch retained: call pya_score_batch with PYA_FLAG_KEEP first");
+    if (psm >= p->n_psm) return h->fail(PYA_ERR_ARG, -1, "PSM index out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t L = p->pep_off[psm + 1] - p->pep_off[psm];
+    const uint32_t list_cap = next_pow2(std::max<uint32_t>(1, (uint32_t)(L - 1) * (uint32_t)p->max_charge[psm] *
+                                                                  (uint32_t)h->cfg.n_uniq));
+    float host_scores[2 * PYA_NTOP];
+    std::memcpy(host_scores, ref_scores, PYA_NTOP * sizeof(float));
+    std::memcpy(host_scores + PYA_NTOP, other_scores, PYA_NTOP * sizeof(float));
+    DevBuf<float> d_scores, d_out;
+    refresh_shared(p);
+    HIPCHK(h, d_scores.upload(host_scores, 2 * PYA_NTOP));
+    HIPCHK(h, d_out.alloc(2));
+    int e = pya_launch_ambiguity(&p->dev, (uint32_t)psm, p->peak_cap, list_cap, ref_bits, other_bits, d_scores.p,
+                                 ref_ws, other_ws, d_out.p, nullptr);
+    if (e) return h->hip_fail((hipError_t)e, "ambiguity launch");
+    float res[2];
+    HIPCHK(h, hipMemcpy(res, d_out.p, sizeof res, hipMemcpyDeviceToHost));
+    if (res[1] != 0.f) return h->fail(PYA_ERR_LIMIT, (int64_t)psm, "trial count outside the score table");
+    *out = res[0];
+    return PYA_OK;
+}
+
+int pya_debug_sort(pya_handle *h, const float *keys, uint32_t n, uint32_t *perm) {
+    if (!h || !keys || !perm) return PYA_ERR_ARG;
+    if (n == 0) return PYA_OK;
+    if (n > PYA_MAX_SIGNATURES) return h->fail(PYA_ERR_LIMIT, -1, "n too large");
+    HIPCHK(h, hipSetDevice(h->device));
+    DevBuf<float> dk;
+    DevBuf<uint32_t> dp;
+    HIPCHK(h, dk.upload(keys, n));
+    HIPCHK(h, dp.alloc(n));
+    int e = pya_launch_debug_sort(dk.p, n, dp.p, nullptr);
+    if (e) return h->hip_fail((hipError_t)e, "debug sort launch");
+    HIPCHK(h, hipMemcpy(perm, dp.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return PYA_OK;
+}
+
+} /* extern "C" */

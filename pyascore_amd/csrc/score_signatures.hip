@@ -1,0 +1,157 @@
+/* score_signatures.hip -- kernel 2: PepScore of every site assignment (one PSM per wavefront).
+ *
+ * Replaces ModifiedPeptide::initializeFragments + the consumePeak match cache + the
+ * FragmentGraph walk of Ascore::accumulateCounts and Ascore::calculateFullScores
+ * (cpp/ModifiedPeptide.cpp:81-150, :326-609; cpp/Ascore.cpp:53-139).
+ *
+ * Mapping: one signature per lane (lanes loop when C(n,k) > 64).  A lane walks the residues
+ * once per direction keeping the reference's float32 running sum in a register, derives every
+ * (neutral-loss variant, ion type, charge) m/z in the reference's double/float order, looks the
+ * m/z up in the wave's LDS copy of the retained-peak table and bumps a packed rank histogram.
+ * Per-residue data sits in one register per lane and is broadcast with v_readlane (no LDS).
+ * The binomial tail is a host-built table (float32 chain in the reference's order), so the
+ * device does integer counting + table reads + the exactly-rounded weighted sum.
+ *
+ * HBM traffic per PSM: retained table (5 B x R) + peptide bytes + 8 B x C(n,k) signature
+ * table (L2 resident, shared by all PSMs of a shape) in; 4 B x C(n,k) weighted scores out.
+ */
+#include "device_common.hip.h"
+
+DEV float lut_score(const BatchDev &b, uint32_t depth, uint32_t k, uint32_t n) {
+    return b.lut[b.lut_off[n] + depth * (n + 1) + k];
+}
+
+__global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
+                                                                  uint32_t n_ids, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (blockIdx.x >= n_ids) return;
+    const uint32_t psm = psm_ids[blockIdx.x];
+    const int lane = lane_id();
+    const DevConfig *cfg = b.cfg;
+
+    uint16_t *nl_present = (uint16_t *)lds_raw;           /* [256] */
+    float *nl_uniq = (float *)(nl_present + 256);           /* [PYA_MAX_UNIQ] */
+    float *t_mz = nl_uniq + PYA_MAX_UNIQ;
+    uint8_t *t_rank = (uint8_t *)(t_mz + cap);
+
+    if (b.status[psm] != PYA_ST_OK) return;
+
+    /* stage the retained-peak table */
+    const int64_t p0 = b.peak_off[psm];
+    const int R = (int)b.ret_n[psm];
+    for (int i = lane; i < R; i += 64) {
+        t_mz[i] = b.ret_mz[p0 + i];
+        t_rank[i] = b.ret_rank[p0 + i];
+    }
+    const int n_nl = cfg->n_nl;
+    if (n_nl) {
+        for (int i = lane; i < 256; i += 64) nl_present[i] = cfg->present[i];
+        if (lane < PYA_MAX_UNIQ) nl_uniq[lane] = cfg->uniq[lane];
+    }
+    PeakTable tab;
+    tab.mz = t_mz;
+    tab.rank = t_rank;
+    tab.n = R;
+    tab.pow2 = 1;
+    while (tab.pow2 < R) tab.pow2 <<= 1;
+    tab.err = cfg->mz_error;
+
+    const Residues res = load_residues(b, cfg, psm);
+    const int L = res.L;
+    const int zmax = b.max_charge[psm];
+    const uint32_t N = b.n_sig[psm];
+    const uint64_t *order = b.order_tab + b.order_off[psm];
+    const int64_t s0 = b.sig_off[psm];
+    const int n_types = cfg->n_types, n_fwd = cfg->n_fwd;
+    wave_lds_sync();
+
+    int lut_fail = 0;
+    for (uint32_t sbase = 0; sbase < N; sbase += 64) {
+        const uint32_t s = sbase + lane;
+        const bool active = s < N;
+        const uint64_t bits = active ? order[s] : 0ull;
+        const uint64_t resmask = deposit_sites(bits, res.site_mask);
+        Hist h = {0ull, 0ull, 0ull};
+        uint32_t nfrag = 0;
+
+        for (int dir = 0; dir < 2; dir++) {
+            const int t0 = dir == 0 ? 0 : n_fwd;
+            const int t1 = dir == 0 ? n_fwd : n_types;
+            if (t0 == t1) continue;
+            float running = 0.f;
+            uint32_t nl_state = 0;
+            for (int step = 0; step + 1 < L; step++) {
+                const int i = dir == 0 ? step : L - 1 - step;            /* wave-uniform */
+                const float m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i));
+                const float m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i));
+                const uint32_t nlp = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, i);
+                const bool mod = (resmask >> i) & 1ull;
+                const float r = mod ? m1 : m0;
+                running = step == 0 ? r : r + running;                   /* ModifiedPeptide.cpp:385-389 */
+                const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
+                if (cls) nl_state = nl_bump(nl_state, cls);
+                uint32_t pm = active ? (n_nl ? (uint32_t)nl_present[nl_state & 255u] : 1u) : 0u;
+                while (__any(pm != 0)) {
+                    const bool on = pm != 0;
+                    const int v = on ? __builtin_ctz(pm) : 0;
+                    pm &= pm - 1;
+                    const float x = running - (n_nl ? nl_uniq[v] : 0.f);             /* float subtract (:572) */
+                    const double xd = (double)x;
+                    for (int t = t0; t < t1; t++) {
+                        const double m = type_offset(xd, cfg->types[t]);
+                        for (int z = 1; z <= zmax; z++) {
+                            const float f = charge_mz(m, z);
+                            if (on) {
+                                const int rk = match_rank(tab, f);
+                                hist_add(h, rk);
+                                nfrag++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        if (active) {
+            /* cumulative counts over rank (Ascore.cpp:115-118) and scores (Ascore.cpp:123-139) */
+            uint32_t cum[PYA_NTOP];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int d = 0; d < PYA_NTOP; d++) {
+                acc += hist_get(h, d);
+                cum[d] = acc;
+            }
+            float ws = -1.f;
+            if (nfrag <= b.lut_n_max) {
+                double sum = 0.;
+#pragma unroll
+                for (int d = 0; d < PYA_NTOP; d++) {
+                    float sc = lut_score(b, (uint32_t)d, cum[d], nfrag);
+                    float prod = cfg->weights[d] * sc;                    /* float product ...   */
+                    sum = sum + (double)prod;                             /* ... double sum      */
+                }
+                ws = (float)sum;
+            } else {
+                lut_fail = 1;
+            }
+            b.ws[s0 + s] = ws;
+            if (b.keep) {
+                uint32_t *rec = b.rec + (s0 + s) * PYA_REC_WORDS;
+#pragma unroll
+                for (int d = 0; d < PYA_NTOP; d += 2) rec[d >> 1] = cum[d] | (cum[d + 1] << 16);
+                rec[5] = nfrag;
+            }
+        }
+    }
+    if (__any(lut_fail) && lane == 0) b.status[psm] = PYA_ST_LUT_RANGE;
+}
+
+extern "C" size_t pya_score_lds_bytes(uint32_t cap) { return (size_t)cap * 5 + 512 + PYA_MAX_UNIQ * 4 + 64; }
+
+extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
+                                hipStream_t stream) {
+    if (n_ids == 0) return 0;
+    hipLaunchKernelGGL(pya_score_signatures_kernel, dim3(n_ids), dim3(64), pya_score_lds_bytes(cap),
+                       stream, *b, d_ids, n_ids, cap);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,167 @@
+"""GPU parity tests proper: the HIP path (through the C ABI / PyAscore) against the committed
+golden vectors, the CPU restatement and -- where its prebuilt library travelled -- the
+reference's own C++ core.  Integer results bit-exact; float scores bit-exact against a checker
+running on the same host libm, rtol 1e-6 against the golden files."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_cases
+from oracle import harness, orc
+from pyascore_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(settings):
+    from pyascore_amd import PyAscore
+    return harness.make_scorer(PyAscore, settings)
+
+
+def _checker(settings):
+    kind = "ref" if orc.available("ref") else "oracle"
+    return harness.make_scorer(orc.OracleAscore, settings, kind=kind)
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_public_api_matches_golden(case):
+    """score() + every property of PyAscore, PSM by PSM, against the reference's outputs."""
+    settings, batch, expected = harness.load_case(os.path.join(GOLDEN, case + ".npz"))
+    got = harness.collect(_gpu(settings), batch, synth.unpack_psm)
+    assert harness.compare(got, expected, exact_float=False, rtol=1e-6, atol=1e-6) == []
+    # same host libm as the generator of the goldens -> expect bit equality too
+    assert harness.compare(got, expected, exact_float=True) == []
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_batch_matches_golden(case):
+    settings, batch, expected = harness.load_case(os.path.join(GOLDEN, case + ".npz"))
+    got = _gpu(settings).score_batch(batch)
+    k = got["ascores"].shape[1]
+    for key in ("best_sig", "n_sig", "alt_mask"):
+        assert np.array_equal(got[key], expected[key][..., :k] if expected[key].ndim == 2 else expected[key]), key
+    assert np.array_equal(got["best_score"], expected["best_score"])
+    assert np.array_equal(got["ascores"], expected["ascores"][:, :k])
+
+
+@pytest.mark.parametrize("cfg,n,seed,override", [
+    ("cfg1", 2000, 201, {}),
+    ("cfg2", 4000, 202, {}),
+    ("cfg3", 4000, 203, {}),
+    ("cfg4", 48, 204, {}),
+    ("cfg5", 24, 205, {}),
+    ("cfg2", 600, 206, dict(fragment_types="yb", max_charge=2)),
+    ("cfg2", 200, 207, dict(fragment_types="Zc", max_charge=3, neutral_loss=("STY", 18.01528))),
+    ("cfg2", 600, 208, dict(mz_error=0.5)),
+    ("cfg3", 1500, 209, dict(mz_error=0.3, max_charge=2)),
+])
+def test_batch_matches_checker(cfg, n, seed, override):
+    """Fresh seeded batches, HIP vs the CPU checker on this box: bit-exact everywhere."""
+    batch, settings = synth.make_batch(cfg, n_psm=n, seed=seed, **override)
+    got = _gpu(settings).score_batch(batch)
+    want = _checker(settings).score_batch(batch, got["ascores"].shape[1])
+    for key in ("n_sig", "best_sig", "best_score", "alt_mask", "ascores"):
+        bad = np.flatnonzero(np.any(np.atleast_2d((got[key] != want[key]).T), axis=0))
+        assert bad.size == 0, "%s differs for PSMs %s" % (key, bad[:10])
+
+
+def test_unsorted_spectrum_and_ties():
+    """Peaks given in arbitrary order (the API does not require sorted m/z)."""
+    batch, settings = synth.make_batch("cfg3", n_psm=300, seed=210)
+    rng = np.random.default_rng(1)
+    mz, it = batch["mz"].copy(), batch["intensity"].copy()
+    for i in range(batch["n_psm"]):
+        a, b = batch["peak_off"][i], batch["peak_off"][i + 1]
+        p = rng.permutation(b - a)
+        mz[a:b], it[a:b] = mz[a:b][p], it[a:b][p]
+    shuffled = dict(batch, mz=mz, intensity=it)
+    got = _gpu(settings).score_batch(shuffled)
+    want = _checker(settings).score_batch(shuffled, got["ascores"].shape[1])
+    for key in want:
+        assert np.array_equal(got[key], want[key]), key
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 20, 33, 64, 65, 200, 495, 1000, 3003, 4097, 15000])
+def test_sort_emulation_matches_std_sort(n):
+    """The on-device emulation of libstdc++ std::sort vs the real thing, ties included."""
+    from pyascore_amd import PyAscore, _lib
+    import ctypes as C
+    s = PyAscore(100.0, 10, "STY", 79.966331)
+    rng = np.random.default_rng(n)
+    cases = [
+        rng.integers(0, 4, n).astype(np.float32),                  # heavy ties
+        rng.random(n).astype(np.float32),                          # no ties
+        np.zeros(n, np.float32),                                   # all equal
+        np.arange(n, dtype=np.float32),                            # ascending (worst for "greater")
+        np.arange(n, dtype=np.float32)[::-1].copy(),               # already sorted
+        np.round(rng.lognormal(3, 1, n), 0).astype(np.float32),    # realistic score ties
+    ]
+    # median-of-3 killer: drives introsort into its heapsort fallback for larger n
+    if n >= 64:
+        k = n // 2
+        killer = np.zeros(n, np.float32)
+        for i in range(k):
+            killer[2 * i if 2 * i < n else n - 1] = i if i % 2 == 0 else k + i
+        cases.append(-killer)
+    for keys in cases:
+        perm = np.zeros(n, np.uint32)
+        rc = s._lib.pya_debug_sort(s._h, keys.ctypes.data_as(C.c_void_p), n, perm.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        assert np.array_equal(perm, orc.std_sort(keys))
+
+
+def test_calculate_ambiguity_and_structure():
+    """The reference's own structural tests (test/test_ascore.py:63-163) on the Velos PSMs."""
+    import re
+    from math import comb
+    settings, batch, expected = harness.load_case(os.path.join(GOLDEN, "velos_z1.npz"))
+    s = _gpu(settings)
+    chk = _checker(settings)
+    for i in range(batch["n_psm"]):
+        kw = synth.unpack_psm(batch, i)
+        s.score(**kw)
+        chk.score(**kw)
+        for alt in s.alt_sites:
+            assert alt.shape[0] == np.unique(alt).shape[0]
+        sites = [ind + 1 for ind, m in enumerate(re.finditer("[A-Z][^A-Z]*", s.best_sequence)) if "[80]" in m.group()]
+        assert np.intersect1d(sites, np.concatenate(s.alt_sites)).shape[0] == 0
+        ps = s.pep_scores
+        assert len(ps) == comb(len(ps[0]["signature"]), kw["n_of_mod"])
+        assert np.all(np.diff([p["weighted_score"] for p in ps]) <= 0)
+        assert s.calculate_ambiguity(ps[0], ps[0]) == 0.0
+        if len(ps) > 1:
+            a = s.calculate_ambiguity(ps[0], ps[1])
+            assert np.any(np.isclose(a, s.ascores))
+            cps = chk.pep_scores
+            for j in (1, len(ps) // 2, len(ps) - 1):
+                assert a == chk.calculate_ambiguity(cps[0], cps[1])
+                assert s.calculate_ambiguity(ps[0], ps[j]) == chk.calculate_ambiguity(cps[0], cps[j])
+                assert s.calculate_ambiguity(ps[j], ps[0]) == chk.calculate_ambiguity(cps[j], cps[0])
+
+
+def test_error_behaviour():
+    from pyascore_amd import PyAscore
+    s = PyAscore(100.0, 10, "STY", 79.966331)
+    assert s.best_sequence == "" and s.best_score == -1.0 and s.ascores.size == 0 and s.pep_scores == []
+    mz = np.array([150.0, 300.5, 420.25]); it = np.array([1.0, 2.0, 3.0])
+    with pytest.raises(ValueError):
+        s.score(mz, it, "PEPTIXDE", 1)                      # unknown residue: reference aborts
+    with pytest.raises(ValueError):
+        s.score(np.zeros(0), np.zeros(0), "PEPTIDE", 1)     # empty spectrum: reference is UB
+    with pytest.raises(ValueError):
+        s.score(mz.astype(np.float32), it, "PEPTIDE", 1)    # dtype mismatch (Cython ValueError)
+    with pytest.raises(ValueError):
+        s.score(np.arange(6.0)[::2], it, "PEPTIDE", 1)      # not C-contiguous
+    with pytest.raises(TypeError):
+        s.score(None, it, "PEPTIDE", 1)
+    with pytest.raises(ValueError):
+        s.score(mz, it, "PEPTIDE", 1, 0)                    # max_fragment_charge 0
+    with pytest.raises(ValueError):
+        s.score(np.array([500.0]), np.array([1.0]), "PEPTIDE", 1)   # no m/z window at all
+    with pytest.raises(ValueError):
+        PyAscore(100.0, 5, "STY", 79.966331)                # n_top < 10: reference reads garbage
+    with pytest.raises(ValueError):
+        PyAscore(100.0, 10, "STY", 79.966331, fragment_types="bx")
+    s.score(mz, it, "PEPTIDE", 1)                           # still usable afterwards
+    assert s.best_sequence == "PEPT[80]IDE"
