@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py -- PSMs/s of the Ascore hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--psms M]
+
+A *step* is one pass of the hot path (bin_spectra -> score_signatures -> rank_and_localize)
+over one batch of synthetic PSMs of the named BASELINE config whose spectra are already
+resident in HBM; for N > 1 every rank scores its own batch of the same size (weak scaling)
+and every step ends with the single RCCL gather of the fixed-size result records to rank 0.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     : the dominant kernel's achieved algorithmic GB/s vs the 8 TB/s HBM peak,
+                 timed with HIP events on the launch stream inside the timed region;
+  cpu_baseline : the reference's own C++ core (oracle/_ref, if its prebuilt library travelled;
+                 otherwise this repo's CPU restatement) timed on one host core on a bounded
+                 sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+METRIC = "PSMs/sec (Ascore.score) at 1/2/4/8 MI355X + HBM-roofline %"
+
+
+def algorithmic_bytes(batch, max_k):
+    """per PSM 16*P + L + 8 + 8*n_aux + 16 + 64 (summary record)."""
+    n = batch["n_psm"]
+    peaks = int(batch["peak_off"][-1] - batch["peak_off"][0])
+    res = int(batch["pep_off"][-1] - batch["pep_off"][0])
+    aux = int(batch["aux_off"][-1] - batch["aux_off"][0])
+    return 16 * peaks + res + 8 * n + 8 * aux + 16 * n + 64 * n
+
+
+def cpu_baseline(batch, settings, target_seconds=12.0):
+    from oracle import harness, orc
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"])
+    kind = "ref" if orc.available("ref") else "oracle"
+    scorer = harness.make_scorer(orc.OracleAscore, settings, kind=kind)
+    from pyascore_amd.synth import slice_batch
+    k = int(batch["n_of_mod"].max())
+    probe = min(200, batch["n_psm"])
+    t = time.perf_counter()
+    scorer.score_batch(slice_batch(batch, 0, probe), k)
+    rate = probe / max(time.perf_counter() - t, 1e-9)
+    n = int(min(batch["n_psm"], max(probe, rate * target_seconds)))
+    t = time.perf_counter()
+    scorer.score_batch(slice_batch(batch, 0, n), k)
+    dt = time.perf_counter() - t
+    return {"value": n / dt, "unit": "PSMs/s", "cores": 1,
+            "kind": "reference" if kind == "ref" else "port",
+            "sample": "first %d PSMs of rank 0's batch, one thread, %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--psms", type=int, default=None, help="PSMs per GPU (default: the config's size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pyascore_amd import PyAscore, synth
+    from pyascore_amd.device import DevicePlan
+    from pyascore_amd.shard import dist_gather
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_psm = args.psms or synth.CONFIGS[args.config]["n_psm"]
+    if args.config == "cfg3" and args.psms is None:
+        n_psm = synth.CONFIGS["cfg3"]["n_psm"] // 8          # the config is quoted on 8 GPUs
+    batch, settings = synth.make_batch(args.config, n_psm=n_psm, seed=1000 + rank)
+    scorer = PyAscore(settings["bin_size"], settings["n_top"], settings["mod_group"], settings["mod_mass"],
+                      settings["mz_error"], settings["fragment_types"], device=local_rank)
+    for g, m in settings["neutral_losses"]:
+        scorer.add_neutral_loss(g, m)
+
+    d_mz = torch.from_numpy(batch["mz"]).to(dev)
+    d_int = torch.from_numpy(batch["intensity"]).to(dev)
+    plan = DevicePlan(scorer, batch, timing=True)
+
+    def step():
+        plan.run(d_mz, d_int)
+        if world > 1:
+            dist_gather(plan.packed_summary(), 0)          # the single RCCL gather of the path
+
+    for _ in range(args.warmup):
+        step()
+    plan.check()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    kern_ms = np.zeros(3)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kern_ms += np.asarray(plan.timings_ms())           # HIP events on the launch stream
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    plan.check()
+    kern_ms /= max(args.steps, 1)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        names = ["pya_bin_spectra_kernel", "pya_score_signatures_kernel", "pya_localize_kernel"]
+        dom = int(np.argmax(kern_ms))
+        alg = algorithmic_bytes(batch, plan.max_k)
+        achieved = alg / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
+        # host API rate (host arrays in -> host results out; PCIe and host pre-pass included)
+        t = time.perf_counter()
+        scorer.score_batch(batch)
+        host_rate = batch["n_psm"] / (time.perf_counter() - t)
+        line = {
+            "metric": METRIC, "value": world * batch["n_psm"] * args.steps / elapsed, "unit": "PSMs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64 scalar + i32 counts",
+            "data": "synthetic (SURVEY.md 8(d) generator, seed 1000+rank)",
+            "config": {"workload": "%s: %d PSMs/GPU" % (args.config, batch["n_psm"]),
+                       "psms_per_gpu": batch["n_psm"], "peaks_per_spectrum": float(batch["peak_off"][-1]) / batch["n_psm"],
+                       "signatures_total_per_gpu": plan.total_signatures, "mz_error": settings["mz_error"],
+                       "fragment_types": settings["fragment_types"],
+                       "max_fragment_charge": int(batch["max_charge"].max()),
+                       "neutral_losses": settings["neutral_losses"], "parallelism": "psm-shard x%d + 1 gather" % world},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg,
+                         "kernel_ms": {n: float(m) for n, m in zip(names, kern_ms)}},
+            "host_api": {"value": host_rate, "unit": "PSMs/s",
+                         "note": "PyAscore.score_batch: host arrays in, host results out (PCIe + host pre-pass)"},
+            "workspace_bytes": plan.workspace_bytes,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(batch, settings)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
