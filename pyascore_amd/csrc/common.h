@@ -13,7 +13,7 @@
 #define PYA_MAX_UNIQ 16            /* distinct sums of <= 2 neutral losses (incl. 0)       */
 #define PYA_MAX_LIST 2048          /* fragments of one signature and one ion type          */
 #define PYA_MAX_LUT_N 4096         /* largest trial count the score table covers           */
-#define PYA_MAX_PUSHED 1024        /* tied best competitors kept per PSM                   */
+#define PYA_MAX_PUSHED 256         /* tied best competitors kept per PSM                   */
 
 /* per-PSM status written by the kernels */
 #define PYA_ST_OK 0

@@ -31,12 +31,12 @@ void pya_score_table_extend(float mz_error, uint32_t n_top, uint32_t n_to, std::
 extern "C" {
 size_t pya_bin_lds_bytes(uint32_t cap);
 size_t pya_score_lds_bytes(uint32_t cap);
-size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t list_cap);
+size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap);
 int pya_launch_bin(const BatchDev *b, uint32_t n_psm, uint32_t cap, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                      hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
-                        uint32_t n_cap, uint32_t list_cap, hipStream_t stream);
+                        uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, hipStream_t stream);
 int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
@@ -159,7 +159,15 @@ struct pya_handle {
 struct Bucket {
     std::vector<uint32_t> ids;
     DevBuf<uint32_t> d_ids;
-    uint32_t n_cap = 0, list_cap = 1;
+    uint32_t n_cap = 0, list_cap = 1, pos_cap = 1;
+    uint32_t pool_cap() const {
+        /* room for one competitor at least, ~7 when the lists are short */
+        uint32_t one = 2u * n_types * list_cap;
+        uint32_t want = 7u * one;
+        if (want > 2048u) want = 2048u;
+        return one > want ? one : want;
+    }
+    uint32_t n_types = 1;
 };
 
 struct pya_plan {
@@ -625,6 +633,8 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
             bk.ids.push_back((uint32_t)i);
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
             bk.list_cap = std::max<uint32_t>(bk.list_cap, next_pow2(std::max<uint32_t>(per_type, 1)));
+            bk.pos_cap = std::max<uint32_t>(bk.pos_cap, (uint32_t)std::max<int64_t>(L - 1, 1));
+            bk.n_types = n_types;
         } else {
             Bucket &bk = p->buckets[0];                 /* unambiguous / empty: cheapest launch */
             bk.ids.push_back((uint32_t)i);
@@ -643,7 +653,7 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
     }
     for (Bucket &bk : p->buckets) {
         if (bk.ids.empty()) continue;
-        size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.list_cap);
+        size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap());
         if (need > kMaxLds)
             return h->fail(PYA_ERR_LIMIT, (int64_t)bk.ids[0], "LDS budget exceeded (%zu bytes) for the bucket of PSM %u",
                            need, bk.ids[0]);
@@ -711,7 +721,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
     for (Bucket &bk : p->buckets) {
-        e = pya_launch_localize(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, bk.n_cap, bk.list_cap, st);
+        e = pya_launch_localize(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));

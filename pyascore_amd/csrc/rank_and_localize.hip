@@ -149,7 +149,7 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
 
 /* Runs the introsort phase in place.  Afterwards the array is partitioned into runs of <= 16
  * (or heap-sorted runs) exactly as libstdc++ leaves it before __final_insertion_sort. */
-DEV void sort_introsort_loop(const SortLds &s, int N) {
+DEV void sort_introsort_loop(const SortLds &s, int N, bool spine_only) {
     if (N <= 16) return;
     const int lane = lane_id();
     int depth0 = 0;
@@ -172,8 +172,10 @@ DEV void sort_introsort_loop(const SortLds &s, int N) {
             }
             d--;
             const int cut = sort_partition(s, f, l);
-            if (lane == sp) { st_f = cut; st_l = l; st_d = d; }
-            sp++;
+            if (!spine_only) {
+                if (lane == sp) { st_f = cut; st_l = l; st_d = d; }
+                sp++;
+            }
             l = cut;
         }
     }
@@ -423,7 +425,7 @@ struct K3Lds {
     uint32_t *pushed;        /* [PYA_MAX_PUSHED] */
     uint32_t *site_max;      /* [64] */
     uint32_t *n_pushed;      /* [1]  */
-    unsigned char *scratch;  /* sort arrays, later the ambiguity lists */
+    unsigned char *scratch;  /* sort arrays, later the localisation work area */
 };
 
 DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
@@ -439,11 +441,55 @@ DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
     return k;
 }
 
-extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t list_cap) {
+#define LOC_SB 8               /* signatures worked on together: the winner + 7 competitors */
+
+/* work area of the batched localisation (aliases the sort arrays) */
+struct LocLds {
+    float *m0, *m1;           /* [64] residue masses                                      */
+    uint8_t *nlp;             /* [64] NL classes                                          */
+    uint64_t *sig_mask;       /* [LOC_SB] residue masks, entry 0 = winner                 */
+    float *run;               /* [LOC_SB*2*pos_cap] running sums per (sig, dir, prefix)   */
+    uint16_t *pmk;            /* same shape: neutral-loss sums present                    */
+    uint16_t *cpre;           /* same shape: exclusive count of variants before prefix    */
+    uint32_t *tot;            /* [LOC_SB*2] variants per (sig, dir)                        */
+    uint32_t *hist;           /* [LOC_SB*11] rank histogram + total fragments             */
+    float *scores;            /* [LOC_SB*10]                                              */
+    uint32_t *c_idx;          /* [LOC_SB] pre-sort index of the competitor                */
+    int32_t *c_depth;         /* [LOC_SB]                                                 */
+    uint32_t *c_cnt;          /* [LOC_SB*2] matched site-determining ions (ref, other)    */
+    uint32_t *c_tr;           /* [LOC_SB*2] site-determining ions                         */
+    float *pool;              /* [pool_cap] fragment lists                                */
+    uint8_t *keep;            /* [pool_cap]                                               */
+};
+
+DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap) {
+    LocLds w;
+    w.sig_mask = (uint64_t *)raw;
+    w.m0 = (float *)(w.sig_mask + LOC_SB);
+    w.m1 = w.m0 + 64;
+    w.run = w.m1 + 64;
+    w.scores = w.run + (size_t)LOC_SB * 2 * pos_cap;
+    w.pool = w.scores + LOC_SB * 10;
+    w.tot = (uint32_t *)(w.pool + pool_cap);
+    w.hist = w.tot + LOC_SB * 2;
+    w.c_idx = w.hist + LOC_SB * 11;
+    w.c_depth = (int32_t *)(w.c_idx + LOC_SB);
+    w.c_cnt = (uint32_t *)(w.c_depth + LOC_SB);
+    w.c_tr = w.c_cnt + LOC_SB * 2;
+    w.pmk = (uint16_t *)(w.c_tr + LOC_SB * 2);
+    w.cpre = w.pmk + (size_t)LOC_SB * 2 * pos_cap;
+    w.nlp = (uint8_t *)(w.cpre + (size_t)LOC_SB * 2 * pos_cap);
+    w.keep = w.nlp + 64;
+    return w;
+}
+
+extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap,
+                                         uint32_t pool_cap) {
     size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + (size_t)peak_cap * 4 +
                    ((peak_cap + 15u) & ~15u);
     size_t srt = (size_t)n_cap * 10 + 64;
-    size_t lst = (size_t)list_cap * 10 + 64;
+    size_t lst = 64 * 4 * 2 + 64 + LOC_SB * 8 + (size_t)LOC_SB * 2 * pos_cap * 8 + LOC_SB * 2 * 4 +
+                 LOC_SB * 11 * 4 + LOC_SB * 10 * 4 + LOC_SB * 4 * 2 + LOC_SB * 2 * 4 * 2 + (size_t)pool_cap * 5 + 64;
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
@@ -471,9 +517,249 @@ DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, u
     tab->err = cfg->mz_error;
 }
 
+/* ---------------------------------------------------------------------------------------
+ * Batched localisation: the winner and up to LOC_SB-1 competitors at a time.
+ *   1. one lane per (signature, direction) walks the residues and tabulates, per prefix
+ *      length, the float32 running sum and the neutral-loss sums that exist;
+ *   2. every (signature, direction, prefix) entry expands to its fragment m/z, looks them up
+ *      and bumps the signature's rank histogram (LDS atomics) -> the 10 depth scores;
+ *   3. per (competitor, ion type) task the two fragment lists are written to an LDS pool,
+ *      sorted if they are not already, cancelled against each other by the reference's
+ *      greedy walk -- one TASK per lane, so all walks of the batch run side by side -- and
+ *      the surviving ions are matched in parallel.
+ * ------------------------------------------------------------------------------------- */
+struct LocCtx {
+    const BatchDev *b;
+    const DevConfig *cfg;
+    NlTables nl;
+    PeakTable tab;
+    LocLds w;
+    int L, zmax;
+    uint32_t pos_cap, pool_cap;
+};
+
+DEV void loc_prefix_tables(const LocCtx &c, int S) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    if (lane < 2 * S) {
+        const int s = lane >> 1, d = lane & 1;
+        const uint64_t mask = w.sig_mask[s];
+        float running = 0.f;
+        uint32_t st = 0, cnt = 0;
+        const size_t base = (size_t)(s * 2 + d) * c.pos_cap;
+        for (int step = 0; step + 1 < c.L; step++) {
+            const int ri = d == 0 ? step : c.L - 1 - step;
+            const bool mod = (mask >> ri) & 1ull;
+            const float r = mod ? w.m1[ri] : w.m0[ri];
+            running = step == 0 ? r : r + running;
+            const uint32_t nlp = w.nlp[ri];
+            const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
+            if (cls) st = nl_bump(st, cls);
+            const uint32_t pm = c.nl.n_nl ? (uint32_t)c.nl.present[st & 255u] : 1u;
+            w.run[base + step] = running;
+            w.pmk[base + step] = (uint16_t)pm;
+            w.cpre[base + step] = (uint16_t)cnt;
+            cnt += __popc(pm);
+        }
+        w.tot[s * 2 + d] = cnt;
+    }
+}
+
+/* rank histograms + total fragments of signatures [s_lo, S) */
+DEV void loc_counts(const LocCtx &c, int s_lo, int S) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    const DevConfig *cfg = c.cfg;
+    const int Lm1 = c.L - 1;
+    for (int i = s_lo * 11 + lane; i < S * 11; i += 64) w.hist[i] = 0;
+    wave_lds_sync();
+    const int E = (S - s_lo) * 2 * Lm1;
+    for (int e = lane; e < E; e += 64) {
+        const int pos = e % Lm1;
+        const int sd = e / Lm1;
+        const int s = s_lo + (sd >> 1), d = sd & 1;
+        const int t0 = d == 0 ? 0 : cfg->n_fwd, t1 = d == 0 ? cfg->n_fwd : cfg->n_types;
+        if (t0 == t1) continue;
+        const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
+        const float running = w.run[idx];
+        uint32_t pm = w.pmk[idx];
+        atomicAdd(&w.hist[s * 11 + 10], (uint32_t)(__popc(pm) * (t1 - t0) * c.zmax));
+        while (pm) {
+            const int v = __builtin_ctz(pm);
+            pm &= pm - 1;
+            const float x = running - (c.nl.n_nl ? c.nl.uniq[v] : 0.f);
+            const double xd = (double)x;
+            for (int t = t0; t < t1; t++) {
+                const double m = type_offset(xd, cfg->types[t]);
+                for (int z = 1; z <= c.zmax; z++) {
+                    const int rk = match_rank(c.tab, charge_mz(m, z));
+                    if (rk < PYA_NTOP) atomicAdd(&w.hist[s * 11 + rk], 1u);
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+}
+
+DEV void loc_scores(const LocCtx &c, int s_lo, int S, int *fail) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    for (int i = s_lo * 10 + lane; i < S * 10; i += 64) {
+        const int s = i / 10, d = i % 10;
+        uint32_t cum = 0;
+        for (int r = 0; r <= d; r++) cum += w.hist[s * 11 + r];
+        const uint32_t nf = w.hist[s * 11 + 10];
+        float sc = 0.f;
+        if (nf <= c.b->lut_n_max) sc = c.b->lut[c.b->lut_off[nf] + (uint32_t)d * (nf + 1) + cum];
+        else *fail = 1;
+        w.scores[i] = sc;
+    }
+    wave_lds_sync();
+}
+
+/* Ascores of competitors 1..S-1 (entry 0 = winner) -> w.c_cnt / w.c_tr filled; depth in c_depth */
+DEV void loc_site_ions(const LocCtx &c, int S) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    const DevConfig *cfg = c.cfg;
+    const int T = cfg->n_types, Lm1 = c.L - 1;
+    /* depth of the largest score gap (Ascore.cpp:164-172) */
+    if (lane >= 1 && lane < S) {
+        float best = 0.f;
+        int depth = 0;
+        for (int d = 0; d < PYA_NTOP; d++) {
+            const float diff = w.scores[d] - w.scores[lane * 10 + d];
+            if (diff > best) {
+                best = diff;
+                depth = d;
+            }
+        }
+        w.c_depth[lane] = depth;
+    }
+    for (int i = lane; i < S * 2; i += 64) {
+        w.c_cnt[i] = 0;
+        w.c_tr[i] = 0;
+    }
+    /* longest list decides the (power of two) stride of the pool */
+    uint32_t mmax = 0;
+    if (lane < 2 * S) mmax = w.tot[lane] * (uint32_t)c.zmax;
+    mmax = wave_max_u32(mmax);
+    uint32_t P2 = 1;
+    while (P2 < mmax) P2 <<= 1;
+    int per_round = (int)(c.pool_cap / (2u * (uint32_t)T * P2));
+    if (per_round < 1) per_round = 1;
+    wave_lds_sync();
+    for (int c0 = 1; c0 < S; c0 += per_round) {
+        const int c1 = c0 + per_round < S ? c0 + per_round : S;
+        const int ntask = (c1 - c0) * T;
+        const int nlist = ntask * 2;
+        /* lists: id = task*2 + side, task = (cc - c0)*T + t */
+        const int E = nlist * Lm1;
+        for (int e = lane; e < E; e += 64) {
+            const int pos = e % Lm1;
+            const int lid = e / Lm1;
+            const int side = lid & 1, task = lid >> 1;
+            const int cc = c0 + task / T, t = task % T;
+            const int s = side ? cc : 0;
+            const uint8_t type = cfg->types[t];
+            const int d = t < cfg->n_fwd ? 0 : 1;
+            const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
+            uint32_t pm = w.pmk[idx];
+            const float running = w.run[idx];
+            float *dst = w.pool + (size_t)lid * P2 + (size_t)w.cpre[idx] * c.zmax;
+            while (pm) {
+                const int v = __builtin_ctz(pm);
+                pm &= pm - 1;
+                const float x = running - (c.nl.n_nl ? c.nl.uniq[v] : 0.f);
+                const double m = type_offset((double)x, type);
+                for (int z = 1; z <= c.zmax; z++) *dst++ = charge_mz(m, z);
+            }
+        }
+        /* pad to the stride */
+        for (int e = lane; e < nlist * (int)P2; e += 64) {
+            const int lid = e / (int)P2, i = e % (int)P2;
+            const int side = lid & 1, task = lid >> 1;
+            const int cc = c0 + task / T, t = task % T;
+            const int s = side ? cc : 0, d = t < cfg->n_fwd ? 0 : 1;
+            const int M = (int)w.tot[s * 2 + d] * c.zmax;
+            if (i >= M) w.pool[e] = __builtin_huge_valf();
+        }
+        wave_lds_sync();
+        /* sort only if some list is out of order */
+        int unsorted = 0;
+        for (int e = lane; e < nlist * (int)P2; e += 64) {
+            const int i = e % (int)P2;
+            if (i + 1 < (int)P2 && w.pool[e] > w.pool[e + 1]) unsorted = 1;
+        }
+        if (__any(unsorted)) {
+            const int half = (int)P2 >> 1;
+            for (int k = 2; k <= (int)P2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int e = lane; e < nlist * half; e += 64) {
+                        const int lid = e / half, tt = e % half;
+                        const int lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
+                        const int hi = lo | j;
+                        const bool up = (lo & k) == 0;
+                        float *base = w.pool + (size_t)lid * P2;
+                        const float a = base[lo], bb = base[hi];
+                        if ((a > bb) == up) {
+                            base[lo] = bb;
+                            base[hi] = a;
+                        }
+                    }
+                    wave_lds_sync();
+                }
+            }
+        }
+        /* greedy cancellation (ModifiedPeptide.cpp:291-316): one task per lane */
+        const float err = cfg->mz_error;
+        for (int task = lane; task < ntask; task += 64) {
+            const int cc = c0 + task / T, t = task % T;
+            const int d = t < cfg->n_fwd ? 0 : 1;
+            const int na = (int)w.tot[0 * 2 + d] * c.zmax, nb = (int)w.tot[cc * 2 + d] * c.zmax;
+            const float *la = w.pool + (size_t)(task * 2) * P2;
+            const float *lb = la + P2;
+            uint8_t *ka = w.keep + (size_t)(task * 2) * P2;
+            uint8_t *kb = ka + P2;
+            int i = 0, j = 0;
+            while (i < na || j < nb) {
+                if (j == nb) {
+                    ka[i++] = 1;
+                } else if (i == na) {
+                    kb[j++] = 1;
+                } else {
+                    const float x = la[i], y = lb[j];
+                    if (__builtin_fabsf(x - y) < err) {
+                        ka[i++] = 0;
+                        kb[j++] = 0;
+                    } else if (x < y) {
+                        ka[i++] = 1;
+                    } else {
+                        kb[j++] = 1;
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+        /* match the surviving ions */
+        for (int e = lane; e < nlist * (int)P2; e += 64) {
+            const int lid = e / (int)P2, i = e % (int)P2;
+            const int side = lid & 1, task = lid >> 1;
+            const int cc = c0 + task / T, t = task % T;
+            const int s = side ? cc : 0, d = t < cfg->n_fwd ? 0 : 1;
+            const int M = (int)w.tot[s * 2 + d] * c.zmax;
+            if (i < M && w.keep[e]) {
+                atomicAdd(&w.c_tr[cc * 2 + side], 1u);
+                if (match_rank(c.tab, w.pool[e]) <= w.c_depth[cc]) atomicAdd(&w.c_cnt[cc * 2 + side], 1u);
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
 __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
                                                           uint32_t n_ids, uint32_t peak_cap,
-                                                          uint32_t list_cap) {
+                                                          uint32_t pos_cap, uint32_t pool_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[blockIdx.x];
@@ -516,9 +802,10 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
     }
 
     K3Lds lds = carve(lds_raw, peak_cap);
-    PeakTable tab;
-    NlTables nl;
-    stage_tables(b, cfg, lds, psm, &tab, &nl);
+    LocCtx ctx;
+    ctx.b = &b;
+    ctx.cfg = cfg;
+    stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl);
 
     /* ---- sort (cpp/Ascore.cpp:141-146) ---- */
     SortLds srt;
@@ -533,7 +820,9 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
     if (lane == 0) *lds.n_pushed = 0;
     lds.site_max[lane] = 0;
     wave_lds_sync();
-    sort_introsort_loop(srt, N);
+    /* only the left spine of the partition tree decides the front element; the full sort is
+     * needed when the caller wants the whole ordering */
+    sort_introsort_loop(srt, N, b.keep == 0);
 
     /* front of the sorted list = left-most maximum of the partitioned array */
     uint32_t kmax = 0;
@@ -578,55 +867,81 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
     const uint32_t n_pushed = *lds.n_pushed;
     int fail = 0;
     if (n_pushed > PYA_MAX_PUSHED) fail = 2;
+    const uint32_t np = n_pushed < PYA_MAX_PUSHED ? n_pushed : PYA_MAX_PUSHED;
 
+    /* ---- Ascores, LOC_SB-1 competitors at a time ---- */
     const Residues res = load_residues(b, cfg, psm);
-    const int zmax = b.max_charge[psm];
-    const uint64_t best_mask = deposit_sites(best_bits, res.site_mask);
-    uint32_t cum[PYA_NTOP], nfrag;
-    float best_scores[PYA_NTOP];
-    signature_counts(res, cfg, nl, tab, best_mask, zmax, cum, &nfrag);
-    scores_from_counts(b, cum, nfrag, best_scores, &fail);
+    ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap);
+    ctx.L = res.L;
+    ctx.zmax = b.max_charge[psm];
+    ctx.pos_cap = pos_cap;
+    ctx.pool_cap = pool_cap;
+    const LocLds &w = ctx.w;
+    w.m0[lane] = res.m0;
+    w.m1[lane] = res.m1;
+    w.nlp[lane] = (uint8_t)res.nl;
+    if (lane == 0) w.sig_mask[0] = deposit_sites(best_bits, res.site_mask);
+    wave_lds_sync();
 
-    AmbLds amb;
-    amb.la = (float *)lds.scratch;
-    amb.lb = amb.la + list_cap;
-    amb.ka = (uint8_t *)(amb.lb + list_cap);
-    amb.kb = amb.ka + list_cap;
-
-    /* per modified site: min Ascore over the tied best competitors, their positions as a mask */
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
-    const uint32_t np = n_pushed < PYA_MAX_PUSHED ? n_pushed : PYA_MAX_PUSHED;
-    for (uint32_t e = 0; e < np; e++) {
-        const uint32_t ci = lds.pushed[e];
-        const uint64_t c = order[ci];
-        const float c_ws = ws[ci];
-        const uint64_t gone = best_bits & ~c, came = c & ~best_bits;
-        const int a = __popcll(best_bits & (gone - 1));
-        const int q = __builtin_ctzll(came);
-        float asc = 0.f;
-        if (!((double)__builtin_fabsf(best_ws - c_ws) < 1e-6)) {
-            const uint64_t c_mask = deposit_sites(c, res.site_mask);
-            float c_scores[PYA_NTOP];
-            signature_counts(res, cfg, nl, tab, c_mask, zmax, cum, &nfrag);
-            scores_from_counts(b, cum, nfrag, c_scores, &fail);
-            asc = ambiguity(b, res, cfg, nl, tab, amb, zmax, best_mask, best_scores, best_ws, c_mask,
-                            c_scores, c_ws, &fail);
+    bool have_best = false;
+    uint32_t e = 0;
+    while (e < np) {
+        /* gather the next competitors that are not exact PepScore ties of the winner */
+        int S = 1;
+        while (e < np && S < LOC_SB) {
+            const uint32_t ci = lds.pushed[e++];
+            const uint64_t c = order[ci];
+            const float c_ws = ws[ci];
+            const uint64_t gone = best_bits & ~c, came = c & ~best_bits;
+            const int a = __popcll(best_bits & (gone - 1));
+            const int q = __builtin_ctzll(came);
+            if (lane == a) my_alt |= 1ull << nth_set_bit(res.site_mask, q);
+            if ((double)__builtin_fabsf(best_ws - c_ws) < 1e-6) {       /* Ascore.cpp:159-161 */
+                if (lane == a) my_asc = 0.f < my_asc ? 0.f : my_asc;
+                continue;
+            }
+            if (lane == 0) {
+                w.sig_mask[S] = deposit_sites(c, res.site_mask);
+                w.c_idx[S] = (uint32_t)a;
+            }
+            S++;
         }
-        if (lane == a) {
-            my_asc = asc < my_asc ? asc : my_asc;
-            my_alt |= 1ull << nth_set_bit(res.site_mask, q);
+        if (S == 1) continue;
+        wave_lds_sync();
+        loc_prefix_tables(ctx, S);
+        wave_lds_sync();
+        loc_counts(ctx, have_best ? 1 : 0, S);
+        loc_scores(ctx, have_best ? 1 : 0, S, &fail);
+        have_best = true;
+        loc_site_ions(ctx, S);
+        for (int cc = 1; cc < S; cc++) {
+            const uint32_t tr0 = w.c_tr[cc * 2], tr1 = w.c_tr[cc * 2 + 1];
+            const uint32_t n0 = w.c_cnt[cc * 2], n1 = w.c_cnt[cc * 2 + 1];
+            const uint32_t depth = (uint32_t)w.c_depth[cc];
+            float asc = 0.f;
+            if (tr0 > b.lut_n_max || tr1 > b.lut_n_max) {
+                fail = 1;
+            } else {
+                const float sc0 = b.lut[b.lut_off[tr0] + depth * (tr0 + 1) + n0];
+                const float sc1 = b.lut[b.lut_off[tr1] + depth * (tr1 + 1) + n1];
+                asc = sc0 - sc1;
+            }
+            if (lane == (int)w.c_idx[cc]) my_asc = asc < my_asc ? asc : my_asc;
         }
+        wave_lds_sync();
     }
     if (lane < k && lane < (int)max_k) {
         out_asc[lane] = my_asc;
         out_alt[lane] = my_alt;
     }
+    const bool any_fail = __any(fail != 0), overflow = __any(fail == 2);
     if (lane == 0) {
         b.best_score[psm] = best_ws;
         b.best_sig[psm] = best_bits;
         b.n_sig_out[psm] = N;
-        if (fail) b.status[psm] = fail == 2 ? PYA_ST_PUSHED_OVERFLOW : PYA_ST_LUT_RANGE;
+        if (any_fail) b.status[psm] = overflow ? PYA_ST_PUSHED_OVERFLOW : PYA_ST_LUT_RANGE;
     }
 }
 
@@ -679,27 +994,32 @@ __global__ __launch_bounds__(64) void pya_debug_sort_kernel(const float *keys, u
         srt.idx[i] = (uint16_t)i;
     }
     wave_lds_sync();
-    sort_introsort_loop(srt, N);
+    sort_introsort_loop(srt, N, false);
     for (int i = lane; i < N; i += 64) perm[sort_final_pos(srt, i, N)] = srt.idx[i];
 }
 
 extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids,
-                                   uint32_t peak_cap, uint32_t n_cap, uint32_t list_cap,
+                                   uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
                                    hipStream_t stream) {
     if (n_ids == 0) return 0;
-    size_t lds = pya_localize_lds_bytes(peak_cap, n_cap, list_cap);
+    size_t lds = pya_localize_lds_bytes(peak_cap, n_cap, pos_cap, pool_cap);
     hipError_t e = hipFuncSetAttribute((const void *)pya_localize_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_localize_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                       peak_cap, list_cap);
+                       peak_cap, pos_cap, pool_cap);
     return (int)hipGetLastError();
+}
+
+extern "C" size_t pya_amb_lds_bytes(uint32_t peak_cap, uint32_t list_cap) {
+    return 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + (size_t)peak_cap * 4 +
+           ((peak_cap + 15u) & ~15u) + (size_t)list_cap * 10 + 128;
 }
 
 extern "C" int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,
                                     uint64_t ref_bits, uint64_t oth_bits, const float *d_scores,
                                     float ref_ws, float oth_ws, float *d_out, hipStream_t stream) {
-    size_t lds = pya_localize_lds_bytes(peak_cap, 0, list_cap);
+    size_t lds = pya_amb_lds_bytes(peak_cap, list_cap);
     hipError_t e = hipFuncSetAttribute((const void *)pya_ambiguity_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
