@@ -113,30 +113,67 @@ DEV float charge_mz(double m, int z) {
 /* ---------------------------------------------------------------------------------------
  * Match lookup = net semantics of consumePeak/hasMatch/getMatch (ModifiedPeptide.cpp:126-150):
  *   min rank over retained peaks p with f32(f-err) < p < f32(f+err) and f >= p - 0.5.
- * Retained peaks are staged in LDS sorted by m/z (float), `pow2` = smallest power of two >= n.
+ * Retained peaks are staged in LDS sorted by m/z (float); a coarse m/z grid gives the start of
+ * the scan (the grid only narrows the search, the window test itself is the reference's).
  * ------------------------------------------------------------------------------------- */
+#define PYA_GRID_CELLS 512         /* cells of the m/z grid that accelerates the lookup       */
+
 struct PeakTable {
-    const float *mz;        /* LDS */
+    const float *mz;        /* LDS, ascending */
     const uint8_t *rank;    /* LDS */
+    const uint16_t *cell;   /* LDS [PYA_GRID_CELLS]: first peak index whose cell is >= c          */
     int n;
-    int pow2;
     float err;
+    float base;             /* m/z of the first retained peak                                    */
+    float inv_w;            /* cells per m/z                                                     */
+    int last_cell;
 };
 
-DEV int match_rank(const PeakTable &t, float f) {
-    float lo = f - t.err;
-    float hi = f + t.err;
-    int idx = 0;                                           /* number of peaks with p <= lo */
-    for (int step = t.pow2; step > 0; step >>= 1) {
-        int probe = idx + step;
-        if (probe <= t.n && t.mz[probe - 1] <= lo) idx = probe;
+/* monotone non-decreasing in x: float subtract, multiply by a positive constant, truncate */
+DEV int grid_cell(const PeakTable &t, float x) {
+    float rel = (x - t.base) * t.inv_w;
+    int c = rel > 0.f ? (int)rel : 0;
+    return c > t.last_cell ? t.last_cell : c;
+}
+
+/* builds the grid for the n staged peaks (wave-cooperative; caller syncs LDS afterwards) */
+DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
+    const int lane = lane_id();
+    t->cell = cell_lds;
+    if (t->n <= 0) {
+        t->base = 0.f;
+        t->inv_w = 0.f;
+        t->last_cell = 0;
+        if (lane == 0) cell_lds[0] = 0;
+        return;
     }
+    const float first = t->mz[0], last = t->mz[t->n - 1];
+    t->base = first;
+    const float range = last - first;
+    float inv_w = 0.25f;                                  /* 4 m/z per cell ...                */
+    if (range * inv_w > (float)(PYA_GRID_CELLS - 2)) inv_w = (float)(PYA_GRID_CELLS - 2) / range;
+    t->inv_w = inv_w;                                     /* ... or wider to fit the grid      */
+    t->last_cell = PYA_GRID_CELLS - 1;
+    int lc = (int)(range * inv_w);
+    if (lc > PYA_GRID_CELLS - 1) lc = PYA_GRID_CELLS - 1;
+    t->last_cell = lc;
+    for (int i = lane; i < t->n; i += 64) {
+        const int c = grid_cell(*t, t->mz[i]);
+        const int cp = i > 0 ? grid_cell(*t, t->mz[i - 1]) : -1;
+        for (int k = cp + 1; k <= c; k++) cell_lds[k] = (uint16_t)i;
+    }
+}
+
+DEV int match_rank(const PeakTable &t, float f) {
+    const float lo = f - t.err;
+    const float hi = f + t.err;
+    int idx = (int)t.cell[grid_cell(t, lo)];              /* every peak > lo has index >= idx  */
     int best = PYA_NO_MATCH;
     while (idx < t.n) {
-        float p = t.mz[idx];
+        const float p = t.mz[idx];
         if (!(p < hi)) break;
-        if ((double)f >= (double)p - 0.5) {
-            int r = (int)t.rank[idx];
+        if (p > lo && (double)f >= (double)p - 0.5) {
+            const int r = (int)t.rank[idx];
             best = r < best ? r : best;
         }
         idx++;

@@ -425,6 +425,7 @@ struct K3Lds {
     uint32_t *pushed;        /* [PYA_MAX_PUSHED] */
     uint32_t *site_max;      /* [64] */
     uint32_t *n_pushed;      /* [1]  */
+    uint16_t *grid;          /* [PYA_GRID_CELLS] */
     unsigned char *scratch;  /* sort arrays, later the localisation work area */
 };
 
@@ -435,7 +436,8 @@ DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
     k.pushed = (uint32_t *)(k.nl_uniq + PYA_MAX_UNIQ);
     k.site_max = k.pushed + PYA_MAX_PUSHED;
     k.n_pushed = k.site_max + 64;
-    k.t_mz = (float *)(k.n_pushed + 4);
+    k.grid = (uint16_t *)(k.n_pushed + 4);
+    k.t_mz = (float *)(k.grid + PYA_GRID_CELLS);
     k.t_rank = (uint8_t *)(k.t_mz + peak_cap);
     k.scratch = (unsigned char *)(k.t_rank + ((peak_cap + 15u) & ~15u));
     return k;
@@ -485,8 +487,8 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap) {
 
 extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap,
                                          uint32_t pool_cap) {
-    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + (size_t)peak_cap * 4 +
-                   ((peak_cap + 15u) & ~15u);
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + PYA_GRID_CELLS * 2 +
+                   (size_t)peak_cap * 4 + ((peak_cap + 15u) & ~15u);
     size_t srt = (size_t)n_cap * 10 + 64;
     size_t lst = 64 * 4 * 2 + 64 + LOC_SB * 8 + (size_t)LOC_SB * 2 * pos_cap * 8 + LOC_SB * 2 * 4 +
                  LOC_SB * 11 * 4 + LOC_SB * 10 * 4 + LOC_SB * 4 * 2 + LOC_SB * 2 * 4 * 2 + (size_t)pool_cap * 5 + 64;
@@ -512,9 +514,10 @@ DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, u
     tab->mz = k.t_mz;
     tab->rank = k.t_rank;
     tab->n = R;
-    tab->pow2 = 1;
-    while (tab->pow2 < R) tab->pow2 <<= 1;
     tab->err = cfg->mz_error;
+    wave_lds_sync();
+    grid_build(tab, k.grid);
+    wave_lds_sync();
 }
 
 /* ---------------------------------------------------------------------------------------
@@ -1012,8 +1015,8 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
 }
 
 extern "C" size_t pya_amb_lds_bytes(uint32_t peak_cap, uint32_t list_cap) {
-    return 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + (size_t)peak_cap * 4 +
-           ((peak_cap + 15u) & ~15u) + (size_t)list_cap * 10 + 128;
+    return 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + PYA_GRID_CELLS * 2 +
+           (size_t)peak_cap * 4 + ((peak_cap + 15u) & ~15u) + (size_t)list_cap * 10 + 128;
 }
 
 extern "C" int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,

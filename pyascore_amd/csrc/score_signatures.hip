@@ -4,13 +4,15 @@
  * FragmentGraph walk of Ascore::accumulateCounts and Ascore::calculateFullScores
  * (cpp/ModifiedPeptide.cpp:81-150, :326-609; cpp/Ascore.cpp:53-139).
  *
- * Mapping: one signature per lane (lanes loop when C(n,k) > 64).  A lane walks the residues
- * once per direction keeping the reference's float32 running sum in a register, derives every
- * (neutral-loss variant, ion type, charge) m/z in the reference's double/float order, looks the
- * m/z up in the wave's LDS copy of the retained-peak table and bumps a packed rank histogram.
- * Per-residue data sits in one register per lane and is broadcast with v_readlane (no LDS).
- * The binomial tail is a host-built table (float32 chain in the reference's order), so the
- * device does integer counting + table reads + the exactly-rounded weighted sum.
+ * Mapping: one (signature, direction) walker per lane -- with C(n,k) <= 32 both directions of
+ * every signature run side by side, otherwise a lane walks forward then backward and lanes
+ * loop over the signatures.  A walker keeps the reference's float32 running sum in a register,
+ * derives every (neutral-loss variant, ion type, charge) m/z in the reference's double/float
+ * order, looks it up in the wave's LDS copy of the retained-peak table (m/z grid + short scan)
+ * and bumps a packed rank histogram.  Per-residue data sits in one register per lane and is
+ * broadcast with v_readlane (no LDS).  The binomial tail is a host-built table (float32 chain in
+ * the reference's order), so the device does integer counting + table reads + the
+ * exactly-rounded weighted sum.
  *
  * HBM traffic per PSM: retained table (5 B x R) + peptide bytes + 8 B x C(n,k) signature
  * table (L2 resident, shared by all PSMs of a shape) in; 4 B x C(n,k) weighted scores out.
@@ -21,6 +23,90 @@ DEV float lut_score(const BatchDev &b, uint32_t depth, uint32_t k, uint32_t n) {
     return b.lut[b.lut_off[n] + depth * (n + 1) + k];
 }
 
+struct WalkEnv {
+    const DevConfig *cfg;
+    const uint16_t *nl_present;
+    const float *nl_uniq;
+    int n_nl, L, zmax;
+};
+
+/* ion-type offsets as (m + A) - B in double: b (0,0), c (+NH3,0), y (+H2O,0), z (+H2O,-NH3),
+ * Z (+H2O,-NH2); adding or subtracting 0.0 is exact, so this equals ModifiedPeptide.cpp:573-583 */
+DEV void type_constants(uint8_t type, double *A, double *B) {
+    *A = (type == 'b') ? 0.0 : (type == 'c' ? 17.026549 : 18.010565);
+    *B = (type == 'z') ? 17.026549 : (type == 'Z' ? 16.018724 : 0.0);
+}
+
+/* Walks one direction per lane (`dir` may differ between lanes: the residue of a step is read
+ * for both directions with two v_readlane and selected).  Adds to h / nfrag. */
+DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
+              bool active, Hist &h, uint32_t &nfrag) {
+    const DevConfig *cfg = e.cfg;
+    const int n_f = cfg->n_fwd, n_b = cfg->n_types - cfg->n_fwd;
+    const int my_types = dir == 0 ? n_f : n_b;
+    const int t_base = dir == 0 ? 0 : n_f;
+    const bool any_f = __any(active && dir == 0), any_b = __any(active && dir == 1);
+    const int t_max = (any_f && any_b) ? (n_f > n_b ? n_f : n_b) : (any_f ? n_f : n_b);
+    float running = 0.f;
+    uint32_t nl_state = 0;
+    for (int step = 0; step + 1 < e.L; step++) {
+        const int i_f = step, i_b = e.L - 1 - step;                      /* wave-uniform */
+        float m0 = 0.f, m1 = 0.f;
+        uint32_t nlp = 0;
+        if (any_f) {
+            m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i_f));
+            m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i_f));
+            nlp = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, i_f);
+        }
+        if (any_b) {
+            const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i_b));
+            const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i_b));
+            const uint32_t bn = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, i_b);
+            m0 = dir ? b0 : m0;
+            m1 = dir ? b1 : m1;
+            nlp = dir ? bn : nlp;
+        }
+        const int i = dir ? i_b : i_f;
+        const bool mod = (resmask >> i) & 1ull;
+        const float r = mod ? m1 : m0;
+        running = step == 0 ? r : r + running;                           /* ModifiedPeptide.cpp:385-389 */
+        uint32_t pm = active ? 1u : 0u;
+        if (e.n_nl) {
+            const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
+            if (cls) nl_state = nl_bump(nl_state, cls);
+            pm = active ? (uint32_t)e.nl_present[nl_state & 255u] : 0u;
+        }
+        while (__any(pm != 0)) {
+            const bool on = pm != 0;
+            const int v = on ? __builtin_ctz(pm) : 0;
+            pm &= pm - 1;
+            const float x = running - (e.n_nl ? e.nl_uniq[v] : 0.f);   /* float subtract (:572) */
+            const double xd = (double)x;
+            for (int t = 0; t < t_max; t++) {
+                const bool on_t = on && t < my_types;
+                double A, B;
+                type_constants(cfg->types[t_base + (t < my_types ? t : 0)], &A, &B);
+                const double m = (xd + A) - B;
+                for (int z = 1; z <= e.zmax; z++) {
+                    const float f = charge_mz(m, z);
+                    if (on_t) {
+                        hist_add(h, match_rank(tab, f));
+                        nfrag++;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* walker of the opposite direction sits 32 lanes up: fold it into lanes 0..31 */
+DEV void fold_upper_half(Hist &h, uint32_t &nfrag) {
+    h.a += __shfl_down(h.a, 32, 64);
+    h.b += __shfl_down(h.b, 32, 64);
+    h.c += __shfl_down(h.c, 32, 64);
+    nfrag += (uint32_t)__shfl_down((int)nfrag, 32, 64);
+}
+
 __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
                                                                   uint32_t n_ids, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -29,12 +115,15 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
 
-    uint16_t *nl_present = (uint16_t *)lds_raw;           /* [256] */
-    float *nl_uniq = (float *)(nl_present + 256);           /* [PYA_MAX_UNIQ] */
+    uint16_t *nl_present = (uint16_t *)lds_raw;             /* [256] */
+    uint16_t *grid = nl_present + 256;                      /* [PYA_GRID_CELLS] */
+    float *nl_uniq = (float *)(grid + PYA_GRID_CELLS);      /* [PYA_MAX_UNIQ] */
     float *t_mz = nl_uniq + PYA_MAX_UNIQ;
     uint8_t *t_rank = (uint8_t *)(t_mz + cap);
 
     if (b.status[psm] != PYA_ST_OK) return;
+    const uint32_t N = b.n_sig[psm];
+    if (N == 0) return;
 
     /* stage the retained-peak table */
     const int64_t p0 = b.peak_off[psm];
@@ -43,8 +132,12 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
         t_mz[i] = b.ret_mz[p0 + i];
         t_rank[i] = b.ret_rank[p0 + i];
     }
-    const int n_nl = cfg->n_nl;
-    if (n_nl) {
+    WalkEnv env;
+    env.cfg = cfg;
+    env.n_nl = cfg->n_nl;
+    env.nl_present = nl_present;
+    env.nl_uniq = nl_uniq;
+    if (env.n_nl) {
         for (int i = lane; i < 256; i += 64) nl_present[i] = cfg->present[i];
         if (lane < PYA_MAX_UNIQ) nl_uniq[lane] = cfg->uniq[lane];
     }
@@ -52,67 +145,36 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     tab.mz = t_mz;
     tab.rank = t_rank;
     tab.n = R;
-    tab.pow2 = 1;
-    while (tab.pow2 < R) tab.pow2 <<= 1;
     tab.err = cfg->mz_error;
+    wave_lds_sync();
+    grid_build(&tab, grid);
 
     const Residues res = load_residues(b, cfg, psm);
-    const int L = res.L;
-    const int zmax = b.max_charge[psm];
-    const uint32_t N = b.n_sig[psm];
+    env.L = res.L;
+    env.zmax = b.max_charge[psm];
     const uint64_t *order = b.order_tab + b.order_off[psm];
     const int64_t s0 = b.sig_off[psm];
-    const int n_types = cfg->n_types, n_fwd = cfg->n_fwd;
+    const bool both_dirs = cfg->n_fwd > 0 && cfg->n_fwd < cfg->n_types;
     wave_lds_sync();
 
     int lut_fail = 0;
+    const bool split = N <= 32 && both_dirs;     /* lanes 0..31 forward, 32..63 backward */
     for (uint32_t sbase = 0; sbase < N; sbase += 64) {
-        const uint32_t s = sbase + lane;
+        const uint32_t s = split ? (uint32_t)(lane & 31) : sbase + lane;
         const bool active = s < N;
         const uint64_t bits = active ? order[s] : 0ull;
         const uint64_t resmask = deposit_sites(bits, res.site_mask);
         Hist h = {0ull, 0ull, 0ull};
         uint32_t nfrag = 0;
-
-        for (int dir = 0; dir < 2; dir++) {
-            const int t0 = dir == 0 ? 0 : n_fwd;
-            const int t1 = dir == 0 ? n_fwd : n_types;
-            if (t0 == t1) continue;
-            float running = 0.f;
-            uint32_t nl_state = 0;
-            for (int step = 0; step + 1 < L; step++) {
-                const int i = dir == 0 ? step : L - 1 - step;            /* wave-uniform */
-                const float m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i));
-                const float m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i));
-                const uint32_t nlp = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, i);
-                const bool mod = (resmask >> i) & 1ull;
-                const float r = mod ? m1 : m0;
-                running = step == 0 ? r : r + running;                   /* ModifiedPeptide.cpp:385-389 */
-                const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
-                if (cls) nl_state = nl_bump(nl_state, cls);
-                uint32_t pm = active ? (n_nl ? (uint32_t)nl_present[nl_state & 255u] : 1u) : 0u;
-                while (__any(pm != 0)) {
-                    const bool on = pm != 0;
-                    const int v = on ? __builtin_ctz(pm) : 0;
-                    pm &= pm - 1;
-                    const float x = running - (n_nl ? nl_uniq[v] : 0.f);             /* float subtract (:572) */
-                    const double xd = (double)x;
-                    for (int t = t0; t < t1; t++) {
-                        const double m = type_offset(xd, cfg->types[t]);
-                        for (int z = 1; z <= zmax; z++) {
-                            const float f = charge_mz(m, z);
-                            if (on) {
-                                const int rk = match_rank(tab, f);
-                                hist_add(h, rk);
-                                nfrag++;
-                            }
-                        }
-                    }
-                }
-            }
+        if (split) {
+            walk(env, res, tab, resmask, lane >> 5, active, h, nfrag);
+            fold_upper_half(h, nfrag);
+        } else {
+            if (cfg->n_fwd > 0) walk(env, res, tab, resmask, 0, active, h, nfrag);
+            if (cfg->n_fwd < cfg->n_types) walk(env, res, tab, resmask, 1, active, h, nfrag);
         }
 
-        if (active) {
+        if (active && (!split || lane < 32)) {
             /* cumulative counts over rank (Ascore.cpp:115-118) and scores (Ascore.cpp:123-139) */
             uint32_t cum[PYA_NTOP];
             uint32_t acc = 0;
@@ -146,7 +208,9 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     if (__any(lut_fail) && lane == 0) b.status[psm] = PYA_ST_LUT_RANGE;
 }
 
-extern "C" size_t pya_score_lds_bytes(uint32_t cap) { return (size_t)cap * 5 + 512 + PYA_MAX_UNIQ * 4 + 64; }
+extern "C" size_t pya_score_lds_bytes(uint32_t cap) {
+    return (size_t)cap * 5 + 512 + PYA_GRID_CELLS * 2 + PYA_MAX_UNIQ * 4 + 64;
+}
 
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                                 hipStream_t stream) {
