@@ -39,6 +39,9 @@ def _run(cmd):
 
 
 def build(force=False):
+    if os.environ.get("PYA_BUILD_STAMPS"):      # diagnostic build with in-kernel phase stamps
+        DEVICE_FLAGS.append("-DPYA_STAMPS")
+        force = True
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     for src in DEVICE_SRC:

@@ -84,6 +84,8 @@ struct BatchDev {
     uint64_t *alt_mask;
     uint32_t max_k;
     uint32_t keep;                  /* write rec / sorted_idx                               */
+    uint32_t debug;                 /* PYA_DEBUG ablation bits (timing experiments only)    */
+    unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */
 };
 
 /* per-signature record (keep mode): 10 cumulative counts as u16 + total fragments */

@@ -13,6 +13,20 @@
 
 #define DEV __device__ __forceinline__
 
+/* In-kernel phase stamps, diagnostic build only (-DPYA_STAMPS): shares, not lengths. */
+#ifdef PYA_STAMPS
+#define STAMP_BEGIN() unsigned long long stamp_t_ = __builtin_amdgcn_s_memtime()
+#define STAMP(b, k)                                                                  \
+    do {                                                                             \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+        if ((b).stamps && (threadIdx.x & 63) == 0) atomicAdd(&(b).stamps[k], now_ - stamp_t_); \
+        stamp_t_ = __builtin_amdgcn_s_memtime();                                     \
+    } while (0)
+#else
+#define STAMP_BEGIN() do {} while (0)
+#define STAMP(b, k) do {} while (0)
+#endif
+
 DEV int lane_id() { return (int)(threadIdx.x & 63); }
 
 DEV uint64_t lanemask_lt() {

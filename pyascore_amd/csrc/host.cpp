@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -156,13 +157,19 @@ struct pya_handle {
         if (e_ != hipSuccess) return (h)->hip_fail(e_, #call); \
     } while (0)
 
+static uint32_t next_pow2_u32(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
 struct Bucket {
     std::vector<uint32_t> ids;
     DevBuf<uint32_t> d_ids;
     uint32_t n_cap = 0, list_cap = 1, pos_cap = 1;
     uint32_t pool_cap() const {
         /* room for one competitor at least, ~7 when the lists are short */
-        uint32_t one = 2u * n_types * list_cap;
+        uint32_t one = 2u * next_pow2_u32(n_types) * list_cap;
         uint32_t want = 7u * one;
         if (want > 2048u) want = 2048u;
         return one > want ? one : want;
@@ -195,6 +202,7 @@ struct pya_plan {
     DevBuf<float> d_best_score, d_ascores;
     DevBuf<uint64_t> d_best_sig, d_alt;
     DevBuf<int32_t> d_n_sig_out;
+    DevBuf<unsigned long long> d_stamps;
     BatchDev dev;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t last_stream = nullptr;
@@ -413,6 +421,15 @@ void fill_dev(pya_plan *p) {
     d.status = p->d_status.p;
     d.max_k = p->max_k;
     d.keep = (p->flags & PYA_FLAG_KEEP) ? 1u : 0u;
+    const char *dbg = std::getenv("PYA_DEBUG");
+    d.debug = dbg ? (uint32_t)std::strtoul(dbg, nullptr, 0) : 0u;
+    if (std::getenv("PYA_STAMPS")) {
+        if (!p->d_stamps.p) {
+            (void)p->d_stamps.alloc(64);
+            (void)hipMemset(p->d_stamps.p, 0, 64 * 8);
+        }
+        d.stamps = p->d_stamps.p;
+    }
 }
 
 }  // namespace
@@ -773,6 +790,16 @@ uint64_t pya_plan_total_signatures(const pya_plan *p) { return p ? (uint64_t)p->
 void pya_plan_destroy(pya_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->h->device);
+    if (p->d_stamps.p) {
+        unsigned long long v[64];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(v, p->d_stamps.p, sizeof v, hipMemcpyDeviceToHost);
+        unsigned long long tot = 0;
+        for (int i = 0; i < 64; i++) tot += v[i];
+        std::fprintf(stderr, "[pya stamps] total %llu\n", tot);
+        for (int i = 0; i < 64; i++)
+            if (v[i]) std::fprintf(stderr, "[pya stamps] phase %2d: %12llu  %5.1f%%\n", i, v[i], 100.0 * v[i] / tot);
+    }
     if (p->h->kept == p) p->h->kept = nullptr;
     delete p;
 }

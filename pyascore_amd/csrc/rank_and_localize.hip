@@ -568,21 +568,30 @@ DEV void loc_prefix_tables(const LocCtx &c, int S) {
     }
 }
 
-/* rank histograms + total fragments of signatures [s_lo, S) */
+DEV int ilog2_ceil(int v) {                     /* smallest g with (1 << g) >= v, v >= 1 */
+    int g = 0;
+    while ((1 << g) < v) g++;
+    return g;
+}
+
+/* rank histograms + total fragments of signatures [s_lo, S).  Work items are (signature,
+ * direction, prefix) with the prefix index padded to a power of two so that decoding an item is
+ * shifts and masks only (integer division is tens of instructions on this hardware). */
 DEV void loc_counts(const LocCtx &c, int s_lo, int S) {
     const int lane = lane_id();
     const LocLds &w = c.w;
     const DevConfig *cfg = c.cfg;
     const int Lm1 = c.L - 1;
+    const int gp = ilog2_ceil(Lm1 > 0 ? Lm1 : 1);
     for (int i = s_lo * 11 + lane; i < S * 11; i += 64) w.hist[i] = 0;
     wave_lds_sync();
-    const int E = (S - s_lo) * 2 * Lm1;
+    const int E = ((S - s_lo) * 2) << gp;
     for (int e = lane; e < E; e += 64) {
-        const int pos = e % Lm1;
-        const int sd = e / Lm1;
+        const int pos = e & ((1 << gp) - 1);
+        const int sd = e >> gp;
         const int s = s_lo + (sd >> 1), d = sd & 1;
         const int t0 = d == 0 ? 0 : cfg->n_fwd, t1 = d == 0 ? cfg->n_fwd : cfg->n_types;
-        if (t0 == t1) continue;
+        if (t0 == t1 || pos >= Lm1) continue;
         const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
         const float running = w.run[idx];
         uint32_t pm = w.pmk[idx];
@@ -620,12 +629,19 @@ DEV void loc_scores(const LocCtx &c, int s_lo, int S, int *fail) {
     wave_lds_sync();
 }
 
-/* Ascores of competitors 1..S-1 (entry 0 = winner) -> w.c_cnt / w.c_tr filled; depth in c_depth */
+/* Site-determining ions of competitors 1..S-1 against the winner (entry 0): fills w.c_cnt /
+ * w.c_tr and the depth in w.c_depth.
+ *
+ * Lists live in an LDS pool addressed as [competitor][type slot][side][P2] with the number of
+ * type slots and P2 powers of two, so an element index decodes with shifts.  A "task" is one
+ * (competitor, ion type): list A = winner, list B = competitor. */
 DEV void loc_site_ions(const LocCtx &c, int S) {
     const int lane = lane_id();
     const LocLds &w = c.w;
     const DevConfig *cfg = c.cfg;
     const int T = cfg->n_types, Lm1 = c.L - 1;
+    const int gt = ilog2_ceil(T);                 /* type slots = 1 << gt */
+    const int gp = ilog2_ceil(Lm1 > 0 ? Lm1 : 1);
     /* depth of the largest score gap (Ascore.cpp:164-172) */
     if (lane >= 1 && lane < S) {
         float best = 0.f;
@@ -644,32 +660,33 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
         w.c_tr[i] = 0;
     }
     /* longest list decides the (power of two) stride of the pool */
-    uint32_t mmax = 0;
+    uint32_t mmax = 1;
     if (lane < 2 * S) mmax = w.tot[lane] * (uint32_t)c.zmax;
     mmax = wave_max_u32(mmax);
-    uint32_t P2 = 1;
-    while (P2 < mmax) P2 <<= 1;
-    int per_round = (int)(c.pool_cap / (2u * (uint32_t)T * P2));
+    const int g2 = ilog2_ceil((int)(mmax > 0 ? mmax : 1));
+    const int P2 = 1 << g2;
+    int per_round = (int)(c.pool_cap >> (1 + gt + g2));
     if (per_round < 1) per_round = 1;
+    const float err = cfg->mz_error;
     wave_lds_sync();
+    STAMP_BEGIN();
     for (int c0 = 1; c0 < S; c0 += per_round) {
         const int c1 = c0 + per_round < S ? c0 + per_round : S;
-        const int ntask = (c1 - c0) * T;
-        const int nlist = ntask * 2;
-        /* lists: id = task*2 + side, task = (cc - c0)*T + t */
-        const int E = nlist * Lm1;
-        for (int e = lane; e < E; e += 64) {
-            const int pos = e % Lm1;
-            const int lid = e / Lm1;
+        const int nlist = ((c1 - c0) << gt) << 1;               /* incl. unused type slots */
+        /* ---- generate: items (list, prefix) ---- */
+        for (int e = lane; e < (nlist << gp); e += 64) {
+            const int pos = e & ((1 << gp) - 1);
+            const int lid = e >> gp;
             const int side = lid & 1, task = lid >> 1;
-            const int cc = c0 + task / T, t = task % T;
+            const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
+            if (pos >= Lm1 || t >= T) continue;
             const int s = side ? cc : 0;
             const uint8_t type = cfg->types[t];
             const int d = t < cfg->n_fwd ? 0 : 1;
             const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
             uint32_t pm = w.pmk[idx];
             const float running = w.run[idx];
-            float *dst = w.pool + (size_t)lid * P2 + (size_t)w.cpre[idx] * c.zmax;
+            float *dst = w.pool + ((size_t)lid << g2) + (size_t)w.cpre[idx] * c.zmax;
             while (pm) {
                 const int v = __builtin_ctz(pm);
                 pm &= pm - 1;
@@ -678,32 +695,35 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                 for (int z = 1; z <= c.zmax; z++) *dst++ = charge_mz(m, z);
             }
         }
-        /* pad to the stride */
-        for (int e = lane; e < nlist * (int)P2; e += 64) {
-            const int lid = e / (int)P2, i = e % (int)P2;
+        STAMP(*c.b, 30);
+        /* ---- pad every list to the stride with +inf ---- */
+        const int total = nlist << g2;
+        for (int e = lane; e < total; e += 64) {
+            const int lid = e >> g2, i = e & (P2 - 1);
             const int side = lid & 1, task = lid >> 1;
-            const int cc = c0 + task / T, t = task % T;
-            const int s = side ? cc : 0, d = t < cfg->n_fwd ? 0 : 1;
-            const int M = (int)w.tot[s * 2 + d] * c.zmax;
+            const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
+            int M = 0;
+            if (t < T) M = (int)w.tot[(side ? cc : 0) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
             if (i >= M) w.pool[e] = __builtin_huge_valf();
         }
         wave_lds_sync();
-        /* sort only if some list is out of order */
+        /* ---- sort only if some list is out of order ---- */
         int unsorted = 0;
-        for (int e = lane; e < nlist * (int)P2; e += 64) {
-            const int i = e % (int)P2;
-            if (i + 1 < (int)P2 && w.pool[e] > w.pool[e + 1]) unsorted = 1;
+        for (int e = lane; e < total; e += 64) {
+            const int i = e & (P2 - 1);
+            if (i + 1 < P2 && w.pool[e] > w.pool[e + 1]) unsorted = 1;
         }
+        STAMP(*c.b, 31);
         if (__any(unsorted)) {
-            const int half = (int)P2 >> 1;
-            for (int k = 2; k <= (int)P2; k <<= 1) {
+            const int gh = g2 - 1;                               /* pairs per list = 1 << gh */
+            for (int k = 2; k <= P2; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int e = lane; e < nlist * half; e += 64) {
-                        const int lid = e / half, tt = e % half;
+                    for (int e = lane; e < (nlist << gh); e += 64) {
+                        const int lid = e >> gh, tt = e & ((1 << gh) - 1);
                         const int lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
                         const int hi = lo | j;
                         const bool up = (lo & k) == 0;
-                        float *base = w.pool + (size_t)lid * P2;
+                        float *base = w.pool + ((size_t)lid << g2);
                         const float a = base[lo], bb = base[hi];
                         if ((a > bb) == up) {
                             base[lo] = bb;
@@ -714,49 +734,106 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                 }
             }
         }
-        /* greedy cancellation (ModifiedPeptide.cpp:291-316): one task per lane */
-        const float err = cfg->mz_error;
-        for (int task = lane; task < ntask; task += 64) {
-            const int cc = c0 + task / T, t = task % T;
-            const int d = t < cfg->n_fwd ? 0 : 1;
-            const int na = (int)w.tot[0 * 2 + d] * c.zmax, nb = (int)w.tot[cc * 2 + d] * c.zmax;
-            const float *la = w.pool + (size_t)(task * 2) * P2;
-            const float *lb = la + P2;
-            uint8_t *ka = w.keep + (size_t)(task * 2) * P2;
-            uint8_t *kb = ka + P2;
-            int i = 0, j = 0;
-            while (i < na || j < nb) {
-                if (j == nb) {
-                    ka[i++] = 1;
-                } else if (i == na) {
-                    kb[j++] = 1;
-                } else {
-                    const float x = la[i], y = lb[j];
-                    if (__builtin_fabsf(x - y) < err) {
-                        ka[i++] = 0;
-                        kb[j++] = 0;
-                    } else if (x < y) {
-                        ka[i++] = 1;
-                    } else {
-                        kb[j++] = 1;
+        /* ---- cancel.  Site-determining ions = what the reference's greedy two-pointer walk
+         * over the two sorted lists leaves (ModifiedPeptide.cpp:291-316).  When every ion has at
+         * most one partner within mz_error in the other list, the walk cancels exactly those
+         * pairs and emits everything else (an unpaired ion is strictly below/above every ion it
+         * meets, because float subtraction is monotone) -- so pairs are found in parallel with
+         * one binary search per ion.  A task in which some ion has two partners is replayed with
+         * the serial walk, one task per lane. ---- */
+        STAMP(*c.b, 32);
+        uint64_t bad_tasks = 0;
+        for (int base = 0; base < total; base += 64) {           /* wave-uniform trip count */
+            const int e = base + lane;
+            bool multi = false;
+            if (e < total) {
+                const int lid = e >> g2, i = e & (P2 - 1);
+                const int side = lid & 1, task = lid >> 1;
+                const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
+                if (t < T) {
+                    const int d = t < cfg->n_fwd ? 0 : 1;
+                    const int M = (int)w.tot[(side ? cc : 0) * 2 + d] * c.zmax;
+                    const int Mo = (int)w.tot[(side ? 0 : cc) * 2 + d] * c.zmax;
+                    if (i < M) {
+                        const float me = w.pool[e];
+                        const float *other = w.pool + ((size_t)(lid ^ 1) << g2);
+                        /* diff is always (list A) - (list B), as the reference computes it.  Seen
+                         * from an A ion the B list ascends, so diff descends: skip B ions with
+                         * diff >= err.  Seen from a B ion diff ascends: skip A ions with diff <= -err. */
+                        int j = 0;
+                        for (int step = P2 >> 1; step > 0; step >>= 1) {
+                            const int probe = j + step;
+                            const float o = other[probe - 1];
+                            const float diff = side ? (o - me) : (me - o);
+                            const bool skip = side ? (diff <= -err) : (diff >= err);
+                            if (skip) j = probe;
+                        }
+                        int cnt = 0;
+                        for (int q = j; q < j + 2 && q < Mo; q++) {
+                            const float o = other[q];
+                            const float diff = side ? (o - me) : (me - o);
+                            cnt += (__builtin_fabsf(diff) < err) ? 1 : 0;
+                        }
+                        w.keep[e] = cnt == 0 ? 1 : 0;
+                        multi = cnt > 1;
                     }
                 }
             }
+            uint64_t rest = __ballot(multi);
+            while (rest) {
+                const int src = __builtin_ctzll(rest);
+                rest &= rest - 1;
+                bad_tasks |= 1ull << (((base + src) >> g2) >> 1);
+            }
         }
         wave_lds_sync();
-        /* match the surviving ions */
-        for (int e = lane; e < nlist * (int)P2; e += 64) {
-            const int lid = e / (int)P2, i = e % (int)P2;
+        STAMP(*c.b, 33);
+        if (bad_tasks) {
+            const int task = lane;                               /* (per_round << gt) <= 64 tasks */
+            if (task < (nlist >> 1) && ((bad_tasks >> task) & 1ull)) {
+                const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
+                const int d = t < cfg->n_fwd ? 0 : 1;
+                const int na = (int)w.tot[0 * 2 + d] * c.zmax, nb = (int)w.tot[cc * 2 + d] * c.zmax;
+                const float *la = w.pool + ((size_t)(task * 2) << g2);
+                const float *lb = la + P2;
+                uint8_t *ka = w.keep + ((size_t)(task * 2) << g2);
+                uint8_t *kb = ka + P2;
+                int i = 0, j = 0;
+                while (i < na || j < nb) {
+                    if (j == nb) {
+                        ka[i++] = 1;
+                    } else if (i == na) {
+                        kb[j++] = 1;
+                    } else {
+                        const float x = la[i], y = lb[j];
+                        if (__builtin_fabsf(x - y) < err) {
+                            ka[i++] = 0;
+                            kb[j++] = 0;
+                        } else if (x < y) {
+                            ka[i++] = 1;
+                        } else {
+                            kb[j++] = 1;
+                        }
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+        STAMP(*c.b, 37);
+        /* ---- match the surviving ions ---- */
+        for (int e = lane; e < total; e += 64) {
+            const int lid = e >> g2, i = e & (P2 - 1);
             const int side = lid & 1, task = lid >> 1;
-            const int cc = c0 + task / T, t = task % T;
-            const int s = side ? cc : 0, d = t < cfg->n_fwd ? 0 : 1;
-            const int M = (int)w.tot[s * 2 + d] * c.zmax;
+            const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
+            if (t >= T) continue;
+            const int M = (int)w.tot[(side ? cc : 0) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
             if (i < M && w.keep[e]) {
                 atomicAdd(&w.c_tr[cc * 2 + side], 1u);
                 if (match_rank(c.tab, w.pool[e]) <= w.c_depth[cc]) atomicAdd(&w.c_cnt[cc * 2 + side], 1u);
             }
         }
         wave_lds_sync();
+        STAMP(*c.b, 34);
     }
 }
 
@@ -804,11 +881,13 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
         return;
     }
 
+    STAMP_BEGIN();
     K3Lds lds = carve(lds_raw, peak_cap);
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
     stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl);
+    STAMP(b, 20);
 
     /* ---- sort (cpp/Ascore.cpp:141-146) ---- */
     SortLds srt;
@@ -825,7 +904,9 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
     wave_lds_sync();
     /* only the left spine of the partition tree decides the front element; the full sort is
      * needed when the caller wants the whole ordering */
-    sort_introsort_loop(srt, N, b.keep == 0);
+    STAMP(b, 21);
+    if (!(b.debug & 8)) sort_introsort_loop(srt, N, b.keep == 0);
+    STAMP(b, 22);
 
     /* front of the sorted list = left-most maximum of the partitioned array */
     uint32_t kmax = 0;
@@ -846,6 +927,7 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
     }
     wave_lds_sync();
 
+    STAMP(b, 23);
     /* ---- single-move competitors (cpp/Ascore.cpp:212-254) ---- */
     for (int pass = 0; pass < 2; pass++) {
         for (int base = 0; base < N; base += 64) {
@@ -870,8 +952,10 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
     const uint32_t n_pushed = *lds.n_pushed;
     int fail = 0;
     if (n_pushed > PYA_MAX_PUSHED) fail = 2;
-    const uint32_t np = n_pushed < PYA_MAX_PUSHED ? n_pushed : PYA_MAX_PUSHED;
+    uint32_t np = n_pushed < PYA_MAX_PUSHED ? n_pushed : PYA_MAX_PUSHED;
+    if (b.debug & 16) np = 0;
 
+    STAMP(b, 24);
     /* ---- Ascores, LOC_SB-1 competitors at a time ---- */
     const Residues res = load_residues(b, cfg, psm);
     ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap);
@@ -886,6 +970,7 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
     if (lane == 0) w.sig_mask[0] = deposit_sites(best_bits, res.site_mask);
     wave_lds_sync();
 
+    STAMP(b, 25);
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
     bool have_best = false;
@@ -911,14 +996,21 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
             }
             S++;
         }
+        STAMP(b, 26);
         if (S == 1) continue;
         wave_lds_sync();
-        loc_prefix_tables(ctx, S);
+        if (!(b.debug & 4)) loc_prefix_tables(ctx, S);
         wave_lds_sync();
-        loc_counts(ctx, have_best ? 1 : 0, S);
-        loc_scores(ctx, have_best ? 1 : 0, S, &fail);
+        STAMP(b, 27);
+        if (!(b.debug & 2)) {
+            loc_counts(ctx, have_best ? 1 : 0, S);
+            STAMP(b, 28);
+            loc_scores(ctx, have_best ? 1 : 0, S, &fail);
+            STAMP(b, 29);
+        }
         have_best = true;
-        loc_site_ions(ctx, S);
+        if (!(b.debug & 1)) loc_site_ions(ctx, S);
+        STAMP(b, 35);
         for (int cc = 1; cc < S; cc++) {
             const uint32_t tr0 = w.c_tr[cc * 2], tr1 = w.c_tr[cc * 2 + 1];
             const uint32_t n0 = w.c_cnt[cc * 2], n1 = w.c_cnt[cc * 2 + 1];
@@ -935,6 +1027,7 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
         }
         wave_lds_sync();
     }
+    STAMP(b, 36);
     if (lane < k && lane < (int)max_k) {
         out_asc[lane] = my_asc;
         out_alt[lane] = my_alt;
