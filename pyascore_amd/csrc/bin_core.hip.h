@@ -1,0 +1,130 @@
+/* bin_core.hip.h -- raw peaks of one spectrum -> retained-peak table in LDS (one wavefront).
+ * Shared by bin_spectra.hip and fused_small.hip; see bin_spectra.hip for the notes. */
+#ifndef PYA_BIN_CORE_H
+#define PYA_BIN_CORE_H
+#include "device_common.hip.h"
+
+/* LDS bytes the binning stage needs for a spectrum of up to `cap` peaks (cap multiple of 64) */
+DEV size_t bin_lds_bytes(uint32_t cap) { return (size_t)cap * (8 + 4 + 2 + 1); }
+
+/* Bins the spectrum of `psm` (Spectra.cpp:43-68, :24-41).  On return *out_mz / *out_rank point
+ * into `lds` and hold the retained peaks (ascending float32 m/z, rank inside their window);
+ * returns their count, or -1 with *status set.  Ends with an LDS sync. */
+DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
+                 const uint8_t **out_rank, int *status) {
+    const int lane = lane_id();
+    double *s_inten = (double *)lds;
+    float *s_mzf = (float *)(s_inten + cap);
+    uint16_t *s_bin = (uint16_t *)(s_mzf + cap);
+    uint8_t *s_rank = (uint8_t *)(s_bin + cap);
+
+    const int64_t p0 = b.peak_off[psm];
+    const int P = (int)(b.peak_off[psm + 1] - p0);
+    const double *mz = b.mz + p0;
+    const double *inten = b.inten + p0;
+    const DevConfig *cfg = b.cfg;
+
+    /* pass 1: min / max / sortedness (Spectra.cpp:46-47 use min_element / max_element) */
+    double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+    int unsorted = 0;
+    for (int i = lane; i < P; i += 64) {
+        double v = mz[i];
+        double nx = (i + 1 < P) ? mz[i + 1] : v;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+        unsorted |= (v > nx) ? 1 : 0;
+    }
+    mn = wave_min_f64(mn);
+    mx = wave_max_f64(mx);
+    unsorted = __any(unsorted);
+
+    const float min_mz = (float)(__builtin_floor(mn / 100.) * 100.);
+    const float max_mz = (float)(__builtin_ceil(mx / 100.) * 100.);
+    const float bin_size = cfg->bin_size;
+    const float nb_f = __builtin_ceilf((max_mz - min_mz) / bin_size);   /* float arithmetic, :48 */
+    *status = PYA_ST_OK;
+    if (!(nb_f >= 1.f)) *status = PYA_ST_NO_BINS;
+    if (nb_f > 65535.f) *status = PYA_ST_TOO_MANY_BINS;
+    if (*status != PYA_ST_OK) return -1;
+    const uint32_t n_bins = (uint32_t)nb_f;
+
+    /* pass 2: window id per peak (double arithmetic, Spectra.cpp:55-58) */
+    for (int i = lane; i < P; i += 64) {
+        double v = mz[i];
+        double q = __builtin_floor((v - (double)min_mz) / (double)bin_size);
+        uint32_t w = q >= (double)(n_bins - 1) ? n_bins - 1 : (uint32_t)q;
+        s_bin[i] = (uint16_t)w;
+        s_inten[i] = inten[i];
+        s_mzf[i] = (float)v;
+    }
+    wave_lds_sync();
+
+    /* pass 3: intensity rank inside the window = number of window mates that are more intense
+     * (ties: the earlier peak ranks first; the reference leaves ties unspecified). */
+    for (int base = 0; base < P; base += 64) {
+        int i = base + lane;
+        int cnt = PYA_NTOP;
+        if (i < P) {
+            const uint16_t w = s_bin[i];
+            const double me = s_inten[i];
+            cnt = 0;
+            if (!unsorted) {
+                for (int j = i - 1; j >= 0 && cnt < PYA_NTOP && s_bin[j] == w; j--)
+                    cnt += (s_inten[j] >= me) ? 1 : 0;
+                for (int j = i + 1; j < P && cnt < PYA_NTOP && s_bin[j] == w; j++)
+                    cnt += (s_inten[j] > me) ? 1 : 0;
+            } else {
+                for (int j = 0; j < P && cnt < PYA_NTOP; j++) {
+                    if (s_bin[j] != w || j == i) continue;
+                    double o = s_inten[j];
+                    cnt += (o > me || (o == me && j < i)) ? 1 : 0;
+                }
+            }
+        }
+        if (i < P) s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
+    }
+    wave_lds_sync();
+
+    /* pass 4: retained peaks in ascending float m/z, written over the (no longer needed)
+     * intensity array */
+    float *o_mz = (float *)s_inten;
+    uint8_t *o_rank = (uint8_t *)(o_mz + cap);
+    int total = 0;
+    if (!unsorted) {
+        for (int base = 0; base < P; base += 64) {
+            int i = base + lane;
+            bool keep = i < P && s_rank[i] < PYA_NTOP;
+            uint64_t m = __ballot(keep);
+            if (keep) {
+                int pos = total + __popcll(m & lanemask_lt());
+                o_mz[pos] = s_mzf[i];
+                o_rank[pos] = s_rank[i];
+            }
+            total += __popcll(m);
+        }
+    } else {
+        /* general order: position = number of retained peaks with a smaller (m/z, index) */
+        for (int base = 0; base < P; base += 64) {
+            int i = base + lane;
+            bool keep = i < P && s_rank[i] < PYA_NTOP;
+            if (keep) {
+                float me = s_mzf[i];
+                int pos = 0;
+                for (int j = 0; j < P; j++) {
+                    if (s_rank[j] >= PYA_NTOP) continue;
+                    float o = s_mzf[j];
+                    pos += (o < me || (o == me && j < i)) ? 1 : 0;
+                }
+                o_mz[pos] = me;
+                o_rank[pos] = s_rank[i];
+            }
+            total += __popcll(__ballot(keep));
+        }
+    }
+    wave_lds_sync();
+    *out_mz = o_mz;
+    *out_rank = o_rank;
+    return total;
+}
+
+#endif

@@ -1,0 +1,260 @@
+/* fused_small.hip -- the whole hot path in ONE kernel for PSMs with C(n,k) <= 64 site
+ * assignments (the bulk of real batches and BASELINE cfg1/cfg2/most of cfg3): one PSM per
+ * wavefront, raw peaks in, summary record out.
+ *
+ *   bin_core          raw peaks -> retained-peak table, kept in LDS (never written to HBM)
+ *   walk              one (signature, direction) walker per lane -> PepScore of every signature
+ *   sort emulation    front element of the reference's std::sort -> winner
+ *   loc_ascore_all    per-site Ascores from the site-determining ions of the tied best
+ *                     single-move competitors
+ *
+ * Same device code as the three-kernel path (bin_core / walk_core / localize_core headers); what
+ * the fusion removes is two kernel boundaries, the HBM round trips of the retained table and of
+ * the weighted scores, and the repeated staging of tables and residues.
+ *
+ * HBM traffic per PSM = the algorithmic bytes of SURVEY.md 8(d): 16 B per raw peak + peptide +
+ * offsets in, one summary record out (+ the L2-resident signature-order and score tables).
+ */
+#include "bin_core.hip.h"
+#include "walk_core.hip.h"
+#include "localize_core.hip.h"
+
+#define FUSED_MAX_SIG 64
+
+struct FusedLds {
+    uint16_t *nl_present;   /* [256] */
+    float *nl_uniq;         /* [PYA_MAX_UNIQ] */
+    uint16_t *grid;         /* [PYA_GRID_CELLS] */
+    uint32_t *pushed;       /* [PYA_MAX_PUSHED] */
+    uint32_t *site_max;     /* [64] */
+    uint32_t *n_pushed;     /* [4] */
+    float *ws_all;          /* [FUSED_MAX_SIG] weighted score per signature (pre-sort order) */
+    float *scores_all;      /* [FUSED_MAX_SIG * 10] */
+    unsigned char *work;    /* bin stage; afterwards retained table + scratch */
+};
+
+DEV size_t fused_fixed_bytes() {
+    return 512 + PYA_MAX_UNIQ * 4 + PYA_GRID_CELLS * 2 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + FUSED_MAX_SIG * 4 +
+           FUSED_MAX_SIG * 10 * 4;
+}
+
+extern "C" size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap) {
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_GRID_CELLS * 2 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 +
+                   FUSED_MAX_SIG * 4 + FUSED_MAX_SIG * 10 * 4;
+    size_t bin = (size_t)peak_cap * 15;
+    size_t table = ((size_t)peak_cap * 5 + 15) & ~(size_t)15;
+    size_t srt = (size_t)FUSED_MAX_SIG * 10 + 64;
+    size_t loc = 64 * 4 * 2 + 64 + LOC_SB * 8 + (size_t)LOC_SB * 2 * pos_cap * 8 + LOC_SB * 2 * 4 +
+                 LOC_SB * 11 * 4 + LOC_SB * 10 * 4 + LOC_SB * 4 * 2 + LOC_SB * 2 * 4 * 2 + (size_t)pool_cap * 5 + 64;
+    size_t after = table + (srt > loc ? srt : loc);
+    return fixed + (bin > after ? bin : after) + 64;
+}
+
+__global__ __launch_bounds__(64) void pya_fused_small_kernel(BatchDev b, const uint32_t *psm_ids,
+                                                             uint32_t n_ids, uint32_t peak_cap,
+                                                             uint32_t pos_cap, uint32_t pool_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (blockIdx.x >= n_ids) return;
+    const uint32_t psm = psm_ids[blockIdx.x];
+    const int lane = lane_id();
+    const DevConfig *cfg = b.cfg;
+    const int k = b.n_of_mod[psm];
+    const uint32_t max_k = b.max_k;
+    float *out_asc = b.ascores + (size_t)psm * max_k;
+    uint64_t *out_alt = b.alt_mask + (size_t)psm * max_k;
+    for (uint32_t a = lane; a < max_k; a += 64) {
+        out_asc[a] = 0.f;
+        out_alt[a] = 0ull;
+    }
+
+    FusedLds f;
+    f.nl_present = (uint16_t *)lds_raw;
+    f.grid = f.nl_present + 256;
+    f.nl_uniq = (float *)(f.grid + PYA_GRID_CELLS);
+    f.pushed = (uint32_t *)(f.nl_uniq + PYA_MAX_UNIQ);
+    f.site_max = f.pushed + PYA_MAX_PUSHED;
+    f.n_pushed = f.site_max + 64;
+    f.ws_all = (float *)(f.n_pushed + 4);
+    f.scores_all = f.ws_all + FUSED_MAX_SIG;
+    f.work = (unsigned char *)(f.scores_all + FUSED_MAX_SIG * 10);
+
+    /* ---- 1. spectrum -> retained-peak table (stays in LDS) ---- */
+    STAMP_BEGIN();
+    LocCtx ctx;
+    ctx.b = &b;
+    ctx.cfg = cfg;
+    int status;
+    const int R = bin_core(b, psm, f.work, peak_cap, &ctx.tab.mz, &ctx.tab.rank, &status);
+    if (R < 0) {
+        if (lane == 0) {
+            b.status[psm] = status;
+            b.best_score[psm] = -1.f;
+            b.best_sig[psm] = 0ull;
+            b.n_sig_out[psm] = -1;
+        }
+        return;
+    }
+    STAMP(b, 1);
+    ctx.tab.n = R;
+    ctx.tab.err = cfg->mz_error;
+    ctx.nl.n_nl = cfg->n_nl;
+    ctx.nl.present = f.nl_present;
+    ctx.nl.uniq = f.nl_uniq;
+    if (ctx.nl.n_nl) {
+        for (int i = lane; i < 256; i += 64) f.nl_present[i] = cfg->present[i];
+        if (lane < PYA_MAX_UNIQ) f.nl_uniq[lane] = cfg->uniq[lane];
+    }
+    grid_build(&ctx.tab, f.grid);
+    if (lane == 0) *f.n_pushed = 0;
+    f.site_max[lane] = 0;
+    unsigned char *scratch = f.work + (((size_t)peak_cap * 5 + 15) & ~(size_t)15);
+
+    /* ---- 2. PepScore of every signature ---- */
+    const Residues res = load_residues(b, cfg, psm);
+    const int N = (int)b.n_sig[psm];
+    const int n_sites = __popcll(res.site_mask);
+    const uint64_t *order = b.order_tab + b.order_off[psm];
+    WalkEnv env;
+    env.cfg = cfg;
+    env.n_nl = ctx.nl.n_nl;
+    env.nl_present = f.nl_present;
+    env.nl_uniq = f.nl_uniq;
+    env.L = res.L;
+    env.zmax = b.max_charge[psm];
+    wave_lds_sync();
+    STAMP(b, 2);
+
+    int fail = 0;
+    float my_ws = -1.f;
+    uint64_t my_bits = 0ull;
+    if (N > 0) {
+        const bool both_dirs = cfg->n_fwd > 0 && cfg->n_fwd < cfg->n_types;
+        const bool split = N <= 32 && both_dirs;
+        const int s = split ? (lane & 31) : lane;
+        const bool active = s < N;
+        my_bits = active ? order[s] : 0ull;
+        const uint64_t resmask = deposit_sites(my_bits, res.site_mask);
+        Hist h = {0ull, 0ull, 0ull};
+        uint32_t nfrag = 0;
+        if (split) {
+            walk(env, res, ctx.tab, resmask, lane >> 5, active, h, nfrag);
+            fold_upper_half(h, nfrag);
+        } else {
+            if (cfg->n_fwd > 0) walk(env, res, ctx.tab, resmask, 0, active, h, nfrag);
+            if (cfg->n_fwd < cfg->n_types) walk(env, res, ctx.tab, resmask, 1, active, h, nfrag);
+        }
+        if (active && (!split || lane < 32)) {
+            uint32_t acc = 0;
+            double sum = 0.;
+            const bool ok = nfrag <= b.lut_n_max;
+            const uint32_t off = ok ? b.lut_off[nfrag] : 0u;
+            if (!ok) fail = 1;
+#pragma unroll
+            for (int d = 0; d < PYA_NTOP; d++) {
+                acc += hist_get(h, d);
+                const float sc = ok ? b.lut[off + (uint32_t)d * (nfrag + 1) + acc] : 0.f;
+                f.scores_all[s * 10 + d] = sc;
+                const float prod = cfg->weights[d] * sc;                 /* float product ...   */
+                sum = sum + (double)prod;                                /* ... double sum      */
+            }
+            my_ws = ok ? (float)sum : -1.f;
+            f.ws_all[s] = my_ws;
+        }
+    }
+    wave_lds_sync();
+    STAMP(b, 3);
+
+    /* Ascore::isUnambiguous, cpp/Ascore.cpp:38-51 */
+    if (k >= n_sites) {
+        for (int a = lane; a < k && a < (int)max_k; a += 64) out_asc[a] = __builtin_huge_valf();
+        const bool any_fail = __any(fail != 0);
+        if (lane == 0) {
+            b.best_score[psm] = N > 0 ? f.ws_all[0] : -1.f;
+            b.best_sig[psm] = N > 0 ? order[0] : 0ull;
+            b.n_sig_out[psm] = N;
+            b.status[psm] = any_fail ? PYA_ST_LUT_RANGE : PYA_ST_OK;
+        }
+        return;
+    }
+
+    /* ---- 3. winner = front of the reference's sort (cpp/Ascore.cpp:141-146) ---- */
+    SortLds srt;
+    srt.key = (float *)scratch;
+    srt.idx = (uint16_t *)(srt.key + N);
+    srt.lpos = srt.idx + N;
+    srt.rpos = srt.lpos + N;
+    if (lane < N) {
+        srt.key[lane] = f.ws_all[lane];
+        srt.idx[lane] = (uint16_t)lane;
+    }
+    wave_lds_sync();
+    sort_introsort_loop(srt, N, true);
+    uint32_t u = lane < N ? __float_as_uint(srt.key[lane]) : 0u;        /* scores >= 0 */
+    const uint32_t kmax = wave_max_u32(u);
+    const uint32_t first_pos = wave_min_u32((lane < N && u == kmax) ? (uint32_t)lane : 0xffffffffu);
+    const uint32_t best_i = srt.idx[first_pos];
+    const float best_ws = __uint_as_float(kmax);
+    const uint64_t best_bits = order[best_i];
+    wave_lds_sync();
+    STAMP(b, 4);
+
+    /* ---- 4. best single-move competitors per modified site (cpp/Ascore.cpp:212-254) ---- */
+    {
+        const bool in = lane < N;
+        const uint64_t c = in ? order[lane] : 0ull;
+        const uint64_t gone = best_bits & ~c, came = c & ~best_bits;
+        const bool single = in && __popcll(gone) == 1 && __popcll(came) == 1;
+        const int a = single ? __popcll(best_bits & (gone - 1)) : 0;
+        const uint32_t wbits = in ? __float_as_uint(f.ws_all[lane]) : 0u;
+        if (single) atomicMax(&f.site_max[a], wbits);
+        wave_lds_sync();
+        if (single && wbits == f.site_max[a]) {
+            const uint32_t slot = atomicAdd(f.n_pushed, 1u);
+            if (slot < PYA_MAX_PUSHED) f.pushed[slot] = (uint32_t)lane;
+        }
+        wave_lds_sync();
+    }
+    const uint32_t np = *f.n_pushed;                    /* <= 64 < PYA_MAX_PUSHED */
+    STAMP(b, 5);
+
+    /* ---- 5. Ascores ---- */
+    ctx.w = loc_carve(scratch, pos_cap, pool_cap);
+    ctx.L = res.L;
+    ctx.zmax = env.zmax;
+    ctx.pos_cap = pos_cap;
+    ctx.pool_cap = pool_cap;
+    ctx.w.m0[lane] = res.m0;
+    ctx.w.m1[lane] = res.m1;
+    ctx.w.nlp[lane] = (uint8_t)res.nl;
+    if (lane == 0) ctx.w.sig_mask[0] = deposit_sites(best_bits, res.site_mask);
+    wave_lds_sync();
+    float my_asc = __builtin_huge_valf();
+    uint64_t my_alt = 0ull;
+    loc_ascore_all(ctx, f.pushed, np, order, f.ws_all, f.scores_all, best_bits, best_ws, best_i,
+                   res.site_mask, &my_asc, &my_alt, &fail);
+    STAMP(b, 6);
+    if (lane < k && lane < (int)max_k) {
+        out_asc[lane] = my_asc;
+        out_alt[lane] = my_alt;
+    }
+    const bool any_fail = __any(fail != 0);
+    if (lane == 0) {
+        b.best_score[psm] = best_ws;
+        b.best_sig[psm] = best_bits;
+        b.n_sig_out[psm] = N;
+        b.status[psm] = any_fail ? PYA_ST_LUT_RANGE : PYA_ST_OK;
+    }
+}
+
+extern "C" int pya_launch_fused_small(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids,
+                                      uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap,
+                                      hipStream_t stream) {
+    if (n_ids == 0) return 0;
+    size_t lds = pya_fused_lds_bytes(peak_cap, pos_cap, pool_cap);
+    hipError_t e = hipFuncSetAttribute((const void *)pya_fused_small_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pya_fused_small_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, peak_cap,
+                       pos_cap, pool_cap);
+    return (int)hipGetLastError();
+}

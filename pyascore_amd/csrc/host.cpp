@@ -33,7 +33,10 @@ extern "C" {
 size_t pya_bin_lds_bytes(uint32_t cap);
 size_t pya_score_lds_bytes(uint32_t cap);
 size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap);
-int pya_launch_bin(const BatchDev *b, uint32_t n_psm, uint32_t cap, hipStream_t stream);
+int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
+size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap);
+int pya_launch_fused_small(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
+                           uint32_t pos_cap, uint32_t pool_cap, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                      hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
@@ -197,6 +200,8 @@ struct pya_plan {
     DevBuf<float> d_aux_mass, d_ret_mz, d_ws;
     DevBuf<uint8_t> d_ret_rank;
     Bucket buckets[kNumBuckets];
+    Bucket fused;                       /* C(n,k) <= 64: whole path in one kernel */
+    Bucket unfused_all;                 /* ids of every PSM on the three-kernel path (for bin_spectra) */
     /* owned copies of inputs/outputs (pya_score_batch path) */
     DevBuf<double> d_mz, d_inten;
     DevBuf<float> d_best_score, d_ascores;
@@ -204,7 +209,7 @@ struct pya_plan {
     DevBuf<int32_t> d_n_sig_out;
     DevBuf<unsigned long long> d_stamps;
     BatchDev dev;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t last_stream = nullptr;
     bool ran = false;
 
@@ -219,6 +224,7 @@ struct pya_plan {
                      d_ret_n.bytes() + d_rec.bytes() + d_sorted.bytes() + d_aux_mass.bytes() +
                      d_ret_mz.bytes() + d_ws.bytes() + d_ret_rank.bytes();
         for (const Bucket &k : buckets) b += k.d_ids.bytes();
+        b += fused.d_ids.bytes() + unfused_all.d_ids.bytes();
         return b;
     }
 };
@@ -592,6 +598,9 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
     p->sig_off.resize(n + 1);
     const uint32_t n_uniq = (uint32_t)h->cfg.n_uniq, n_types = (uint32_t)h->cfg.n_types;
     uint32_t max_P = 1, lut_need = 0, max_k = 1;
+    /* The one-kernel path is parity-tested but measures slower than the three-kernel path at
+     * its current LDS/VGPR footprint (profiles/r01_b): opt-in until that is fixed. */
+    const bool use_fused = !(flags & PYA_FLAG_KEEP) && std::getenv("PYA_FUSE") != nullptr;
     int64_t sig_total = 0;
     for (uint64_t i = 0; i < n; i++) {
         const int64_t P = p->peak_off[i + 1] - p->peak_off[i];
@@ -643,7 +652,15 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
                            (unsigned long long)i, per_type, PYA_MAX_LIST);
         lut_need = std::max(lut_need, per_type * n_types);
         if ((uint32_t)k > max_k) max_k = (uint32_t)k;
-        if (N > 0 && (uint32_t)k < ns) {
+        const bool fuse = use_fused && N <= 64;
+        if (fuse) {
+            Bucket &bk = p->fused;
+            bk.ids.push_back((uint32_t)i);
+            bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
+            bk.list_cap = std::max<uint32_t>(bk.list_cap, next_pow2(std::max<uint32_t>(per_type, 1)));
+            bk.pos_cap = std::max<uint32_t>(bk.pos_cap, (uint32_t)std::max<int64_t>(L - 1, 1));
+            bk.n_types = n_types;
+        } else if (N > 0 && (uint32_t)k < ns) {
             int bi = 0;
             while (N > kBucketLimits[bi]) bi++;
             Bucket &bk = p->buckets[bi];
@@ -657,6 +674,7 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
             bk.ids.push_back((uint32_t)i);
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
         }
+        if (!fuse) p->unfused_all.ids.push_back((uint32_t)i);
     }
     p->sig_off[n] = sig_total;
     p->total_sigs = sig_total;
@@ -668,6 +686,14 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
         HIPCHK(h, h->d_order.upload(h->order_tab.data(), h->order_tab.size()));
         h->order_uploaded = h->order_tab.size();
     }
+    if (!p->fused.ids.empty()) {
+        size_t need = pya_fused_lds_bytes(p->peak_cap, p->fused.pos_cap, p->fused.pool_cap());
+        if (need > kMaxLds)
+            return h->fail(PYA_ERR_LIMIT, (int64_t)p->fused.ids[0], "LDS budget exceeded (%zu bytes) on the fused path", need);
+        HIPCHK(h, p->fused.d_ids.upload(p->fused.ids.data(), p->fused.ids.size()));
+    }
+    if (!p->unfused_all.ids.empty())
+        HIPCHK(h, p->unfused_all.d_ids.upload(p->unfused_all.ids.data(), p->unfused_all.ids.size()));
     for (Bucket &bk : p->buckets) {
         if (bk.ids.empty()) continue;
         size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap());
@@ -729,7 +755,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     d.max_k = o->max_k;
     const bool timing = p->flags & PYA_FLAG_TIMING;
     if (timing) HIPCHK(h, hipEventRecord(p->ev[0], st));
-    int e = pya_launch_bin(&d, (uint32_t)p->n_psm, p->peak_cap, st);
+    int e = pya_launch_bin(&d, p->unfused_all.d_ids.p, (uint32_t)p->unfused_all.ids.size(), p->peak_cap, st);
     if (e) return h->hip_fail((hipError_t)e, "bin_spectra launch");
     if (timing) HIPCHK(h, hipEventRecord(p->ev[1], st));
     for (Bucket &bk : p->buckets) {
@@ -742,18 +768,22 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
+    e = pya_launch_fused_small(&d, p->fused.d_ids.p, (uint32_t)p->fused.ids.size(), p->peak_cap, p->fused.pos_cap,
+                               p->fused.pool_cap(), st);
+    if (e) return h->hip_fail((hipError_t)e, "fused_small launch");
+    if (timing) HIPCHK(h, hipEventRecord(p->ev[4], st));
     p->last_stream = st;
     p->ran = true;
     p->dev = d;
     return PYA_OK;
 }
 
-int pya_plan_timings(pya_plan *p, float ms[3]) {
+int pya_plan_timings(pya_plan *p, float ms[4]) {
     if (!p || !ms) return PYA_ERR_ARG;
     pya_handle *h = p->h;
     if (!(p->flags & PYA_FLAG_TIMING) || !p->ran) return h->fail(PYA_ERR_STATE, -1, "plan has no timing events");
-    HIPCHK(h, hipEventSynchronize(p->ev[3]));
-    for (int i = 0; i < 3; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
+    HIPCHK(h, hipEventSynchronize(p->ev[4]));
+    for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
     return PYA_OK;
 }
 

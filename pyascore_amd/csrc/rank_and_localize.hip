@@ -19,471 +19,7 @@
  * lane 0) and matched against the retained-peak table in parallel.
  */
 #include "device_common.hip.h"
-
-/* ======================================================================================= */
-/* std::sort emulation                                                                      */
-/* ======================================================================================= */
-struct SortLds {
-    float *key;       /* [N] */
-    uint16_t *idx;    /* [N] */
-    uint16_t *lpos;   /* [N] */
-    uint16_t *rpos;   /* [N] */
-};
-
-DEV void sort_swap(const SortLds &s, int i, int j) {
-    float k = s.key[i];
-    s.key[i] = s.key[j];
-    s.key[j] = k;
-    uint16_t t = s.idx[i];
-    s.idx[i] = s.idx[j];
-    s.idx[j] = t;
-}
-
-/* libstdc++ __adjust_heap / __push_heap with comp(a,b) = key[a] > key[b]; lane 0 only */
-DEV void heap_adjust(const SortLds &s, int first, int hole, int len, float vk, uint16_t vi) {
-    const int top = hole;
-    int child = hole;
-    while (child < (len - 1) / 2) {
-        child = 2 * (child + 1);
-        if (s.key[first + child] > s.key[first + child - 1]) child--;
-        s.key[first + hole] = s.key[first + child];
-        s.idx[first + hole] = s.idx[first + child];
-        hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-        child = 2 * (child + 1);
-        s.key[first + hole] = s.key[first + child - 1];
-        s.idx[first + hole] = s.idx[first + child - 1];
-        hole = child - 1;
-    }
-    int parent = (hole - 1) / 2;
-    while (hole > top && s.key[first + parent] > vk) {
-        s.key[first + hole] = s.key[first + parent];
-        s.idx[first + hole] = s.idx[first + parent];
-        hole = parent;
-        parent = (hole - 1) / 2;
-    }
-    s.key[first + hole] = vk;
-    s.idx[first + hole] = vi;
-}
-
-/* __partial_sort(first, last, last) = make_heap + sort_heap; lane 0 only */
-DEV void heap_sort_serial(const SortLds &s, int first, int last) {
-    int len = last - first;
-    if (len < 2) return;
-    for (int parent = (len - 2) / 2;; parent--) {
-        float vk = s.key[first + parent];
-        uint16_t vi = s.idx[first + parent];
-        heap_adjust(s, first, parent, len, vk, vi);
-        if (parent == 0) break;
-    }
-    while (last - first > 1) {
-        --last;
-        float vk = s.key[last];
-        uint16_t vi = s.idx[last];
-        s.key[last] = s.key[first];
-        s.idx[last] = s.idx[first];
-        heap_adjust(s, first, 0, last - first, vk, vi);
-    }
-}
-
-/* __unguarded_partition_pivot(first=f, last=l); returns the cut.  Wave-cooperative. */
-DEV int sort_partition(const SortLds &s, int f, int l) {
-    const int lane = lane_id();
-    const int mid = f + (l - f) / 2;
-    /* __move_median_to_first(f, f+1, mid, l-1) */
-    {
-        const float a = s.key[f + 1], b = s.key[mid], c = s.key[l - 1];
-        int pick;
-        if (a > b) {
-            if (b > c) pick = mid;
-            else if (a > c) pick = l - 1;
-            else pick = f + 1;
-        } else if (a > c) pick = f + 1;
-        else if (b > c) pick = l - 1;
-        else pick = mid;
-        wave_lds_sync();
-        if (lane == 0) sort_swap(s, f, pick);
-        wave_lds_sync();
-    }
-    const float pv = s.key[f];
-    /* stops of the left cursor: positions in [f+1, l) ascending whose key is NOT > pivot */
-    int nL = 0;
-    for (int base = f + 1; base < l; base += 64) {
-        const int i = base + lane;
-        const bool stop = i < l && !(s.key[i] > pv);
-        const uint64_t m = __ballot(stop);
-        if (stop) s.lpos[nL + __popcll(m & lanemask_lt())] = (uint16_t)i;
-        nL += __popcll(m);
-    }
-    /* stops of the right cursor: positions in [f, l) descending for which pivot is NOT > key */
-    int nR = 0;
-    for (int base = l - 1; base >= f; base -= 64) {
-        const int i = base - lane;
-        const bool stop = i >= f && !(pv > s.key[i]);
-        const uint64_t m = __ballot(stop);
-        if (stop) s.rpos[nR + __popcll(m & lanemask_lt())] = (uint16_t)i;
-        nR += __popcll(m);
-    }
-    wave_lds_sync();
-    /* pair the r-th stops; they are exchanged while the cursors have not met */
-    const int np = nL < nR ? nL : nR;
-    int m_sw = 0;
-    for (int base = 0; base < np; base += 64) {
-        const int r = base + lane;
-        bool sw = false;
-        int a = 0, b = 0;
-        if (r < np) {
-            a = s.lpos[r];
-            b = s.rpos[r];
-            sw = a < b;
-        }
-        if (sw) sort_swap(s, a, b);
-        m_sw += __popcll(__ballot(sw));
-    }
-    const int cand_l = m_sw < nL ? (int)s.lpos[m_sw] : 0x7fffffff;
-    const int cand_r = m_sw >= 1 ? (int)s.rpos[m_sw - 1] : l;
-    wave_lds_sync();
-    return cand_l < cand_r ? cand_l : cand_r;
-}
-
-/* Runs the introsort phase in place.  Afterwards the array is partitioned into runs of <= 16
- * (or heap-sorted runs) exactly as libstdc++ leaves it before __final_insertion_sort. */
-DEV void sort_introsort_loop(const SortLds &s, int N, bool spine_only) {
-    if (N <= 16) return;
-    const int lane = lane_id();
-    int depth0 = 0;
-    for (int t = N; t > 1; t >>= 1) depth0++;
-    depth0 *= 2;
-    /* explicit stack, one entry per lane */
-    int st_f = 0, st_l = 0, st_d = 0;
-    int sp = 0;
-    if (lane == sp) { st_f = 0; st_l = N; st_d = depth0; }
-    sp = 1;
-    while (sp > 0) {
-        sp--;
-        int f = __shfl(st_f, sp, 64), l = __shfl(st_l, sp, 64), d = __shfl(st_d, sp, 64);
-        while (l - f > 16) {
-            if (d == 0) {
-                wave_lds_sync();
-                if (lane == 0) heap_sort_serial(s, f, l);
-                wave_lds_sync();
-                break;
-            }
-            d--;
-            const int cut = sort_partition(s, f, l);
-            if (!spine_only) {
-                if (lane == sp) { st_f = cut; st_l = l; st_d = d; }
-                sp++;
-            }
-            l = cut;
-        }
-    }
-    wave_lds_sync();
-}
-
-/* final position of element i after the closing (stable) insertion sort */
-DEV int sort_final_pos(const SortLds &s, int i, int N) {
-    const float me = s.key[i];
-    int pos = i;
-    const int lo = i - 15 < 0 ? 0 : i - 15;
-    const int hi = i + 15 >= N ? N - 1 : i + 15;
-    for (int j = lo; j < i; j++) pos -= (me > s.key[j]) ? 1 : 0;     /* moves ahead of smaller keys */
-    for (int j = i + 1; j <= hi; j++) pos += (s.key[j] > me) ? 1 : 0;
-    return pos;
-}
-
-/* ======================================================================================= */
-/* signature -> fragments, one prefix length per lane                                       */
-/* ======================================================================================= */
-struct NlTables {
-    const uint16_t *present;  /* LDS [256] */
-    const float *uniq;        /* LDS [PYA_MAX_UNIQ] */
-    int n_nl;
-};
-
-struct Prefix {
-    float running;            /* float32 running sum of the lane's prefix                    */
-    uint32_t pm;              /* bit set of neutral-loss sums that exist for the prefix      */
-};
-
-/* lane i <-> fragment of i+1 residues in direction `dir` of the signature `resmask` */
-DEV Prefix prefix_state(const Residues &res, uint64_t resmask, int dir, const NlTables &nl) {
-    const int lane = lane_id();
-    const int L = res.L;
-    float running = 0.f;
-    uint32_t st = 0;
-    for (int step = 0; step + 1 < L; step++) {
-        const int ri = dir == 0 ? step : L - 1 - step;
-        const float m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), ri));
-        const float m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), ri));
-        const uint32_t nlp = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, ri);
-        const bool mod = (resmask >> ri) & 1ull;
-        const float r = mod ? m1 : m0;
-        const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
-        if (step <= lane) {
-            running = step == 0 ? r : r + running;
-            if (cls) st = nl_bump(st, cls);
-        }
-    }
-    Prefix p;
-    p.running = running;
-    p.pm = (lane + 1 < L) ? (nl.n_nl ? (uint32_t)nl.present[st & 255u] : 1u) : 0u;
-    return p;
-}
-
-/* PepScore ingredients of one signature: cumulative counts and total fragments (wave-uniform) */
-DEV void signature_counts(const Residues &res, const DevConfig *cfg, const NlTables &nl,
-                          const PeakTable &tab, uint64_t resmask, int zmax, uint32_t cum[PYA_NTOP],
-                          uint32_t *nfrag_out) {
-    Hist h = {0ull, 0ull, 0ull};
-    int nfrag = 0;
-    for (int dir = 0; dir < 2; dir++) {
-        const int t0 = dir == 0 ? 0 : cfg->n_fwd;
-        const int t1 = dir == 0 ? cfg->n_fwd : cfg->n_types;
-        if (t0 == t1) continue;
-        Prefix p = prefix_state(res, resmask, dir, nl);
-        uint32_t pm = p.pm;
-        while (__any(pm != 0)) {
-            const bool on = pm != 0;
-            const int v = on ? __builtin_ctz(pm) : 0;
-            pm &= pm - 1;
-            const float x = p.running - (nl.n_nl ? nl.uniq[v] : 0.f);
-            const double xd = (double)x;
-            for (int t = t0; t < t1; t++) {
-                const double m = type_offset(xd, cfg->types[t]);
-                for (int z = 1; z <= zmax; z++) {
-                    const float fmz = charge_mz(m, z);
-                    if (on) {
-                        hist_add(h, match_rank(tab, fmz));
-                        nfrag++;
-                    }
-                }
-            }
-        }
-    }
-    h = hist_wave_sum(h);
-    *nfrag_out = (uint32_t)wave_sum_i32(nfrag);
-    uint32_t acc = 0;
-#pragma unroll
-    for (int d = 0; d < PYA_NTOP; d++) {
-        acc += hist_get(h, d);
-        cum[d] = acc;
-    }
-}
-
-/* all fragments of (signature, type) over charges 1..zmax into list[]; returns the count */
-DEV int fragment_list(const Residues &res, const DevConfig *cfg, const NlTables &nl, uint64_t resmask,
-                      uint8_t type, int zmax, float *list) {
-    const int dir = (type == 'b' || type == 'c') ? 0 : 1;
-    Prefix p = prefix_state(res, resmask, dir, nl);
-    const int mine = __popc(p.pm) * zmax;
-    int total;
-    int off = wave_excl_scan_i32(mine, &total);
-    uint32_t pm = p.pm;
-    while (pm) {
-        const int v = __builtin_ctz(pm);
-        pm &= pm - 1;
-        const float x = p.running - (nl.n_nl ? nl.uniq[v] : 0.f);
-        const double m = type_offset((double)x, type);
-        for (int z = 1; z <= zmax; z++) list[off++] = charge_mz(m, z);
-    }
-    return total;
-}
-
-/* ascending bitonic sort of list[0..n) in LDS; list has room for the next power of two */
-DEV int bitonic_sort(float *list, int n) {
-    const int lane = lane_id();
-    int p2 = 1;
-    while (p2 < n) p2 <<= 1;
-    for (int i = n + lane; i < p2; i += 64) list[i] = __builtin_huge_valf();
-    wave_lds_sync();
-    for (int k = 2; k <= p2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < (p2 >> 1); t += 64) {
-                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int hi = lo | j;
-                const bool up = (lo & k) == 0;
-                const float a = list[lo], b = list[hi];
-                if ((a > b) == up) {
-                    list[lo] = b;
-                    list[hi] = a;
-                }
-            }
-            wave_lds_sync();
-        }
-    }
-    return p2;
-}
-
-struct AmbLds {
-    float *la;          /* [list_cap] */
-    float *lb;          /* [list_cap] */
-    uint8_t *ka;        /* [list_cap] */
-    uint8_t *kb;        /* [list_cap] */
-};
-
-/* Ascore::calculateAmbiguity (cpp/Ascore.cpp:157-210).  Scores are passed in (wave-uniform). */
-DEV float ambiguity(const BatchDev &b, const Residues &res, const DevConfig *cfg, const NlTables &nl,
-                    const PeakTable &tab, const AmbLds &w, int zmax, uint64_t ref_mask,
-                    const float ref_scores[PYA_NTOP], float ref_ws, uint64_t oth_mask,
-                    const float oth_scores[PYA_NTOP], float oth_ws, int *fail) {
-    const int lane = lane_id();
-    if ((double)__builtin_fabsf(ref_ws - oth_ws) < 1e-6) return 0.f;
-    float best = 0.f;
-    int depth = 0;
-#pragma unroll
-    for (int d = 0; d < PYA_NTOP; d++) {
-        const float diff = ref_scores[d] - oth_scores[d];
-        if (diff > best) {
-            best = diff;
-            depth = d;
-        }
-    }
-    int cnt0 = 0, cnt1 = 0, tr0 = 0, tr1 = 0;
-    const float err = cfg->mz_error;
-    for (int t = 0; t < cfg->n_types; t++) {
-        const uint8_t type = cfg->types[t];
-        wave_lds_sync();
-        const int na = fragment_list(res, cfg, nl, ref_mask, type, zmax, w.la);
-        const int nb = fragment_list(res, cfg, nl, oth_mask, type, zmax, w.lb);
-        wave_lds_sync();
-        bitonic_sort(w.la, na);
-        bitonic_sort(w.lb, nb);
-        /* greedy cancellation, ModifiedPeptide.cpp:291-316 */
-        if (lane == 0) {
-            int i = 0, j = 0;
-            while (i < na || j < nb) {
-                if (j == nb) {
-                    w.ka[i++] = 1;
-                } else if (i == na) {
-                    w.kb[j++] = 1;
-                } else {
-                    const float x = w.la[i], y = w.lb[j];
-                    if (__builtin_fabsf(x - y) < err) {
-                        w.ka[i++] = 0;
-                        w.kb[j++] = 0;
-                    } else if (x < y) {
-                        w.ka[i++] = 1;
-                    } else {
-                        w.kb[j++] = 1;
-                    }
-                }
-            }
-        }
-        wave_lds_sync();
-        for (int i = lane; i < na; i += 64) {
-            if (w.ka[i]) {
-                tr0++;
-                cnt0 += match_rank(tab, w.la[i]) <= depth ? 1 : 0;
-            }
-        }
-        for (int j = lane; j < nb; j += 64) {
-            if (w.kb[j]) {
-                tr1++;
-                cnt1 += match_rank(tab, w.lb[j]) <= depth ? 1 : 0;
-            }
-        }
-    }
-    cnt0 = wave_sum_i32(cnt0);
-    cnt1 = wave_sum_i32(cnt1);
-    tr0 = wave_sum_i32(tr0);
-    tr1 = wave_sum_i32(tr1);
-    if ((uint32_t)tr0 > b.lut_n_max || (uint32_t)tr1 > b.lut_n_max) {
-        *fail = 1;
-        return 0.f;
-    }
-    const float s0 = b.lut[b.lut_off[tr0] + (uint32_t)depth * (uint32_t)(tr0 + 1) + (uint32_t)cnt0];
-    const float s1 = b.lut[b.lut_off[tr1] + (uint32_t)depth * (uint32_t)(tr1 + 1) + (uint32_t)cnt1];
-    return s0 - s1;
-}
-
-DEV void scores_from_counts(const BatchDev &b, const uint32_t cum[PYA_NTOP], uint32_t nfrag,
-                            float out[PYA_NTOP], int *fail) {
-    if (nfrag > b.lut_n_max) {
-        *fail = 1;
-#pragma unroll
-        for (int d = 0; d < PYA_NTOP; d++) out[d] = 0.f;
-        return;
-    }
-    const uint32_t off = b.lut_off[nfrag];
-#pragma unroll
-    for (int d = 0; d < PYA_NTOP; d++) out[d] = b.lut[off + (uint32_t)d * (nfrag + 1) + cum[d]];
-}
-
-DEV int nth_set_bit(uint64_t m, int n) {
-    for (int i = 0; i < n; i++) m &= m - 1;
-    return __builtin_ctzll(m);
-}
-
-/* LDS carve-up shared by the localisation and the ambiguity kernels */
-struct K3Lds {
-    uint16_t *nl_present;
-    float *nl_uniq;
-    float *t_mz;
-    uint8_t *t_rank;
-    uint32_t *pushed;        /* [PYA_MAX_PUSHED] */
-    uint32_t *site_max;      /* [64] */
-    uint32_t *n_pushed;      /* [1]  */
-    uint16_t *grid;          /* [PYA_GRID_CELLS] */
-    unsigned char *scratch;  /* sort arrays, later the localisation work area */
-};
-
-DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
-    K3Lds k;
-    k.nl_present = (uint16_t *)raw;
-    k.nl_uniq = (float *)(k.nl_present + 256);
-    k.pushed = (uint32_t *)(k.nl_uniq + PYA_MAX_UNIQ);
-    k.site_max = k.pushed + PYA_MAX_PUSHED;
-    k.n_pushed = k.site_max + 64;
-    k.grid = (uint16_t *)(k.n_pushed + 4);
-    k.t_mz = (float *)(k.grid + PYA_GRID_CELLS);
-    k.t_rank = (uint8_t *)(k.t_mz + peak_cap);
-    k.scratch = (unsigned char *)(k.t_rank + ((peak_cap + 15u) & ~15u));
-    return k;
-}
-
-#define LOC_SB 8               /* signatures worked on together: the winner + 7 competitors */
-
-/* work area of the batched localisation (aliases the sort arrays) */
-struct LocLds {
-    float *m0, *m1;           /* [64] residue masses                                      */
-    uint8_t *nlp;             /* [64] NL classes                                          */
-    uint64_t *sig_mask;       /* [LOC_SB] residue masks, entry 0 = winner                 */
-    float *run;               /* [LOC_SB*2*pos_cap] running sums per (sig, dir, prefix)   */
-    uint16_t *pmk;            /* same shape: neutral-loss sums present                    */
-    uint16_t *cpre;           /* same shape: exclusive count of variants before prefix    */
-    uint32_t *tot;            /* [LOC_SB*2] variants per (sig, dir)                        */
-    uint32_t *hist;           /* [LOC_SB*11] rank histogram + total fragments             */
-    float *scores;            /* [LOC_SB*10]                                              */
-    uint32_t *c_idx;          /* [LOC_SB] pre-sort index of the competitor                */
-    int32_t *c_depth;         /* [LOC_SB]                                                 */
-    uint32_t *c_cnt;          /* [LOC_SB*2] matched site-determining ions (ref, other)    */
-    uint32_t *c_tr;           /* [LOC_SB*2] site-determining ions                         */
-    float *pool;              /* [pool_cap] fragment lists                                */
-    uint8_t *keep;            /* [pool_cap]                                               */
-};
-
-DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap) {
-    LocLds w;
-    w.sig_mask = (uint64_t *)raw;
-    w.m0 = (float *)(w.sig_mask + LOC_SB);
-    w.m1 = w.m0 + 64;
-    w.run = w.m1 + 64;
-    w.scores = w.run + (size_t)LOC_SB * 2 * pos_cap;
-    w.pool = w.scores + LOC_SB * 10;
-    w.tot = (uint32_t *)(w.pool + pool_cap);
-    w.hist = w.tot + LOC_SB * 2;
-    w.c_idx = w.hist + LOC_SB * 11;
-    w.c_depth = (int32_t *)(w.c_idx + LOC_SB);
-    w.c_cnt = (uint32_t *)(w.c_depth + LOC_SB);
-    w.c_tr = w.c_cnt + LOC_SB * 2;
-    w.pmk = (uint16_t *)(w.c_tr + LOC_SB * 2);
-    w.cpre = w.pmk + (size_t)LOC_SB * 2 * pos_cap;
-    w.nlp = (uint8_t *)(w.cpre + (size_t)LOC_SB * 2 * pos_cap);
-    w.keep = w.nlp + 64;
-    return w;
-}
+#include "localize_core.hip.h"
 
 extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap,
                                          uint32_t pool_cap) {
@@ -493,348 +29,6 @@ extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint
     size_t lst = 64 * 4 * 2 + 64 + LOC_SB * 8 + (size_t)LOC_SB * 2 * pos_cap * 8 + LOC_SB * 2 * 4 +
                  LOC_SB * 11 * 4 + LOC_SB * 10 * 4 + LOC_SB * 4 * 2 + LOC_SB * 2 * 4 * 2 + (size_t)pool_cap * 5 + 64;
     return fixed + (srt > lst ? srt : lst) + 64;
-}
-
-DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, uint32_t psm,
-                      PeakTable *tab, NlTables *nl) {
-    const int lane = lane_id();
-    const int64_t p0 = b.peak_off[psm];
-    const int R = (int)b.ret_n[psm];
-    for (int i = lane; i < R; i += 64) {
-        k.t_mz[i] = b.ret_mz[p0 + i];
-        k.t_rank[i] = b.ret_rank[p0 + i];
-    }
-    nl->n_nl = cfg->n_nl;
-    if (nl->n_nl) {
-        for (int i = lane; i < 256; i += 64) k.nl_present[i] = cfg->present[i];
-        if (lane < PYA_MAX_UNIQ) k.nl_uniq[lane] = cfg->uniq[lane];
-    }
-    nl->present = k.nl_present;
-    nl->uniq = k.nl_uniq;
-    tab->mz = k.t_mz;
-    tab->rank = k.t_rank;
-    tab->n = R;
-    tab->err = cfg->mz_error;
-    wave_lds_sync();
-    grid_build(tab, k.grid);
-    wave_lds_sync();
-}
-
-/* ---------------------------------------------------------------------------------------
- * Batched localisation: the winner and up to LOC_SB-1 competitors at a time.
- *   1. one lane per (signature, direction) walks the residues and tabulates, per prefix
- *      length, the float32 running sum and the neutral-loss sums that exist;
- *   2. every (signature, direction, prefix) entry expands to its fragment m/z, looks them up
- *      and bumps the signature's rank histogram (LDS atomics) -> the 10 depth scores;
- *   3. per (competitor, ion type) task the two fragment lists are written to an LDS pool,
- *      sorted if they are not already, cancelled against each other by the reference's
- *      greedy walk -- one TASK per lane, so all walks of the batch run side by side -- and
- *      the surviving ions are matched in parallel.
- * ------------------------------------------------------------------------------------- */
-struct LocCtx {
-    const BatchDev *b;
-    const DevConfig *cfg;
-    NlTables nl;
-    PeakTable tab;
-    LocLds w;
-    int L, zmax;
-    uint32_t pos_cap, pool_cap;
-};
-
-DEV void loc_prefix_tables(const LocCtx &c, int S) {
-    const int lane = lane_id();
-    const LocLds &w = c.w;
-    if (lane < 2 * S) {
-        const int s = lane >> 1, d = lane & 1;
-        const uint64_t mask = w.sig_mask[s];
-        float running = 0.f;
-        uint32_t st = 0, cnt = 0;
-        const size_t base = (size_t)(s * 2 + d) * c.pos_cap;
-        for (int step = 0; step + 1 < c.L; step++) {
-            const int ri = d == 0 ? step : c.L - 1 - step;
-            const bool mod = (mask >> ri) & 1ull;
-            const float r = mod ? w.m1[ri] : w.m0[ri];
-            running = step == 0 ? r : r + running;
-            const uint32_t nlp = w.nlp[ri];
-            const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
-            if (cls) st = nl_bump(st, cls);
-            const uint32_t pm = c.nl.n_nl ? (uint32_t)c.nl.present[st & 255u] : 1u;
-            w.run[base + step] = running;
-            w.pmk[base + step] = (uint16_t)pm;
-            w.cpre[base + step] = (uint16_t)cnt;
-            cnt += __popc(pm);
-        }
-        w.tot[s * 2 + d] = cnt;
-    }
-}
-
-DEV int ilog2_ceil(int v) {                     /* smallest g with (1 << g) >= v, v >= 1 */
-    int g = 0;
-    while ((1 << g) < v) g++;
-    return g;
-}
-
-/* rank histograms + total fragments of signatures [s_lo, S).  Work items are (signature,
- * direction, prefix) with the prefix index padded to a power of two so that decoding an item is
- * shifts and masks only (integer division is tens of instructions on this hardware). */
-DEV void loc_counts(const LocCtx &c, int s_lo, int S) {
-    const int lane = lane_id();
-    const LocLds &w = c.w;
-    const DevConfig *cfg = c.cfg;
-    const int Lm1 = c.L - 1;
-    const int gp = ilog2_ceil(Lm1 > 0 ? Lm1 : 1);
-    for (int i = s_lo * 11 + lane; i < S * 11; i += 64) w.hist[i] = 0;
-    wave_lds_sync();
-    const int E = ((S - s_lo) * 2) << gp;
-    for (int e = lane; e < E; e += 64) {
-        const int pos = e & ((1 << gp) - 1);
-        const int sd = e >> gp;
-        const int s = s_lo + (sd >> 1), d = sd & 1;
-        const int t0 = d == 0 ? 0 : cfg->n_fwd, t1 = d == 0 ? cfg->n_fwd : cfg->n_types;
-        if (t0 == t1 || pos >= Lm1) continue;
-        const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
-        const float running = w.run[idx];
-        uint32_t pm = w.pmk[idx];
-        atomicAdd(&w.hist[s * 11 + 10], (uint32_t)(__popc(pm) * (t1 - t0) * c.zmax));
-        while (pm) {
-            const int v = __builtin_ctz(pm);
-            pm &= pm - 1;
-            const float x = running - (c.nl.n_nl ? c.nl.uniq[v] : 0.f);
-            const double xd = (double)x;
-            for (int t = t0; t < t1; t++) {
-                const double m = type_offset(xd, cfg->types[t]);
-                for (int z = 1; z <= c.zmax; z++) {
-                    const int rk = match_rank(c.tab, charge_mz(m, z));
-                    if (rk < PYA_NTOP) atomicAdd(&w.hist[s * 11 + rk], 1u);
-                }
-            }
-        }
-    }
-    wave_lds_sync();
-}
-
-DEV void loc_scores(const LocCtx &c, int s_lo, int S, int *fail) {
-    const int lane = lane_id();
-    const LocLds &w = c.w;
-    for (int i = s_lo * 10 + lane; i < S * 10; i += 64) {
-        const int s = i / 10, d = i % 10;
-        uint32_t cum = 0;
-        for (int r = 0; r <= d; r++) cum += w.hist[s * 11 + r];
-        const uint32_t nf = w.hist[s * 11 + 10];
-        float sc = 0.f;
-        if (nf <= c.b->lut_n_max) sc = c.b->lut[c.b->lut_off[nf] + (uint32_t)d * (nf + 1) + cum];
-        else *fail = 1;
-        w.scores[i] = sc;
-    }
-    wave_lds_sync();
-}
-
-/* Site-determining ions of competitors 1..S-1 against the winner (entry 0): fills w.c_cnt /
- * w.c_tr and the depth in w.c_depth.
- *
- * Lists live in an LDS pool addressed as [competitor][type slot][side][P2] with the number of
- * type slots and P2 powers of two, so an element index decodes with shifts.  A "task" is one
- * (competitor, ion type): list A = winner, list B = competitor. */
-DEV void loc_site_ions(const LocCtx &c, int S) {
-    const int lane = lane_id();
-    const LocLds &w = c.w;
-    const DevConfig *cfg = c.cfg;
-    const int T = cfg->n_types, Lm1 = c.L - 1;
-    const int gt = ilog2_ceil(T);                 /* type slots = 1 << gt */
-    const int gp = ilog2_ceil(Lm1 > 0 ? Lm1 : 1);
-    /* depth of the largest score gap (Ascore.cpp:164-172) */
-    if (lane >= 1 && lane < S) {
-        float best = 0.f;
-        int depth = 0;
-        for (int d = 0; d < PYA_NTOP; d++) {
-            const float diff = w.scores[d] - w.scores[lane * 10 + d];
-            if (diff > best) {
-                best = diff;
-                depth = d;
-            }
-        }
-        w.c_depth[lane] = depth;
-    }
-    for (int i = lane; i < S * 2; i += 64) {
-        w.c_cnt[i] = 0;
-        w.c_tr[i] = 0;
-    }
-    /* longest list decides the (power of two) stride of the pool */
-    uint32_t mmax = 1;
-    if (lane < 2 * S) mmax = w.tot[lane] * (uint32_t)c.zmax;
-    mmax = wave_max_u32(mmax);
-    const int g2 = ilog2_ceil((int)(mmax > 0 ? mmax : 1));
-    const int P2 = 1 << g2;
-    int per_round = (int)(c.pool_cap >> (1 + gt + g2));
-    if (per_round < 1) per_round = 1;
-    const float err = cfg->mz_error;
-    wave_lds_sync();
-    STAMP_BEGIN();
-    for (int c0 = 1; c0 < S; c0 += per_round) {
-        const int c1 = c0 + per_round < S ? c0 + per_round : S;
-        const int nlist = ((c1 - c0) << gt) << 1;               /* incl. unused type slots */
-        /* ---- generate: items (list, prefix) ---- */
-        for (int e = lane; e < (nlist << gp); e += 64) {
-            const int pos = e & ((1 << gp) - 1);
-            const int lid = e >> gp;
-            const int side = lid & 1, task = lid >> 1;
-            const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
-            if (pos >= Lm1 || t >= T) continue;
-            const int s = side ? cc : 0;
-            const uint8_t type = cfg->types[t];
-            const int d = t < cfg->n_fwd ? 0 : 1;
-            const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
-            uint32_t pm = w.pmk[idx];
-            const float running = w.run[idx];
-            float *dst = w.pool + ((size_t)lid << g2) + (size_t)w.cpre[idx] * c.zmax;
-            while (pm) {
-                const int v = __builtin_ctz(pm);
-                pm &= pm - 1;
-                const float x = running - (c.nl.n_nl ? c.nl.uniq[v] : 0.f);
-                const double m = type_offset((double)x, type);
-                for (int z = 1; z <= c.zmax; z++) *dst++ = charge_mz(m, z);
-            }
-        }
-        STAMP(*c.b, 30);
-        /* ---- pad every list to the stride with +inf ---- */
-        const int total = nlist << g2;
-        for (int e = lane; e < total; e += 64) {
-            const int lid = e >> g2, i = e & (P2 - 1);
-            const int side = lid & 1, task = lid >> 1;
-            const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
-            int M = 0;
-            if (t < T) M = (int)w.tot[(side ? cc : 0) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
-            if (i >= M) w.pool[e] = __builtin_huge_valf();
-        }
-        wave_lds_sync();
-        /* ---- sort only if some list is out of order ---- */
-        int unsorted = 0;
-        for (int e = lane; e < total; e += 64) {
-            const int i = e & (P2 - 1);
-            if (i + 1 < P2 && w.pool[e] > w.pool[e + 1]) unsorted = 1;
-        }
-        STAMP(*c.b, 31);
-        if (__any(unsorted)) {
-            const int gh = g2 - 1;                               /* pairs per list = 1 << gh */
-            for (int k = 2; k <= P2; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int e = lane; e < (nlist << gh); e += 64) {
-                        const int lid = e >> gh, tt = e & ((1 << gh) - 1);
-                        const int lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
-                        const int hi = lo | j;
-                        const bool up = (lo & k) == 0;
-                        float *base = w.pool + ((size_t)lid << g2);
-                        const float a = base[lo], bb = base[hi];
-                        if ((a > bb) == up) {
-                            base[lo] = bb;
-                            base[hi] = a;
-                        }
-                    }
-                    wave_lds_sync();
-                }
-            }
-        }
-        /* ---- cancel.  Site-determining ions = what the reference's greedy two-pointer walk
-         * over the two sorted lists leaves (ModifiedPeptide.cpp:291-316).  When every ion has at
-         * most one partner within mz_error in the other list, the walk cancels exactly those
-         * pairs and emits everything else (an unpaired ion is strictly below/above every ion it
-         * meets, because float subtraction is monotone) -- so pairs are found in parallel with
-         * one binary search per ion.  A task in which some ion has two partners is replayed with
-         * the serial walk, one task per lane. ---- */
-        STAMP(*c.b, 32);
-        uint64_t bad_tasks = 0;
-        for (int base = 0; base < total; base += 64) {           /* wave-uniform trip count */
-            const int e = base + lane;
-            bool multi = false;
-            if (e < total) {
-                const int lid = e >> g2, i = e & (P2 - 1);
-                const int side = lid & 1, task = lid >> 1;
-                const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
-                if (t < T) {
-                    const int d = t < cfg->n_fwd ? 0 : 1;
-                    const int M = (int)w.tot[(side ? cc : 0) * 2 + d] * c.zmax;
-                    const int Mo = (int)w.tot[(side ? 0 : cc) * 2 + d] * c.zmax;
-                    if (i < M) {
-                        const float me = w.pool[e];
-                        const float *other = w.pool + ((size_t)(lid ^ 1) << g2);
-                        /* diff is always (list A) - (list B), as the reference computes it.  Seen
-                         * from an A ion the B list ascends, so diff descends: skip B ions with
-                         * diff >= err.  Seen from a B ion diff ascends: skip A ions with diff <= -err. */
-                        int j = 0;
-                        for (int step = P2 >> 1; step > 0; step >>= 1) {
-                            const int probe = j + step;
-                            const float o = other[probe - 1];
-                            const float diff = side ? (o - me) : (me - o);
-                            const bool skip = side ? (diff <= -err) : (diff >= err);
-                            if (skip) j = probe;
-                        }
-                        int cnt = 0;
-                        for (int q = j; q < j + 2 && q < Mo; q++) {
-                            const float o = other[q];
-                            const float diff = side ? (o - me) : (me - o);
-                            cnt += (__builtin_fabsf(diff) < err) ? 1 : 0;
-                        }
-                        w.keep[e] = cnt == 0 ? 1 : 0;
-                        multi = cnt > 1;
-                    }
-                }
-            }
-            uint64_t rest = __ballot(multi);
-            while (rest) {
-                const int src = __builtin_ctzll(rest);
-                rest &= rest - 1;
-                bad_tasks |= 1ull << (((base + src) >> g2) >> 1);
-            }
-        }
-        wave_lds_sync();
-        STAMP(*c.b, 33);
-        if (bad_tasks) {
-            const int task = lane;                               /* (per_round << gt) <= 64 tasks */
-            if (task < (nlist >> 1) && ((bad_tasks >> task) & 1ull)) {
-                const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
-                const int d = t < cfg->n_fwd ? 0 : 1;
-                const int na = (int)w.tot[0 * 2 + d] * c.zmax, nb = (int)w.tot[cc * 2 + d] * c.zmax;
-                const float *la = w.pool + ((size_t)(task * 2) << g2);
-                const float *lb = la + P2;
-                uint8_t *ka = w.keep + ((size_t)(task * 2) << g2);
-                uint8_t *kb = ka + P2;
-                int i = 0, j = 0;
-                while (i < na || j < nb) {
-                    if (j == nb) {
-                        ka[i++] = 1;
-                    } else if (i == na) {
-                        kb[j++] = 1;
-                    } else {
-                        const float x = la[i], y = lb[j];
-                        if (__builtin_fabsf(x - y) < err) {
-                            ka[i++] = 0;
-                            kb[j++] = 0;
-                        } else if (x < y) {
-                            ka[i++] = 1;
-                        } else {
-                            kb[j++] = 1;
-                        }
-                    }
-                }
-            }
-            wave_lds_sync();
-        }
-        STAMP(*c.b, 37);
-        /* ---- match the surviving ions ---- */
-        for (int e = lane; e < total; e += 64) {
-            const int lid = e >> g2, i = e & (P2 - 1);
-            const int side = lid & 1, task = lid >> 1;
-            const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
-            if (t >= T) continue;
-            const int M = (int)w.tot[(side ? cc : 0) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
-            if (i < M && w.keep[e]) {
-                atomicAdd(&w.c_tr[cc * 2 + side], 1u);
-                if (match_rank(c.tab, w.pool[e]) <= w.c_depth[cc]) atomicAdd(&w.c_cnt[cc * 2 + side], 1u);
-            }
-        }
-        wave_lds_sync();
-        STAMP(*c.b, 34);
-    }
 }
 
 __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
@@ -973,60 +167,8 @@ __global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint
     STAMP(b, 25);
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
-    bool have_best = false;
-    uint32_t e = 0;
-    while (e < np) {
-        /* gather the next competitors that are not exact PepScore ties of the winner */
-        int S = 1;
-        while (e < np && S < LOC_SB) {
-            const uint32_t ci = lds.pushed[e++];
-            const uint64_t c = order[ci];
-            const float c_ws = ws[ci];
-            const uint64_t gone = best_bits & ~c, came = c & ~best_bits;
-            const int a = __popcll(best_bits & (gone - 1));
-            const int q = __builtin_ctzll(came);
-            if (lane == a) my_alt |= 1ull << nth_set_bit(res.site_mask, q);
-            if ((double)__builtin_fabsf(best_ws - c_ws) < 1e-6) {       /* Ascore.cpp:159-161 */
-                if (lane == a) my_asc = 0.f < my_asc ? 0.f : my_asc;
-                continue;
-            }
-            if (lane == 0) {
-                w.sig_mask[S] = deposit_sites(c, res.site_mask);
-                w.c_idx[S] = (uint32_t)a;
-            }
-            S++;
-        }
-        STAMP(b, 26);
-        if (S == 1) continue;
-        wave_lds_sync();
-        if (!(b.debug & 4)) loc_prefix_tables(ctx, S);
-        wave_lds_sync();
-        STAMP(b, 27);
-        if (!(b.debug & 2)) {
-            loc_counts(ctx, have_best ? 1 : 0, S);
-            STAMP(b, 28);
-            loc_scores(ctx, have_best ? 1 : 0, S, &fail);
-            STAMP(b, 29);
-        }
-        have_best = true;
-        if (!(b.debug & 1)) loc_site_ions(ctx, S);
-        STAMP(b, 35);
-        for (int cc = 1; cc < S; cc++) {
-            const uint32_t tr0 = w.c_tr[cc * 2], tr1 = w.c_tr[cc * 2 + 1];
-            const uint32_t n0 = w.c_cnt[cc * 2], n1 = w.c_cnt[cc * 2 + 1];
-            const uint32_t depth = (uint32_t)w.c_depth[cc];
-            float asc = 0.f;
-            if (tr0 > b.lut_n_max || tr1 > b.lut_n_max) {
-                fail = 1;
-            } else {
-                const float sc0 = b.lut[b.lut_off[tr0] + depth * (tr0 + 1) + n0];
-                const float sc1 = b.lut[b.lut_off[tr1] + depth * (tr1 + 1) + n1];
-                asc = sc0 - sc1;
-            }
-            if (lane == (int)w.c_idx[cc]) my_asc = asc < my_asc ? asc : my_asc;
-        }
-        wave_lds_sync();
-    }
+    loc_ascore_all(ctx, lds.pushed, np, order, ws, nullptr, best_bits, best_ws, best_i, res.site_mask,
+                   &my_asc, &my_alt, &fail);
     STAMP(b, 36);
     if (lane < k && lane < (int)max_k) {
         out_asc[lane] = my_asc;

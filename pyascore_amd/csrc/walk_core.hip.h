@@ -1,0 +1,92 @@
+/* walk_core.hip.h -- the per-(signature, direction) fragment walker shared by
+ * score_signatures.hip and fused_small.hip.  See score_signatures.hip for the notes. */
+#ifndef PYA_WALK_CORE_H
+#define PYA_WALK_CORE_H
+#include "device_common.hip.h"
+
+struct WalkEnv {
+    const DevConfig *cfg;
+    const uint16_t *nl_present;
+    const float *nl_uniq;
+    int n_nl, L, zmax;
+};
+
+/* ion-type offsets as (m + A) - B in double: b (0,0), c (+NH3,0), y (+H2O,0), z (+H2O,-NH3),
+ * Z (+H2O,-NH2); adding or subtracting 0.0 is exact, so this equals ModifiedPeptide.cpp:573-583 */
+DEV void type_constants(uint8_t type, double *A, double *B) {
+    *A = (type == 'b') ? 0.0 : (type == 'c' ? 17.026549 : 18.010565);
+    *B = (type == 'z') ? 17.026549 : (type == 'Z' ? 16.018724 : 0.0);
+}
+
+/* Walks one direction per lane (`dir` may differ between lanes: the residue of a step is read
+ * for both directions with two v_readlane and selected).  Adds to h / nfrag. */
+DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
+              bool active, Hist &h, uint32_t &nfrag) {
+    const DevConfig *cfg = e.cfg;
+    const int n_f = cfg->n_fwd, n_b = cfg->n_types - cfg->n_fwd;
+    const int my_types = dir == 0 ? n_f : n_b;
+    const int t_base = dir == 0 ? 0 : n_f;
+    const bool any_f = __any(active && dir == 0), any_b = __any(active && dir == 1);
+    const int t_max = (any_f && any_b) ? (n_f > n_b ? n_f : n_b) : (any_f ? n_f : n_b);
+    float running = 0.f;
+    uint32_t nl_state = 0;
+    for (int step = 0; step + 1 < e.L; step++) {
+        const int i_f = step, i_b = e.L - 1 - step;                      /* wave-uniform */
+        float m0 = 0.f, m1 = 0.f;
+        uint32_t nlp = 0;
+        if (any_f) {
+            m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i_f));
+            m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i_f));
+            nlp = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, i_f);
+        }
+        if (any_b) {
+            const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i_b));
+            const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i_b));
+            const uint32_t bn = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, i_b);
+            m0 = dir ? b0 : m0;
+            m1 = dir ? b1 : m1;
+            nlp = dir ? bn : nlp;
+        }
+        const int i = dir ? i_b : i_f;
+        const bool mod = (resmask >> i) & 1ull;
+        const float r = mod ? m1 : m0;
+        running = step == 0 ? r : r + running;                           /* ModifiedPeptide.cpp:385-389 */
+        uint32_t pm = active ? 1u : 0u;
+        if (e.n_nl) {
+            const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
+            if (cls) nl_state = nl_bump(nl_state, cls);
+            pm = active ? (uint32_t)e.nl_present[nl_state & 255u] : 0u;
+        }
+        while (__any(pm != 0)) {
+            const bool on = pm != 0;
+            const int v = on ? __builtin_ctz(pm) : 0;
+            pm &= pm - 1;
+            const float x = running - (e.n_nl ? e.nl_uniq[v] : 0.f);   /* float subtract (:572) */
+            const double xd = (double)x;
+            for (int t = 0; t < t_max; t++) {
+                const bool on_t = on && t < my_types;
+                double A, B;
+                type_constants(cfg->types[t_base + (t < my_types ? t : 0)], &A, &B);
+                const double m = (xd + A) - B;
+                for (int z = 1; z <= e.zmax; z++) {
+                    const float f = charge_mz(m, z);
+                    if (on_t) {
+                        hist_add(h, match_rank(tab, f));
+                        nfrag++;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* walker of the opposite direction sits 32 lanes up: fold it into lanes 0..31 */
+DEV void fold_upper_half(Hist &h, uint32_t &nfrag) {
+    h.a += __shfl_down(h.a, 32, 64);
+    h.b += __shfl_down(h.b, 32, 64);
+    h.c += __shfl_down(h.c, 32, 64);
+    nfrag += (uint32_t)__shfl_down((int)nfrag, 32, 64);
+}
+
+
+#endif

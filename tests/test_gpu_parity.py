@@ -14,6 +14,17 @@ from pyascore_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["fused", "three_kernel"])
+def path(request, monkeypatch):
+    """Batches run twice: through bin_spectra / score_signatures / localize (default), and with
+    PSMs of C(n,k) <= 64 routed through the one-kernel path (PYA_FUSE=1)."""
+    if request.param == "fused":
+        monkeypatch.setenv("PYA_FUSE", "1")
+    else:
+        monkeypatch.delenv("PYA_FUSE", raising=False)
+    return request.param
+
+
 def _gpu(settings):
     from pyascore_amd import PyAscore
     return harness.make_scorer(PyAscore, settings)
@@ -35,7 +46,7 @@ def test_public_api_matches_golden(case):
 
 
 @pytest.mark.parametrize("case", golden_cases())
-def test_batch_matches_golden(case):
+def test_batch_matches_golden(case, path):
     settings, batch, expected = harness.load_case(os.path.join(GOLDEN, case + ".npz"))
     got = _gpu(settings).score_batch(batch)
     k = got["ascores"].shape[1]
@@ -56,7 +67,7 @@ def test_batch_matches_golden(case):
     ("cfg2", 600, 208, dict(mz_error=0.5)),
     ("cfg3", 1500, 209, dict(mz_error=0.3, max_charge=2)),
 ])
-def test_batch_matches_checker(cfg, n, seed, override):
+def test_batch_matches_checker(cfg, n, seed, override, path):
     """Fresh seeded batches, HIP vs the CPU checker on this box: bit-exact everywhere."""
     batch, settings = synth.make_batch(cfg, n_psm=n, seed=seed, **override)
     got = _gpu(settings).score_batch(batch)
@@ -66,7 +77,7 @@ def test_batch_matches_checker(cfg, n, seed, override):
         assert bad.size == 0, "%s differs for PSMs %s" % (key, bad[:10])
 
 
-def test_unsorted_spectrum_and_ties():
+def test_unsorted_spectrum_and_ties(path):
     """Peaks given in arbitrary order (the API does not require sorted m/z)."""
     batch, settings = synth.make_batch("cfg3", n_psm=300, seed=210)
     rng = np.random.default_rng(1)
