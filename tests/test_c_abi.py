@@ -1,0 +1,64 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/pyascore_hip.h
+declares; without a device the product fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "pyascore_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pyascore_amd import build
+    build.build()                      # hipcc cross-compiles gfx950 without a GPU
+    from pyascore_amd import _lib
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pya_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 18
+    from pyascore_amd import _lib
+    assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (pya_[a-z_0-9]+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, "declared but not exported: %s" % missing
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_version_string(lib):
+    assert b"gfx950" in lib.pya_version()
+
+
+def test_fails_loudly_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    from pyascore_amd import PyAscore
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        PyAscore(100.0, 10, "STY", 79.966331)
+
+
+def test_product_does_not_import_the_oracle():
+    """Nothing under pyascore_amd/ may import, load or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "pyascore_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "libascore_oracle" not in text and "libascore_ref" not in text, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "oracle_abi.h" not in text, f
