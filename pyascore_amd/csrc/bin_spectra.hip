@@ -11,11 +11,16 @@
  */
 #include "bin_core.hip.h"
 
-__global__ __launch_bounds__(64) void pya_bin_spectra_kernel(BatchDev b, const uint32_t *psm_ids,
-                                                             uint32_t n_ids, uint32_t cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    if (blockIdx.x >= n_ids) return;
-    const uint32_t psm = psm_ids[blockIdx.x];
+#define BIN_WAVES 4     /* independent spectra per workgroup when LDS allows (no cross-wave sync) */
+
+__global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDev b, const uint32_t *psm_ids,
+                                                                         uint32_t n_ids, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (slot >= n_ids) return;
+    unsigned char *lds_raw = lds_all + (size_t)wave * (((size_t)cap * 15 + 63) & ~(size_t)63);
+    const uint32_t psm = psm_ids[slot];
     const int lane = lane_id();
     const float *r_mz;
     const uint8_t *r_rank;
@@ -44,10 +49,13 @@ extern "C" size_t pya_bin_lds_bytes(uint32_t cap) { return (size_t)cap * (8 + 4 
 extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                               hipStream_t stream) {
     if (n_ids == 0) return 0;
-    size_t lds = pya_bin_lds_bytes(cap);
+    const size_t per_wave = (((size_t)cap * 15 + 63) & ~(size_t)63);
+    const uint32_t nw = per_wave * BIN_WAVES <= 64 * 1024 ? BIN_WAVES : 1;
+    size_t lds = nw * per_wave;
     hipError_t e = hipFuncSetAttribute((const void *)pya_bin_spectra_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pya_bin_spectra_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, cap);
+    hipLaunchKernelGGL(pya_bin_spectra_kernel, dim3((n_ids + nw - 1) / nw), dim3(64 * nw), lds, stream, *b, d_ids,
+                       n_ids, cap);
     return (int)hipGetLastError();
 }

@@ -130,7 +130,7 @@ DEV float charge_mz(double m, int z) {
  * Retained peaks are staged in LDS sorted by m/z (float); a coarse m/z grid gives the start of
  * the scan (the grid only narrows the search, the window test itself is the reference's).
  * ------------------------------------------------------------------------------------- */
-#define PYA_GRID_CELLS 512         /* cells of the m/z grid that accelerates the lookup       */
+#define PYA_GRID_CELLS 256         /* cells of the m/z grid that accelerates the lookup       */
 
 struct PeakTable {
     const float *mz;        /* LDS, ascending */
@@ -164,7 +164,7 @@ DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
     const float first = t->mz[0], last = t->mz[t->n - 1];
     t->base = first;
     const float range = last - first;
-    float inv_w = 0.25f;                                  /* 4 m/z per cell ...                */
+    float inv_w = 0.125f;                                 /* 8 m/z per cell ...                */
     if (range * inv_w > (float)(PYA_GRID_CELLS - 2)) inv_w = (float)(PYA_GRID_CELLS - 2) / range;
     t->inv_w = inv_w;                                     /* ... or wider to fit the grid      */
     t->last_cell = PYA_GRID_CELLS - 1;

@@ -171,9 +171,9 @@ struct Bucket {
     DevBuf<uint32_t> d_ids;
     uint32_t n_cap = 0, list_cap = 1, pos_cap = 1;
     uint32_t pool_cap() const {
-        /* room for one competitor at least, ~7 when the lists are short */
+        /* room for one competitor at least, 3 (= LOC_SB - 1) when the lists are short */
         uint32_t one = 2u * next_pow2_u32(n_types) * list_cap;
-        uint32_t want = 7u * one;
+        uint32_t want = 3u * one;
         if (want > 2048u) want = 2048u;
         return one > want ? one : want;
     }

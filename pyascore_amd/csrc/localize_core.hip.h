@@ -429,7 +429,7 @@ DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
     return k;
 }
 
-#define LOC_SB 8               /* signatures worked on together: the winner + 7 competitors */
+#define LOC_SB 4               /* signatures worked on together: the winner + 3 competitors */
 
 /* work area of the batched localisation (aliases the sort arrays) */
 struct LocLds {

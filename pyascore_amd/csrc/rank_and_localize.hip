@@ -31,7 +31,7 @@ extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
-__global__ __launch_bounds__(64) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
+__global__ __launch_bounds__(64, 6) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
                                                           uint32_t n_ids, uint32_t peak_cap,
                                                           uint32_t pos_cap, uint32_t pool_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
