@@ -1,56 +1,51 @@
-/* fused_small.hip -- the whole hot path in ONE kernel for PSMs with C(n,k) <= 64 site
+/* fused_small.hip -- scoring + localisation in ONE kernel for PSMs with C(n,k) <= 64 site
  * assignments (the bulk of real batches and BASELINE cfg1/cfg2/most of cfg3): one PSM per
- * wavefront, raw peaks in, summary record out.
+ * wavefront, retained-peak table in (from bin_spectra), summary record out.
  *
- *   bin_core          raw peaks -> retained-peak table, kept in LDS (never written to HBM)
  *   walk              one (signature, direction) walker per lane -> PepScore of every signature
+ *                     (depth scores and weighted score stay in the lane's registers)
  *   sort emulation    front element of the reference's std::sort -> winner
  *   loc_ascore_all    per-site Ascores from the site-determining ions of the tied best
  *                     single-move competitors
  *
- * Same device code as the three-kernel path (bin_core / walk_core / localize_core headers); what
- * the fusion removes is two kernel boundaries, the HBM round trips of the retained table and of
- * the weighted scores, and the repeated staging of tables and residues.
- *
- * HBM traffic per PSM = the algorithmic bytes of SURVEY.md 8(d): 16 B per raw peak + peptide +
- * offsets in, one summary record out (+ the L2-resident signature-order and score tables).
+ * Same device code as score_signatures + localize (walk_core / localize_core headers); what the
+ * fusion removes is a kernel boundary, the HBM round trip of the weighted scores, the second
+ * staging of the retained table / grid / residues and the recomputation of the winner's and the
+ * competitors' depth scores.  Binning stays a separate kernel: it runs at 32 waves per CU, which a
+ * fused kernel with this one's registers and LDS cannot (measured, profiles/r01_b).
  */
-#include "bin_core.hip.h"
 #include "walk_core.hip.h"
 #include "localize_core.hip.h"
 
 #define FUSED_MAX_SIG 64
 
+#define FUSED_PUSHED 64          /* single-move competitors of a winner among <= 64 signatures */
+
 struct FusedLds {
     uint16_t *nl_present;   /* [256] */
     float *nl_uniq;         /* [PYA_MAX_UNIQ] */
     uint16_t *grid;         /* [PYA_GRID_CELLS] */
-    uint32_t *pushed;       /* [PYA_MAX_PUSHED] */
+    uint32_t *pushed;       /* [FUSED_PUSHED] */
     uint32_t *site_max;     /* [64] */
     uint32_t *n_pushed;     /* [4] */
     float *ws_all;          /* [FUSED_MAX_SIG] weighted score per signature (pre-sort order) */
     float *scores_all;      /* [FUSED_MAX_SIG * 10] */
-    unsigned char *work;    /* bin stage; afterwards retained table + scratch */
+    float *t_mz;            /* [peak_cap] */
+    uint8_t *t_rank;        /* [peak_cap] */
+    unsigned char *scratch; /* sort arrays, later the localisation work area */
 };
 
-DEV size_t fused_fixed_bytes() {
-    return 512 + PYA_MAX_UNIQ * 4 + PYA_GRID_CELLS * 2 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + FUSED_MAX_SIG * 4 +
-           FUSED_MAX_SIG * 10 * 4;
-}
-
 extern "C" size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap) {
-    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_GRID_CELLS * 2 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 +
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_GRID_CELLS * 2 + FUSED_PUSHED * 4 + 64 * 4 + 16 +
                    FUSED_MAX_SIG * 4 + FUSED_MAX_SIG * 10 * 4;
-    size_t bin = (size_t)peak_cap * 15;
-    size_t table = ((size_t)peak_cap * 5 + 15) & ~(size_t)15;
+    size_t table = (size_t)peak_cap * 4 + (((size_t)peak_cap + 15) & ~(size_t)15);
     size_t srt = (size_t)FUSED_MAX_SIG * 10 + 64;
     size_t loc = 64 * 4 * 2 + 64 + LOC_SB * 8 + (size_t)LOC_SB * 2 * pos_cap * 8 + LOC_SB * 2 * 4 +
                  LOC_SB * 11 * 4 + LOC_SB * 10 * 4 + LOC_SB * 4 * 2 + LOC_SB * 2 * 4 * 2 + (size_t)pool_cap * 5 + 64;
-    size_t after = table + (srt > loc ? srt : loc);
-    return fixed + (bin > after ? bin : after) + 64;
+    return fixed + table + (srt > loc ? srt : loc) + 64;
 }
 
-__global__ __launch_bounds__(64) void pya_fused_small_kernel(BatchDev b, const uint32_t *psm_ids,
+__global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, const uint32_t *psm_ids,
                                                              uint32_t n_ids, uint32_t peak_cap,
                                                              uint32_t pos_cap, uint32_t pool_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -72,30 +67,39 @@ __global__ __launch_bounds__(64) void pya_fused_small_kernel(BatchDev b, const u
     f.grid = f.nl_present + 256;
     f.nl_uniq = (float *)(f.grid + PYA_GRID_CELLS);
     f.pushed = (uint32_t *)(f.nl_uniq + PYA_MAX_UNIQ);
-    f.site_max = f.pushed + PYA_MAX_PUSHED;
+    f.site_max = f.pushed + FUSED_PUSHED;
     f.n_pushed = f.site_max + 64;
     f.ws_all = (float *)(f.n_pushed + 4);
     f.scores_all = f.ws_all + FUSED_MAX_SIG;
-    f.work = (unsigned char *)(f.scores_all + FUSED_MAX_SIG * 10);
+    f.t_mz = f.scores_all + FUSED_MAX_SIG * 10;
+    f.t_rank = (uint8_t *)(f.t_mz + peak_cap);
+    f.scratch = f.t_rank + ((peak_cap + 15u) & ~15u);
 
-    /* ---- 1. spectrum -> retained-peak table (stays in LDS) ---- */
-    STAMP_BEGIN();
-    LocCtx ctx;
-    ctx.b = &b;
-    ctx.cfg = cfg;
-    int status;
-    const int R = bin_core(b, psm, f.work, peak_cap, &ctx.tab.mz, &ctx.tab.rank, &status);
-    if (R < 0) {
+    if (b.status[psm] != PYA_ST_OK) {
         if (lane == 0) {
-            b.status[psm] = status;
             b.best_score[psm] = -1.f;
             b.best_sig[psm] = 0ull;
             b.n_sig_out[psm] = -1;
         }
         return;
     }
-    STAMP(b, 1);
-    ctx.tab.n = R;
+
+    /* ---- 1. stage the retained-peak table and its m/z grid ---- */
+    STAMP_BEGIN();
+    LocCtx ctx;
+    ctx.b = &b;
+    ctx.cfg = cfg;
+    {
+        const int64_t p0 = b.peak_off[psm];
+        const int R = (int)b.ret_n[psm];
+        for (int i = lane; i < R; i += 64) {
+            f.t_mz[i] = b.ret_mz[p0 + i];
+            f.t_rank[i] = b.ret_rank[p0 + i];
+        }
+        ctx.tab.mz = f.t_mz;
+        ctx.tab.rank = f.t_rank;
+        ctx.tab.n = R;
+    }
     ctx.tab.err = cfg->mz_error;
     ctx.nl.n_nl = cfg->n_nl;
     ctx.nl.present = f.nl_present;
@@ -104,10 +108,12 @@ __global__ __launch_bounds__(64) void pya_fused_small_kernel(BatchDev b, const u
         for (int i = lane; i < 256; i += 64) f.nl_present[i] = cfg->present[i];
         if (lane < PYA_MAX_UNIQ) f.nl_uniq[lane] = cfg->uniq[lane];
     }
-    grid_build(&ctx.tab, f.grid);
     if (lane == 0) *f.n_pushed = 0;
     f.site_max[lane] = 0;
-    unsigned char *scratch = f.work + (((size_t)peak_cap * 5 + 15) & ~(size_t)15);
+    wave_lds_sync();
+    grid_build(&ctx.tab, f.grid);
+    unsigned char *scratch = f.scratch;
+    STAMP(b, 1);
 
     /* ---- 2. PepScore of every signature ---- */
     const Residues res = load_residues(b, cfg, psm);
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(64) void pya_fused_small_kernel(BatchDev b, const u
             b.best_score[psm] = N > 0 ? f.ws_all[0] : -1.f;
             b.best_sig[psm] = N > 0 ? order[0] : 0ull;
             b.n_sig_out[psm] = N;
-            b.status[psm] = any_fail ? PYA_ST_LUT_RANGE : PYA_ST_OK;
+            if (any_fail) b.status[psm] = PYA_ST_LUT_RANGE;
         }
         return;
     }
@@ -210,11 +216,11 @@ __global__ __launch_bounds__(64) void pya_fused_small_kernel(BatchDev b, const u
         wave_lds_sync();
         if (single && wbits == f.site_max[a]) {
             const uint32_t slot = atomicAdd(f.n_pushed, 1u);
-            if (slot < PYA_MAX_PUSHED) f.pushed[slot] = (uint32_t)lane;
+            if (slot < FUSED_PUSHED) f.pushed[slot] = (uint32_t)lane;
         }
         wave_lds_sync();
     }
-    const uint32_t np = *f.n_pushed;                    /* <= 64 < PYA_MAX_PUSHED */
+    const uint32_t np = *f.n_pushed;                    /* <= FUSED_PUSHED */
     STAMP(b, 5);
 
     /* ---- 5. Ascores ---- */
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(64) void pya_fused_small_kernel(BatchDev b, const u
         b.best_score[psm] = best_ws;
         b.best_sig[psm] = best_bits;
         b.n_sig_out[psm] = N;
-        b.status[psm] = any_fail ? PYA_ST_LUT_RANGE : PYA_ST_OK;
+        if (any_fail) b.status[psm] = PYA_ST_LUT_RANGE;
     }
 }
 

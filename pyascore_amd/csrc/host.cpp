@@ -201,7 +201,7 @@ struct pya_plan {
     DevBuf<uint8_t> d_ret_rank;
     Bucket buckets[kNumBuckets];
     Bucket fused;                       /* C(n,k) <= 64: whole path in one kernel */
-    Bucket unfused_all;                 /* ids of every PSM on the three-kernel path (for bin_spectra) */
+    Bucket all_ids;                     /* every PSM (bin_spectra launch) */
     /* owned copies of inputs/outputs (pya_score_batch path) */
     DevBuf<double> d_mz, d_inten;
     DevBuf<float> d_best_score, d_ascores;
@@ -224,7 +224,7 @@ struct pya_plan {
                      d_ret_n.bytes() + d_rec.bytes() + d_sorted.bytes() + d_aux_mass.bytes() +
                      d_ret_mz.bytes() + d_ws.bytes() + d_ret_rank.bytes();
         for (const Bucket &k : buckets) b += k.d_ids.bytes();
-        b += fused.d_ids.bytes() + unfused_all.d_ids.bytes();
+        b += fused.d_ids.bytes() + all_ids.d_ids.bytes();
         return b;
     }
 };
@@ -598,8 +598,9 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
     p->sig_off.resize(n + 1);
     const uint32_t n_uniq = (uint32_t)h->cfg.n_uniq, n_types = (uint32_t)h->cfg.n_types;
     uint32_t max_P = 1, lut_need = 0, max_k = 1;
-    /* The one-kernel path is parity-tested but measures slower than the three-kernel path at
-     * its current LDS/VGPR footprint (profiles/r01_b): opt-in until that is fixed. */
+    /* The fused score+localize kernel for C(n,k) <= 64 is parity-tested but measures slower than
+     * score_signatures + localize (it runs the walk at localize's occupancy):
+     * opt-in with PYA_FUSE=1. */
     const bool use_fused = !(flags & PYA_FLAG_KEEP) && std::getenv("PYA_FUSE") != nullptr;
     int64_t sig_total = 0;
     for (uint64_t i = 0; i < n; i++) {
@@ -674,7 +675,7 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
             bk.ids.push_back((uint32_t)i);
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
         }
-        if (!fuse) p->unfused_all.ids.push_back((uint32_t)i);
+        p->all_ids.ids.push_back((uint32_t)i);
     }
     p->sig_off[n] = sig_total;
     p->total_sigs = sig_total;
@@ -692,8 +693,8 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
             return h->fail(PYA_ERR_LIMIT, (int64_t)p->fused.ids[0], "LDS budget exceeded (%zu bytes) on the fused path", need);
         HIPCHK(h, p->fused.d_ids.upload(p->fused.ids.data(), p->fused.ids.size()));
     }
-    if (!p->unfused_all.ids.empty())
-        HIPCHK(h, p->unfused_all.d_ids.upload(p->unfused_all.ids.data(), p->unfused_all.ids.size()));
+    if (!p->all_ids.ids.empty())
+        HIPCHK(h, p->all_ids.d_ids.upload(p->all_ids.ids.data(), p->all_ids.ids.size()));
     for (Bucket &bk : p->buckets) {
         if (bk.ids.empty()) continue;
         size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap());
@@ -755,7 +756,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     d.max_k = o->max_k;
     const bool timing = p->flags & PYA_FLAG_TIMING;
     if (timing) HIPCHK(h, hipEventRecord(p->ev[0], st));
-    int e = pya_launch_bin(&d, p->unfused_all.d_ids.p, (uint32_t)p->unfused_all.ids.size(), p->peak_cap, st);
+    int e = pya_launch_bin(&d, p->all_ids.d_ids.p, (uint32_t)p->all_ids.ids.size(), p->peak_cap, st);
     if (e) return h->hip_fail((hipError_t)e, "bin_spectra launch");
     if (timing) HIPCHK(h, hipEventRecord(p->ev[1], st));
     for (Bucket &bk : p->buckets) {

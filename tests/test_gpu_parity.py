@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["fused", "three_kernel"])
 def path(request, monkeypatch):
-    """Batches run twice: through bin_spectra / score_signatures / localize (default), and with
-    PSMs of C(n,k) <= 64 routed through the one-kernel path (PYA_FUSE=1)."""
+    """Batches run twice: on bin_spectra / score_signatures / localize (default) and with PSMs of
+    C(n,k) <= 64 on the fused score+localize kernel (PYA_FUSE=1)."""
     if request.param == "fused":
         monkeypatch.setenv("PYA_FUSE", "1")
     else:
