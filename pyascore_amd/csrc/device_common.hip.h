@@ -131,26 +131,59 @@ DEV float charge_mz(double m, int z) {
  * the scan (the grid only narrows the search, the window test itself is the reference's).
  * ------------------------------------------------------------------------------------- */
 #define PYA_GRID_CELLS 256         /* cells of the m/z grid that accelerates the lookup       */
+#define PYA_TABLE_PAD 4            /* +inf sentinels after the last retained peak             */
+
+/* one retained peak in LDS: float m/z and its rank, 8 bytes so both come with one ds_read_b64 */
+struct PeakEntry {
+    float mz;
+    uint32_t rank;
+};
 
 struct PeakTable {
-    const float *mz;        /* LDS, ascending */
-    const uint8_t *rank;    /* LDS */
+    const PeakEntry *e;     /* LDS, ascending m/z, n entries + PYA_TABLE_PAD (+inf, rank 15)      */
     const uint16_t *cell;   /* LDS [PYA_GRID_CELLS]: first peak index whose cell is >= c          */
     int n;
     float err;
     float base;             /* m/z of the first retained peak                                    */
     float inv_w;            /* cells per m/z                                                     */
     int last_cell;
+    bool half_check;        /* mz_error > 0.49: the reference's lower_bound(mz - .5) can bite    */
 };
+
+/* LDS bytes of a staged table for up to `cap` retained peaks */
+DEV size_t peak_table_bytes(uint32_t cap) { return ((size_t)cap + PYA_TABLE_PAD) * sizeof(PeakEntry); }
+
+/* copies the retained peaks of `psm` (written by bin_spectra) into LDS and appends sentinels */
+DEV void stage_peak_table(const BatchDev &b, uint32_t psm, PeakEntry *dst, PeakTable *t) {
+    const int lane = lane_id();
+    const int64_t p0 = b.peak_off[psm];
+    const int R = (int)b.ret_n[psm];
+    for (int i = lane; i < R; i += 64) {
+        PeakEntry x;
+        x.mz = b.ret_mz[p0 + i];
+        x.rank = b.ret_rank[p0 + i];
+        dst[i] = x;
+    }
+    if (lane < PYA_TABLE_PAD) {
+        PeakEntry x;
+        x.mz = __builtin_huge_valf();
+        x.rank = PYA_NO_MATCH;
+        dst[R + lane] = x;
+    }
+    t->e = dst;
+    t->n = R;
+    t->err = b.cfg->mz_error;
+    t->half_check = b.cfg->mz_error > 0.49f;
+}
 
 /* monotone non-decreasing in x: float subtract, multiply by a positive constant, truncate */
 DEV int grid_cell(const PeakTable &t, float x) {
     float rel = (x - t.base) * t.inv_w;
-    int c = rel > 0.f ? (int)rel : 0;
+    int c = (int)__builtin_fmaxf(rel, 0.f);
     return c > t.last_cell ? t.last_cell : c;
 }
 
-/* builds the grid for the n staged peaks (wave-cooperative; caller syncs LDS afterwards) */
+/* builds the grid for the n staged peaks (wave-cooperative; caller syncs LDS before and after) */
 DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
     const int lane = lane_id();
     t->cell = cell_lds;
@@ -161,7 +194,7 @@ DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
         if (lane == 0) cell_lds[0] = 0;
         return;
     }
-    const float first = t->mz[0], last = t->mz[t->n - 1];
+    const float first = t->e[0].mz, last = t->e[t->n - 1].mz;
     t->base = first;
     const float range = last - first;
     float inv_w = 0.125f;                                 /* 8 m/z per cell ...                */
@@ -172,25 +205,43 @@ DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
     if (lc > PYA_GRID_CELLS - 1) lc = PYA_GRID_CELLS - 1;
     t->last_cell = lc;
     for (int i = lane; i < t->n; i += 64) {
-        const int c = grid_cell(*t, t->mz[i]);
-        const int cp = i > 0 ? grid_cell(*t, t->mz[i - 1]) : -1;
+        const int c = grid_cell(*t, t->e[i].mz);
+        const int cp = i > 0 ? grid_cell(*t, t->e[i - 1].mz) : -1;
         for (int k = cp + 1; k <= c; k++) cell_lds[k] = (uint16_t)i;
     }
 }
 
+/* Branch-light lookup: the grid gives an index at or before the first peak > lo; four entries
+ * are fetched at once (the sentinels make this safe) and reduced with selects; only when the
+ * window is not closed by the fourth entry does a lane continue with the scalar scan. */
 DEV int match_rank(const PeakTable &t, float f) {
     const float lo = f - t.err;
     const float hi = f + t.err;
     int idx = (int)t.cell[grid_cell(t, lo)];              /* every peak > lo has index >= idx  */
+    const PeakEntry e0 = t.e[idx], e1 = t.e[idx + 1], e2 = t.e[idx + 2], e3 = t.e[idx + 3];
     int best = PYA_NO_MATCH;
-    while (idx < t.n) {
-        const float p = t.mz[idx];
-        if (!(p < hi)) break;
-        if (p > lo && (double)f >= (double)p - 0.5) {
-            const int r = (int)t.rank[idx];
-            best = r < best ? r : best;
+    if (!t.half_check) {
+        int r;
+        r = e0.mz > lo ? (int)e0.rank : PYA_NO_MATCH; r = e0.mz < hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
+        r = e1.mz > lo ? (int)e1.rank : PYA_NO_MATCH; r = e1.mz < hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
+        r = e2.mz > lo ? (int)e2.rank : PYA_NO_MATCH; r = e2.mz < hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
+        r = e3.mz > lo ? (int)e3.rank : PYA_NO_MATCH; r = e3.mz < hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
+        if (e3.mz < hi) {                                  /* rare: more than four entries to look at */
+            idx += 4;
+            for (;;) {
+                const PeakEntry x = t.e[idx];
+                if (!(x.mz < hi)) break;
+                if (x.mz > lo) best = (int)x.rank < best ? (int)x.rank : best;
+                idx++;
+            }
         }
-        idx++;
+    } else {
+        for (;;) {
+            const PeakEntry x = t.e[idx];
+            if (!(x.mz < hi)) break;
+            if (x.mz > lo && (double)f >= (double)x.mz - 0.5) best = (int)x.rank < best ? (int)x.rank : best;
+            idx++;
+        }
     }
     return best;
 }

@@ -30,15 +30,14 @@ struct FusedLds {
     uint32_t *n_pushed;     /* [4] */
     float *ws_all;          /* [FUSED_MAX_SIG] weighted score per signature (pre-sort order) */
     float *scores_all;      /* [FUSED_MAX_SIG * 10] */
-    float *t_mz;            /* [peak_cap] */
-    uint8_t *t_rank;        /* [peak_cap] */
+    PeakEntry *t_e;         /* [peak_cap + PYA_TABLE_PAD] */
     unsigned char *scratch; /* sort arrays, later the localisation work area */
 };
 
 extern "C" size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap) {
     size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_GRID_CELLS * 2 + FUSED_PUSHED * 4 + 64 * 4 + 16 +
                    FUSED_MAX_SIG * 4 + FUSED_MAX_SIG * 10 * 4;
-    size_t table = (size_t)peak_cap * 4 + (((size_t)peak_cap + 15) & ~(size_t)15);
+    size_t table = ((size_t)peak_cap + PYA_TABLE_PAD) * 8;
     size_t srt = (size_t)FUSED_MAX_SIG * 10 + 64;
     size_t loc = 64 * 4 * 2 + 64 + LOC_SB * 8 + (size_t)LOC_SB * 2 * pos_cap * 8 + LOC_SB * 2 * 4 +
                  LOC_SB * 11 * 4 + LOC_SB * 10 * 4 + LOC_SB * 4 * 2 + LOC_SB * 2 * 4 * 2 + (size_t)pool_cap * 5 + 64;
@@ -71,9 +70,8 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
     f.n_pushed = f.site_max + 64;
     f.ws_all = (float *)(f.n_pushed + 4);
     f.scores_all = f.ws_all + FUSED_MAX_SIG;
-    f.t_mz = f.scores_all + FUSED_MAX_SIG * 10;
-    f.t_rank = (uint8_t *)(f.t_mz + peak_cap);
-    f.scratch = f.t_rank + ((peak_cap + 15u) & ~15u);
+    f.t_e = (PeakEntry *)(f.scores_all + FUSED_MAX_SIG * 10);
+    f.scratch = (unsigned char *)(f.t_e + peak_cap + PYA_TABLE_PAD);
 
     if (b.status[psm] != PYA_ST_OK) {
         if (lane == 0) {
@@ -89,18 +87,7 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
-    {
-        const int64_t p0 = b.peak_off[psm];
-        const int R = (int)b.ret_n[psm];
-        for (int i = lane; i < R; i += 64) {
-            f.t_mz[i] = b.ret_mz[p0 + i];
-            f.t_rank[i] = b.ret_rank[p0 + i];
-        }
-        ctx.tab.mz = f.t_mz;
-        ctx.tab.rank = f.t_rank;
-        ctx.tab.n = R;
-    }
-    ctx.tab.err = cfg->mz_error;
+    stage_peak_table(b, psm, f.t_e, &ctx.tab);
     ctx.nl.n_nl = cfg->n_nl;
     ctx.nl.present = f.nl_present;
     ctx.nl.uniq = f.nl_uniq;
@@ -142,7 +129,15 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
         const uint64_t resmask = deposit_sites(my_bits, res.site_mask);
         Hist h = {0ull, 0ull, 0ull};
         uint32_t nfrag = 0;
-        if (split) {
+        if (walk_is_simple(env)) {
+            if (split) {
+                walk_simple(env, res, ctx.tab, resmask, lane >> 5, active, h, nfrag);
+                fold_upper_half(h, nfrag);
+            } else {
+                if (cfg->n_fwd > 0) walk_simple(env, res, ctx.tab, resmask, 0, active, h, nfrag);
+                if (cfg->n_fwd < cfg->n_types) walk_simple(env, res, ctx.tab, resmask, 1, active, h, nfrag);
+            }
+        } else if (split) {
             walk(env, res, ctx.tab, resmask, lane >> 5, active, h, nfrag);
             fold_upper_half(h, nfrag);
         } else {

@@ -406,8 +406,7 @@ DEV int nth_set_bit(uint64_t m, int n) {
 struct K3Lds {
     uint16_t *nl_present;
     float *nl_uniq;
-    float *t_mz;
-    uint8_t *t_rank;
+    PeakEntry *t_e;          /* [peak_cap + PYA_TABLE_PAD] */
     uint32_t *pushed;        /* [PYA_MAX_PUSHED] */
     uint32_t *site_max;      /* [64] */
     uint32_t *n_pushed;      /* [1]  */
@@ -423,9 +422,8 @@ DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
     k.site_max = k.pushed + PYA_MAX_PUSHED;
     k.n_pushed = k.site_max + 64;
     k.grid = (uint16_t *)(k.n_pushed + 4);
-    k.t_mz = (float *)(k.grid + PYA_GRID_CELLS);
-    k.t_rank = (uint8_t *)(k.t_mz + peak_cap);
-    k.scratch = (unsigned char *)(k.t_rank + ((peak_cap + 15u) & ~15u));
+    k.t_e = (PeakEntry *)(k.grid + PYA_GRID_CELLS);
+    k.scratch = (unsigned char *)(k.t_e + peak_cap + PYA_TABLE_PAD);
     return k;
 }
 
@@ -474,12 +472,7 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap) {
 DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, uint32_t psm,
                       PeakTable *tab, NlTables *nl) {
     const int lane = lane_id();
-    const int64_t p0 = b.peak_off[psm];
-    const int R = (int)b.ret_n[psm];
-    for (int i = lane; i < R; i += 64) {
-        k.t_mz[i] = b.ret_mz[p0 + i];
-        k.t_rank[i] = b.ret_rank[p0 + i];
-    }
+    stage_peak_table(b, psm, k.t_e, tab);
     nl->n_nl = cfg->n_nl;
     if (nl->n_nl) {
         for (int i = lane; i < 256; i += 64) k.nl_present[i] = cfg->present[i];
@@ -487,10 +480,6 @@ DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, u
     }
     nl->present = k.nl_present;
     nl->uniq = k.nl_uniq;
-    tab->mz = k.t_mz;
-    tab->rank = k.t_rank;
-    tab->n = R;
-    tab->err = cfg->mz_error;
     wave_lds_sync();
     grid_build(tab, k.grid);
     wave_lds_sync();

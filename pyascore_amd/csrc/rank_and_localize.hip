@@ -24,7 +24,7 @@
 extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap,
                                          uint32_t pool_cap) {
     size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + PYA_GRID_CELLS * 2 +
-                   (size_t)peak_cap * 4 + ((peak_cap + 15u) & ~15u);
+                   ((size_t)peak_cap + PYA_TABLE_PAD) * 8;
     size_t srt = (size_t)n_cap * 10 + 64;
     size_t lst = 64 * 4 * 2 + 64 + LOC_SB * 8 + (size_t)LOC_SB * 2 * pos_cap * 8 + LOC_SB * 2 * 4 +
                  LOC_SB * 11 * 4 + LOC_SB * 10 * 4 + LOC_SB * 4 * 2 + LOC_SB * 2 * 4 * 2 + (size_t)pool_cap * 5 + 64;
@@ -251,7 +251,7 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
 
 extern "C" size_t pya_amb_lds_bytes(uint32_t peak_cap, uint32_t list_cap) {
     return 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + PYA_GRID_CELLS * 2 +
-           (size_t)peak_cap * 4 + ((peak_cap + 15u) & ~15u) + (size_t)list_cap * 10 + 128;
+           ((size_t)peak_cap + PYA_TABLE_PAD) * 8 + (size_t)list_cap * 10 + 128;
 }
 
 extern "C" int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,

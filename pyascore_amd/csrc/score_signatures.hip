@@ -36,20 +36,15 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     uint16_t *nl_present = (uint16_t *)lds_raw;             /* [256] */
     uint16_t *grid = nl_present + 256;                      /* [PYA_GRID_CELLS] */
     float *nl_uniq = (float *)(grid + PYA_GRID_CELLS);      /* [PYA_MAX_UNIQ] */
-    float *t_mz = nl_uniq + PYA_MAX_UNIQ;
-    uint8_t *t_rank = (uint8_t *)(t_mz + cap);
+    PeakEntry *t_e = (PeakEntry *)(nl_uniq + PYA_MAX_UNIQ); /* [cap + PYA_TABLE_PAD] */
 
     if (b.status[psm] != PYA_ST_OK) return;
     const uint32_t N = b.n_sig[psm];
     if (N == 0) return;
 
     /* stage the retained-peak table */
-    const int64_t p0 = b.peak_off[psm];
-    const int R = (int)b.ret_n[psm];
-    for (int i = lane; i < R; i += 64) {
-        t_mz[i] = b.ret_mz[p0 + i];
-        t_rank[i] = b.ret_rank[p0 + i];
-    }
+    PeakTable tab;
+    stage_peak_table(b, psm, t_e, &tab);
     WalkEnv env;
     env.cfg = cfg;
     env.n_nl = cfg->n_nl;
@@ -59,11 +54,6 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
         for (int i = lane; i < 256; i += 64) nl_present[i] = cfg->present[i];
         if (lane < PYA_MAX_UNIQ) nl_uniq[lane] = cfg->uniq[lane];
     }
-    PeakTable tab;
-    tab.mz = t_mz;
-    tab.rank = t_rank;
-    tab.n = R;
-    tab.err = cfg->mz_error;
     wave_lds_sync();
     grid_build(&tab, grid);
 
@@ -77,6 +67,7 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
 
     int lut_fail = 0;
     const bool split = N <= 32 && both_dirs;     /* lanes 0..31 forward, 32..63 backward */
+    const bool simple = walk_is_simple(env);
     for (uint32_t sbase = 0; sbase < N; sbase += 64) {
         const uint32_t s = split ? (uint32_t)(lane & 31) : sbase + lane;
         const bool active = s < N;
@@ -84,7 +75,15 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
         const uint64_t resmask = deposit_sites(bits, res.site_mask);
         Hist h = {0ull, 0ull, 0ull};
         uint32_t nfrag = 0;
-        if (split) {
+        if (simple) {
+            if (split) {
+                walk_simple(env, res, tab, resmask, lane >> 5, active, h, nfrag);
+                fold_upper_half(h, nfrag);
+            } else {
+                if (cfg->n_fwd > 0) walk_simple(env, res, tab, resmask, 0, active, h, nfrag);
+                if (cfg->n_fwd < cfg->n_types) walk_simple(env, res, tab, resmask, 1, active, h, nfrag);
+            }
+        } else if (split) {
             walk(env, res, tab, resmask, lane >> 5, active, h, nfrag);
             fold_upper_half(h, nfrag);
         } else {
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
 }
 
 extern "C" size_t pya_score_lds_bytes(uint32_t cap) {
-    return (size_t)cap * 5 + 512 + PYA_GRID_CELLS * 2 + PYA_MAX_UNIQ * 4 + 64;
+    return ((size_t)cap + PYA_TABLE_PAD) * 8 + 512 + PYA_GRID_CELLS * 2 + PYA_MAX_UNIQ * 4 + 64;
 }
 
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,

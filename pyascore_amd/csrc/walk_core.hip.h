@@ -80,6 +80,46 @@ DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint6
     }
 }
 
+
+/* Fast path of `walk` for the common scorer settings -- no neutral losses, charge 1, at most
+ * one ion type per direction (BASELINE cfg1/2/3/5): straight-line code per residue step.
+ * `tmask` bit t = "the t-th residue in THIS lane's travel direction is modified". */
+DEV void walk_simple(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
+                     bool active, Hist &h, uint32_t &nfrag) {
+    const DevConfig *cfg = e.cfg;
+    const int L = e.L;
+    /* per-lane ion-type constants (the type letters are wave-uniform scalars) */
+    double Af = 0., Bf = 0., Ab = 0., Bb = 0.;
+    if (cfg->n_fwd > 0) type_constants(cfg->types[0], &Af, &Bf);
+    if (cfg->n_fwd < cfg->n_types) type_constants(cfg->types[cfg->n_fwd], &Ab, &Bb);
+    const double A = dir ? Ab : Af, B = dir ? Bb : Bf;
+    const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
+    const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
+    float running = 0.f;                                   /* 0 + r == r exactly */
+    for (int step = 0; step + 1 < L; step++) {
+        const int i_b = L - 1 - step;
+        const float f0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), step));
+        const float f1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), step));
+        const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i_b));
+        const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i_b));
+        const uint32_t word = step < 32 ? tlo : thi;       /* wave-uniform choice */
+        const bool mod = (word >> (step & 31)) & 1u;
+        const float m0 = dir ? b0 : f0, m1 = dir ? b1 : f1;
+        const float r = mod ? m1 : m0;
+        running = r + running;                             /* ModifiedPeptide.cpp:385-389 */
+        const double m = ((double)running + A) - B;
+        const float f = (float)(m + 1.007825);
+        const int rk = match_rank(tab, f);
+        if (active) hist_add(h, rk);
+    }
+    if (active) nfrag += (uint32_t)(L - 1);
+}
+
+DEV bool walk_is_simple(const WalkEnv &e) {
+    const int n_f = e.cfg->n_fwd, n_b = e.cfg->n_types - e.cfg->n_fwd;
+    return e.n_nl == 0 && e.zmax == 1 && n_f <= 1 && n_b <= 1;
+}
+
 /* walker of the opposite direction sits 32 lanes up: fold it into lanes 0..31 */
 DEV void fold_upper_half(Hist &h, uint32_t &nfrag) {
     h.a += __shfl_down(h.a, 32, 64);
