@@ -88,7 +88,15 @@ struct BatchDev {
     unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */
 };
 
-/* per-signature record (keep mode): 10 cumulative counts as u16 + total fragments */
+/* LDS bytes of the batched-localisation work area (localize_core.hip.h: LocLds) */
+#define PYA_LOC_SB 4               /* signatures worked on together: the winner + 3 competitors */
+static inline unsigned long pya_loc_lds_bytes(unsigned pos_cap, unsigned pool_cap) {
+    return 64ul * 4 * 2 + 64 + PYA_LOC_SB * 8ul + (unsigned long)PYA_LOC_SB * 2 * pos_cap * 8 +
+           PYA_LOC_SB * 2 * 4ul + PYA_LOC_SB * 11 * 4ul + PYA_LOC_SB * 10 * 4ul + PYA_LOC_SB * 4 * 3ul +
+           PYA_LOC_SB * 2 * 4 * 2ul + (unsigned long)pool_cap * 5 + 64;
+}
+
+/* per-signature record: 10 cumulative counts as u16 + total fragments */
 #define PYA_REC_WORDS 6
 
 #endif

@@ -118,6 +118,20 @@ DEV double type_offset(double m, uint8_t type) {
     }
     return m;
 }
+/* ion-type offsets as (m + A) - B in double: b (0,0), c (+NH3,0), y (+H2O,0), z (+H2O,-NH3),
+ * Z (+H2O,-NH2); adding or subtracting 0.0 is exact, so this equals ModifiedPeptide.cpp:573-583 */
+DEV void type_constants(uint8_t type, double *A, double *B) {
+    *A = (type == 'b') ? 0.0 : (type == 'c' ? 17.026549 : 18.010565);
+    *B = (type == 'z') ? 17.026549 : (type == 'Z' ? 16.018724 : 0.0);
+}
+
+/* the (up to 8) ion-type letters of the configuration as one wave-uniform 64-bit value */
+DEV uint64_t load_types64(const DevConfig *cfg) {
+    const uint32_t lo = *(const uint32_t *)&cfg->types[0], hi = *(const uint32_t *)&cfg->types[4];
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+DEV uint8_t type_at(uint64_t types64, int t) { return (uint8_t)(types64 >> (8 * t)); }
+
 DEV float charge_mz(double m, int z) {
     if (z == 1) return (float)(m + 1.007825);             /* (m + 1*P)/1 is exact in both steps */
     double zd = (double)z;

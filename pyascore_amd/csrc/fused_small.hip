@@ -39,8 +39,7 @@ extern "C" size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint3
                    FUSED_MAX_SIG * 4 + FUSED_MAX_SIG * 10 * 4;
     size_t table = ((size_t)peak_cap + PYA_TABLE_PAD) * 8;
     size_t srt = (size_t)FUSED_MAX_SIG * 10 + 64;
-    size_t loc = 64 * 4 * 2 + 64 + LOC_SB * 8 + (size_t)LOC_SB * 2 * pos_cap * 8 + LOC_SB * 2 * 4 +
-                 LOC_SB * 11 * 4 + LOC_SB * 10 * 4 + LOC_SB * 4 * 2 + LOC_SB * 2 * 4 * 2 + (size_t)pool_cap * 5 + 64;
+    size_t loc = pya_loc_lds_bytes(pos_cap, pool_cap);
     return fixed + table + (srt > loc ? srt : loc) + 64;
 }
 
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
     wave_lds_sync();
     float my_asc = __builtin_huge_valf();
     uint64_t my_alt = 0ull;
-    loc_ascore_all(ctx, f.pushed, np, order, f.ws_all, f.scores_all, best_bits, best_ws, best_i,
+    loc_ascore_all(ctx, f.pushed, np, order, f.ws_all, f.scores_all, nullptr, best_bits, best_ws, best_i,
                    res.site_mask, &my_asc, &my_alt, &fail);
     STAMP(b, 6);
     if (lane < k && lane < (int)max_k) {

@@ -720,10 +720,8 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
     HIPCHK(h, p->d_ret_mz.alloc((size_t)p->total_peaks));
     HIPCHK(h, p->d_ret_rank.alloc((size_t)p->total_peaks));
     HIPCHK(h, p->d_ws.alloc((size_t)sig_total));
-    if (flags & PYA_FLAG_KEEP) {
-        HIPCHK(h, p->d_rec.alloc((size_t)sig_total * PYA_REC_WORDS));
-        HIPCHK(h, p->d_sorted.alloc((size_t)sig_total));
-    }
+    HIPCHK(h, p->d_rec.alloc((size_t)sig_total * PYA_REC_WORDS));
+    if (flags & PYA_FLAG_KEEP) HIPCHK(h, p->d_sorted.alloc((size_t)sig_total));
     if (flags & PYA_FLAG_TIMING)
         for (auto &e : p->ev) HIPCHK(h, hipEventCreate(&e));
     HIPCHK(h, hipDeviceSynchronize());

@@ -427,7 +427,7 @@ DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
     return k;
 }
 
-#define LOC_SB 4               /* signatures worked on together: the winner + 3 competitors */
+#define LOC_SB PYA_LOC_SB
 
 /* work area of the batched localisation (aliases the sort arrays) */
 struct LocLds {
@@ -440,7 +440,8 @@ struct LocLds {
     uint32_t *tot;            /* [LOC_SB*2] variants per (sig, dir)                        */
     uint32_t *hist;           /* [LOC_SB*11] rank histogram + total fragments             */
     float *scores;            /* [LOC_SB*10]                                              */
-    uint32_t *c_idx;          /* [LOC_SB] pre-sort index of the competitor                */
+    uint32_t *c_idx;          /* [LOC_SB] which modified site of the winner the competitor moves */
+    uint32_t *c_pre;          /* [LOC_SB] pre-sort index of the signature (entry 0 = winner)     */
     int32_t *c_depth;         /* [LOC_SB]                                                 */
     uint32_t *c_cnt;          /* [LOC_SB*2] matched site-determining ions (ref, other)    */
     uint32_t *c_tr;           /* [LOC_SB*2] site-determining ions                         */
@@ -459,7 +460,8 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap) {
     w.tot = (uint32_t *)(w.pool + pool_cap);
     w.hist = w.tot + LOC_SB * 2;
     w.c_idx = w.hist + LOC_SB * 11;
-    w.c_depth = (int32_t *)(w.c_idx + LOC_SB);
+    w.c_pre = w.c_idx + LOC_SB;
+    w.c_depth = (int32_t *)(w.c_pre + LOC_SB);
     w.c_cnt = (uint32_t *)(w.c_depth + LOC_SB);
     w.c_tr = w.c_cnt + LOC_SB * 2;
     w.pmk = (uint16_t *)(w.c_tr + LOC_SB * 2);
@@ -548,6 +550,7 @@ DEV void loc_counts(const LocCtx &c, int s_lo, int S) {
     const DevConfig *cfg = c.cfg;
     const int Lm1 = c.L - 1;
     const int gp = ilog2_ceil(Lm1 > 0 ? Lm1 : 1);
+    const uint64_t types64 = load_types64(cfg);
     for (int i = s_lo * 11 + lane; i < S * 11; i += 64) w.hist[i] = 0;
     wave_lds_sync();
     const int E = ((S - s_lo) * 2) << gp;
@@ -567,7 +570,9 @@ DEV void loc_counts(const LocCtx &c, int s_lo, int S) {
             const float x = running - (c.nl.n_nl ? c.nl.uniq[v] : 0.f);
             const double xd = (double)x;
             for (int t = t0; t < t1; t++) {
-                const double m = type_offset(xd, cfg->types[t]);
+                double A, B;
+                type_constants(type_at(types64, t), &A, &B);
+                const double m = (xd + A) - B;
                 for (int z = 1; z <= c.zmax; z++) {
                     const int rk = match_rank(c.tab, charge_mz(m, z));
                     if (rk < PYA_NTOP) atomicAdd(&w.hist[s * 11 + rk], 1u);
@@ -606,6 +611,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
     const DevConfig *cfg = c.cfg;
     const int T = cfg->n_types, Lm1 = c.L - 1;
     const int gt = ilog2_ceil(T);                 /* type slots = 1 << gt */
+    const uint64_t types64 = load_types64(cfg);
     const int gp = ilog2_ceil(Lm1 > 0 ? Lm1 : 1);
     /* depth of the largest score gap (Ascore.cpp:164-172) */
     if (lane >= 1 && lane < S) {
@@ -646,7 +652,8 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
             if (pos >= Lm1 || t >= T) continue;
             const int s = side ? cc : 0;
-            const uint8_t type = cfg->types[t];
+            double A, B;
+            type_constants(type_at(types64, t), &A, &B);
             const int d = t < cfg->n_fwd ? 0 : 1;
             const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
             uint32_t pm = w.pmk[idx];
@@ -656,7 +663,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                 const int v = __builtin_ctz(pm);
                 pm &= pm - 1;
                 const float x = running - (c.nl.n_nl ? c.nl.uniq[v] : 0.f);
-                const double m = type_offset((double)x, type);
+                const double m = ((double)x + A) - B;
                 for (int z = 1; z <= c.zmax; z++) *dst++ = charge_mz(m, z);
             }
         }
@@ -805,10 +812,12 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
 
 /* Ascores of every modified site of the winner (cpp/Ascore.cpp:212-254): walks the pushed
  * competitors LOC_SB-1 at a time.  `ws` may live in LDS or global memory; `scores_all`, when
- * given, holds the 10 depth scores of every signature (pre-sort index) so they are not
- * recomputed.  Lane a accumulates site a in *my_asc / *my_alt. */
+ * given, holds the 10 depth scores of every signature (pre-sort index); otherwise `rec` holds the
+ * cumulative counts score_signatures wrote, from which the depth scores are read off the score
+ * table (the same reads score_signatures made).  Lane a accumulates site a in *my_asc / *my_alt. */
 DEV void loc_ascore_all(LocCtx &ctx, const uint32_t *pushed, uint32_t np, const uint64_t *order,
-                        const float *ws, const float *scores_all, uint64_t best_bits, float best_ws,
+                        const float *ws, const float *scores_all, const uint32_t *rec, uint64_t best_bits,
+                        float best_ws,
                         uint32_t best_i, uint64_t site_mask, float *my_asc_io, uint64_t *my_alt_io,
                         int *fail_io) {
     const int lane = lane_id();
@@ -838,6 +847,7 @@ DEV void loc_ascore_all(LocCtx &ctx, const uint32_t *pushed, uint32_t np, const 
             if (lane == 0) {
                 w.sig_mask[S] = deposit_sites(c, site_mask);
                 w.c_idx[S] = (uint32_t)a;
+                w.c_pre[S] = ci;
             }
             if (scores_all && lane < PYA_NTOP) w.scores[S * 10 + lane] = scores_all[ci * 10 + lane];
             S++;
@@ -845,11 +855,26 @@ DEV void loc_ascore_all(LocCtx &ctx, const uint32_t *pushed, uint32_t np, const 
         STAMP(b, 26);
         if (S == 1) continue;
         if (scores_all && !have_best && lane < PYA_NTOP) w.scores[lane] = scores_all[best_i * 10 + lane];
+        if (lane == 0) w.c_pre[0] = best_i;
         wave_lds_sync();
         if (!(b.debug & 4)) loc_prefix_tables(ctx, S);
         wave_lds_sync();
         STAMP(b, 27);
-        if (!scores_all && !(b.debug & 2)) {
+        if (!scores_all && rec) {
+            /* depth scores of signatures [have_best, S) from the recorded cumulative counts */
+            for (int i = (have_best ? 10 : 0) + lane; i < S * 10; i += 64) {
+                const int s = i / 10, d = i % 10;
+                const uint32_t *r6 = rec + (size_t)w.c_pre[s] * PYA_REC_WORDS;
+                const uint32_t cum = (r6[d >> 1] >> ((d & 1) * 16)) & 0xffffu;
+                const uint32_t nf = r6[5];
+                float sc = 0.f;
+                if (nf <= b.lut_n_max) sc = b.lut[b.lut_off[nf] + (uint32_t)d * (nf + 1) + cum];
+                else fail = 1;
+                w.scores[i] = sc;
+            }
+            wave_lds_sync();
+            STAMP(b, 28);
+        } else if (!scores_all && !(b.debug & 2)) {
             loc_counts(ctx, have_best ? 1 : 0, S);
             STAMP(b, 28);
             loc_scores(ctx, have_best ? 1 : 0, S, &fail);

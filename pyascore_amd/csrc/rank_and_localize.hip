@@ -26,8 +26,7 @@ extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint
     size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + PYA_GRID_CELLS * 2 +
                    ((size_t)peak_cap + PYA_TABLE_PAD) * 8;
     size_t srt = (size_t)n_cap * 10 + 64;
-    size_t lst = 64 * 4 * 2 + 64 + LOC_SB * 8 + (size_t)LOC_SB * 2 * pos_cap * 8 + LOC_SB * 2 * 4 +
-                 LOC_SB * 11 * 4 + LOC_SB * 10 * 4 + LOC_SB * 4 * 2 + LOC_SB * 2 * 4 * 2 + (size_t)pool_cap * 5 + 64;
+    size_t lst = pya_loc_lds_bytes(pos_cap, pool_cap);
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
@@ -167,7 +166,8 @@ __global__ __launch_bounds__(64, 6) void pya_localize_kernel(BatchDev b, const u
     STAMP(b, 25);
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
-    loc_ascore_all(ctx, lds.pushed, np, order, ws, nullptr, best_bits, best_ws, best_i, res.site_mask,
+    loc_ascore_all(ctx, lds.pushed, np, order, ws, nullptr, b.rec ? b.rec + s0 * PYA_REC_WORDS : nullptr,
+                   best_bits, best_ws, best_i, res.site_mask,
                    &my_asc, &my_alt, &fail);
     STAMP(b, 36);
     if (lane < k && lane < (int)max_k) {

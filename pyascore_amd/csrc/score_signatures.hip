@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
                 lut_fail = 1;
             }
             b.ws[s0 + s] = ws;
-            if (b.keep) {
+            if (b.rec) {
                 uint32_t *rec = b.rec + (s0 + s) * PYA_REC_WORDS;
 #pragma unroll
                 for (int d = 0; d < PYA_NTOP; d += 2) rec[d >> 1] = cum[d] | (cum[d + 1] << 16);

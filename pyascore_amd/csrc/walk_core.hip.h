@@ -11,13 +11,6 @@ struct WalkEnv {
     int n_nl, L, zmax;
 };
 
-/* ion-type offsets as (m + A) - B in double: b (0,0), c (+NH3,0), y (+H2O,0), z (+H2O,-NH3),
- * Z (+H2O,-NH2); adding or subtracting 0.0 is exact, so this equals ModifiedPeptide.cpp:573-583 */
-DEV void type_constants(uint8_t type, double *A, double *B) {
-    *A = (type == 'b') ? 0.0 : (type == 'c' ? 17.026549 : 18.010565);
-    *B = (type == 'z') ? 17.026549 : (type == 'Z' ? 16.018724 : 0.0);
-}
-
 /* Walks one direction per lane (`dir` may differ between lanes: the residue of a step is read
  * for both directions with two v_readlane and selected).  Adds to h / nfrag. */
 DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
@@ -28,6 +21,7 @@ DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint6
     const int t_base = dir == 0 ? 0 : n_f;
     const bool any_f = __any(active && dir == 0), any_b = __any(active && dir == 1);
     const int t_max = (any_f && any_b) ? (n_f > n_b ? n_f : n_b) : (any_f ? n_f : n_b);
+    const uint64_t types64 = load_types64(cfg);
     float running = 0.f;
     uint32_t nl_state = 0;
     for (int step = 0; step + 1 < e.L; step++) {
@@ -66,7 +60,7 @@ DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint6
             for (int t = 0; t < t_max; t++) {
                 const bool on_t = on && t < my_types;
                 double A, B;
-                type_constants(cfg->types[t_base + (t < my_types ? t : 0)], &A, &B);
+                type_constants(type_at(types64, t_base + (t < my_types ? t : 0)), &A, &B);
                 const double m = (xd + A) - B;
                 for (int z = 1; z <= e.zmax; z++) {
                     const float f = charge_mz(m, z);
