@@ -61,7 +61,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
 
     /* pass 3: intensity rank inside the window = number of window mates that are more intense
      * (ties: the earlier peak ranks first; the reference leaves ties unspecified). */
-    for (int base = 0; base < P; base += 64) {
+    for (int base = 0; base < P && !(b.debug & 32); base += 64) {
         int i = base + lane;
         int cnt = PYA_NTOP;
         if (i < P) {
@@ -90,7 +90,8 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     float *o_mz = (float *)s_inten;
     uint8_t *o_rank = (uint8_t *)(o_mz + cap);
     int total = 0;
-    if (!unsorted) {
+    if (b.debug & 64) {
+    } else if (!unsorted) {
         for (int base = 0; base < P; base += 64) {
             int i = base + lane;
             bool keep = i < P && s_rank[i] < PYA_NTOP;

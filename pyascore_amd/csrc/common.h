@@ -13,7 +13,7 @@
 #define PYA_MAX_UNIQ 16            /* distinct sums of <= 2 neutral losses (incl. 0)       */
 #define PYA_MAX_LIST 2048          /* fragments of one signature and one ion type          */
 #define PYA_MAX_LUT_N 4096         /* largest trial count the score table covers           */
-#define PYA_MAX_PUSHED 256         /* tied best competitors kept per PSM                   */
+#define PYA_MAX_PUSHED 64          /* tied best competitors kept per PSM                   */
 
 /* per-PSM status written by the kernels */
 #define PYA_ST_OK 0
@@ -86,6 +86,13 @@ struct BatchDev {
     uint32_t keep;                  /* write rec / sorted_idx                               */
     uint32_t debug;                 /* PYA_DEBUG ablation bits (timing experiments only)    */
     unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */
+};
+
+/* one tied best competitor as the scan leaves it in LDS */
+struct PushedEntry {
+    uint64_t bits;   /* signature */
+    float ws;        /* its PepScore */
+    uint32_t idx;    /* its pre-sort index */
 };
 
 /* LDS bytes of the batched-localisation work area (localize_core.hip.h: LocLds) */

@@ -25,7 +25,7 @@ struct FusedLds {
     uint16_t *nl_present;   /* [256] */
     float *nl_uniq;         /* [PYA_MAX_UNIQ] */
     uint16_t *grid;         /* [PYA_GRID_CELLS] */
-    uint32_t *pushed;       /* [FUSED_PUSHED] */
+    PushedEntry *pushed;    /* [FUSED_PUSHED] */
     uint32_t *site_max;     /* [64] */
     uint32_t *n_pushed;     /* [4] */
     float *ws_all;          /* [FUSED_MAX_SIG] weighted score per signature (pre-sort order) */
@@ -35,7 +35,7 @@ struct FusedLds {
 };
 
 extern "C" size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap) {
-    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_GRID_CELLS * 2 + FUSED_PUSHED * 4 + 64 * 4 + 16 +
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_GRID_CELLS * 2 + FUSED_PUSHED * 16 + 64 * 4 + 16 +
                    FUSED_MAX_SIG * 4 + FUSED_MAX_SIG * 10 * 4;
     size_t table = ((size_t)peak_cap + PYA_TABLE_PAD) * 8;
     size_t srt = (size_t)FUSED_MAX_SIG * 10 + 64;
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
     f.nl_present = (uint16_t *)lds_raw;
     f.grid = f.nl_present + 256;
     f.nl_uniq = (float *)(f.grid + PYA_GRID_CELLS);
-    f.pushed = (uint32_t *)(f.nl_uniq + PYA_MAX_UNIQ);
-    f.site_max = f.pushed + FUSED_PUSHED;
+    f.pushed = (PushedEntry *)(f.nl_uniq + PYA_MAX_UNIQ);
+    f.site_max = (uint32_t *)(f.pushed + FUSED_PUSHED);
     f.n_pushed = f.site_max + 64;
     f.ws_all = (float *)(f.n_pushed + 4);
     f.scores_all = f.ws_all + FUSED_MAX_SIG;
@@ -210,7 +210,13 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
         wave_lds_sync();
         if (single && wbits == f.site_max[a]) {
             const uint32_t slot = atomicAdd(f.n_pushed, 1u);
-            if (slot < FUSED_PUSHED) f.pushed[slot] = (uint32_t)lane;
+            if (slot < FUSED_PUSHED) {
+                PushedEntry pe;
+                pe.bits = c;
+                pe.ws = __uint_as_float(wbits);
+                pe.idx = (uint32_t)lane;
+                f.pushed[slot] = pe;
+            }
         }
         wave_lds_sync();
     }
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
     wave_lds_sync();
     float my_asc = __builtin_huge_valf();
     uint64_t my_alt = 0ull;
-    loc_ascore_all(ctx, f.pushed, np, order, f.ws_all, f.scores_all, nullptr, best_bits, best_ws, best_i,
+    loc_ascore_all(ctx, f.pushed, np, f.scores_all, nullptr, best_bits, best_ws, best_i,
                    res.site_mask, &my_asc, &my_alt, &fail);
     STAMP(b, 6);
     if (lane < k && lane < (int)max_k) {

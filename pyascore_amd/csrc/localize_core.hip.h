@@ -407,9 +407,11 @@ struct K3Lds {
     uint16_t *nl_present;
     float *nl_uniq;
     PeakEntry *t_e;          /* [peak_cap + PYA_TABLE_PAD] */
-    uint32_t *pushed;        /* [PYA_MAX_PUSHED] */
-    uint32_t *site_max;      /* [64] */
-    uint32_t *n_pushed;      /* [1]  */
+    PushedEntry *pushed;     /* [PYA_MAX_PUSHED] */
+    uint32_t *site_max;      /* [64] best competitor PepScore (bits) per modified site */
+    uint32_t *site_tie;      /* [64] some best competitor ties the winner (Ascore 0)   */
+    unsigned long long *site_alt;  /* [64] positions of competitors that tie the winner */
+    uint32_t *n_pushed;      /* [4]  */
     uint16_t *grid;          /* [PYA_GRID_CELLS] */
     unsigned char *scratch;  /* sort arrays, later the localisation work area */
 };
@@ -418,9 +420,11 @@ DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
     K3Lds k;
     k.nl_present = (uint16_t *)raw;
     k.nl_uniq = (float *)(k.nl_present + 256);
-    k.pushed = (uint32_t *)(k.nl_uniq + PYA_MAX_UNIQ);
-    k.site_max = k.pushed + PYA_MAX_PUSHED;
-    k.n_pushed = k.site_max + 64;
+    k.pushed = (PushedEntry *)(k.nl_uniq + PYA_MAX_UNIQ);
+    k.site_alt = (unsigned long long *)(k.pushed + PYA_MAX_PUSHED);
+    k.site_max = (uint32_t *)(k.site_alt + 64);
+    k.site_tie = k.site_max + 64;
+    k.n_pushed = k.site_tie + 64;
     k.grid = (uint16_t *)(k.n_pushed + 4);
     k.t_e = (PeakEntry *)(k.grid + PYA_GRID_CELLS);
     k.scratch = (unsigned char *)(k.t_e + peak_cap + PYA_TABLE_PAD);
@@ -811,13 +815,12 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
 
 
 /* Ascores of every modified site of the winner (cpp/Ascore.cpp:212-254): walks the pushed
- * competitors LOC_SB-1 at a time.  `ws` may live in LDS or global memory; `scores_all`, when
+ * competitors LOC_SB-1 at a time.  `scores_all`, when
  * given, holds the 10 depth scores of every signature (pre-sort index); otherwise `rec` holds the
  * cumulative counts score_signatures wrote, from which the depth scores are read off the score
  * table (the same reads score_signatures made).  Lane a accumulates site a in *my_asc / *my_alt. */
-DEV void loc_ascore_all(LocCtx &ctx, const uint32_t *pushed, uint32_t np, const uint64_t *order,
-                        const float *ws, const float *scores_all, const uint32_t *rec, uint64_t best_bits,
-                        float best_ws,
+DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, const float *scores_all,
+                        const uint32_t *rec, uint64_t best_bits, float best_ws,
                         uint32_t best_i, uint64_t site_mask, float *my_asc_io, uint64_t *my_alt_io,
                         int *fail_io) {
     const int lane = lane_id();
@@ -833,9 +836,10 @@ DEV void loc_ascore_all(LocCtx &ctx, const uint32_t *pushed, uint32_t np, const 
         /* gather the next competitors that are not exact PepScore ties of the winner */
         int S = 1;
         while (e < np && S < LOC_SB) {
-            const uint32_t ci = pushed[e++];
-            const uint64_t c = order[ci];
-            const float c_ws = ws[ci];
+            const PushedEntry pe = pushed[e++];               /* LDS, wave-uniform */
+            const uint32_t ci = pe.idx;
+            const uint64_t c = pe.bits;
+            const float c_ws = pe.ws;
             const uint64_t gone = best_bits & ~c, came = c & ~best_bits;
             const int a = __popcll(best_bits & (gone - 1));
             const int q = __builtin_ctzll(came);

@@ -23,14 +23,14 @@
 
 extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap,
                                          uint32_t pool_cap) {
-    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + PYA_GRID_CELLS * 2 +
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 16 + 64 * 16 + 16 + PYA_GRID_CELLS * 2 +
                    ((size_t)peak_cap + PYA_TABLE_PAD) * 8;
     size_t srt = (size_t)n_cap * 10 + 64;
     size_t lst = pya_loc_lds_bytes(pos_cap, pool_cap);
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
-__global__ __launch_bounds__(64, 6) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
+__global__ __launch_bounds__(64, 5) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
                                                           uint32_t n_ids, uint32_t peak_cap,
                                                           uint32_t pos_cap, uint32_t pool_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -80,6 +80,8 @@ __global__ __launch_bounds__(64, 6) void pya_localize_kernel(BatchDev b, const u
     ctx.b = &b;
     ctx.cfg = cfg;
     stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl);
+    const Residues res = load_residues(b, cfg, psm);
+    const uint64_t site_mask_u = res.site_mask;
     STAMP(b, 20);
 
     /* ---- sort (cpp/Ascore.cpp:141-146) ---- */
@@ -94,6 +96,8 @@ __global__ __launch_bounds__(64, 6) void pya_localize_kernel(BatchDev b, const u
     }
     if (lane == 0) *lds.n_pushed = 0;
     lds.site_max[lane] = 0;
+    lds.site_tie[lane] = 0;
+    lds.site_alt[lane] = 0ull;
     wave_lds_sync();
     /* only the left spine of the partition tree decides the front element; the full sort is
      * needed when the caller wants the whole ordering */
@@ -134,8 +138,20 @@ __global__ __launch_bounds__(64, 6) void pya_localize_kernel(BatchDev b, const u
                     if (pass == 0) {
                         atomicMax(&lds.site_max[a], u);
                     } else if (u == lds.site_max[a]) {
+                        if ((double)__builtin_fabsf(best_ws - __uint_as_float(u)) < 1e-6) {
+                            /* ties the winner: Ascore 0 (Ascore.cpp:159-161), no ion work needed */
+                            lds.site_tie[a] = 1u;
+                            atomicOr(&lds.site_alt[a], 1ull << nth_set_bit(site_mask_u, __builtin_ctzll(came)));
+                            continue;
+                        }
                         const uint32_t slot = atomicAdd(lds.n_pushed, 1u);
-                        if (slot < PYA_MAX_PUSHED) lds.pushed[slot] = (uint32_t)i;
+                        if (slot < PYA_MAX_PUSHED) {
+                            PushedEntry pe;
+                            pe.bits = c;
+                            pe.ws = __uint_as_float(u);
+                            pe.idx = (uint32_t)i;
+                            lds.pushed[slot] = pe;
+                        }
                     }
                 }
             }
@@ -150,7 +166,6 @@ __global__ __launch_bounds__(64, 6) void pya_localize_kernel(BatchDev b, const u
 
     STAMP(b, 24);
     /* ---- Ascores, LOC_SB-1 competitors at a time ---- */
-    const Residues res = load_residues(b, cfg, psm);
     ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap);
     ctx.L = res.L;
     ctx.zmax = b.max_charge[psm];
@@ -166,10 +181,12 @@ __global__ __launch_bounds__(64, 6) void pya_localize_kernel(BatchDev b, const u
     STAMP(b, 25);
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
-    loc_ascore_all(ctx, lds.pushed, np, order, ws, nullptr, b.rec ? b.rec + s0 * PYA_REC_WORDS : nullptr,
+    loc_ascore_all(ctx, lds.pushed, np, nullptr, b.rec ? b.rec + s0 * PYA_REC_WORDS : nullptr,
                    best_bits, best_ws, best_i, res.site_mask,
                    &my_asc, &my_alt, &fail);
     STAMP(b, 36);
+    if (lane < k && lds.site_tie[lane]) my_asc = 0.f < my_asc ? 0.f : my_asc;
+    if (lane < k) my_alt |= lds.site_alt[lane];
     if (lane < k && lane < (int)max_k) {
         out_asc[lane] = my_asc;
         out_alt[lane] = my_alt;
@@ -250,7 +267,7 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
 }
 
 extern "C" size_t pya_amb_lds_bytes(uint32_t peak_cap, uint32_t list_cap) {
-    return 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 4 + 64 * 4 + 16 + PYA_GRID_CELLS * 2 +
+    return 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 16 + 64 * 16 + 16 + PYA_GRID_CELLS * 2 +
            ((size_t)peak_cap + PYA_TABLE_PAD) * 8 + (size_t)list_cap * 10 + 128;
 }
 
