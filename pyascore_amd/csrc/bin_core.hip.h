@@ -60,28 +60,63 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     wave_lds_sync();
 
     /* pass 3: intensity rank inside the window = number of window mates that are more intense
-     * (ties: the earlier peak ranks first; the reference leaves ties unspecified). */
-    for (int base = 0; base < P && !(b.debug & 32); base += 64) {
-        int i = base + lane;
-        int cnt = PYA_NTOP;
-        if (i < P) {
-            const uint16_t w = s_bin[i];
-            const double me = s_inten[i];
-            cnt = 0;
-            if (!unsorted) {
-                for (int j = i - 1; j >= 0 && cnt < PYA_NTOP && s_bin[j] == w; j--)
-                    cnt += (s_inten[j] >= me) ? 1 : 0;
-                for (int j = i + 1; j < P && cnt < PYA_NTOP && s_bin[j] == w; j++)
-                    cnt += (s_inten[j] > me) ? 1 : 0;
-            } else {
-                for (int j = 0; j < P && cnt < PYA_NTOP; j++) {
-                    if (s_bin[j] != w || j == i) continue;
-                    double o = s_inten[j];
+     * (ties: the earlier peak ranks first; the reference leaves ties unspecified).
+     * Sorted spectra (the normal case): a window is a run of consecutive peaks, so each lane gets
+     * the bounds [lo, hi] of its run from a ballot of the run starts and all lanes sweep their
+     * runs in lock step -- a wave-uniform loop without per-lane exit tests; positions past the end
+     * of a shorter run are clamped to the lane's own peak, which never counts. */
+    if (!(b.debug & 32)) {
+        if (!unsorted) {
+            int carry_lo = 0;
+            for (int base = 0; base < P; base += 64) {
+                const int i = base + lane;
+                const bool in = i < P;
+                const uint32_t w = in ? (uint32_t)s_bin[i] : 0x10000u;
+                const uint32_t pw = (in && i > 0) ? (uint32_t)s_bin[i - 1] : 0x10001u;
+                const double me = s_inten[in ? i : 0];
+                const uint64_t starts = __ballot(in && pw != w);
+                const uint64_t upto = lanemask_lt() | (1ull << lane);
+                const uint64_t le = starts & upto, gt = starts & ~upto;
+                /* where does the run that is still open at the end of this chunk stop? */
+                int run_end = P - 1;
+                for (int nb = base + 64; nb < P; nb += 64) {
+                    const int j = nb + lane;
+                    const uint64_t m2 = __ballot(j < P && s_bin[j] != s_bin[j - 1]);
+                    if (m2) {
+                        run_end = nb + __builtin_ctzll(m2) - 1;
+                        break;
+                    }
+                }
+                const int lo = le ? base + 63 - __builtin_clzll(le) : carry_lo;
+                const int hi = gt ? base + __builtin_ctzll(gt) - 1 : run_end;
+                const int len = in ? hi - lo + 1 : 0;
+                const int t_max = (int)wave_max_u32((uint32_t)len);
+                carry_lo = __builtin_amdgcn_readlane(lo, 63);
+                int cnt = 0;
+#pragma unroll 2
+                for (int t = 0; t < t_max; t++) {
+                    const int j = t < len ? lo + t : i;
+                    const double o = s_inten[j];
                     cnt += (o > me || (o == me && j < i)) ? 1 : 0;
+                }
+                if (in) s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
+            }
+        } else {
+            for (int base = 0; base < P; base += 64) {
+                const int i = base + lane;
+                if (i < P) {
+                    const uint16_t w = s_bin[i];
+                    const double me = s_inten[i];
+                    int cnt = 0;
+                    for (int j = 0; j < P && cnt < PYA_NTOP; j++) {
+                        if (s_bin[j] != w || j == i) continue;
+                        const double o = s_inten[j];
+                        cnt += (o > me || (o == me && j < i)) ? 1 : 0;
+                    }
+                    s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
                 }
             }
         }
-        if (i < P) s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
     }
     wave_lds_sync();
 
