@@ -154,7 +154,10 @@ struct PeakEntry {
 };
 
 struct PeakTable {
-    const PeakEntry *e;     /* LDS, ascending m/z, n entries + PYA_TABLE_PAD (+inf, rank 15)      */
+    const PeakEntry *e;     /* LDS, ascending m/z, n entries + PYA_TABLE_PAD (+inf, rank 15);     */
+                            /* NULL = not staged: look up in the global arrays below             */
+    const float *g_mz;      /* global retained m/z of the PSM (ascending)                        */
+    const uint8_t *g_rank;
     const uint16_t *cell;   /* LDS [PYA_GRID_CELLS]: first peak index whose cell is >= c          */
     int n;
     float err;
@@ -185,6 +188,8 @@ DEV void stage_peak_table(const BatchDev &b, uint32_t psm, PeakEntry *dst, PeakT
         dst[R + lane] = x;
     }
     t->e = dst;
+    t->g_mz = b.ret_mz + p0;
+    t->g_rank = b.ret_rank + p0;
     t->n = R;
     t->err = b.cfg->mz_error;
     t->half_check = b.cfg->mz_error > 0.49f;
@@ -228,7 +233,48 @@ DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
 /* Branch-light lookup: the grid gives an index at or before the first peak > lo; four entries
  * are fetched at once (the sentinels make this safe) and reduced with selects; only when the
  * window is not closed by the fourth entry does a lane continue with the scalar scan. */
-DEV int match_rank(const PeakTable &t, float f) {
+/* the table of `psm` left in global memory (for kernels that make only a handful of lookups) */
+DEV void global_peak_table(const BatchDev &b, uint32_t psm, PeakTable *t) {
+    const int64_t p0 = b.peak_off[psm];
+    t->e = nullptr;
+    t->cell = nullptr;
+    t->g_mz = b.ret_mz + p0;
+    t->g_rank = b.ret_rank + p0;
+    t->n = (int)b.ret_n[psm];
+    t->err = b.cfg->mz_error;
+    t->half_check = b.cfg->mz_error > 0.49f;
+    t->base = 0.f;
+    t->inv_w = 0.f;
+    t->last_cell = 0;
+}
+
+/* same window test on the global arrays: binary search for the first peak > lo, then scan */
+DEV int match_rank_global(const PeakTable &t, float f) {
+    const float lo = f - t.err;
+    const float hi = f + t.err;
+    int idx = 0, len = t.n;                               /* first index with mz > lo */
+    while (len > 0) {
+        const int half = len >> 1;
+        if (t.g_mz[idx + half] <= lo) {
+            idx += half + 1;
+            len -= half + 1;
+        } else {
+            len = half;
+        }
+    }
+    int best = PYA_NO_MATCH;
+    for (; idx < t.n; idx++) {
+        const float p = t.g_mz[idx];
+        if (!(p < hi)) break;
+        if (!t.half_check || (double)f >= (double)p - 0.5) {
+            const int r = (int)t.g_rank[idx];
+            best = r < best ? r : best;
+        }
+    }
+    return best;
+}
+
+DEV int match_rank_lds(const PeakTable &t, float f) {
     const float lo = f - t.err;
     const float hi = f + t.err;
     int idx = (int)t.cell[grid_cell(t, lo)];              /* every peak > lo has index >= idx  */
@@ -258,6 +304,10 @@ DEV int match_rank(const PeakTable &t, float f) {
         }
     }
     return best;
+}
+
+DEV int match_rank(const PeakTable &t, float f) {
+    return t.e ? match_rank_lds(t, f) : match_rank_global(t, f);
 }
 
 /* rank histogram: 10 x 16-bit fields in three 64-bit words (ranks 0-3 | 4-7 | 8-9) */

@@ -416,7 +416,7 @@ struct K3Lds {
     unsigned char *scratch;  /* sort arrays, later the localisation work area */
 };
 
-DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
+DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap, bool with_table = true) {
     K3Lds k;
     k.nl_present = (uint16_t *)raw;
     k.nl_uniq = (float *)(k.nl_present + 256);
@@ -426,8 +426,8 @@ DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap) {
     k.site_tie = k.site_max + 64;
     k.n_pushed = k.site_tie + 64;
     k.grid = (uint16_t *)(k.n_pushed + 4);
-    k.t_e = (PeakEntry *)(k.grid + PYA_GRID_CELLS);
-    k.scratch = (unsigned char *)(k.t_e + peak_cap + PYA_TABLE_PAD);
+    k.t_e = (PeakEntry *)(k.grid + (with_table ? PYA_GRID_CELLS : 0));
+    k.scratch = (unsigned char *)(k.t_e + (with_table ? peak_cap + PYA_TABLE_PAD : 0));
     return k;
 }
 
@@ -476,9 +476,10 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap) {
 }
 
 DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, uint32_t psm,
-                      PeakTable *tab, NlTables *nl) {
+                      PeakTable *tab, NlTables *nl, bool with_table = true) {
     const int lane = lane_id();
-    stage_peak_table(b, psm, k.t_e, tab);
+    if (with_table) stage_peak_table(b, psm, k.t_e, tab);
+    else global_peak_table(b, psm, tab);
     nl->n_nl = cfg->n_nl;
     if (nl->n_nl) {
         for (int i = lane; i < 256; i += 64) k.nl_present[i] = cfg->present[i];
@@ -487,8 +488,10 @@ DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, u
     nl->present = k.nl_present;
     nl->uniq = k.nl_uniq;
     wave_lds_sync();
-    grid_build(tab, k.grid);
-    wave_lds_sync();
+    if (with_table) {
+        grid_build(tab, k.grid);
+        wave_lds_sync();
+    }
 }
 
 /* ---------------------------------------------------------------------------------------

@@ -23,8 +23,8 @@
 
 extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap,
                                          uint32_t pool_cap) {
-    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 16 + 64 * 16 + 16 + PYA_GRID_CELLS * 2 +
-                   ((size_t)peak_cap + PYA_TABLE_PAD) * 8;
+    (void)peak_cap;                 /* the localize kernel looks peaks up in global memory */
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 16 + 64 * 16 + 16;
     size_t srt = (size_t)n_cap * 10 + 64;
     size_t lst = pya_loc_lds_bytes(pos_cap, pool_cap);
     return fixed + (srt > lst ? srt : lst) + 64;
@@ -75,11 +75,13 @@ __global__ __launch_bounds__(64, 5) void pya_localize_kernel(BatchDev b, const u
     }
 
     STAMP_BEGIN();
-    K3Lds lds = carve(lds_raw, peak_cap);
+    /* only a handful of ions are matched here, so the retained-peak table is not staged in LDS:
+     * that keeps this kernel's LDS small (occupancy) and saves the staging + grid build */
+    K3Lds lds = carve(lds_raw, peak_cap, false);
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
-    stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl);
+    stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, false);
     const Residues res = load_residues(b, cfg, psm);
     const uint64_t site_mask_u = res.site_mask;
     STAMP(b, 20);

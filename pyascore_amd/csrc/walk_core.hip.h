@@ -65,7 +65,7 @@ DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint6
                 for (int z = 1; z <= e.zmax; z++) {
                     const float f = charge_mz(m, z);
                     if (on_t) {
-                        hist_add(h, match_rank(tab, f));
+                        hist_add(h, match_rank_lds(tab, f));
                         nfrag++;
                     }
                 }
@@ -103,7 +103,7 @@ DEV void walk_simple(const WalkEnv &e, const Residues &res, const PeakTable &tab
         running = r + running;                             /* ModifiedPeptide.cpp:385-389 */
         const double m = ((double)running + A) - B;
         const float f = (float)(m + 1.007825);
-        const int rk = match_rank(tab, f);
+        const int rk = match_rank_lds(tab, f);
         if (active) hist_add(h, rk);
     }
     if (active) nfrag += (uint32_t)(L - 1);
