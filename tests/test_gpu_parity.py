@@ -176,3 +176,86 @@ def test_error_behaviour():
         PyAscore(100.0, 10, "STY", 79.966331, fragment_types="bx")
     s.score(mz, it, "PEPTIDE", 1)                           # still usable afterwards
     assert s.best_sequence == "PEPT[80]IDE"
+
+
+# ---------------------------------------------------------------------------------------------
+# Full BASELINE sizes: size-independent properties (the checker cannot run 100k+ PSMs in seconds)
+# ---------------------------------------------------------------------------------------------
+def _same(a, b, keys=("n_sig", "best_sig", "best_score", "ascores", "alt_mask")):
+    for k in keys:
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("cfg,n", [("cfg2", 100_000), ("cfg3", 125_000)])
+def test_full_size_properties(cfg, n):
+    """(1) determinism, (2) a batch scores exactly like its two halves, (3) PSM order does not
+    matter, (4) a random sample agrees bit for bit with the CPU checker."""
+    batch, settings = synth.make_batch(cfg, n_psm=n, seed=4242)
+    gpu = _gpu(settings)
+    full = gpu.score_batch(batch)
+    _same(gpu.score_batch(batch), full)
+    half = n // 2
+    lo, hi = gpu.score_batch(synth.slice_batch(batch, 0, half)), gpu.score_batch(synth.slice_batch(batch, half, n))
+    k = full["ascores"].shape[1]
+    for key in ("n_sig", "best_sig", "best_score"):
+        assert np.array_equal(np.concatenate([lo[key], hi[key]]), full[key]), key
+    for key in ("ascores", "alt_mask"):
+        assert np.array_equal(np.concatenate([lo[key][:, :k], hi[key][:, :k]]), full[key][:, :k]), key
+    rng = np.random.default_rng(7)
+    pick = np.sort(rng.choice(n, 1500, replace=False))
+    sub = synth.pack_batch([dict(mz=kw["mz_arr"], intensity=kw["int_arr"], peptide=kw["peptide"],
+                                 n_of_mod=kw["n_of_mod"], max_charge=kw["max_fragment_charge"])
+                            for kw in (synth.unpack_psm(batch, int(i)) for i in pick[::-1])])   # reversed order
+    got = gpu.score_batch(sub)
+    want = _checker(settings).score_batch(sub, got["ascores"].shape[1])
+    _same(got, want)
+    kk = got["ascores"].shape[1]
+    for key in ("n_sig", "best_sig", "best_score"):
+        assert np.array_equal(got[key][::-1], full[key][pick]), key
+    assert np.array_equal(got["ascores"][::-1][:, :kk], full["ascores"][pick][:, :kk])
+
+
+def test_peak_order_invariance_at_scale():
+    """Shuffling the peaks inside every spectrum (unsorted-input path of bin_spectra) must not
+    change any result."""
+    batch, settings = synth.make_batch("cfg2", n_psm=20_000, seed=99)
+    rng = np.random.default_rng(3)
+    mz, it = batch["mz"].copy(), batch["intensity"].copy()
+    off = batch["peak_off"]
+    for i in range(batch["n_psm"]):
+        p = rng.permutation(off[i + 1] - off[i])
+        mz[off[i]:off[i + 1]], it[off[i]:off[i + 1]] = mz[off[i]:off[i + 1]][p], it[off[i]:off[i + 1]][p]
+    gpu = _gpu(settings)
+    _same(gpu.score_batch(dict(batch, mz=mz, intensity=it)), gpu.score_batch(batch))
+
+
+def test_device_plan_and_shard_path_on_one_gpu():
+    """pyascore_amd.device.DevicePlan + shard.score_sharded with world_size 1: records gathered
+    from the device-resident path equal the host API's results."""
+    import torch
+    from pyascore_amd import shard
+    from pyascore_amd.device import DevicePlan, unpack_summary
+    batch, settings = synth.make_batch("cfg3", n_psm=3000, seed=31)
+    gpu = _gpu(settings)
+    want = gpu.score_batch(batch)
+    k = int(batch["n_of_mod"].max())
+
+    def score_fn(sh):
+        dev = torch.device("cuda", gpu.device)
+        plan = DevicePlan(gpu, sh)
+        plan.run(torch.from_numpy(sh["mz"]).to(dev), torch.from_numpy(sh["intensity"]).to(dev))
+        plan.check()
+        assert plan.max_k <= k
+        rec = plan.packed_summary()
+        if plan.max_k < k:          # pad to the batch-wide record width
+            n = rec.shape[0]
+            pad = torch.zeros((n, 4 + 3 * k), dtype=rec.dtype, device=rec.device)
+            mk = plan.max_k
+            pad[:, :4 + mk] = rec[:, :4 + mk]
+            pad[:, 4 + k:4 + k + 2 * mk] = rec[:, 4 + mk:]
+            rec = pad
+        return rec
+
+    rec, ranges = shard.score_sharded(score_fn, batch, 0, 1, lambda t, dst: [t])
+    got = unpack_summary(rec.cpu().numpy(), k)
+    _same(got, want)
