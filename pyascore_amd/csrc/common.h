@@ -96,11 +96,10 @@ struct PushedEntry {
 };
 
 /* LDS bytes of the batched-localisation work area (localize_core.hip.h: LocLds) */
-#define PYA_LOC_SB 4               /* signatures worked on together: the winner + 3 competitors */
-static inline unsigned long pya_loc_lds_bytes(unsigned pos_cap, unsigned pool_cap) {
-    return 64ul * 4 * 2 + 64 + PYA_LOC_SB * 8ul + (unsigned long)PYA_LOC_SB * 2 * pos_cap * 8 +
-           PYA_LOC_SB * 2 * 4ul + PYA_LOC_SB * 11 * 4ul + PYA_LOC_SB * 10 * 4ul + PYA_LOC_SB * 4 * 3ul +
-           PYA_LOC_SB * 2 * 4 * 2ul + (unsigned long)pool_cap * 5 + 64;
+#define PYA_LOC_SB_MAX 8           /* signatures worked on together: the winner + 7 competitors */
+static inline unsigned long pya_loc_lds_bytes(unsigned pos_cap, unsigned pool_cap, unsigned sb) {
+    return 64ul * 4 * 2 + 64 + sb * 8ul + (unsigned long)sb * 2 * pos_cap * 8 + sb * 2 * 4ul + sb * 11 * 4ul +
+           sb * 10 * 4ul + sb * 4 * 3ul + sb * 2 * 4 * 2ul + (unsigned long)pool_cap * 6 + 128 * 8 + 64;
 }
 
 /* per-signature record: 10 cumulative counts as u16 + total fragments */

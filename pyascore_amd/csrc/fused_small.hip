@@ -34,18 +34,18 @@ struct FusedLds {
     unsigned char *scratch; /* sort arrays, later the localisation work area */
 };
 
-extern "C" size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap) {
+extern "C" size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb) {
     size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_GRID_CELLS * 2 + FUSED_PUSHED * 16 + 64 * 4 + 16 +
                    FUSED_MAX_SIG * 4 + FUSED_MAX_SIG * 10 * 4;
     size_t table = ((size_t)peak_cap + PYA_TABLE_PAD) * 8;
     size_t srt = (size_t)FUSED_MAX_SIG * 10 + 64;
-    size_t loc = pya_loc_lds_bytes(pos_cap, pool_cap);
+    size_t loc = pya_loc_lds_bytes(pos_cap, pool_cap, sb);
     return fixed + table + (srt > loc ? srt : loc) + 64;
 }
 
 __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, const uint32_t *psm_ids,
                                                              uint32_t n_ids, uint32_t peak_cap,
-                                                             uint32_t pos_cap, uint32_t pool_cap) {
+                                                             uint32_t pos_cap, uint32_t pool_cap, uint32_t sb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[blockIdx.x];
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
     STAMP(b, 5);
 
     /* ---- 5. Ascores ---- */
-    ctx.w = loc_carve(scratch, pos_cap, pool_cap);
+    ctx.w = loc_carve(scratch, pos_cap, pool_cap, sb);
+    ctx.sb = (int)sb;
     ctx.L = res.L;
     ctx.zmax = env.zmax;
     ctx.pos_cap = pos_cap;
@@ -253,14 +254,14 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
 }
 
 extern "C" int pya_launch_fused_small(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids,
-                                      uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap,
+                                      uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
                                       hipStream_t stream) {
     if (n_ids == 0) return 0;
-    size_t lds = pya_fused_lds_bytes(peak_cap, pos_cap, pool_cap);
+    size_t lds = pya_fused_lds_bytes(peak_cap, pos_cap, pool_cap, sb);
     hipError_t e = hipFuncSetAttribute((const void *)pya_fused_small_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_fused_small_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, peak_cap,
-                       pos_cap, pool_cap);
+                       pos_cap, pool_cap, sb);
     return (int)hipGetLastError();
 }

@@ -32,15 +32,15 @@ void pya_score_table_extend(float mz_error, uint32_t n_top, uint32_t n_to, std::
 extern "C" {
 size_t pya_bin_lds_bytes(uint32_t cap);
 size_t pya_score_lds_bytes(uint32_t cap);
-size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap);
+size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
-size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap);
+size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_fused_small(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
-                           uint32_t pos_cap, uint32_t pool_cap, hipStream_t stream);
+                           uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                      hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
-                        uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, hipStream_t stream);
+                        uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, hipStream_t stream);
 int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
@@ -170,12 +170,19 @@ struct Bucket {
     std::vector<uint32_t> ids;
     DevBuf<uint32_t> d_ids;
     uint32_t n_cap = 0, list_cap = 1, pos_cap = 1;
+    /* Signatures localised together (winner included): 8 while the per-signature tables and
+     * fragment lists are small, 4 otherwise -- LDS per wave decides the occupancy of localize. */
+    uint32_t sb() const {
+        const uint32_t per_sig = next_pow2_u32(n_types) * list_cap;
+        return (pos_cap <= 32 && per_sig <= 64) ? PYA_LOC_SB_MAX : 4u;
+    }
+    /* fragment-list slots [signature][type slot][list_cap]: room for sb() signatures when the
+     * lists are short, the winner + one competitor at least */
     uint32_t pool_cap() const {
-        /* room for one competitor at least, 3 (= LOC_SB - 1) when the lists are short */
-        uint32_t one = 2u * next_pow2_u32(n_types) * list_cap;
-        uint32_t want = 3u * one;
+        const uint32_t per_sig = next_pow2_u32(n_types) * list_cap;
+        uint32_t want = sb() * per_sig;
         if (want > 2048u) want = 2048u;
-        return one > want ? one : want;
+        return 2u * per_sig > want ? 2u * per_sig : want;
     }
     uint32_t n_types = 1;
 };
@@ -688,7 +695,7 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
         h->order_uploaded = h->order_tab.size();
     }
     if (!p->fused.ids.empty()) {
-        size_t need = pya_fused_lds_bytes(p->peak_cap, p->fused.pos_cap, p->fused.pool_cap());
+        size_t need = pya_fused_lds_bytes(p->peak_cap, p->fused.pos_cap, p->fused.pool_cap(), p->fused.sb());
         if (need > kMaxLds)
             return h->fail(PYA_ERR_LIMIT, (int64_t)p->fused.ids[0], "LDS budget exceeded (%zu bytes) on the fused path", need);
         HIPCHK(h, p->fused.d_ids.upload(p->fused.ids.data(), p->fused.ids.size()));
@@ -697,7 +704,7 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
         HIPCHK(h, p->all_ids.d_ids.upload(p->all_ids.ids.data(), p->all_ids.ids.size()));
     for (Bucket &bk : p->buckets) {
         if (bk.ids.empty()) continue;
-        size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap());
+        size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb());
         if (need > kMaxLds)
             return h->fail(PYA_ERR_LIMIT, (int64_t)bk.ids[0], "LDS budget exceeded (%zu bytes) for the bucket of PSM %u",
                            need, bk.ids[0]);
@@ -763,12 +770,12 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
     for (Bucket &bk : p->buckets) {
-        e = pya_launch_localize(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), st);
+        e = pya_launch_localize(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(), st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
     e = pya_launch_fused_small(&d, p->fused.d_ids.p, (uint32_t)p->fused.ids.size(), p->peak_cap, p->fused.pos_cap,
-                               p->fused.pool_cap(), st);
+                               p->fused.pool_cap(), p->fused.sb(), st);
     if (e) return h->hip_fail((hipError_t)e, "fused_small launch");
     if (timing) HIPCHK(h, hipEventRecord(p->ev[4], st));
     p->last_stream = st;

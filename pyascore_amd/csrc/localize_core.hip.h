@@ -431,29 +431,30 @@ DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap, bool with_table = true) {
     return k;
 }
 
-#define LOC_SB PYA_LOC_SB
 
 /* work area of the batched localisation (aliases the sort arrays) */
 struct LocLds {
     float *m0, *m1;           /* [64] residue masses                                      */
     uint8_t *nlp;             /* [64] NL classes                                          */
-    uint64_t *sig_mask;       /* [LOC_SB] residue masks, entry 0 = winner                 */
-    float *run;               /* [LOC_SB*2*pos_cap] running sums per (sig, dir, prefix)   */
+    uint64_t *sig_mask;       /* [sb] residue masks, entry 0 = winner                 */
+    float *run;               /* [sb*2*pos_cap] running sums per (sig, dir, prefix)   */
     uint16_t *pmk;            /* same shape: neutral-loss sums present                    */
     uint16_t *cpre;           /* same shape: exclusive count of variants before prefix    */
-    uint32_t *tot;            /* [LOC_SB*2] variants per (sig, dir)                        */
-    uint32_t *hist;           /* [LOC_SB*11] rank histogram + total fragments             */
-    float *scores;            /* [LOC_SB*10]                                              */
-    uint32_t *c_idx;          /* [LOC_SB] which modified site of the winner the competitor moves */
-    uint32_t *c_pre;          /* [LOC_SB] pre-sort index of the signature (entry 0 = winner)     */
-    int32_t *c_depth;         /* [LOC_SB]                                                 */
-    uint32_t *c_cnt;          /* [LOC_SB*2] matched site-determining ions (ref, other)    */
-    uint32_t *c_tr;           /* [LOC_SB*2] site-determining ions                         */
-    float *pool;              /* [pool_cap] fragment lists                                */
-    uint8_t *keep;            /* [pool_cap]                                               */
+    uint32_t *tot;            /* [sb*2] variants per (sig, dir)                        */
+    uint32_t *hist;           /* [sb*11] rank histogram + total fragments             */
+    float *scores;            /* [sb*10]                                              */
+    uint32_t *c_idx;          /* [sb] which modified site of the winner the competitor moves */
+    uint32_t *c_pre;          /* [sb] pre-sort index of the signature (entry 0 = winner)     */
+    int32_t *c_depth;         /* [sb]                                                 */
+    uint32_t *c_cnt;          /* [sb*2] matched site-determining ions (ref, other)    */
+    uint32_t *c_tr;           /* [sb*2] site-determining ions                         */
+    float *pool;              /* [pool_cap] fragment lists [slot][type slot][P2]          */
+    uint8_t *keep;            /* [2 * pool_cap] keep flags [task][side][P2]               */
+    float *stage_val;         /* [LOC_STAGE] surviving ions waiting for their lookup      */
+    uint32_t *stage_tag;      /* [LOC_STAGE] competitor * 2 + side                        */
 };
 
-DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap) {
+DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, uint32_t LOC_SB) {
     LocLds w;
     w.sig_mask = (uint64_t *)raw;
     w.m0 = (float *)(w.sig_mask + LOC_SB);
@@ -461,7 +462,9 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap) {
     w.run = w.m1 + 64;
     w.scores = w.run + (size_t)LOC_SB * 2 * pos_cap;
     w.pool = w.scores + LOC_SB * 10;
-    w.tot = (uint32_t *)(w.pool + pool_cap);
+    w.stage_val = w.pool + pool_cap;
+    w.stage_tag = (uint32_t *)(w.stage_val + 128);
+    w.tot = w.stage_tag + 128;
     w.hist = w.tot + LOC_SB * 2;
     w.c_idx = w.hist + LOC_SB * 11;
     w.c_pre = w.c_idx + LOC_SB;
@@ -495,7 +498,7 @@ DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, u
 }
 
 /* ---------------------------------------------------------------------------------------
- * Batched localisation: the winner and up to LOC_SB-1 competitors at a time.
+ * Batched localisation: the winner and up to sb-1 competitors at a time.
  *   1. one lane per (signature, direction) walks the residues and tabulates, per prefix
  *      length, the float32 running sum and the neutral-loss sums that exist;
  *   2. every (signature, direction, prefix) entry expands to its fragment m/z, looks them up
@@ -513,6 +516,7 @@ struct LocCtx {
     LocLds w;
     int L, zmax;
     uint32_t pos_cap, pool_cap;
+    int sb;                   /* signatures per batch (winner included), <= PYA_LOC_SB_MAX */
 };
 
 DEV void loc_prefix_tables(const LocCtx &c, int S) {
@@ -606,12 +610,31 @@ DEV void loc_scores(const LocCtx &c, int s_lo, int S, int *fail) {
     wave_lds_sync();
 }
 
+/* e / d for e*d < 2^32 with a precomputed multiplier (integer division is ~40 instructions) */
+struct FastDiv {
+    uint32_t d, m;
+};
+DEV FastDiv fastdiv_make(uint32_t d) {
+    FastDiv f;
+    f.d = d ? d : 1u;
+    f.m = (uint32_t)__builtin_ceil(4294967296.0 / (double)f.d);
+    return f;
+}
+DEV uint32_t fastdiv(uint32_t e, const FastDiv &f) {
+    if (f.d == 1u) return e;                             /* 2^32 / 1 does not fit the multiplier */
+    uint32_t q = __umulhi(e, f.m);
+    return q * f.d > e ? q - 1u : q;                     /* the multiplier can be one too large */
+}
+
+#define LOC_STAGE 128          /* surviving ions collected before they are looked up together */
+
 /* Site-determining ions of competitors 1..S-1 against the winner (entry 0): fills w.c_cnt /
  * w.c_tr and the depth in w.c_depth.
  *
- * Lists live in an LDS pool addressed as [competitor][type slot][side][P2] with the number of
- * type slots and P2 powers of two, so an element index decodes with shifts.  A "task" is one
- * (competitor, ion type): list A = winner, list B = competitor. */
+ * Fragment lists live in an LDS pool addressed [signature slot][type slot][P2] (type slots and P2
+ * powers of two; slot 0 = the winner, generated once and shared by every task).  A "task" is one
+ * (competitor, ion type): list A = winner, list B = competitor; its keep flags are
+ * [task][side][P2]. */
 DEV void loc_site_ions(const LocCtx &c, int S) {
     const int lane = lane_id();
     const LocLds &w = c.w;
@@ -619,7 +642,6 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
     const int T = cfg->n_types, Lm1 = c.L - 1;
     const int gt = ilog2_ceil(T);                 /* type slots = 1 << gt */
     const uint64_t types64 = load_types64(cfg);
-    const int gp = ilog2_ceil(Lm1 > 0 ? Lm1 : 1);
     /* depth of the largest score gap (Ascore.cpp:164-172) */
     if (lane >= 1 && lane < S) {
         float best = 0.f;
@@ -641,31 +663,37 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
     uint32_t mmax = 1;
     if (lane < 2 * S) mmax = w.tot[lane] * (uint32_t)c.zmax;
     mmax = wave_max_u32(mmax);
-    const int g2 = ilog2_ceil((int)(mmax > 0 ? mmax : 1));
+    if (mmax < 1) mmax = 1;
+    const int g2 = ilog2_ceil((int)mmax);
     const int P2 = 1 << g2;
-    int per_round = (int)(c.pool_cap >> (1 + gt + g2));
+    int per_round = (int)(c.pool_cap >> (gt + g2)) - 1;          /* competitor slots besides the winner */
     if (per_round < 1) per_round = 1;
     const float err = cfg->mz_error;
+    const FastDiv divL = fastdiv_make((uint32_t)(Lm1 > 0 ? Lm1 : 1));
+    const FastDiv divM = fastdiv_make(mmax);
     wave_lds_sync();
     STAMP_BEGIN();
     for (int c0 = 1; c0 < S; c0 += per_round) {
         const int c1 = c0 + per_round < S ? c0 + per_round : S;
-        const int nlist = ((c1 - c0) << gt) << 1;               /* incl. unused type slots */
-        /* ---- generate: items (list, prefix) ---- */
-        for (int e = lane; e < (nlist << gp); e += 64) {
-            const int pos = e & ((1 << gp) - 1);
-            const int lid = e >> gp;
-            const int side = lid & 1, task = lid >> 1;
-            const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
-            if (pos >= Lm1 || t >= T) continue;
-            const int s = side ? cc : 0;
+        const int ncomp = c1 - c0;
+        /* signature slots of this round: slot 0 = winner (kept from the first round), slot j = c0+j-1 */
+        const int slot_lo = c0 == 1 ? 0 : 1;
+        const int nsl = 1 + ncomp;
+        /* ---- generate: items (slot, type, prefix) ---- */
+        const int gen_items = ((nsl - slot_lo) << gt) * Lm1;
+        for (int e = lane; e < gen_items; e += 64) {
+            const uint32_t li = fastdiv((uint32_t)e, divL);          /* (slot - slot_lo, type slot) */
+            const int pos = e - (int)li * Lm1;
+            const int t = (int)li & ((1 << gt) - 1), slot = slot_lo + ((int)li >> gt);
+            if (t >= T) continue;
+            const int s = slot == 0 ? 0 : c0 + slot - 1;
             double A, B;
             type_constants(type_at(types64, t), &A, &B);
             const int d = t < cfg->n_fwd ? 0 : 1;
             const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
             uint32_t pm = w.pmk[idx];
             const float running = w.run[idx];
-            float *dst = w.pool + ((size_t)lid << g2) + (size_t)w.cpre[idx] * c.zmax;
+            float *dst = w.pool + ((size_t)((slot << gt) + t) << g2) + (size_t)w.cpre[idx] * c.zmax;
             while (pm) {
                 const int v = __builtin_ctz(pm);
                 pm &= pm - 1;
@@ -674,30 +702,36 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                 for (int z = 1; z <= c.zmax; z++) *dst++ = charge_mz(m, z);
             }
         }
-        STAMP(*c.b, 30);
-        /* ---- pad every list to the stride with +inf ---- */
-        const int total = nlist << g2;
-        for (int e = lane; e < total; e += 64) {
-            const int lid = e >> g2, i = e & (P2 - 1);
-            const int side = lid & 1, task = lid >> 1;
-            const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
-            int M = 0;
-            if (t < T) M = (int)w.tot[(side ? cc : 0) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
-            if (i >= M) w.pool[e] = __builtin_huge_valf();
-        }
         wave_lds_sync();
-        /* ---- sort only if some list is out of order ---- */
+        STAMP(*c.b, 30);
+        /* ---- out of order anywhere?  then pad to the stride and run the bitonic network ---- */
+        const int nlists = nsl << gt;
+        const int dense = nlists * (int)mmax;
         int unsorted = 0;
-        for (int e = lane; e < total; e += 64) {
-            const int i = e & (P2 - 1);
-            if (i + 1 < P2 && w.pool[e] > w.pool[e + 1]) unsorted = 1;
+        for (int e = lane; e < dense; e += 64) {
+            const uint32_t lid = fastdiv((uint32_t)e, divM);
+            const int i = e - (int)lid * (int)mmax;
+            const int t = (int)lid & ((1 << gt) - 1), slot = (int)lid >> gt;
+            if (t >= T) continue;
+            const int s = slot == 0 ? 0 : c0 + slot - 1;
+            const int M = (int)w.tot[s * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
+            const float *base = w.pool + ((size_t)lid << g2);
+            if (i + 1 < M && base[i] > base[i + 1]) unsorted = 1;
         }
         STAMP(*c.b, 31);
         if (__any(unsorted)) {
+            for (int e = lane; e < (nlists << g2); e += 64) {
+                const int lid = e >> g2, i = e & (P2 - 1);
+                const int t = lid & ((1 << gt) - 1), slot = lid >> gt;
+                int M = 0;
+                if (t < T) M = (int)w.tot[(slot == 0 ? 0 : c0 + slot - 1) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
+                if (i >= M) w.pool[e] = __builtin_huge_valf();
+            }
+            wave_lds_sync();
             const int gh = g2 - 1;                               /* pairs per list = 1 << gh */
             for (int k = 2; k <= P2; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int e = lane; e < (nlist << gh); e += 64) {
+                    for (int e = lane; e < (nlists << gh); e += 64) {
                         const int lid = e >> gh, tt = e & ((1 << gh) - 1);
                         const int lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
                         const int hi = lo | j;
@@ -713,36 +747,41 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                 }
             }
         }
+        STAMP(*c.b, 32);
         /* ---- cancel.  Site-determining ions = what the reference's greedy two-pointer walk
          * over the two sorted lists leaves (ModifiedPeptide.cpp:291-316).  When every ion has at
          * most one partner within mz_error in the other list, the walk cancels exactly those
          * pairs and emits everything else (an unpaired ion is strictly below/above every ion it
          * meets, because float subtraction is monotone) -- so pairs are found in parallel with
          * one binary search per ion.  A task in which some ion has two partners is replayed with
-         * the serial walk, one task per lane. ---- */
-        STAMP(*c.b, 32);
+         * the serial walk, one task per lane.  Items: (task, side, index), dense. ---- */
+        const int ntask = ncomp << gt;
+        const int pair_items = ntask * 2 * (int)mmax;
         uint64_t bad_tasks = 0;
-        for (int base = 0; base < total; base += 64) {           /* wave-uniform trip count */
+        for (int base = 0; base < pair_items; base += 64) {      /* wave-uniform trip count */
             const int e = base + lane;
             bool multi = false;
-            if (e < total) {
-                const int lid = e >> g2, i = e & (P2 - 1);
-                const int side = lid & 1, task = lid >> 1;
-                const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
+            if (e < pair_items) {
+                const uint32_t ts = fastdiv((uint32_t)e, divM);     /* task*2 + side */
+                const int i = e - (int)ts * (int)mmax;
+                const int side = (int)ts & 1, task = (int)ts >> 1;
+                const int t = task & ((1 << gt) - 1), cj = task >> gt;   /* competitor slot - 1 */
                 if (t < T) {
+                    const int cc = c0 + cj;
                     const int d = t < cfg->n_fwd ? 0 : 1;
                     const int M = (int)w.tot[(side ? cc : 0) * 2 + d] * c.zmax;
                     const int Mo = (int)w.tot[(side ? 0 : cc) * 2 + d] * c.zmax;
                     if (i < M) {
-                        const float me = w.pool[e];
-                        const float *other = w.pool + ((size_t)(lid ^ 1) << g2);
+                        const float *mine = w.pool + ((size_t)(((side ? cj + 1 : 0) << gt) + t) << g2);
+                        const float *other = w.pool + ((size_t)(((side ? 0 : cj + 1) << gt) + t) << g2);
+                        const float me = mine[i];
                         /* diff is always (list A) - (list B), as the reference computes it.  Seen
                          * from an A ion the B list ascends, so diff descends: skip B ions with
                          * diff >= err.  Seen from a B ion diff ascends: skip A ions with diff <= -err. */
                         int j = 0;
                         for (int step = P2 >> 1; step > 0; step >>= 1) {
                             const int probe = j + step;
-                            const float o = other[probe - 1];
+                            const float o = probe - 1 < Mo ? other[probe - 1] : __builtin_huge_valf();
                             const float diff = side ? (o - me) : (me - o);
                             const bool skip = side ? (diff <= -err) : (diff >= err);
                             if (skip) j = probe;
@@ -753,7 +792,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                             const float diff = side ? (o - me) : (me - o);
                             cnt += (__builtin_fabsf(diff) < err) ? 1 : 0;
                         }
-                        w.keep[e] = cnt == 0 ? 1 : 0;
+                        w.keep[((size_t)ts << g2) + i] = cnt == 0 ? 1 : 0;
                         multi = cnt > 1;
                     }
                 }
@@ -762,19 +801,20 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             while (rest) {
                 const int src = __builtin_ctzll(rest);
                 rest &= rest - 1;
-                bad_tasks |= 1ull << (((base + src) >> g2) >> 1);
+                bad_tasks |= 1ull << (fastdiv((uint32_t)(base + src), divM) >> 1);
             }
         }
         wave_lds_sync();
         STAMP(*c.b, 33);
         if (bad_tasks) {
-            const int task = lane;                               /* (per_round << gt) <= 64 tasks */
-            if (task < (nlist >> 1) && ((bad_tasks >> task) & 1ull)) {
-                const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
+            const int task = lane;                               /* ntask <= 64 */
+            if (task < ntask && ((bad_tasks >> task) & 1ull)) {
+                const int t = task & ((1 << gt) - 1), cj = task >> gt;
+                const int cc = c0 + cj;
                 const int d = t < cfg->n_fwd ? 0 : 1;
                 const int na = (int)w.tot[0 * 2 + d] * c.zmax, nb = (int)w.tot[cc * 2 + d] * c.zmax;
-                const float *la = w.pool + ((size_t)(task * 2) << g2);
-                const float *lb = la + P2;
+                const float *la = w.pool + ((size_t)t << g2);
+                const float *lb = w.pool + ((size_t)(((cj + 1) << gt) + t) << g2);
                 uint8_t *ka = w.keep + ((size_t)(task * 2) << g2);
                 uint8_t *kb = ka + P2;
                 int i = 0, j = 0;
@@ -799,23 +839,68 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             wave_lds_sync();
         }
         STAMP(*c.b, 37);
-        /* ---- match the surviving ions ---- */
-        for (int e = lane; e < total; e += 64) {
-            const int lid = e >> g2, i = e & (P2 - 1);
-            const int side = lid & 1, task = lid >> 1;
-            const int t = task & ((1 << gt) - 1), cc = c0 + (task >> gt);
-            if (t >= T) continue;
-            const int M = (int)w.tot[(side ? cc : 0) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
-            if (i < M && w.keep[e]) {
-                atomicAdd(&w.c_tr[cc * 2 + side], 1u);
-                if (match_rank(c.tab, w.pool[e]) <= w.c_depth[cc]) atomicAdd(&w.c_cnt[cc * 2 + side], 1u);
+        /* ---- match the surviving ions: they are few and scattered, so they are first collected
+         * into a dense staging buffer and then looked up a full wave at a time ---- */
+        int staged = 0;
+        for (int base = 0; base < pair_items || staged > 0; base += 64) {
+            const int e = base + lane;
+            bool kept = false;
+            float val = 0.f;
+            uint32_t tag = 0;
+            if (e < pair_items) {
+                const uint32_t ts = fastdiv((uint32_t)e, divM);
+                const int i = e - (int)ts * (int)mmax;
+                const int side = (int)ts & 1, task = (int)ts >> 1;
+                const int t = task & ((1 << gt) - 1), cj = task >> gt;
+                if (t < T) {
+                    const int cc = c0 + cj;
+                    const int M = (int)w.tot[(side ? cc : 0) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
+                    if (i < M && w.keep[((size_t)ts << g2) + i]) {
+                        kept = true;
+                        val = w.pool[((size_t)(((side ? cj + 1 : 0) << gt) + t) << g2) + i];
+                        tag = (uint32_t)(cc * 2 + side);
+                    }
+                }
             }
+            const uint64_t km = __ballot(kept);
+            if (kept) {
+                const int slot = staged + __popcll(km & lanemask_lt());
+                w.stage_val[slot] = val;
+                w.stage_tag[slot] = tag;
+            }
+            staged += __popcll(km);
+            const bool last = base + 64 >= pair_items;
+            if (staged >= 64 || (last && staged > 0)) {
+                wave_lds_sync();
+                const int take = staged < 64 ? staged : 64;
+                if (lane < take) {
+                    const uint32_t tg = w.stage_tag[lane];
+                    atomicAdd(&w.c_tr[tg], 1u);
+                    if (match_rank(c.tab, w.stage_val[lane]) <= w.c_depth[tg >> 1]) atomicAdd(&w.c_cnt[tg], 1u);
+                }
+                wave_lds_sync();
+                /* move the overflow (at most 63 entries) to the front */
+                const int rem = staged - take;
+                float mv = 0.f;
+                uint32_t mt = 0;
+                if (lane < rem) {
+                    mv = w.stage_val[take + lane];
+                    mt = w.stage_tag[take + lane];
+                }
+                wave_lds_sync();
+                if (lane < rem) {
+                    w.stage_val[lane] = mv;
+                    w.stage_tag[lane] = mt;
+                }
+                staged = rem;
+                wave_lds_sync();
+            }
+            if (last && staged == 0) break;
         }
         wave_lds_sync();
         STAMP(*c.b, 34);
     }
 }
-
 
 /* Ascores of every modified site of the winner (cpp/Ascore.cpp:212-254): walks the pushed
  * competitors LOC_SB-1 at a time.  `scores_all`, when
@@ -838,7 +923,7 @@ DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, con
     while (e < np) {
         /* gather the next competitors that are not exact PepScore ties of the winner */
         int S = 1;
-        while (e < np && S < LOC_SB) {
+        while (e < np && S < ctx.sb) {
             const PushedEntry pe = pushed[e++];               /* LDS, wave-uniform */
             const uint32_t ci = pe.idx;
             const uint64_t c = pe.bits;

@@ -22,17 +22,17 @@
 #include "localize_core.hip.h"
 
 extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap,
-                                         uint32_t pool_cap) {
+                                         uint32_t pool_cap, uint32_t sb) {
     (void)peak_cap;                 /* the localize kernel looks peaks up in global memory */
     size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 16 + 64 * 16 + 16;
     size_t srt = (size_t)n_cap * 10 + 64;
-    size_t lst = pya_loc_lds_bytes(pos_cap, pool_cap);
+    size_t lst = pya_loc_lds_bytes(pos_cap, pool_cap, sb);
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
 __global__ __launch_bounds__(64, 5) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
                                                           uint32_t n_ids, uint32_t peak_cap,
-                                                          uint32_t pos_cap, uint32_t pool_cap) {
+                                                          uint32_t pos_cap, uint32_t pool_cap, uint32_t sb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[blockIdx.x];
@@ -167,8 +167,9 @@ __global__ __launch_bounds__(64, 5) void pya_localize_kernel(BatchDev b, const u
     if (b.debug & 16) np = 0;
 
     STAMP(b, 24);
-    /* ---- Ascores, LOC_SB-1 competitors at a time ---- */
-    ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap);
+    /* ---- Ascores, sb-1 competitors at a time ---- */
+    ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap, sb);
+    ctx.sb = (int)sb;
     ctx.L = res.L;
     ctx.zmax = b.max_charge[psm];
     ctx.pos_cap = pos_cap;
@@ -257,14 +258,14 @@ __global__ __launch_bounds__(64) void pya_debug_sort_kernel(const float *keys, u
 
 extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids,
                                    uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
-                                   hipStream_t stream) {
+                                   uint32_t sb, hipStream_t stream) {
     if (n_ids == 0) return 0;
-    size_t lds = pya_localize_lds_bytes(peak_cap, n_cap, pos_cap, pool_cap);
+    size_t lds = pya_localize_lds_bytes(peak_cap, n_cap, pos_cap, pool_cap, sb);
     hipError_t e = hipFuncSetAttribute((const void *)pya_localize_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_localize_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                       peak_cap, pos_cap, pool_cap);
+                       peak_cap, pos_cap, pool_cap, sb);
     return (int)hipGetLastError();
 }
 
