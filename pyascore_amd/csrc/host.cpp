@@ -170,11 +170,17 @@ struct Bucket {
     std::vector<uint32_t> ids;
     DevBuf<uint32_t> d_ids;
     uint32_t n_cap = 0, list_cap = 1, pos_cap = 1;
-    /* Signatures localised together (winner included): 8 while the per-signature tables and
-     * fragment lists are small, 4 otherwise -- LDS per wave decides the occupancy of localize. */
+    /* Signatures localised together (winner included) -- LDS per wave decides the occupancy of
+     * localize, the number of batches its instruction count. */
     uint32_t sb() const {
-        const uint32_t per_sig = next_pow2_u32(n_types) * list_cap;
-        return (pos_cap <= 32 && per_sig <= 64) ? PYA_LOC_SB_MAX : 4u;
+        if (const char *o = std::getenv("PYA_SB")) return (uint32_t)std::atoi(o);   /* A/B experiments */
+        /* one batch should hold the winner and one competitor per modified site; long peptides
+         * have large per-signature tables, so they get fewer (measured: profiles/r01_c) */
+        uint32_t v = k_max + 1;
+        if (v < 2) v = 2;
+        if (v > PYA_LOC_SB_MAX) v = PYA_LOC_SB_MAX;
+        if (pos_cap > 32 && v > 3) v = v - 2 < 3 ? 3 : v - 2;
+        return v;
     }
     /* fragment-list slots [signature][type slot][list_cap]: room for sb() signatures when the
      * lists are short, the winner + one competitor at least */
@@ -184,7 +190,7 @@ struct Bucket {
         if (want > 2048u) want = 2048u;
         return 2u * per_sig > want ? 2u * per_sig : want;
     }
-    uint32_t n_types = 1;
+    uint32_t n_types = 1, k_max = 1;
 };
 
 struct pya_plan {
@@ -668,6 +674,7 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
             bk.list_cap = std::max<uint32_t>(bk.list_cap, next_pow2(std::max<uint32_t>(per_type, 1)));
             bk.pos_cap = std::max<uint32_t>(bk.pos_cap, (uint32_t)std::max<int64_t>(L - 1, 1));
             bk.n_types = n_types;
+            bk.k_max = std::max<uint32_t>(bk.k_max, (uint32_t)k);
         } else if (N > 0 && (uint32_t)k < ns) {
             int bi = 0;
             while (N > kBucketLimits[bi]) bi++;
@@ -677,6 +684,7 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
             bk.list_cap = std::max<uint32_t>(bk.list_cap, next_pow2(std::max<uint32_t>(per_type, 1)));
             bk.pos_cap = std::max<uint32_t>(bk.pos_cap, (uint32_t)std::max<int64_t>(L - 1, 1));
             bk.n_types = n_types;
+            bk.k_max = std::max<uint32_t>(bk.k_max, (uint32_t)k);
         } else {
             Bucket &bk = p->buckets[0];                 /* unambiguous / empty: cheapest launch */
             bk.ids.push_back((uint32_t)i);
