@@ -1,0 +1,36 @@
+"""Randomised parity: random scorer settings (mod groups incl. termini, ion types, neutral-loss
+groups, tolerances) x random small batches (lengths, site counts, charges, fixed mods incl. the
+n-terminus, sorted and unsorted peaks), HIP path vs the CPU checker on this box, bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import harness, orc
+from pyascore_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+from fuzzcase import random_case as _random_case
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_settings_and_batches(seed, monkeypatch):
+    rng = np.random.default_rng(9000 + seed)
+    if seed % 4 == 3:
+        monkeypatch.setenv("PYA_FUSE", "1")
+    settings, batch = _random_case(rng)
+    if batch["n_psm"] == 0:
+        pytest.skip("empty draw")
+    from pyascore_amd import PyAscore
+    gpu = harness.make_scorer(PyAscore, settings)
+    kind = "ref" if orc.available("ref") else "oracle"
+    chk = harness.make_scorer(orc.OracleAscore, settings, kind=kind)
+    got = gpu.score_batch(batch)
+    want = chk.score_batch(batch, got["ascores"].shape[1])
+    for key in ("n_sig", "best_sig", "best_score", "alt_mask", "ascores"):
+        bad = np.flatnonzero(np.any(np.atleast_2d((got[key] != want[key]).T), axis=0))
+        assert bad.size == 0, "%s differs for PSMs %s (settings %s)" % (key, bad[:5], settings)
+    # and the full per-PSM API on a few of them
+    sub = synth.slice_batch(batch, 0, min(4, batch["n_psm"]))
+    a = harness.collect(gpu, sub, synth.unpack_psm)
+    b = harness.collect(chk, sub, synth.unpack_psm)
+    assert harness.compare(a, b, exact_float=True) == []
