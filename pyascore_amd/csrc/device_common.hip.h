@@ -386,6 +386,12 @@ DEV uint64_t deposit_sites(uint64_t bits, uint64_t site_mask) {
     return out;
 }
 
+/* position of the n-th (0-based) set bit */
+DEV int nth_set_bit(uint64_t m, int n) {
+    for (int i = 0; i < n; i++) m &= m - 1;
+    return __builtin_ctzll(m);
+}
+
 DEV uint32_t nl_bump(uint32_t state, uint32_t cls) {
     /* 2 bits per class, saturating at 2; cls in 1..4 */
     uint32_t sh = (cls - 1) * 2;

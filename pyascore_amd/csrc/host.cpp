@@ -31,13 +31,13 @@ void pya_score_table_extend(float mz_error, uint32_t n_top, uint32_t n_to, std::
                             std::vector<uint32_t> &off);
 extern "C" {
 size_t pya_bin_lds_bytes(uint32_t cap);
-size_t pya_score_lds_bytes(uint32_t cap);
+size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix);
 size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
 size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_fused_small(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
                            uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, hipStream_t stream);
-int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
+int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t prefix,
                      hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, hipStream_t stream);
@@ -773,7 +773,9 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     if (e) return h->hip_fail((hipError_t)e, "bin_spectra launch");
     if (timing) HIPCHK(h, hipEventRecord(p->ev[1], st));
     for (Bucket &bk : p->buckets) {
-        e = pya_launch_score(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, st);
+        /* buckets with C(n,k) > 64 share the walk over the first sites between signatures */
+        const uint32_t prefix = (bk.n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
+        e = pya_launch_score(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, prefix, st);
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));

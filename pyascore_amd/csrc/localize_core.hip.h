@@ -397,10 +397,6 @@ DEV void scores_from_counts(const BatchDev &b, const uint32_t cum[PYA_NTOP], uin
     for (int d = 0; d < PYA_NTOP; d++) out[d] = b.lut[off + (uint32_t)d * (nfrag + 1) + cum[d]];
 }
 
-DEV int nth_set_bit(uint64_t m, int n) {
-    for (int i = 0; i < n; i++) m &= m - 1;
-    return __builtin_ctzll(m);
-}
 
 /* LDS carve-up shared by the localisation and the ambiguity kernels */
 struct K3Lds {

@@ -25,8 +25,24 @@ DEV float lut_score(const BatchDev &b, uint32_t depth, uint32_t k, uint32_t n) {
 
 #include "walk_core.hip.h"
 
+/* With many site assignments most of them agree on the first modifiable residues of a
+ * direction, and a fragment's m/z depends only on the pattern of the residues it contains.  So
+ * the first PREFIX_SITES sites of each direction are walked once per PATTERN (2^6 = 64 patterns,
+ * one per lane) and every signature resumes from its pattern's state (float32 running sum,
+ * neutral-loss stack, rank histogram) -- bit-identical to walking from the start, because it IS
+ * the same sequence of float additions.  This is the first level of the reference's prefix-
+ * sharing fragment tree (cpp/Ascore.cpp:69-109) laid out for a wavefront. */
+#define PREFIX_SITES 6
+struct PrefixState {
+    float running;
+    uint32_t nl_state;
+    uint32_t nfrag;
+    uint32_t pad;
+    uint64_t ha, hb, hc;
+};
+
 __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
-                                                                  uint32_t n_ids, uint32_t cap) {
+                                                                  uint32_t n_ids, uint32_t cap, uint32_t prefix) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[blockIdx.x];
@@ -37,6 +53,7 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     uint16_t *grid = nl_present + 256;                      /* [PYA_GRID_CELLS] */
     float *nl_uniq = (float *)(grid + PYA_GRID_CELLS);      /* [PYA_MAX_UNIQ] */
     PeakEntry *t_e = (PeakEntry *)(nl_uniq + PYA_MAX_UNIQ); /* [cap + PYA_TABLE_PAD] */
+    PrefixState *pre = (PrefixState *)(t_e + cap + PYA_TABLE_PAD);   /* [2][64], only if `prefix` */
 
     if (b.status[psm] != PYA_ST_OK) return;
     const uint32_t N = b.n_sig[psm];
@@ -68,6 +85,35 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     int lut_fail = 0;
     const bool split = N <= 32 && both_dirs;     /* lanes 0..31 forward, 32..63 backward */
     const bool simple = walk_is_simple(env);
+    const int n_sites = __popcll(res.site_mask);
+    const bool shared = prefix && N >= 128 && n_sites >= PREFIX_SITES + 2;
+    int stop[2] = {0, 0};
+    if (shared) {
+        /* steps [0, stop) of a direction cover exactly its first PREFIX_SITES sites */
+        stop[0] = nth_set_bit(res.site_mask, PREFIX_SITES);
+        stop[1] = res.L - 1 - nth_set_bit(res.site_mask, n_sites - 1 - PREFIX_SITES);
+        for (int dir = 0; dir < 2; dir++) {
+            if (dir == 0 ? cfg->n_fwd == 0 : cfg->n_fwd == cfg->n_types) continue;
+            if (stop[dir] > res.L - 1) stop[dir] = res.L - 1;
+            const uint64_t pbits = dir == 0 ? (uint64_t)lane : (__brevll((uint64_t)lane) >> (64 - n_sites));
+            const uint64_t pmask = deposit_sites(pbits, res.site_mask);
+            WalkState st = {0.f, 0u};
+            Hist h = {0ull, 0ull, 0ull};
+            uint32_t nf = 0;
+            if (simple) walk_simple_range(env, res, tab, pmask, dir, true, 0, stop[dir], st, h, nf);
+            else walk_range(env, res, tab, pmask, dir, true, 0, stop[dir], st, h, nf);
+            PrefixState ps;
+            ps.running = st.running;
+            ps.nl_state = st.nl_state;
+            ps.nfrag = nf;
+            ps.pad = 0;
+            ps.ha = h.a;
+            ps.hb = h.b;
+            ps.hc = h.c;
+            pre[dir * 64 + lane] = ps;
+        }
+        wave_lds_sync();
+    }
     for (uint32_t sbase = 0; sbase < N; sbase += 64) {
         const uint32_t s = split ? (uint32_t)(lane & 31) : sbase + lane;
         const bool active = s < N;
@@ -75,7 +121,21 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
         const uint64_t resmask = deposit_sites(bits, res.site_mask);
         Hist h = {0ull, 0ull, 0ull};
         uint32_t nfrag = 0;
-        if (simple) {
+        if (shared) {
+            for (int dir = 0; dir < 2; dir++) {
+                if (dir == 0 ? cfg->n_fwd == 0 : cfg->n_fwd == cfg->n_types) continue;
+                const uint32_t pat = dir == 0 ? (uint32_t)(bits & 63ull)
+                                              : (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 63ull);
+                const PrefixState ps = pre[dir * 64 + pat];
+                WalkState st = {ps.running, ps.nl_state};
+                h.a += ps.ha;
+                h.b += ps.hb;
+                h.c += ps.hc;
+                nfrag += ps.nfrag;
+                if (simple) walk_simple_range(env, res, tab, resmask, dir, active, stop[dir], res.L - 1, st, h, nfrag);
+                else walk_range(env, res, tab, resmask, dir, active, stop[dir], res.L - 1, st, h, nfrag);
+            }
+        } else if (simple) {
             if (split) {
                 walk_simple(env, res, tab, resmask, lane >> 5, active, h, nfrag);
                 fold_upper_half(h, nfrag);
@@ -125,14 +185,15 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     if (__any(lut_fail) && lane == 0) b.status[psm] = PYA_ST_LUT_RANGE;
 }
 
-extern "C" size_t pya_score_lds_bytes(uint32_t cap) {
-    return ((size_t)cap + PYA_TABLE_PAD) * 8 + 512 + PYA_GRID_CELLS * 2 + PYA_MAX_UNIQ * 4 + 64;
+extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix) {
+    return ((size_t)cap + PYA_TABLE_PAD) * 8 + 512 + PYA_GRID_CELLS * 2 + PYA_MAX_UNIQ * 4 + 64 +
+           (prefix ? 2 * 64 * sizeof(PrefixState) : 0);
 }
 
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
-                                hipStream_t stream) {
+                                uint32_t prefix, hipStream_t stream) {
     if (n_ids == 0) return 0;
-    hipLaunchKernelGGL(pya_score_signatures_kernel, dim3(n_ids), dim3(64), pya_score_lds_bytes(cap),
-                       stream, *b, d_ids, n_ids, cap);
+    hipLaunchKernelGGL(pya_score_signatures_kernel, dim3(n_ids), dim3(64), pya_score_lds_bytes(cap, prefix),
+                       stream, *b, d_ids, n_ids, cap, prefix);
     return (int)hipGetLastError();
 }

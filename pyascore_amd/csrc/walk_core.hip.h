@@ -13,8 +13,14 @@ struct WalkEnv {
 
 /* Walks one direction per lane (`dir` may differ between lanes: the residue of a step is read
  * for both directions with two v_readlane and selected).  Adds to h / nfrag. */
-DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
-              bool active, Hist &h, uint32_t &nfrag) {
+/* resumable state of a walker: float32 running sum and neutral-loss stack state */
+struct WalkState {
+    float running;
+    uint32_t nl_state;
+};
+
+DEV void walk_range(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
+                    bool active, int step_begin, int step_end, WalkState &st, Hist &h, uint32_t &nfrag) {
     const DevConfig *cfg = e.cfg;
     const int n_f = cfg->n_fwd, n_b = cfg->n_types - cfg->n_fwd;
     const int my_types = dir == 0 ? n_f : n_b;
@@ -22,9 +28,9 @@ DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint6
     const bool any_f = __any(active && dir == 0), any_b = __any(active && dir == 1);
     const int t_max = (any_f && any_b) ? (n_f > n_b ? n_f : n_b) : (any_f ? n_f : n_b);
     const uint64_t types64 = load_types64(cfg);
-    float running = 0.f;
-    uint32_t nl_state = 0;
-    for (int step = 0; step + 1 < e.L; step++) {
+    float running = st.running;                            /* 0 at the start: 0 + r == r exactly */
+    uint32_t nl_state = st.nl_state;
+    for (int step = step_begin; step < step_end; step++) {
         const int i_f = step, i_b = e.L - 1 - step;                      /* wave-uniform */
         float m0 = 0.f, m1 = 0.f;
         uint32_t nlp = 0;
@@ -44,7 +50,7 @@ DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint6
         const int i = dir ? i_b : i_f;
         const bool mod = (resmask >> i) & 1ull;
         const float r = mod ? m1 : m0;
-        running = step == 0 ? r : r + running;                           /* ModifiedPeptide.cpp:385-389 */
+        running = r + running;                                           /* ModifiedPeptide.cpp:385-389 */
         uint32_t pm = active ? 1u : 0u;
         if (e.n_nl) {
             const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
@@ -72,14 +78,22 @@ DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint6
             }
         }
     }
+    st.running = running;
+    st.nl_state = nl_state;
 }
 
+DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
+              bool active, Hist &h, uint32_t &nfrag) {
+    WalkState st = {0.f, 0u};
+    walk_range(e, res, tab, resmask, dir, active, 0, e.L - 1, st, h, nfrag);
+}
 
 /* Fast path of `walk` for the common scorer settings -- no neutral losses, charge 1, at most
  * one ion type per direction (BASELINE cfg1/2/3/5): straight-line code per residue step.
  * `tmask` bit t = "the t-th residue in THIS lane's travel direction is modified". */
-DEV void walk_simple(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
-                     bool active, Hist &h, uint32_t &nfrag) {
+DEV void walk_simple_range(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask,
+                           int dir, bool active, int step_begin, int step_end, WalkState &st, Hist &h,
+                           uint32_t &nfrag) {
     const DevConfig *cfg = e.cfg;
     const int L = e.L;
     /* per-lane ion-type constants (the type letters are wave-uniform scalars) */
@@ -89,8 +103,8 @@ DEV void walk_simple(const WalkEnv &e, const Residues &res, const PeakTable &tab
     const double A = dir ? Ab : Af, B = dir ? Bb : Bf;
     const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
     const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
-    float running = 0.f;                                   /* 0 + r == r exactly */
-    for (int step = 0; step + 1 < L; step++) {
+    float running = st.running;                            /* 0 at the start: 0 + r == r exactly */
+    for (int step = step_begin; step < step_end; step++) {
         const int i_b = L - 1 - step;
         const float f0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), step));
         const float f1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), step));
@@ -106,7 +120,14 @@ DEV void walk_simple(const WalkEnv &e, const Residues &res, const PeakTable &tab
         const int rk = match_rank_lds(tab, f);
         if (active) hist_add(h, rk);
     }
-    if (active) nfrag += (uint32_t)(L - 1);
+    if (active && step_end > step_begin) nfrag += (uint32_t)(step_end - step_begin);
+    st.running = running;
+}
+
+DEV void walk_simple(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
+                     bool active, Hist &h, uint32_t &nfrag) {
+    WalkState st = {0.f, 0u};
+    walk_simple_range(e, res, tab, resmask, dir, active, 0, e.L - 1, st, h, nfrag);
 }
 
 DEV bool walk_is_simple(const WalkEnv &e) {
