@@ -39,6 +39,9 @@ def _run(cmd):
 
 
 def build(force=False):
+    if os.environ.get("PYA_LOC_WAVES"):         # A/B experiments on the localize kernel's occupancy target
+        DEVICE_FLAGS.append("-DLOC_WAVES=" + os.environ["PYA_LOC_WAVES"])
+        force = True
     if os.environ.get("PYA_BUILD_STAMPS"):      # diagnostic build with in-kernel phase stamps
         DEVICE_FLAGS.append("-DPYA_STAMPS")
         force = True

@@ -30,7 +30,10 @@ extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
-__global__ __launch_bounds__(64, 5) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
+#ifndef LOC_WAVES
+#define LOC_WAVES 5
+#endif
+__global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
                                                           uint32_t n_ids, uint32_t peak_cap,
                                                           uint32_t pos_cap, uint32_t pool_cap, uint32_t sb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];

@@ -41,8 +41,11 @@ struct PrefixState {
     uint64_t ha, hb, hc;
 };
 
+/* PREFIX is a template parameter so that the small-C(n,k) instantiation does not carry the
+ * registers of the shared-prefix path (60 vs 77 VGPRs = 8 vs 6 waves per SIMD). */
+template <bool PREFIX>
 __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
-                                                                  uint32_t n_ids, uint32_t cap, uint32_t prefix) {
+                                                                  uint32_t n_ids, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[blockIdx.x];
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     const bool split = N <= 32 && both_dirs;     /* lanes 0..31 forward, 32..63 backward */
     const bool simple = walk_is_simple(env);
     const int n_sites = __popcll(res.site_mask);
-    const bool shared = prefix && N >= 128 && n_sites >= PREFIX_SITES + 2;
+    const bool shared = PREFIX && N >= 128 && n_sites >= PREFIX_SITES + 2;
     int stop[2] = {0, 0};
     if (shared) {
         /* steps [0, stop) of a direction cover exactly its first PREFIX_SITES sites */
@@ -193,7 +196,11 @@ extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix) {
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                                 uint32_t prefix, hipStream_t stream) {
     if (n_ids == 0) return 0;
-    hipLaunchKernelGGL(pya_score_signatures_kernel, dim3(n_ids), dim3(64), pya_score_lds_bytes(cap, prefix),
-                       stream, *b, d_ids, n_ids, cap, prefix);
+    if (prefix)
+        hipLaunchKernelGGL(pya_score_signatures_kernel<true>, dim3(n_ids), dim3(64), pya_score_lds_bytes(cap, 1),
+                           stream, *b, d_ids, n_ids, cap);
+    else
+        hipLaunchKernelGGL(pya_score_signatures_kernel<false>, dim3(n_ids), dim3(64), pya_score_lds_bytes(cap, 0),
+                           stream, *b, d_ids, n_ids, cap);
     return (int)hipGetLastError();
 }
