@@ -196,6 +196,14 @@ extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix) {
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                                 uint32_t prefix, hipStream_t stream) {
     if (n_ids == 0) return 0;
+    /* spectra near the 8192-peak limit need more than the default 64 KB of dynamic LDS */
+    hipError_t e = prefix ? hipFuncSetAttribute((const void *)pya_score_signatures_kernel<true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)pya_score_lds_bytes(cap, 1))
+                          : hipFuncSetAttribute((const void *)pya_score_signatures_kernel<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)pya_score_lds_bytes(cap, 0));
+    if (e != hipSuccess) return (int)e;
     if (prefix)
         hipLaunchKernelGGL(pya_score_signatures_kernel<true>, dim3(n_ids), dim3(64), pya_score_lds_bytes(cap, 1),
                            stream, *b, d_ids, n_ids, cap);

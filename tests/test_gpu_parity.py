@@ -259,3 +259,27 @@ def test_device_plan_and_shard_path_on_one_gpu():
     rec, ranges = shard.score_sharded(score_fn, batch, 0, 1, lambda t, dst: [t])
     got = unpack_summary(rec.cpu().numpy(), k)
     _same(got, want)
+
+
+def test_largest_spectra_and_limits():
+    """Spectra at the documented 8192-peak limit (more than 64 KB of LDS per wave in bin_spectra
+    and score_signatures), one peak, and the limit errors."""
+    from pyascore_amd import PyAscore
+    rng = np.random.default_rng(17)
+    settings = dict(bin_size=100.0, n_top=10, mod_group="STY", mod_mass=79.966331, mz_error=0.05,
+                    fragment_types="by", neutral_losses=[])
+    psms = []
+    for P in (8192, 8000, 5000, 1, 2):
+        mz = np.sort(rng.uniform(100.0, 3000.0, P))
+        psms.append(dict(mz=mz, intensity=rng.lognormal(5, 1, P), peptide="ASTLGYKRSTYAGK", n_of_mod=2, max_charge=2))
+    batch = synth.pack_batch(psms)
+    got = _gpu(settings).score_batch(batch)
+    want = _checker(settings).score_batch(batch, got["ascores"].shape[1])
+    _same(got, want)
+    s = PyAscore(100.0, 10, "STY", 79.966331)
+    with pytest.raises(ValueError, match="8192"):
+        s.score(np.sort(rng.uniform(100.0, 3000.0, 8193)), np.ones(8193), "ASTK", 1)
+    with pytest.raises(ValueError, match="length"):
+        s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 65, 0)
+    with pytest.raises(ValueError, match="site assignments"):
+        s.score(np.array([100.5, 200.5]), np.ones(2), "STSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTST", 12)
