@@ -283,3 +283,33 @@ def test_largest_spectra_and_limits():
         s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 65, 0)
     with pytest.raises(ValueError, match="site assignments"):
         s.score(np.array([100.5, 200.5]), np.ones(2), "STSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTST", 12)
+
+
+def test_rccl_gather_path_single_rank():
+    """bench.py's N > 1 step = plan.run + ONE dist.gather of the packed records over RCCL.  With
+    one GPU only a world of one can be formed, which still drives the same calls on device
+    tensors (backend "nccl" is RCCL on ROCm)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pyascore_amd import shard
+    from pyascore_amd.device import DevicePlan, unpack_summary
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        batch, settings = synth.make_batch("cfg2", n_psm=5000, seed=55)
+        gpu = _gpu(settings)
+        plan = DevicePlan(gpu, batch)
+        plan.run(torch.from_numpy(batch["mz"]).to(dev), torch.from_numpy(batch["intensity"]).to(dev))
+        parts = shard.dist_gather(plan.packed_summary(), 0)
+        plan.check()
+        assert len(parts) == 1
+        got = unpack_summary(parts[0].cpu().numpy(), plan.max_k)
+        _same(got, gpu.score_batch(batch))
+    finally:
+        dist.destroy_process_group()
