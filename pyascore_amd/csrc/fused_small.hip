@@ -45,7 +45,8 @@ extern "C" size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint3
 
 __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, const uint32_t *psm_ids,
                                                              uint32_t n_ids, uint32_t peak_cap,
-                                                             uint32_t pos_cap, uint32_t pool_cap, uint32_t sb) {
+                                                             uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
+                                                             uint32_t gtp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[blockIdx.x];
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
     /* ---- 5. Ascores ---- */
     ctx.w = loc_carve(scratch, pos_cap, pool_cap, sb);
     ctx.sb = (int)sb;
+    ctx.gtp = (int)gtp;
     ctx.L = res.L;
     ctx.zmax = env.zmax;
     ctx.pos_cap = pos_cap;
@@ -255,13 +257,13 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
 
 extern "C" int pya_launch_fused_small(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids,
                                       uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
-                                      hipStream_t stream) {
+                                      uint32_t gtp, hipStream_t stream) {
     if (n_ids == 0) return 0;
     size_t lds = pya_fused_lds_bytes(peak_cap, pos_cap, pool_cap, sb);
     hipError_t e = hipFuncSetAttribute((const void *)pya_fused_small_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_fused_small_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, peak_cap,
-                       pos_cap, pool_cap, sb);
+                       pos_cap, pool_cap, sb, gtp);
     return (int)hipGetLastError();
 }

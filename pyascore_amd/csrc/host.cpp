@@ -36,11 +36,12 @@ size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_ca
 int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
 size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_fused_small(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
-                           uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, hipStream_t stream);
+                           uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t prefix,
                      hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
-                        uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, hipStream_t stream);
+                        uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
+                        hipStream_t stream);
 int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
@@ -182,10 +183,18 @@ struct Bucket {
         if (pos_cap > 32 && v > 3) v = v - 2 < 3 ? 3 : v - 2;
         return v;
     }
-    /* fragment-list slots [signature][type slot][list_cap]: room for sb() signatures when the
-     * lists are short, the winner + one competitor at least */
+    /* Ion types localised per pass (log2): as many as keep one signature's lists <= 256 floats,
+     * so long multi-charge lists (cfg4: 228 per type) go one type at a time and the pool -- hence
+     * the LDS per wave, hence the occupancy of localize -- stays small. */
+    uint32_t gtp() const {
+        uint32_t g = 0;
+        while ((1u << g) < n_types) g++;
+        while (g > 0 && (list_cap << g) > 256u) g--;
+        return g;
+    }
+    /* fragment-list slots [signature][type slot][list_cap]: room for sb() signatures */
     uint32_t pool_cap() const {
-        const uint32_t per_sig = next_pow2_u32(n_types) * list_cap;
+        const uint32_t per_sig = list_cap << gtp();
         uint32_t want = sb() * per_sig;
         if (want > 2048u) want = 2048u;
         return 2u * per_sig > want ? 2u * per_sig : want;
@@ -780,12 +789,12 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
     for (Bucket &bk : p->buckets) {
-        e = pya_launch_localize(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(), st);
+        e = pya_launch_localize(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
     e = pya_launch_fused_small(&d, p->fused.d_ids.p, (uint32_t)p->fused.ids.size(), p->peak_cap, p->fused.pos_cap,
-                               p->fused.pool_cap(), p->fused.sb(), st);
+                               p->fused.pool_cap(), p->fused.sb(), p->fused.gtp(), st);
     if (e) return h->hip_fail((hipError_t)e, "fused_small launch");
     if (timing) HIPCHK(h, hipEventRecord(p->ev[4], st));
     p->last_stream = st;

@@ -513,6 +513,7 @@ struct LocCtx {
     int L, zmax;
     uint32_t pos_cap, pool_cap;
     int sb;                   /* signatures per batch (winner included), <= PYA_LOC_SB_MAX */
+    int gtp;                  /* log2 of the ion types localised per pass                  */
 };
 
 DEV void loc_prefix_tables(const LocCtx &c, int S) {
@@ -636,7 +637,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
     const LocLds &w = c.w;
     const DevConfig *cfg = c.cfg;
     const int T = cfg->n_types, Lm1 = c.L - 1;
-    const int gt = ilog2_ceil(T);                 /* type slots = 1 << gt */
+    const int gt = c.gtp;                         /* ion types handled per pass = 1 << gt (power of two) */
     const uint64_t types64 = load_types64(cfg);
     /* depth of the largest score gap (Ascore.cpp:164-172) */
     if (lane >= 1 && lane < S) {
@@ -663,12 +664,15 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
     const int g2 = ilog2_ceil((int)mmax);
     const int P2 = 1 << g2;
     int per_round = (int)(c.pool_cap >> (gt + g2)) - 1;          /* competitor slots besides the winner */
+    const int tpp = 1 << gt;
     if (per_round < 1) per_round = 1;
     const float err = cfg->mz_error;
     const FastDiv divL = fastdiv_make((uint32_t)(Lm1 > 0 ? Lm1 : 1));
     const FastDiv divM = fastdiv_make(mmax);
     wave_lds_sync();
     STAMP_BEGIN();
+    /* ion types are taken tpp at a time so that the fragment lists of a pass fit a small pool */
+    for (int tb = 0; tb < T; tb += tpp)
     for (int c0 = 1; c0 < S; c0 += per_round) {
         const int c1 = c0 + per_round < S ? c0 + per_round : S;
         const int ncomp = c1 - c0;
@@ -681,11 +685,11 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             const uint32_t li = fastdiv((uint32_t)e, divL);          /* (slot - slot_lo, type slot) */
             const int pos = e - (int)li * Lm1;
             const int t = (int)li & ((1 << gt) - 1), slot = slot_lo + ((int)li >> gt);
-            if (t >= T) continue;
+            if (tb + t >= T) continue;
             const int s = slot == 0 ? 0 : c0 + slot - 1;
             double A, B;
-            type_constants(type_at(types64, t), &A, &B);
-            const int d = t < cfg->n_fwd ? 0 : 1;
+            type_constants(type_at(types64, tb + t), &A, &B);
+            const int d = tb + t < cfg->n_fwd ? 0 : 1;
             const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
             uint32_t pm = w.pmk[idx];
             const float running = w.run[idx];
@@ -708,9 +712,9 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             const uint32_t lid = fastdiv((uint32_t)e, divM);
             const int i = e - (int)lid * (int)mmax;
             const int t = (int)lid & ((1 << gt) - 1), slot = (int)lid >> gt;
-            if (t >= T) continue;
+            if (tb + t >= T) continue;
             const int s = slot == 0 ? 0 : c0 + slot - 1;
-            const int M = (int)w.tot[s * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
+            const int M = (int)w.tot[s * 2 + (tb + t < cfg->n_fwd ? 0 : 1)] * c.zmax;
             const float *base = w.pool + ((size_t)lid << g2);
             if (i + 1 < M && base[i] > base[i + 1]) unsorted = 1;
         }
@@ -720,7 +724,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                 const int lid = e >> g2, i = e & (P2 - 1);
                 const int t = lid & ((1 << gt) - 1), slot = lid >> gt;
                 int M = 0;
-                if (t < T) M = (int)w.tot[(slot == 0 ? 0 : c0 + slot - 1) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
+                if (tb + t < T) M = (int)w.tot[(slot == 0 ? 0 : c0 + slot - 1) * 2 + (tb + t < cfg->n_fwd ? 0 : 1)] * c.zmax;
                 if (i >= M) w.pool[e] = __builtin_huge_valf();
             }
             wave_lds_sync();
@@ -762,9 +766,9 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                 const int i = e - (int)ts * (int)mmax;
                 const int side = (int)ts & 1, task = (int)ts >> 1;
                 const int t = task & ((1 << gt) - 1), cj = task >> gt;   /* competitor slot - 1 */
-                if (t < T) {
+                if (tb + t < T) {
                     const int cc = c0 + cj;
-                    const int d = t < cfg->n_fwd ? 0 : 1;
+                    const int d = tb + t < cfg->n_fwd ? 0 : 1;
                     const int M = (int)w.tot[(side ? cc : 0) * 2 + d] * c.zmax;
                     const int Mo = (int)w.tot[(side ? 0 : cc) * 2 + d] * c.zmax;
                     if (i < M) {
@@ -807,7 +811,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             if (task < ntask && ((bad_tasks >> task) & 1ull)) {
                 const int t = task & ((1 << gt) - 1), cj = task >> gt;
                 const int cc = c0 + cj;
-                const int d = t < cfg->n_fwd ? 0 : 1;
+                const int d = tb + t < cfg->n_fwd ? 0 : 1;
                 const int na = (int)w.tot[0 * 2 + d] * c.zmax, nb = (int)w.tot[cc * 2 + d] * c.zmax;
                 const float *la = w.pool + ((size_t)t << g2);
                 const float *lb = w.pool + ((size_t)(((cj + 1) << gt) + t) << g2);
@@ -848,9 +852,9 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                 const int i = e - (int)ts * (int)mmax;
                 const int side = (int)ts & 1, task = (int)ts >> 1;
                 const int t = task & ((1 << gt) - 1), cj = task >> gt;
-                if (t < T) {
+                if (tb + t < T) {
                     const int cc = c0 + cj;
-                    const int M = (int)w.tot[(side ? cc : 0) * 2 + (t < cfg->n_fwd ? 0 : 1)] * c.zmax;
+                    const int M = (int)w.tot[(side ? cc : 0) * 2 + (tb + t < cfg->n_fwd ? 0 : 1)] * c.zmax;
                     if (i < M && w.keep[((size_t)ts << g2) + i]) {
                         kept = true;
                         val = w.pool[((size_t)(((side ? cj + 1 : 0) << gt) + t) << g2) + i];

@@ -35,7 +35,8 @@ extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint
 #endif
 __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
                                                           uint32_t n_ids, uint32_t peak_cap,
-                                                          uint32_t pos_cap, uint32_t pool_cap, uint32_t sb) {
+                                                          uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
+                                                          uint32_t gtp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[blockIdx.x];
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
     /* ---- Ascores, sb-1 competitors at a time ---- */
     ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap, sb);
     ctx.sb = (int)sb;
+    ctx.gtp = (int)gtp;
     ctx.L = res.L;
     ctx.zmax = b.max_charge[psm];
     ctx.pos_cap = pos_cap;
@@ -261,14 +263,14 @@ __global__ __launch_bounds__(64) void pya_debug_sort_kernel(const float *keys, u
 
 extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids,
                                    uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
-                                   uint32_t sb, hipStream_t stream) {
+                                   uint32_t sb, uint32_t gtp, hipStream_t stream) {
     if (n_ids == 0) return 0;
     size_t lds = pya_localize_lds_bytes(peak_cap, n_cap, pos_cap, pool_cap, sb);
     hipError_t e = hipFuncSetAttribute((const void *)pya_localize_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_localize_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                       peak_cap, pos_cap, pool_cap, sb);
+                       peak_cap, pos_cap, pool_cap, sb, gtp);
     return (int)hipGetLastError();
 }
 
