@@ -23,39 +23,59 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     const double *mz = b.mz + p0;
     const double *inten = b.inten + p0;
     const DevConfig *cfg = b.cfg;
+    (void)cfg;
 
-    /* pass 1: min / max / sortedness (Spectra.cpp:46-47 use min_element / max_element) */
-    double mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+    /* passes 1+2 fused for the normal case: a spectrum sorted by m/z has its extremes at the
+     * ends, so the window bounds are computed from mz[0] / mz[P-1] up front and ONE sweep bins
+     * the peaks while it checks the order and tracks the true min / max.  If the order check
+     * fails (or the ends were not the extremes) the bins are recomputed from the true extremes
+     * (Spectra.cpp:46-47 use min_element / max_element). */
+    const DevConfig *cfg_ = cfg;
+    const float bin_size = cfg_->bin_size;
+    double mn = mz[0], mx = mz[P - 1];
+    float min_mz = 0.f;
+    uint32_t n_bins = 0;
     int unsorted = 0;
-    for (int i = lane; i < P; i += 64) {
-        double v = mz[i];
-        double nx = (i + 1 < P) ? mz[i + 1] : v;
-        mn = v < mn ? v : mn;
-        mx = v > mx ? v : mx;
-        unsorted |= (v > nx) ? 1 : 0;
-    }
-    mn = wave_min_f64(mn);
-    mx = wave_max_f64(mx);
-    unsorted = __any(unsorted);
-
-    const float min_mz = (float)(__builtin_floor(mn / 100.) * 100.);
-    const float max_mz = (float)(__builtin_ceil(mx / 100.) * 100.);
-    const float bin_size = cfg->bin_size;
-    const float nb_f = __builtin_ceilf((max_mz - min_mz) / bin_size);   /* float arithmetic, :48 */
     *status = PYA_ST_OK;
-    if (!(nb_f >= 1.f)) *status = PYA_ST_NO_BINS;
-    if (nb_f > 65535.f) *status = PYA_ST_TOO_MANY_BINS;
-    if (*status != PYA_ST_OK) return -1;
-    const uint32_t n_bins = (uint32_t)nb_f;
-
-    /* pass 2: window id per peak (double arithmetic, Spectra.cpp:55-58) */
-    for (int i = lane; i < P; i += 64) {
-        double v = mz[i];
-        double q = __builtin_floor((v - (double)min_mz) / (double)bin_size);
-        uint32_t w = q >= (double)(n_bins - 1) ? n_bins - 1 : (uint32_t)q;
-        s_bin[i] = (uint16_t)w;
-        s_inten[i] = inten[i];
-        s_mzf[i] = (float)v;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        min_mz = (float)(__builtin_floor(mn / 100.) * 100.);
+        const float max_mz = (float)(__builtin_ceil(mx / 100.) * 100.);
+        const float nb_f = __builtin_ceilf((max_mz - min_mz) / bin_size);   /* float arithmetic, :48 */
+        const bool ok = nb_f >= 1.f && nb_f <= 65535.f;
+        if (!ok && attempt == 1) {
+            *status = nb_f > 65535.f ? PYA_ST_TOO_MANY_BINS : PYA_ST_NO_BINS;
+            return -1;
+        }
+        n_bins = ok ? (uint32_t)nb_f : 1u;
+        /* window id per peak (double arithmetic, Spectra.cpp:55-58) */
+        double tmn = __builtin_huge_val(), tmx = -__builtin_huge_val();
+        int uns = 0;
+        for (int i = lane; i < P; i += 64) {
+            const double v = mz[i];
+            if (attempt == 0) {
+                const double nx = (i + 1 < P) ? mz[i + 1] : v;
+                tmn = v < tmn ? v : tmn;
+                tmx = v > tmx ? v : tmx;
+                uns |= (v > nx) ? 1 : 0;
+                s_inten[i] = inten[i];
+                s_mzf[i] = (float)v;
+            }
+            const double q = __builtin_floor((v - (double)min_mz) / (double)bin_size);
+            const uint32_t w = q >= (double)(n_bins - 1) ? n_bins - 1 : (uint32_t)q;
+            s_bin[i] = (uint16_t)w;
+        }
+        if (attempt == 0) {
+            unsorted = __any(uns);
+            bool redo = !ok;
+            if (unsorted) {
+                tmn = wave_min_f64(tmn);
+                tmx = wave_max_f64(tmx);
+                redo = redo || tmn != mn || tmx != mx;
+                mn = tmn;
+                mx = tmx;
+            }
+            if (!redo) break;
+        }
     }
     wave_lds_sync();
 

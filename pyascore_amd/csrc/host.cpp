@@ -187,6 +187,7 @@ struct Bucket {
      * so long multi-charge lists (cfg4: 228 per type) go one type at a time and the pool -- hence
      * the LDS per wave, hence the occupancy of localize -- stays small. */
     uint32_t gtp() const {
+        if (const char *o = std::getenv("PYA_GTP")) return (uint32_t)std::atoi(o);   /* A/B experiments */
         uint32_t g = 0;
         while ((1u << g) < n_types) g++;
         while (g > 0 && (list_cap << g) > 256u) g--;
