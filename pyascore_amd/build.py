@@ -22,7 +22,7 @@ HEADERS = ["common.h", "device_common.hip.h", "bin_core.hip.h", "walk_core.hip.h
 
 DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
                 "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-HOST_FLAGS = ["-O2", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-result",
+HOST_FLAGS = ["-O2", "-fPIC", "-pthread", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-result",
               "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")]
 
 
@@ -58,7 +58,7 @@ def build(force=False):
             _run(["g++"] + HOST_FLAGS + ["-c", s, "-o", o])
         objs.append(o)
     if force or _stale(LIB, objs):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
     return LIB
 
 

@@ -17,10 +17,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -58,14 +60,27 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool owned = true;
     DevBuf() {}
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        owned = true;
+    }
+    /* points into somebody else's allocation (the plan's arena) */
+    void adopt(void *ptr, size_t count) {
+        release();
+        p = (T *)ptr;
+        n = count;
+        owned = false;
+    }
+    hipError_t fill(const T *src, hipStream_t s = nullptr) {
+        if (n == 0 || !src) return hipSuccess;
+        return hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s);
     }
     hipError_t alloc(size_t count) {
         release();
@@ -79,6 +94,25 @@ struct DevBuf {
         return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
     }
     size_t bytes() const { return n * sizeof(T); }
+    /* moves the allocation of `other` here if it is big enough; returns whether it did */
+    bool take_if_fits(DevBuf &other, size_t count) {
+        if (!other.p || !other.owned || other.n < count) return false;
+        release();
+        p = other.p;
+        n = other.n;
+        other.p = nullptr;
+        other.n = 0;
+        return true;
+    }
+    void give_to(DevBuf &other) {
+        if (!p || !owned) return;
+        if (other.p && other.n >= n) return;          /* keep the larger one */
+        other.release();
+        other.p = p;
+        other.n = n;
+        p = nullptr;
+        n = 0;
+    }
 };
 
 uint64_t binom(uint32_t n, uint32_t k) {
@@ -131,6 +165,10 @@ struct pya_handle {
     size_t order_uploaded = 0;
     DevBuf<uint64_t> d_order;
 
+    /* device allocations recycled between pya_score_batch calls (hipMalloc/hipFree of a few
+     * hundred MB cost milliseconds) */
+    DevBuf<unsigned char> spare_arena, spare_io;
+
     std::string err;
     int64_t err_index = -1;
     pya_plan *kept = nullptr;                 /* plan of the last PYA_FLAG_KEEP batch */
@@ -148,10 +186,21 @@ struct pya_handle {
     int hip_fail(hipError_t e, const char *what) {
         return fail(PYA_ERR_HIP, -1, "HIP error in %s: %s", what, hipGetErrorString(e));
     }
+    uint64_t binom_cache[64][64] = {{0}};     /* C(n,k), 0 = not computed yet (C >= 1 always) */
+    uint32_t shape_cache[64][64];             /* offset of the shape's order table, ~0 = unknown */
+    uint8_t in_group[256] = {0};              /* letter is in mod_group */
+    uint8_t is_residue[256] = {0};            /* letter has a mass in Types.h */
+    bool allow_n = false, allow_c = false;
+    void build_letter_tables() {
+        std::memset(in_group, 0, sizeof in_group);
+        std::memset(is_residue, 0, sizeof is_residue);
+        for (unsigned char c : mod_group) in_group[c] = 1;
+        for (int c = 'A'; c <= 'Z'; c++) is_residue[c] = std_residue_mass((char)c) != 0.f;
+        allow_n = mod_group.find('n') != std::string::npos;
+        allow_c = mod_group.find('c') != std::string::npos;
+    }
     bool letter_modifiable(char c, size_t i, size_t L) const {
-        return mod_group.find(c) != std::string::npos ||
-               (i == 0 && mod_group.find('n') != std::string::npos) ||
-               (i + 1 == L && mod_group.find('c') != std::string::npos);
+        return in_group[(unsigned char)c] || (i == 0 && allow_n) || (i + 1 == L && allow_c);
     }
 };
 
@@ -231,6 +280,8 @@ struct pya_plan {
     DevBuf<uint64_t> d_best_sig, d_alt;
     DevBuf<int32_t> d_n_sig_out;
     DevBuf<unsigned long long> d_stamps;
+    DevBuf<unsigned char> arena;          /* one allocation behind the metadata + workspace buffers */
+    DevBuf<unsigned char> io_arena;       /* spectra + results of pya_score_batch */
     BatchDev dev;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t last_stream = nullptr;
@@ -241,11 +292,7 @@ struct pya_plan {
             if (e) (void)hipEventDestroy(e);
     }
     uint64_t workspace_bytes() const {
-        uint64_t b = d_peak_off.bytes() + d_pep_off.bytes() + d_aux_off.bytes() + d_sig_off.bytes() +
-                     d_pep.bytes() + d_n_sites.bytes() + d_n_of_mod.bytes() + d_max_charge.bytes() +
-                     d_status.bytes() + d_aux_pos.bytes() + d_n_sig.bytes() + d_order_off.bytes() +
-                     d_ret_n.bytes() + d_rec.bytes() + d_sorted.bytes() + d_aux_mass.bytes() +
-                     d_ret_mz.bytes() + d_ws.bytes() + d_ret_rank.bytes();
+        uint64_t b = arena.bytes();
         for (const Bucket &k : buckets) b += k.d_ids.bytes();
         b += fused.d_ids.bytes() + all_ids.d_ids.bytes();
         return b;
@@ -492,6 +539,8 @@ int pya_create(const pya_config *cfg, pya_handle **out) {
     hp->mz_error = cfg->mz_error;
     hp->mod_group = cfg->mod_group;
     hp->fragment_types = ft;
+    hp->build_letter_tables();
+    std::memset(hp->shape_cache, 0xff, sizeof hp->shape_cache);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -507,7 +556,7 @@ int pya_create(const pya_config *cfg, pya_handle **out) {
 void pya_destroy(pya_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    delete h->kept;
+    if (h->kept) pya_plan_destroy(h->kept);
     delete h;
 }
 
@@ -593,6 +642,14 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
     if (n > 0 && (!b->peak_off || !b->pep || !b->pep_off || !b->n_of_mod || !b->max_charge))
         return h->fail(PYA_ERR_ARG, -1, "NULL array in batch");
     if (n >= (1ull << 31)) return h->fail(PYA_ERR_LIMIT, -1, "more than 2^31 PSMs in one batch");
+    const bool host_timing = std::getenv("PYA_HOST_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!host_timing) return;
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pya plan] %-14s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     std::unique_ptr<pya_plan> p(new pya_plan);
     p->h = h;
     p->flags = flags;
@@ -615,6 +672,7 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
         p->pep_off[i] -= pep_base;
         p->aux_off[i] -= aux_base;
     }
+    lap("copy meta");
     p->n_sites.resize(n);
     p->n_sig.resize(n);
     p->order_off.resize(n);
@@ -626,10 +684,54 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
      * opt-in with PYA_FUSE=1. */
     const bool use_fused = !(flags & PYA_FLAG_KEEP) && std::getenv("PYA_FUSE") != nullptr;
     int64_t sig_total = 0;
+    /* Pass A (threaded for big batches): the per-letter work -- validate every PSM and count its
+     * modifiable residues.  It only finds the first offending PSM; the detailed message comes from
+     * the serial checks below, run for that PSM alone. */
+    uint64_t first_bad = n;
+    {
+        auto scan = [&](uint64_t lo, uint64_t hi, uint64_t *bad) {
+            for (uint64_t i = lo; i < hi; i++) {
+                const int64_t P = p->peak_off[i + 1] - p->peak_off[i];
+                const int64_t L = p->pep_off[i + 1] - p->pep_off[i];
+                const int32_t k = p->n_of_mod[i], z = p->max_charge[i];
+                bool ok = P > 0 && P <= PYA_MAX_PEAKS && L >= 1 && L <= PYA_MAX_PEPTIDE_LEN && k >= 0 && z >= 1 && z <= 16;
+                uint32_t ns = 0;
+                if (ok) {
+                    const uint8_t *s = p->pep.data() + p->pep_off[i];
+                    for (int64_t j = 0; j < L; j++) {
+                        ok = ok && h->is_residue[s[j]];
+                        ns += h->letter_modifiable((char)s[j], (size_t)j, (size_t)L) ? 1u : 0u;
+                    }
+                    for (int64_t a = p->aux_off[i]; has_aux && a < p->aux_off[i + 1]; a++)
+                        ok = ok && b->aux_pos[aux_base + a] <= (uint32_t)L;
+                    ok = ok && ns <= PYA_MAX_SITES;
+                }
+                if (!ok) {
+                    *bad = i;
+                    return;
+                }
+                p->n_sites[i] = (uint8_t)ns;
+            }
+        };
+        unsigned nt = n >= 20000 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        std::vector<uint64_t> bad(nt, n);
+        if (nt == 1) {
+            scan(0, n, &bad[0]);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++)
+                th.emplace_back(scan, n * t / nt, n * (t + 1) / nt, &bad[t]);
+            for (auto &x : th) x.join();
+        }
+        for (uint64_t v : bad) first_bad = std::min(first_bad, v);
+    }
     for (uint64_t i = 0; i < n; i++) {
         const int64_t P = p->peak_off[i + 1] - p->peak_off[i];
         const int64_t L = p->pep_off[i + 1] - p->pep_off[i];
         const int32_t k = p->n_of_mod[i], z = p->max_charge[i];
+        uint32_t ns = p->n_sites[i];
+        if (i == first_bad) {
+        ns = 0;
         if (P <= 0) return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: empty spectrum", (unsigned long long)i);
         if (P > PYA_MAX_PEAKS)
             return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: %lld peaks exceed the limit of %d",
@@ -643,10 +745,9 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
             return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: max_fragment_charge %d outside 1..16",
                            (unsigned long long)i, z);
         const uint8_t *s = p->pep.data() + p->pep_off[i];
-        uint32_t ns = 0;
         for (int64_t j = 0; j < L; j++) {
             char c = (char)s[j];
-            if (c < 'A' || c > 'Z' || std_residue_mass(c) == 0.f)
+            if (!h->is_residue[(unsigned char)c])
                 return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: unknown residue '%c' at position %lld",
                                (unsigned long long)i, c, (long long)(j + 1));
             if (h->letter_modifiable(c, (size_t)j, (size_t)L)) ns++;
@@ -660,13 +761,26 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
         if (ns > PYA_MAX_SITES)
             return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: %u modifiable residues exceed %d",
                            (unsigned long long)i, ns, PYA_MAX_SITES);
-        uint64_t N = (uint32_t)k > ns ? 0 : binom(ns, (uint32_t)k);
+        return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: rejected by the batch scan", (unsigned long long)i);
+        }
+        uint64_t N = 0;
+        if ((uint32_t)k <= ns) {
+            uint64_t &cached = h->binom_cache[ns][k];
+            if (cached == 0) cached = binom(ns, (uint32_t)k);
+            N = cached;
+        }
         if (N > PYA_MAX_SIGNATURES)
             return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: C(%u,%d) site assignments exceed the limit of %d",
                            (unsigned long long)i, ns, k, PYA_MAX_SIGNATURES);
         p->n_sites[i] = (uint8_t)ns;
         p->n_sig[i] = (uint32_t)N;
-        p->order_off[i] = N ? shape_offset(h, ns, (uint32_t)k) : 0;
+        uint32_t ooff = 0;
+        if (N) {
+            uint32_t &co = h->shape_cache[ns][k];
+            if (co == 0xffffffffu) co = shape_offset(h, ns, (uint32_t)k);
+            ooff = co;
+        }
+        p->order_off[i] = ooff;
         p->sig_off[i] = sig_total;
         sig_total += (int64_t)N;
         max_P = std::max<uint32_t>(max_P, (uint32_t)P);
@@ -702,6 +816,7 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
         }
         p->all_ids.ids.push_back((uint32_t)i);
     }
+    lap("psm loop");
     p->sig_off[n] = sig_total;
     p->total_sigs = sig_total;
     p->max_k = max_k;
@@ -728,28 +843,65 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
                            need, bk.ids[0]);
         HIPCHK(h, bk.d_ids.upload(bk.ids.data(), bk.ids.size()));
     }
-    HIPCHK(h, p->d_peak_off.upload(p->peak_off.data(), n + 1));
-    HIPCHK(h, p->d_pep_off.upload(p->pep_off.data(), n + 1));
-    HIPCHK(h, p->d_aux_off.upload(p->aux_off.data(), n + 1));
-    HIPCHK(h, p->d_sig_off.upload(p->sig_off.data(), n + 1));
-    HIPCHK(h, p->d_pep.upload(p->pep.data(), p->pep.size()));
-    HIPCHK(h, p->d_n_sites.upload(p->n_sites.data(), n));
-    HIPCHK(h, p->d_n_of_mod.upload(p->n_of_mod.data(), n));
-    HIPCHK(h, p->d_max_charge.upload(p->max_charge.data(), n));
-    HIPCHK(h, p->d_n_sig.upload(p->n_sig.data(), n));
-    HIPCHK(h, p->d_order_off.upload(p->order_off.data(), n));
-    HIPCHK(h, p->d_aux_pos.upload(has_aux ? b->aux_pos + aux_base : nullptr, (size_t)total_aux));
-    HIPCHK(h, p->d_aux_mass.upload(has_aux ? b->aux_mass + aux_base : nullptr, (size_t)total_aux));
-    HIPCHK(h, p->d_status.alloc(n));
-    HIPCHK(h, p->d_ret_n.alloc(n));
-    HIPCHK(h, p->d_ret_mz.alloc((size_t)p->total_peaks));
-    HIPCHK(h, p->d_ret_rank.alloc((size_t)p->total_peaks));
-    HIPCHK(h, p->d_ws.alloc((size_t)sig_total));
-    HIPCHK(h, p->d_rec.alloc((size_t)sig_total * PYA_REC_WORDS));
-    if (flags & PYA_FLAG_KEEP) HIPCHK(h, p->d_sorted.alloc((size_t)sig_total));
+    lap("tables+ids");
+    /* one device allocation for all metadata and workspace (hipMalloc is ~100 us a call) */
+    {
+        size_t total = 0;
+        auto reserve = [&](size_t bytes) {
+            size_t o = total;
+            total += (bytes + 255) & ~(size_t)255;
+            return o;
+        };
+        const size_t o_peak_off = reserve((n + 1) * 8), o_pep_off = reserve((n + 1) * 8),
+                     o_aux_off = reserve((n + 1) * 8), o_sig_off = reserve((n + 1) * 8),
+                     o_pep = reserve(p->pep.size()), o_n_sites = reserve(n), o_n_of_mod = reserve(n * 4),
+                     o_max_charge = reserve(n * 4), o_n_sig = reserve(n * 4), o_order_off = reserve(n * 4),
+                     o_aux_pos = reserve((size_t)total_aux * 4), o_aux_mass = reserve((size_t)total_aux * 4),
+                     o_status = reserve(n * 4), o_ret_n = reserve(n * 4),
+                     o_ret_mz = reserve((size_t)p->total_peaks * 4), o_ret_rank = reserve((size_t)p->total_peaks),
+                     o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
+                     o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
+        if (!p->arena.take_if_fits(h->spare_arena, total)) HIPCHK(h, p->arena.alloc(total));
+        unsigned char *base = p->arena.p;
+        p->d_peak_off.adopt(base + o_peak_off, n + 1);
+        p->d_pep_off.adopt(base + o_pep_off, n + 1);
+        p->d_aux_off.adopt(base + o_aux_off, n + 1);
+        p->d_sig_off.adopt(base + o_sig_off, n + 1);
+        p->d_pep.adopt(base + o_pep, p->pep.size());
+        p->d_n_sites.adopt(base + o_n_sites, n);
+        p->d_n_of_mod.adopt(base + o_n_of_mod, n);
+        p->d_max_charge.adopt(base + o_max_charge, n);
+        p->d_n_sig.adopt(base + o_n_sig, n);
+        p->d_order_off.adopt(base + o_order_off, n);
+        p->d_aux_pos.adopt(base + o_aux_pos, (size_t)total_aux);
+        p->d_aux_mass.adopt(base + o_aux_mass, (size_t)total_aux);
+        p->d_status.adopt(base + o_status, n);
+        p->d_ret_n.adopt(base + o_ret_n, n);
+        p->d_ret_mz.adopt(base + o_ret_mz, (size_t)p->total_peaks);
+        p->d_ret_rank.adopt(base + o_ret_rank, (size_t)p->total_peaks);
+        p->d_ws.adopt(base + o_ws, (size_t)sig_total);
+        p->d_rec.adopt(base + o_rec, (size_t)sig_total * PYA_REC_WORDS);
+        if (flags & PYA_FLAG_KEEP) p->d_sorted.adopt(base + o_sorted, (size_t)sig_total);
+        HIPCHK(h, p->d_peak_off.fill(p->peak_off.data()));
+        HIPCHK(h, p->d_pep_off.fill(p->pep_off.data()));
+        HIPCHK(h, p->d_aux_off.fill(p->aux_off.data()));
+        HIPCHK(h, p->d_sig_off.fill(p->sig_off.data()));
+        HIPCHK(h, p->d_pep.fill(p->pep.data()));
+        HIPCHK(h, p->d_n_sites.fill(p->n_sites.data()));
+        HIPCHK(h, p->d_n_of_mod.fill(p->n_of_mod.data()));
+        HIPCHK(h, p->d_max_charge.fill(p->max_charge.data()));
+        HIPCHK(h, p->d_n_sig.fill(p->n_sig.data()));
+        HIPCHK(h, p->d_order_off.fill(p->order_off.data()));
+        if (has_aux) {
+            HIPCHK(h, p->d_aux_pos.fill(b->aux_pos + aux_base));
+            HIPCHK(h, p->d_aux_mass.fill(b->aux_mass + aux_base));
+        }
+    }
+    lap("arena+upload");
     if (flags & PYA_FLAG_TIMING)
         for (auto &e : p->ev) HIPCHK(h, hipEventCreate(&e));
     HIPCHK(h, hipDeviceSynchronize());
+    lap("sync");
     fill_dev(p.get());
     *out = p.release();
     return PYA_OK;
@@ -857,6 +1009,9 @@ void pya_plan_destroy(pya_plan *p) {
             if (v[i]) std::fprintf(stderr, "[pya stamps] phase %2d: %12llu  %5.1f%%\n", i, v[i], 100.0 * v[i] / tot);
     }
     if (p->h->kept == p) p->h->kept = nullptr;
+    (void)hipDeviceSynchronize();                       /* nothing may still be using the buffers */
+    p->arena.give_to(p->h->spare_arena);
+    p->io_arena.give_to(p->h->spare_io);
     delete p;
 }
 
@@ -865,33 +1020,61 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
     if (!h || !b || !out) return PYA_ERR_ARG;
     if (b->n_psm == 0) return PYA_OK;
     if (!mz || !inten) return h->fail(PYA_ERR_ARG, -1, "NULL spectrum arrays");
+    const bool host_timing = std::getenv("PYA_HOST_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!host_timing) return;
+        (void)hipDeviceSynchronize();
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pya host] %-14s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     pya_plan *p = nullptr;
     int rc = pya_plan_create(h, b, flags & ~PYA_FLAG_TIMING, &p);
     if (rc) return rc;
-    std::unique_ptr<pya_plan> guard(p);
+    std::unique_ptr<pya_plan, void (*)(pya_plan *)> guard(p, pya_plan_destroy);
+    lap("plan");
     const uint64_t n = b->n_psm;
     const int64_t base = b->peak_off[0];
     const uint32_t mk = out->max_k;
     if (mk < p->max_k) return h->fail(PYA_ERR_ARG, -1, "results.max_k too small");
-    HIPCHK(h, p->d_mz.upload(mz + base, (size_t)p->total_peaks));
-    HIPCHK(h, p->d_inten.upload(inten + base, (size_t)p->total_peaks));
-    HIPCHK(h, p->d_best_score.alloc(n));
-    HIPCHK(h, p->d_best_sig.alloc(n));
-    HIPCHK(h, p->d_n_sig_out.alloc(n));
-    HIPCHK(h, p->d_ascores.alloc(n * mk));
-    HIPCHK(h, p->d_alt.alloc(n * mk));
+    {
+        size_t total = 0;
+        auto reserve = [&](size_t bytes) {
+            size_t o = total;
+            total += (bytes + 255) & ~(size_t)255;
+            return o;
+        };
+        const size_t o_mz = reserve((size_t)p->total_peaks * 8), o_in = reserve((size_t)p->total_peaks * 8),
+                     o_bs = reserve(n * 4), o_sig = reserve(n * 8), o_ns = reserve(n * 4),
+                     o_as = reserve(n * mk * 4), o_alt = reserve(n * mk * 8);
+        if (!p->io_arena.take_if_fits(h->spare_io, total)) HIPCHK(h, p->io_arena.alloc(total));
+        unsigned char *ib = p->io_arena.p;
+        p->d_mz.adopt(ib + o_mz, (size_t)p->total_peaks);
+        p->d_inten.adopt(ib + o_in, (size_t)p->total_peaks);
+        p->d_best_score.adopt(ib + o_bs, n);
+        p->d_best_sig.adopt(ib + o_sig, n);
+        p->d_n_sig_out.adopt(ib + o_ns, n);
+        p->d_ascores.adopt(ib + o_as, n * mk);
+        p->d_alt.adopt(ib + o_alt, n * mk);
+        HIPCHK(h, p->d_mz.fill(mz + base));
+        HIPCHK(h, p->d_inten.fill(inten + base));
+    }
+    lap("h2d + alloc");
     pya_results d_out = {mk, p->d_best_score.p, p->d_best_sig.p, p->d_n_sig_out.p, p->d_ascores.p, p->d_alt.p};
     rc = pya_plan_run(p, p->d_mz.p, p->d_inten.p, nullptr, &d_out);
     if (rc) return rc;
     rc = pya_plan_check(p);
     if (rc) return rc;
+    lap("kernels");
     HIPCHK(h, hipMemcpy(out->best_score, p->d_best_score.p, n * sizeof(float), hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(out->best_sig, p->d_best_sig.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(out->n_sig, p->d_n_sig_out.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(out->ascores, p->d_ascores.p, n * mk * sizeof(float), hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(out->alt_mask, p->d_alt.p, n * mk * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    lap("d2h");
     if (flags & PYA_FLAG_KEEP) {
-        delete h->kept;
+        if (h->kept) pya_plan_destroy(h->kept);
         h->kept = guard.release();
     }
     return PYA_OK;
