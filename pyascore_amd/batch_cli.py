@@ -1,0 +1,124 @@
+"""Batched counterpart of pyAscore's CLI scoring loop.
+
+The reference's `pyascore/__main__.py:127-172` walks the identifications one PSM at a time:
+split each PSM's modifications into the unlocalised (variable) ones and the fixed ones
+(`process_mods`, :83-103), pick the fragment-charge limit from the PSM charge (:138-145), call
+``PyAscore.score`` and read four properties, then write a TSV.  With scoring on the GPU that
+Python loop is the end-to-end bottleneck, so here the same decisions are taken per PSM on the
+host, all PSMs are packed into ONE batch, scored with one ``PyAscore.score_batch`` call, and the
+rows are produced from the batch results.  Inputs are the already-parsed records the reference's
+parsers produce (dicts); file parsing itself (pyteomics) stays out of scope.
+
+Output rows/columns follow docs/source/cli.rst:135-180: Scan, LocalizedSequence, PepScore,
+Ascores (';' separated), AltSites (',' within ';').
+"""
+import ctypes as C
+from itertools import groupby
+
+import numpy as np
+
+from .ascore import PyAscore, _as_ptr
+from .synth import pack_batch
+
+COLUMNS = ("Scan", "LocalizedSequence", "PepScore", "Ascores", "AltSites")
+
+
+def process_mods(residues, mod_mass, sequence, positions, masses, mod_correction_tol=1.0,
+                 zero_based=False):
+    """Variable/fixed split of one PSM's modifications (`__main__.py:83-103`).
+
+    A modification counts as one of the unlocalised ones when its mass matches ``mod_mass``
+    (numpy.isclose, rtol 1e-6, atol ``mod_correction_tol``) AND it sits on a residue of
+    ``residues`` ('n' for position 0).  Everything else is returned as a fixed modification at its
+    1-based position (0 = n-terminus).  Returns (uint32 positions, float32 masses, n_variable)."""
+    shift = 1 if zero_based else 0
+    n_variable = 0
+    const_pos, const_masses = [], []
+    for pos, mass in zip(positions, masses):
+        pos = int(pos)
+        aa = "n" if pos + shift == 0 else sequence[pos - 1 + shift]
+        if np.isclose(mod_mass, mass, rtol=1e-6, atol=mod_correction_tol) and aa in residues:
+            n_variable += 1
+        else:
+            const_pos.append(pos + shift)
+            const_masses.append(mass)
+    return np.array(const_pos, dtype=np.uint32), np.array(const_masses, dtype=np.float32), n_variable
+
+
+def psm_charge(match, spectrum):
+    """Charge used to bound the fragment charge (`__main__.py:138-145`): the identification's
+    charge, else the spectrum's precursor charge, else 2; never below 2."""
+    if match.get("charge_state") is not None and match["charge_state"] != 0:
+        z = match["charge_state"]
+    elif spectrum.get("precursor_charge") is not None and spectrum["precursor_charge"] != 0:
+        z = spectrum["precursor_charge"]
+    else:
+        z = 2
+    return max(int(z), 2)
+
+
+def select_psms(psms, spectra_map, residues, mod_mass, hit_depth=1, max_fragment_charge=5,
+                mod_correction_tol=1.0, zero_based=False):
+    """The reference's loop header (`__main__.py:129-147`): group by scan (input sorted by scan),
+    take the first ``hit_depth`` hits of a scan (negative = all), drop PSMs without an
+    unlocalised modification.  Returns (list of PSM dicts for pack_batch, list of scans)."""
+    picked, scans = [], []
+    for _, group in groupby(psms, lambda m: m["scan"]):
+        for ind, match in enumerate(group):
+            if ind == hit_depth:
+                break
+            spectrum = spectra_map[match["scan"]]
+            const_pos, const_masses, n_variable = process_mods(
+                residues, mod_mass, match["peptide"], match["mod_positions"], match["mod_masses"],
+                mod_correction_tol, zero_based)
+            if n_variable <= 0:
+                continue
+            picked.append(dict(mz=spectrum["mz_values"], intensity=spectrum["intensity_values"],
+                               peptide=match["peptide"], n_of_mod=n_variable,
+                               max_charge=min(max_fragment_charge, psm_charge(match, spectrum) - 1),
+                               aux_pos=const_pos, aux_mass=const_masses))
+            scans.append(match["scan"])
+    return picked, scans
+
+
+def localize(ascore, psms, spectra_map, residues, mod_mass, hit_depth=1, max_fragment_charge=5,
+             mod_correction_tol=1.0, zero_based=False):
+    """Scores every selected PSM in one batched call and returns the TSV rows
+    ``[scan, localized_sequence, pep_score, "a;b", "1,2;3"]`` in input order."""
+    if not isinstance(ascore, PyAscore):
+        raise TypeError("ascore must be a pyascore_amd.PyAscore")
+    picked, scans = select_psms(psms, spectra_map, residues, mod_mass, hit_depth, max_fragment_charge,
+                                mod_correction_tol, zero_based)
+    if not picked:
+        return []
+    batch = pack_batch(picked)
+    res = ascore.score_batch(batch)
+    rows = []
+    buf = C.create_string_buffer(1024)
+    for i, psm in enumerate(picked):
+        k = psm["n_of_mod"]
+        pep = np.frombuffer(psm["peptide"].encode("utf8"), dtype=np.uint8)
+        ns = C.c_int32()
+        ascore._lib.pya_count_sites(ascore._h, _as_ptr(pep), pep.size, C.byref(ns), None)
+        seq = ""
+        if res["n_sig"][i] > 0:
+            n = ascore._lib.pya_format_peptide(ascore._h, _as_ptr(pep), pep.size, k, _as_ptr(psm["aux_pos"]),
+                                               _as_ptr(psm["aux_mass"]), psm["aux_pos"].size,
+                                               int(res["best_sig"][i]), ns.value, buf, 1024)
+            if n < 0:
+                ascore._raise(n)
+            seq = buf.value.decode("utf8")
+        ascores = ";".join(str(s) for s in res["ascores"][i, :k])
+        alts = ";".join(",".join(str(p + 1) for p in range(64) if (int(m) >> p) & 1)
+                        for m in res["alt_mask"][i, :k])
+        rows.append([scans[i], seq, float(res["best_score"][i]), ascores, alts])
+    return rows
+
+
+def write_tsv(rows, path):
+    """Same file pandas' ``DataFrame(rows, columns=COLUMNS).to_csv(path, sep="\\t", index=False)``
+    writes in the reference (`__main__.py:166-172`)."""
+    with open(path, "w") as out:
+        out.write("\t".join(COLUMNS) + "\n")
+        for scan, seq, pep_score, ascores, alts in rows:
+            out.write("%s\t%s\t%s\t%s\t%s\n" % (scan, seq, repr(float(pep_score)), ascores, alts))
