@@ -55,6 +55,7 @@ namespace {
 const size_t kMaxLds = 160 * 1024;
 const uint32_t kBucketLimits[] = {64, 512, 4096, PYA_MAX_SIGNATURES};
 const int kNumBuckets = 4;
+const size_t kStageLimit = 1u << 20;   /* batches whose transfers are smaller than this go through one staged copy */
 
 template <typename T>
 struct DevBuf {
@@ -167,7 +168,8 @@ struct pya_handle {
 
     /* device allocations recycled between pya_score_batch calls (hipMalloc/hipFree of a few
      * hundred MB cost milliseconds) */
-    DevBuf<unsigned char> spare_arena, spare_io;
+    DevBuf<unsigned char> spare_arena;
+    std::vector<unsigned char> stage;          /* host staging of small batches: one copy each way */
 
     std::string err;
     int64_t err_index = -1;
@@ -209,12 +211,6 @@ struct pya_handle {
         hipError_t e_ = (call);                                \
         if (e_ != hipSuccess) return (h)->hip_fail(e_, #call); \
     } while (0)
-
-static uint32_t next_pow2_u32(uint32_t v) {
-    uint32_t p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
 
 struct Bucket {
     std::vector<uint32_t> ids;
@@ -280,8 +276,11 @@ struct pya_plan {
     DevBuf<uint64_t> d_best_sig, d_alt;
     DevBuf<int32_t> d_n_sig_out;
     DevBuf<unsigned long long> d_stamps;
-    DevBuf<unsigned char> arena;          /* one allocation behind the metadata + workspace buffers */
-    DevBuf<unsigned char> io_arena;       /* spectra + results of pya_score_batch */
+    DevBuf<unsigned char> arena;          /* one allocation behind every device buffer of the plan */
+    /* arena layout: [uploaded metadata (+ spectra) | status (+ results) | workspace]; the middle
+     * part comes back to the host in one copy on the pya_score_batch path */
+    size_t o_status = 0, d2h_bytes = 0, o_best_score = 0, o_best_sig = 0, o_n_sig_out = 0, o_ascores = 0, o_alt = 0;
+    uint32_t io_max_k = 0;
     BatchDev dev;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t last_stream = nullptr;
@@ -291,12 +290,7 @@ struct pya_plan {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
     }
-    uint64_t workspace_bytes() const {
-        uint64_t b = arena.bytes();
-        for (const Bucket &k : buckets) b += k.d_ids.bytes();
-        b += fused.d_ids.bytes() + all_ids.d_ids.bytes();
-        return b;
-    }
+    uint64_t workspace_bytes() const { return arena.bytes(); }
 };
 
 namespace {
@@ -630,7 +624,14 @@ int pya_format_peptide(const pya_handle *h, const uint8_t *pep, uint64_t L, int3
     return (int)out.size();
 }
 
-int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan **out) {
+namespace {
+struct IoReq {                       /* pya_score_batch: spectra and results live in the plan's arena too */
+    const double *mz, *inten;
+    uint32_t max_k;
+};
+}
+
+static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const IoReq *io, pya_plan **out) {
     if (!h || !b || !out) return PYA_ERR_ARG;
     *out = nullptr;
     h->err.clear();
@@ -827,37 +828,64 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
         HIPCHK(h, h->d_order.upload(h->order_tab.data(), h->order_tab.size()));
         h->order_uploaded = h->order_tab.size();
     }
+    if (io && io->max_k < max_k)
+        return h->fail(PYA_ERR_ARG, -1, "results.max_k (%u) is smaller than the largest n_of_mod (%u)", io->max_k, max_k);
     if (!p->fused.ids.empty()) {
         size_t need = pya_fused_lds_bytes(p->peak_cap, p->fused.pos_cap, p->fused.pool_cap(), p->fused.sb());
         if (need > kMaxLds)
             return h->fail(PYA_ERR_LIMIT, (int64_t)p->fused.ids[0], "LDS budget exceeded (%zu bytes) on the fused path", need);
-        HIPCHK(h, p->fused.d_ids.upload(p->fused.ids.data(), p->fused.ids.size()));
     }
-    if (!p->all_ids.ids.empty())
-        HIPCHK(h, p->all_ids.d_ids.upload(p->all_ids.ids.data(), p->all_ids.ids.size()));
     for (Bucket &bk : p->buckets) {
         if (bk.ids.empty()) continue;
         size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb());
         if (need > kMaxLds)
             return h->fail(PYA_ERR_LIMIT, (int64_t)bk.ids[0], "LDS budget exceeded (%zu bytes) for the bucket of PSM %u",
                            need, bk.ids[0]);
-        HIPCHK(h, bk.d_ids.upload(bk.ids.data(), bk.ids.size()));
     }
-    lap("tables+ids");
-    /* one device allocation for all metadata and workspace (hipMalloc is ~100 us a call) */
+    lap("tables");
+    /* One device allocation for everything (hipMalloc is ~100 us a call), laid out so that what
+     * goes up and what comes back are each one contiguous range. */
     {
+        struct Up { size_t off; const void *src; size_t bytes; };
+        std::vector<Up> ups;
         size_t total = 0;
         auto reserve = [&](size_t bytes) {
             size_t o = total;
             total += (bytes + 255) & ~(size_t)255;
             return o;
         };
-        const size_t o_peak_off = reserve((n + 1) * 8), o_pep_off = reserve((n + 1) * 8),
-                     o_aux_off = reserve((n + 1) * 8), o_sig_off = reserve((n + 1) * 8),
-                     o_pep = reserve(p->pep.size()), o_n_sites = reserve(n), o_n_of_mod = reserve(n * 4),
-                     o_max_charge = reserve(n * 4), o_n_sig = reserve(n * 4), o_order_off = reserve(n * 4),
-                     o_aux_pos = reserve((size_t)total_aux * 4), o_aux_mass = reserve((size_t)total_aux * 4),
-                     o_status = reserve(n * 4), o_ret_n = reserve(n * 4),
+        auto meta = [&](const void *src, size_t bytes) {
+            size_t o = reserve(bytes);
+            if (src && bytes) ups.push_back({o, src, bytes});
+            return o;
+        };
+        const size_t o_peak_off = meta(p->peak_off.data(), (n + 1) * 8), o_pep_off = meta(p->pep_off.data(), (n + 1) * 8),
+                     o_aux_off = meta(p->aux_off.data(), (n + 1) * 8), o_sig_off = meta(p->sig_off.data(), (n + 1) * 8),
+                     o_pep = meta(p->pep.data(), p->pep.size()), o_n_sites = meta(p->n_sites.data(), n),
+                     o_n_of_mod = meta(p->n_of_mod.data(), n * 4), o_max_charge = meta(p->max_charge.data(), n * 4),
+                     o_n_sig = meta(p->n_sig.data(), n * 4), o_order_off = meta(p->order_off.data(), n * 4),
+                     o_aux_pos = meta(has_aux ? b->aux_pos + aux_base : nullptr, (size_t)total_aux * 4),
+                     o_aux_mass = meta(has_aux ? b->aux_mass + aux_base : nullptr, (size_t)total_aux * 4),
+                     o_all_ids = meta(p->all_ids.ids.data(), p->all_ids.ids.size() * 4),
+                     o_fused_ids = meta(p->fused.ids.data(), p->fused.ids.size() * 4);
+        size_t o_bucket_ids[kNumBuckets];
+        for (int i = 0; i < kNumBuckets; i++)
+            o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
+        const size_t o_mz = io ? meta(io->mz + peak_base, (size_t)p->total_peaks * 8) : 0,
+                     o_inten = io ? meta(io->inten + peak_base, (size_t)p->total_peaks * 8) : 0;
+        const size_t h2d_bytes = total;
+        p->o_status = reserve(n * 4);
+        if (io) {
+            const size_t mk = io->max_k;
+            p->io_max_k = io->max_k;
+            p->o_best_score = reserve(n * 4);
+            p->o_best_sig = reserve(n * 8);
+            p->o_n_sig_out = reserve(n * 4);
+            p->o_ascores = reserve(n * mk * 4);
+            p->o_alt = reserve(n * mk * 8);
+        }
+        p->d2h_bytes = total - p->o_status;
+        const size_t o_ret_n = reserve(n * 4),
                      o_ret_mz = reserve((size_t)p->total_peaks * 4), o_ret_rank = reserve((size_t)p->total_peaks),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
@@ -875,36 +903,46 @@ int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan 
         p->d_order_off.adopt(base + o_order_off, n);
         p->d_aux_pos.adopt(base + o_aux_pos, (size_t)total_aux);
         p->d_aux_mass.adopt(base + o_aux_mass, (size_t)total_aux);
-        p->d_status.adopt(base + o_status, n);
+        p->all_ids.d_ids.adopt(base + o_all_ids, p->all_ids.ids.size());
+        p->fused.d_ids.adopt(base + o_fused_ids, p->fused.ids.size());
+        for (int i = 0; i < kNumBuckets; i++)
+            p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
+        if (io) {
+            p->d_mz.adopt(base + o_mz, (size_t)p->total_peaks);
+            p->d_inten.adopt(base + o_inten, (size_t)p->total_peaks);
+            p->d_best_score.adopt(base + p->o_best_score, n);
+            p->d_best_sig.adopt(base + p->o_best_sig, n);
+            p->d_n_sig_out.adopt(base + p->o_n_sig_out, n);
+            p->d_ascores.adopt(base + p->o_ascores, n * io->max_k);
+            p->d_alt.adopt(base + p->o_alt, n * io->max_k);
+        }
+        p->d_status.adopt(base + p->o_status, n);
         p->d_ret_n.adopt(base + o_ret_n, n);
         p->d_ret_mz.adopt(base + o_ret_mz, (size_t)p->total_peaks);
         p->d_ret_rank.adopt(base + o_ret_rank, (size_t)p->total_peaks);
         p->d_ws.adopt(base + o_ws, (size_t)sig_total);
         p->d_rec.adopt(base + o_rec, (size_t)sig_total * PYA_REC_WORDS);
         if (flags & PYA_FLAG_KEEP) p->d_sorted.adopt(base + o_sorted, (size_t)sig_total);
-        HIPCHK(h, p->d_peak_off.fill(p->peak_off.data()));
-        HIPCHK(h, p->d_pep_off.fill(p->pep_off.data()));
-        HIPCHK(h, p->d_aux_off.fill(p->aux_off.data()));
-        HIPCHK(h, p->d_sig_off.fill(p->sig_off.data()));
-        HIPCHK(h, p->d_pep.fill(p->pep.data()));
-        HIPCHK(h, p->d_n_sites.fill(p->n_sites.data()));
-        HIPCHK(h, p->d_n_of_mod.fill(p->n_of_mod.data()));
-        HIPCHK(h, p->d_max_charge.fill(p->max_charge.data()));
-        HIPCHK(h, p->d_n_sig.fill(p->n_sig.data()));
-        HIPCHK(h, p->d_order_off.fill(p->order_off.data()));
-        if (has_aux) {
-            HIPCHK(h, p->d_aux_pos.fill(b->aux_pos + aux_base));
-            HIPCHK(h, p->d_aux_mass.fill(b->aux_mass + aux_base));
+        if (h2d_bytes <= kStageLimit) {
+            /* small batch: HIP call overhead dominates, so gather on the host and copy once */
+            h->stage.resize(std::max(h->stage.size(), h2d_bytes));
+            for (const Up &u : ups) std::memcpy(h->stage.data() + u.off, u.src, u.bytes);
+            HIPCHK(h, hipMemcpy(base, h->stage.data(), h2d_bytes, hipMemcpyHostToDevice));
+        } else {
+            for (const Up &u : ups) HIPCHK(h, hipMemcpyAsync(base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
+            HIPCHK(h, hipDeviceSynchronize());
         }
     }
     lap("arena+upload");
     if (flags & PYA_FLAG_TIMING)
         for (auto &e : p->ev) HIPCHK(h, hipEventCreate(&e));
-    HIPCHK(h, hipDeviceSynchronize());
-    lap("sync");
     fill_dev(p.get());
     *out = p.release();
     return PYA_OK;
+}
+
+int pya_plan_create(pya_handle *h, const pya_batch *b, uint32_t flags, pya_plan **out) {
+    return plan_create_impl(h, b, flags, nullptr, out);
 }
 
 int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *hip_stream,
@@ -965,15 +1003,8 @@ int pya_plan_timings(pya_plan *p, float ms[4]) {
     return PYA_OK;
 }
 
-int pya_plan_check(pya_plan *p) {
-    if (!p) return PYA_ERR_ARG;
-    pya_handle *h = p->h;
-    if (!p->ran || p->n_psm == 0) return PYA_OK;
-    HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(p->last_stream));
-    std::vector<int32_t> st(p->n_psm);
-    HIPCHK(h, hipMemcpy(st.data(), p->d_status.p, p->n_psm * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < p->n_psm; i++) {
+static int check_status(pya_handle *h, const int32_t *st, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) {
         switch (st[i]) {
             case PYA_ST_OK: break;
             case PYA_ST_NO_BINS:
@@ -990,6 +1021,17 @@ int pya_plan_check(pya_plan *p) {
         }
     }
     return PYA_OK;
+}
+
+int pya_plan_check(pya_plan *p) {
+    if (!p) return PYA_ERR_ARG;
+    pya_handle *h = p->h;
+    if (!p->ran || p->n_psm == 0) return PYA_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(p->last_stream));
+    std::vector<int32_t> st(p->n_psm);
+    HIPCHK(h, hipMemcpy(st.data(), p->d_status.p, p->n_psm * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return check_status(h, st.data(), p->n_psm);
 }
 
 uint64_t pya_plan_workspace_bytes(const pya_plan *p) { return p ? p->workspace_bytes() : 0; }
@@ -1011,7 +1053,6 @@ void pya_plan_destroy(pya_plan *p) {
     if (p->h->kept == p) p->h->kept = nullptr;
     (void)hipDeviceSynchronize();                       /* nothing may still be using the buffers */
     p->arena.give_to(p->h->spare_arena);
-    p->io_arena.give_to(p->h->spare_io);
     delete p;
 }
 
@@ -1030,48 +1071,40 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
         t0 = t1;
     };
     pya_plan *p = nullptr;
-    int rc = pya_plan_create(h, b, flags & ~PYA_FLAG_TIMING, &p);
+    const IoReq io = {mz, inten, out->max_k};
+    int rc = plan_create_impl(h, b, flags & ~PYA_FLAG_TIMING, &io, &p);
     if (rc) return rc;
     std::unique_ptr<pya_plan, void (*)(pya_plan *)> guard(p, pya_plan_destroy);
-    lap("plan");
+    lap("plan + h2d");
     const uint64_t n = b->n_psm;
-    const int64_t base = b->peak_off[0];
     const uint32_t mk = out->max_k;
-    if (mk < p->max_k) return h->fail(PYA_ERR_ARG, -1, "results.max_k too small");
-    {
-        size_t total = 0;
-        auto reserve = [&](size_t bytes) {
-            size_t o = total;
-            total += (bytes + 255) & ~(size_t)255;
-            return o;
-        };
-        const size_t o_mz = reserve((size_t)p->total_peaks * 8), o_in = reserve((size_t)p->total_peaks * 8),
-                     o_bs = reserve(n * 4), o_sig = reserve(n * 8), o_ns = reserve(n * 4),
-                     o_as = reserve(n * mk * 4), o_alt = reserve(n * mk * 8);
-        if (!p->io_arena.take_if_fits(h->spare_io, total)) HIPCHK(h, p->io_arena.alloc(total));
-        unsigned char *ib = p->io_arena.p;
-        p->d_mz.adopt(ib + o_mz, (size_t)p->total_peaks);
-        p->d_inten.adopt(ib + o_in, (size_t)p->total_peaks);
-        p->d_best_score.adopt(ib + o_bs, n);
-        p->d_best_sig.adopt(ib + o_sig, n);
-        p->d_n_sig_out.adopt(ib + o_ns, n);
-        p->d_ascores.adopt(ib + o_as, n * mk);
-        p->d_alt.adopt(ib + o_alt, n * mk);
-        HIPCHK(h, p->d_mz.fill(mz + base));
-        HIPCHK(h, p->d_inten.fill(inten + base));
-    }
-    lap("h2d + alloc");
     pya_results d_out = {mk, p->d_best_score.p, p->d_best_sig.p, p->d_n_sig_out.p, p->d_ascores.p, p->d_alt.p};
     rc = pya_plan_run(p, p->d_mz.p, p->d_inten.p, nullptr, &d_out);
     if (rc) return rc;
-    rc = pya_plan_check(p);
-    if (rc) return rc;
-    lap("kernels");
-    HIPCHK(h, hipMemcpy(out->best_score, p->d_best_score.p, n * sizeof(float), hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(out->best_sig, p->d_best_sig.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(out->n_sig, p->d_n_sig_out.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(out->ascores, p->d_ascores.p, n * mk * sizeof(float), hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(out->alt_mask, p->d_alt.p, n * mk * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (p->d2h_bytes <= kStageLimit) {
+        /* status and results are adjacent in the arena: one copy, which also waits for the kernels */
+        h->stage.resize(std::max(h->stage.size(), p->d2h_bytes));
+        unsigned char *sg = h->stage.data();
+        HIPCHK(h, hipMemcpy(sg, p->arena.p + p->o_status, p->d2h_bytes, hipMemcpyDeviceToHost));
+        lap("kernels + d2h");
+        rc = check_status(h, (const int32_t *)sg, n);
+        if (rc) return rc;
+        const size_t o = p->o_status;
+        std::memcpy(out->best_score, sg + (p->o_best_score - o), n * sizeof(float));
+        std::memcpy(out->best_sig, sg + (p->o_best_sig - o), n * sizeof(uint64_t));
+        std::memcpy(out->n_sig, sg + (p->o_n_sig_out - o), n * sizeof(int32_t));
+        std::memcpy(out->ascores, sg + (p->o_ascores - o), n * mk * sizeof(float));
+        std::memcpy(out->alt_mask, sg + (p->o_alt - o), n * mk * sizeof(uint64_t));
+    } else {
+        rc = pya_plan_check(p);
+        if (rc) return rc;
+        lap("kernels");
+        HIPCHK(h, hipMemcpy(out->best_score, p->d_best_score.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(out->best_sig, p->d_best_sig.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(out->n_sig, p->d_n_sig_out.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(out->ascores, p->d_ascores.p, n * mk * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(out->alt_mask, p->d_alt.p, n * mk * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
     lap("d2h");
     if (flags & PYA_FLAG_KEEP) {
         if (h->kept) pya_plan_destroy(h->kept);
