@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyascore_hip.so")
+LIB_PATH = os.environ.get("PYA_LIB") or os.path.join(_HERE, "libpyascore_hip.so")   # PYA_LIB: A/B builds
 
 PYA_OK, PYA_ERR_ARG, PYA_ERR_HIP, PYA_ERR_PSM, PYA_ERR_LIMIT, PYA_ERR_STATE = 0, -1, -2, -3, -4, -5
 PYA_FLAG_KEEP, PYA_FLAG_TIMING = 1, 2

@@ -32,6 +32,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
      * (Spectra.cpp:46-47 use min_element / max_element). */
     const DevConfig *cfg_ = cfg;
     const float bin_size = cfg_->bin_size;
+    const double bsd = (double)bin_size, inv_bs = 1. / bsd;
     double mn = mz[0], mx = mz[P - 1];
     float min_mz = 0.f;
     uint32_t n_bins = 0;
@@ -60,7 +61,15 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                 s_inten[i] = inten[i];
                 s_mzf[i] = (float)v;
             }
-            const double q = __builtin_floor((v - (double)min_mz) / (double)bin_size);
+            /* floor((v - min) / bin_size) as the reference's double division gives it, without
+             * the division: every multiple k * bin_size (k < 2^16, bin_size a float) is exact in
+             * double, so the rounded quotient reaches k exactly when the true one does and the
+             * floor equals the mathematical one -- which a reciprocal estimate plus an exact
+             * remainder (fma) pins down. */
+            const double x = v - (double)min_mz;
+            double q = __builtin_floor(x * inv_bs);
+            const double r = __builtin_fma(-q, bsd, x);
+            q = r < 0. ? q - 1. : (r >= bsd ? q + 1. : q);
             const uint32_t w = q >= (double)(n_bins - 1) ? n_bins - 1 : (uint32_t)q;
             s_bin[i] = (uint16_t)w;
         }
@@ -86,8 +95,13 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
      * runs in lock step -- a wave-uniform loop without per-lane exit tests; positions past the end
      * of a shorter run are clamped to the lane's own peak, which never counts. */
     if (!(b.debug & 32)) {
-        if (!unsorted) {
-            int carry_lo = 0;
+        /* Fast sweep: count the strictly more intense run mates only (one compare and one
+         * add-with-carry per mate).  Without equal intensities inside a window that IS the rank;
+         * with them the counts of a window no longer add up to len*(len-1)/2, which the check
+         * after the sweep notices, and the exact sweep below redoes the spectrum. */
+        bool exact = unsorted || (b.debug & 128);
+        if (!exact) {
+            int carry_lo = 0, deficit = 0;
             for (int base = 0; base < P; base += 64) {
                 const int i = base + lane;
                 const bool in = i < P;
@@ -98,6 +112,48 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                 const uint64_t upto = lanemask_lt() | (1ull << lane);
                 const uint64_t le = starts & upto, gt = starts & ~upto;
                 /* where does the run that is still open at the end of this chunk stop? */
+                int run_end = P - 1;
+                for (int nb = base + 64; nb < P; nb += 64) {
+                    const int j = nb + lane;
+                    const uint64_t m2 = __ballot(j < P && s_bin[j] != s_bin[j - 1]);
+                    if (m2) {
+                        run_end = nb + __builtin_ctzll(m2) - 1;
+                        break;
+                    }
+                }
+                const int lo = le ? base + 63 - __builtin_clzll(le) : carry_lo;
+                const int hi = gt ? base + __builtin_ctzll(gt) - 1 : run_end;
+                const int len = in ? hi - lo + 1 : 0;
+                const int t_max = (int)wave_max_u32((uint32_t)len);
+                carry_lo = __builtin_amdgcn_readlane(lo, 63);
+                /* mates are read at lo + t straight through the end of the lane's run (whatever
+                 * follows in LDS is masked by t < len), so the address is one running pointer */
+                const double *src = s_inten + (in ? lo : 0);
+                int cnt = 0;
+                const int t_end = __builtin_amdgcn_readfirstlane(t_max);
+#pragma unroll 4
+                for (int t = 0; t < t_end; t++) {
+                    const double o = src[t];                      /* unconditional: no branch around the read */
+                    cnt += (int)((t < len) & (o > me));
+                }
+                deficit += in ? (len - 1) - 2 * cnt : 0;
+                if (in) s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
+            }
+            exact = wave_sum_i32(deficit) != 0;
+            if (exact) wave_lds_sync();
+        }
+        if (!exact) {
+        } else if (!unsorted) {
+            int carry_lo = 0;
+            for (int base = 0; base < P; base += 64) {
+                const int i = base + lane;
+                const bool in = i < P;
+                const uint32_t w = in ? (uint32_t)s_bin[i] : 0x10000u;
+                const uint32_t pw = (in && i > 0) ? (uint32_t)s_bin[i - 1] : 0x10001u;
+                const double me = s_inten[in ? i : 0];
+                const uint64_t starts = __ballot(in && pw != w);
+                const uint64_t upto = lanemask_lt() | (1ull << lane);
+                const uint64_t le = starts & upto, gt = starts & ~upto;
                 int run_end = P - 1;
                 for (int nb = base + 64; nb < P; nb += 64) {
                     const int j = nb + lane;

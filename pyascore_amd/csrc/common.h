@@ -72,6 +72,7 @@ struct BatchDev {
     float *ret_mz;                  /* retained peaks, m/z ascending, at peak_off[psm]      */
     uint8_t *ret_rank;
     uint32_t *ret_n;                /* [n_psm]                                              */
+    uint16_t *grid;                 /* [n_psm][PYA_GRID_CELLS] m/z grid over the retained peaks (score_signatures) */
     float *ws;                      /* weighted score per signature, pre-sort order         */
     uint32_t *rec;                  /* optional per-signature records: 6 words each         */
     uint32_t *sorted_idx;           /* optional sorted permutation, at sig_off              */
@@ -96,6 +97,7 @@ struct PushedEntry {
 };
 
 /* LDS bytes of the batched-localisation work area (localize_core.hip.h: LocLds) */
+#define PYA_GRID_CELLS 256         /* cells of the m/z grid that accelerates the peak lookup    */
 #define PYA_LOC_SB_MAX 8           /* signatures worked on together: the winner + 7 competitors */
 static inline unsigned long pya_loc_lds_bytes(unsigned pos_cap, unsigned pool_cap, unsigned sb) {
     return 64ul * 4 * 2 + 64 + sb * 8ul + (unsigned long)sb * 2 * pos_cap * 8 + sb * 2 * 4ul + sb * 11 * 4ul +

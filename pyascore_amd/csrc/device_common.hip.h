@@ -144,7 +144,6 @@ DEV float charge_mz(double m, int z) {
  * Retained peaks are staged in LDS sorted by m/z (float); a coarse m/z grid gives the start of
  * the scan (the grid only narrows the search, the window test itself is the reference's).
  * ------------------------------------------------------------------------------------- */
-#define PYA_GRID_CELLS 256         /* cells of the m/z grid that accelerates the lookup       */
 #define PYA_TABLE_PAD 4            /* +inf sentinels after the last retained peak             */
 
 /* one retained peak in LDS: float m/z and its rank, 8 bytes so both come with one ds_read_b64 */
@@ -159,6 +158,7 @@ struct PeakTable {
     const float *g_mz;      /* global retained m/z of the PSM (ascending)                        */
     const uint8_t *g_rank;
     const uint16_t *cell;   /* LDS [PYA_GRID_CELLS]: first peak index whose cell is >= c          */
+    const uint16_t *g_cell; /* the same grid in global memory (score_signatures leaves it there)  */
     int n;
     float err;
     float base;             /* m/z of the first retained peak                                    */
@@ -188,6 +188,7 @@ DEV void stage_peak_table(const BatchDev &b, uint32_t psm, PeakEntry *dst, PeakT
         dst[R + lane] = x;
     }
     t->e = dst;
+    t->g_cell = nullptr;
     t->g_mz = b.ret_mz + p0;
     t->g_rank = b.ret_rank + p0;
     t->n = R;
@@ -202,6 +203,18 @@ DEV int grid_cell(const PeakTable &t, float x) {
     return c > t.last_cell ? t.last_cell : c;
 }
 
+/* cell geometry from the first and last retained m/z (same arithmetic wherever it is needed) */
+DEV void grid_params(PeakTable *t, float first, float last) {
+    t->base = first;
+    const float range = last - first;
+    float inv_w = 0.125f;                                 /* 8 m/z per cell ...                */
+    if (range * inv_w > (float)(PYA_GRID_CELLS - 2)) inv_w = (float)(PYA_GRID_CELLS - 2) / range;
+    t->inv_w = inv_w;                                     /* ... or wider to fit the grid      */
+    int lc = (int)(range * inv_w);
+    if (lc > PYA_GRID_CELLS - 1) lc = PYA_GRID_CELLS - 1;
+    t->last_cell = lc;
+}
+
 /* builds the grid for the n staged peaks (wave-cooperative; caller syncs LDS before and after) */
 DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
     const int lane = lane_id();
@@ -213,16 +226,7 @@ DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
         if (lane == 0) cell_lds[0] = 0;
         return;
     }
-    const float first = t->e[0].mz, last = t->e[t->n - 1].mz;
-    t->base = first;
-    const float range = last - first;
-    float inv_w = 0.125f;                                 /* 8 m/z per cell ...                */
-    if (range * inv_w > (float)(PYA_GRID_CELLS - 2)) inv_w = (float)(PYA_GRID_CELLS - 2) / range;
-    t->inv_w = inv_w;                                     /* ... or wider to fit the grid      */
-    t->last_cell = PYA_GRID_CELLS - 1;
-    int lc = (int)(range * inv_w);
-    if (lc > PYA_GRID_CELLS - 1) lc = PYA_GRID_CELLS - 1;
-    t->last_cell = lc;
+    grid_params(t, t->e[0].mz, t->e[t->n - 1].mz);
     for (int i = lane; i < t->n; i += 64) {
         const int c = grid_cell(*t, t->e[i].mz);
         const int cp = i > 0 ? grid_cell(*t, t->e[i - 1].mz) : -1;
@@ -238,6 +242,7 @@ DEV void global_peak_table(const BatchDev &b, uint32_t psm, PeakTable *t) {
     const int64_t p0 = b.peak_off[psm];
     t->e = nullptr;
     t->cell = nullptr;
+    t->g_cell = b.grid + (size_t)psm * PYA_GRID_CELLS;
     t->g_mz = b.ret_mz + p0;
     t->g_rank = b.ret_rank + p0;
     t->n = (int)b.ret_n[psm];
@@ -246,29 +251,44 @@ DEV void global_peak_table(const BatchDev &b, uint32_t psm, PeakTable *t) {
     t->base = 0.f;
     t->inv_w = 0.f;
     t->last_cell = 0;
+    if (t->n > 0) grid_params(t, t->g_mz[0], t->g_mz[t->n - 1]);
 }
 
-/* same window test on the global arrays: binary search for the first peak > lo, then scan */
+/* Same window test on the global arrays.  The grid score_signatures built for this PSM gives the
+ * start; the next four entries are fetched together, so a lookup is two dependent round trips to
+ * memory instead of the ten of a binary search. */
 DEV int match_rank_global(const PeakTable &t, float f) {
+    if (t.n <= 0) return PYA_NO_MATCH;
     const float lo = f - t.err;
     const float hi = f + t.err;
-    int idx = 0, len = t.n;                               /* first index with mz > lo */
-    while (len > 0) {
-        const int half = len >> 1;
-        if (t.g_mz[idx + half] <= lo) {
-            idx += half + 1;
-            len -= half + 1;
-        } else {
-            len = half;
-        }
+    int idx = (int)t.g_cell[grid_cell(t, lo)];            /* every peak > lo has index >= idx  */
+    const int last = t.n - 1;
+    /* entries idx .. idx+3 through one address and immediate offsets; reading up to three entries
+     * past the PSM's table stays inside the plan's arena and is masked below */
+    const float *pm = t.g_mz + idx;
+    const uint8_t *pr = t.g_rank + idx;
+    float m[4];
+    int r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        m[j] = pm[j];
+        r[j] = (int)pr[j];
     }
     int best = PYA_NO_MATCH;
-    for (; idx < t.n; idx++) {
-        const float p = t.g_mz[idx];
-        if (!(p < hi)) break;
-        if (!t.half_check || (double)f >= (double)p - 0.5) {
-            const int r = (int)t.g_rank[idx];
-            best = r < best ? r : best;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        bool in = idx + j <= last && m[j] > lo && m[j] < hi;
+        if (t.half_check) in = in && (double)f >= (double)m[j] - 0.5;
+        best = in && r[j] < best ? r[j] : best;
+    }
+    if (idx + 3 < last && m[3] < hi) {                    /* rare: more than four entries to look at */
+        for (idx += 4; idx <= last; idx++) {
+            const float p = t.g_mz[idx];
+            if (!(p < hi)) break;
+            if (p > lo && (!t.half_check || (double)f >= (double)p - 0.5)) {
+                const int rr = (int)t.g_rank[idx];
+                best = rr < best ? rr : best;
+            }
         }
     }
     return best;
@@ -309,6 +329,10 @@ DEV int match_rank_lds(const PeakTable &t, float f) {
 DEV int match_rank(const PeakTable &t, float f) {
     return t.e ? match_rank_lds(t, f) : match_rank_global(t, f);
 }
+
+/* Row n of the score table starts at 10 * (1 + 2 + ... + n) floats: rows are dense from n = 0 and
+ * hold PYA_NTOP x (n + 1) entries (score_table.cpp; the host checks this when it uploads). */
+DEV uint32_t lut_row(uint32_t n) { return 5u * n * (n + 1u); }
 
 /* rank histogram: 10 x 16-bit fields in three 64-bit words (ranks 0-3 | 4-7 | 8-9) */
 struct Hist {

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64, 5) void pya_fused_small_kernel(BatchDev b, cons
             uint32_t acc = 0;
             double sum = 0.;
             const bool ok = nfrag <= b.lut_n_max;
-            const uint32_t off = ok ? b.lut_off[nfrag] : 0u;
+            const uint32_t off = ok ? lut_row(nfrag) : 0u;
             if (!ok) fail = 1;
 #pragma unroll
             for (int d = 0; d < PYA_NTOP; d++) {

@@ -267,6 +267,7 @@ struct pya_plan {
     DevBuf<uint32_t> d_aux_pos, d_n_sig, d_order_off, d_ret_n, d_rec, d_sorted;
     DevBuf<float> d_aux_mass, d_ret_mz, d_ws;
     DevBuf<uint8_t> d_ret_rank;
+    DevBuf<uint16_t> d_grid;
     Bucket buckets[kNumBuckets];
     Bucket fused;                       /* C(n,k) <= 64: whole path in one kernel */
     Bucket all_ids;                     /* every PSM (bin_spectra launch) */
@@ -406,6 +407,9 @@ int ensure_lut(pya_handle *h, uint32_t n_max) {
     if (h->lut_uploaded_n > n_max) return PYA_OK;
     uint32_t target = std::max<uint32_t>(n_max, 128);
     pya_score_table_extend(h->mz_error, PYA_NTOP, target, h->lut, h->lut_off);
+    for (size_t n = 0; n < h->lut_off.size(); n++)             /* the kernels compute row offsets */
+        if (h->lut_off[n] != 5u * (uint32_t)n * ((uint32_t)n + 1u))
+            return h->fail(PYA_ERR_STATE, -1, "score table rows are not dense");
     HIPCHK(h, h->d_lut.upload(h->lut.data(), h->lut.size()));
     HIPCHK(h, h->d_lut_off.upload(h->lut_off.data(), h->lut_off.size()));
     HIPCHK(h, hipDeviceSynchronize());
@@ -485,6 +489,7 @@ void fill_dev(pya_plan *p) {
     d.ret_mz = p->d_ret_mz.p;
     d.ret_rank = p->d_ret_rank.p;
     d.ret_n = p->d_ret_n.p;
+    d.grid = p->d_grid.p;
     d.ws = p->d_ws.p;
     d.rec = p->d_rec.p;
     d.sorted_idx = p->d_sorted.p;
@@ -887,6 +892,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
                      o_ret_mz = reserve((size_t)p->total_peaks * 4), o_ret_rank = reserve((size_t)p->total_peaks),
+                     o_grid = reserve(n * PYA_GRID_CELLS * 2),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         if (!p->arena.take_if_fits(h->spare_arena, total)) HIPCHK(h, p->arena.alloc(total));
@@ -920,6 +926,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_ret_n.adopt(base + o_ret_n, n);
         p->d_ret_mz.adopt(base + o_ret_mz, (size_t)p->total_peaks);
         p->d_ret_rank.adopt(base + o_ret_rank, (size_t)p->total_peaks);
+        p->d_grid.adopt(base + o_grid, n * PYA_GRID_CELLS);
         p->d_ws.adopt(base + o_ws, (size_t)sig_total);
         p->d_rec.adopt(base + o_rec, (size_t)sig_total * PYA_REC_WORDS);
         if (flags & PYA_FLAG_KEEP) p->d_sorted.adopt(base + o_sorted, (size_t)sig_total);

@@ -379,8 +379,8 @@ DEV float ambiguity(const BatchDev &b, const Residues &res, const DevConfig *cfg
         *fail = 1;
         return 0.f;
     }
-    const float s0 = b.lut[b.lut_off[tr0] + (uint32_t)depth * (uint32_t)(tr0 + 1) + (uint32_t)cnt0];
-    const float s1 = b.lut[b.lut_off[tr1] + (uint32_t)depth * (uint32_t)(tr1 + 1) + (uint32_t)cnt1];
+    const float s0 = b.lut[lut_row(tr0) + (uint32_t)depth * (uint32_t)(tr0 + 1) + (uint32_t)cnt0];
+    const float s1 = b.lut[lut_row(tr1) + (uint32_t)depth * (uint32_t)(tr1 + 1) + (uint32_t)cnt1];
     return s0 - s1;
 }
 
@@ -392,7 +392,7 @@ DEV void scores_from_counts(const BatchDev &b, const uint32_t cum[PYA_NTOP], uin
         for (int d = 0; d < PYA_NTOP; d++) out[d] = 0.f;
         return;
     }
-    const uint32_t off = b.lut_off[nfrag];
+    const uint32_t off = lut_row(nfrag);
 #pragma unroll
     for (int d = 0; d < PYA_NTOP; d++) out[d] = b.lut[off + (uint32_t)d * (nfrag + 1) + cum[d]];
 }
@@ -600,7 +600,7 @@ DEV void loc_scores(const LocCtx &c, int s_lo, int S, int *fail) {
         for (int r = 0; r <= d; r++) cum += w.hist[s * 11 + r];
         const uint32_t nf = w.hist[s * 11 + 10];
         float sc = 0.f;
-        if (nf <= c.b->lut_n_max) sc = c.b->lut[c.b->lut_off[nf] + (uint32_t)d * (nf + 1) + cum];
+        if (nf <= c.b->lut_n_max) sc = c.b->lut[lut_row(nf) + (uint32_t)d * (nf + 1) + cum];
         else *fail = 1;
         w.scores[i] = sc;
     }
@@ -960,7 +960,7 @@ DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, con
                 const uint32_t cum = (r6[d >> 1] >> ((d & 1) * 16)) & 0xffffu;
                 const uint32_t nf = r6[5];
                 float sc = 0.f;
-                if (nf <= b.lut_n_max) sc = b.lut[b.lut_off[nf] + (uint32_t)d * (nf + 1) + cum];
+                if (nf <= b.lut_n_max) sc = b.lut[lut_row(nf) + (uint32_t)d * (nf + 1) + cum];
                 else fail = 1;
                 w.scores[i] = sc;
             }
@@ -975,18 +975,22 @@ DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, con
         have_best = true;
         if (!(b.debug & 1)) loc_site_ions(ctx, S);
         STAMP(b, 35);
-        for (int cc = 1; cc < S; cc++) {
-            const uint32_t tr0 = w.c_tr[cc * 2], tr1 = w.c_tr[cc * 2 + 1];
-            const uint32_t n0 = w.c_cnt[cc * 2], n1 = w.c_cnt[cc * 2 + 1];
-            const uint32_t depth = (uint32_t)w.c_depth[cc];
-            float asc = 0.f;
+        /* one competitor per lane: the table reads of all of them are in flight together */
+        float asc_l = 0.f;
+        if (lane >= 1 && lane < S) {
+            const uint32_t tr0 = w.c_tr[lane * 2], tr1 = w.c_tr[lane * 2 + 1];
+            const uint32_t n0 = w.c_cnt[lane * 2], n1 = w.c_cnt[lane * 2 + 1];
+            const uint32_t depth = (uint32_t)w.c_depth[lane];
             if (tr0 > b.lut_n_max || tr1 > b.lut_n_max) {
                 fail = 1;
             } else {
-                const float sc0 = b.lut[b.lut_off[tr0] + depth * (tr0 + 1) + n0];
-                const float sc1 = b.lut[b.lut_off[tr1] + depth * (tr1 + 1) + n1];
-                asc = sc0 - sc1;
+                const float sc0 = b.lut[lut_row(tr0) + depth * (tr0 + 1) + n0];
+                const float sc1 = b.lut[lut_row(tr1) + depth * (tr1 + 1) + n1];
+                asc_l = sc0 - sc1;
             }
+        }
+        for (int cc = 1; cc < S; cc++) {
+            const float asc = __shfl(asc_l, cc);
             if (lane == (int)w.c_idx[cc]) my_asc = asc < my_asc ? asc : my_asc;
         }
         wave_lds_sync();

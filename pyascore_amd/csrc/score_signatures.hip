@@ -20,7 +20,7 @@
 #include "device_common.hip.h"
 
 DEV float lut_score(const BatchDev &b, uint32_t depth, uint32_t k, uint32_t n) {
-    return b.lut[b.lut_off[n] + depth * (n + 1) + k];
+    return b.lut[lut_row(n) + depth * (n + 1) + k];
 }
 
 #include "walk_core.hip.h"
@@ -84,6 +84,8 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     const int64_t s0 = b.sig_off[psm];
     const bool both_dirs = cfg->n_fwd > 0 && cfg->n_fwd < cfg->n_types;
     wave_lds_sync();
+    /* localize looks up its few ions in the global table: leave it the grid (one 512-byte store) */
+    ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)grid)[lane];
 
     int lut_fail = 0;
     const bool split = N <= 32 && both_dirs;     /* lanes 0..31 forward, 32..63 backward */

@@ -93,6 +93,37 @@ def test_unsorted_spectrum_and_ties(path):
         assert np.array_equal(got[key], want[key]), key
 
 
+def test_equal_intensities_take_the_exact_sweep(monkeypatch):
+    """bin_spectra ranks with a strict-compare sweep and redoes a spectrum with the exact
+    (intensity, then index) sweep when the counts show equal intensities inside a window: both
+    routes must agree (PYA_DEBUG=128 forces the exact sweep), and ties that sit below the top ten
+    of their window must not change the result the reference gives."""
+    batch, settings = synth.make_batch("cfg2", n_psm=400, seed=77)
+    rng = np.random.default_rng(5)
+    it = batch["intensity"].copy()
+    heavy = dict(batch, intensity=np.floor(it / np.median(it) * 3.0) + 1.0)       # many ties everywhere
+    gpu = _gpu(settings)
+    monkeypatch.delenv("PYA_DEBUG", raising=False)
+    fast = gpu.score_batch(heavy)
+    monkeypatch.setenv("PYA_DEBUG", "128")
+    exact = gpu.score_batch(heavy)
+    monkeypatch.delenv("PYA_DEBUG", raising=False)
+    for key in fast:
+        assert np.array_equal(fast[key], exact[key]), key
+    # ties only among weak peaks: give the weakest peak of each spectrum a twin of equal
+    # intensity -- never retained, so the reference's unspecified tie order cannot matter
+    low = it.copy()
+    for i in range(batch["n_psm"]):
+        a, b = batch["peak_off"][i], batch["peak_off"][i + 1]
+        order = np.argsort(low[a:b])
+        low[a + order[1]] = low[a + order[0]]
+    tied = dict(batch, intensity=low)
+    got = gpu.score_batch(tied)
+    want = _checker(settings).score_batch(tied, got["ascores"].shape[1])
+    for key in want:
+        assert np.array_equal(got[key], want[key]), key
+
+
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 20, 33, 64, 65, 200, 495, 1000, 3003, 4097, 15000])
 def test_sort_emulation_matches_std_sort(n):
     """The on-device emulation of libstdc++ std::sort vs the real thing, ties included."""
