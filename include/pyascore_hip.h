@@ -114,8 +114,8 @@ int pya_plan_create(pya_handle *h, const pya_batch *batch, uint32_t flags, pya_p
 int pya_plan_run(pya_plan *plan, const double *d_mz, const double *d_intensity,
                  void *hip_stream, const pya_results *d_out);
 /* ms per kernel family of the last pya_plan_run (PYA_FLAG_TIMING): bin_spectra,
- * score_signatures, localize (three-kernel path), fused_small; synchronises */
-int pya_plan_timings(pya_plan *plan, float ms[4]);
+ * score_signatures, localize; synchronises */
+int pya_plan_timings(pya_plan *plan, float ms[3]);
 /* waits for the stream of the last run and reports the first PSM the kernels rejected */
 int pya_plan_check(pya_plan *plan);
 uint64_t pya_plan_workspace_bytes(const pya_plan *plan);

@@ -1,5 +1,5 @@
 /* bin_core.hip.h -- raw peaks of one spectrum -> retained-peak table in LDS (one wavefront).
- * Shared by bin_spectra.hip and fused_small.hip; see bin_spectra.hip for the notes. */
+ * See bin_spectra.hip for the notes. */
 #ifndef PYA_BIN_CORE_H
 #define PYA_BIN_CORE_H
 #include "device_common.hip.h"

@@ -380,15 +380,26 @@ DEV Residues load_residues(const BatchDev &b, const DevConfig *cfg, int64_t psm)
     float m1 = m0 + cfg->mod_mass;
     uint32_t nl0 = cfg->nl_upper[li];
     uint32_t nl1 = modifiable ? (uint32_t)cfg->nl_lower[li] : 0u;
-    int64_t a0 = b.aux_off[psm], a1 = b.aux_off[psm + 1];
-    for (int64_t a = a0; a < a1; a++) {                   /* ModifiedPeptide.cpp:59-79 */
-        uint32_t pos = b.aux_pos[a];
-        int idx = pos > 0 ? (int)pos - 1 : 0;
-        float am = b.aux_mass[a];
-        if (idx == i) {
-            m0 += am;
-            m1 += am;
-            if (cfg->nl_lower[li]) nl0 = cfg->nl_lower[li];
+    /* fixed modifications (ModifiedPeptide.cpp:59-79): fetched 64 at a time, one per lane, so the
+     * loop over them runs on registers instead of one dependent memory round trip per entry */
+    const int64_t a0 = b.aux_off[psm], a1 = b.aux_off[psm + 1];
+    for (int64_t base = a0; base < a1; base += 64) {
+        const int n = (int)(a1 - base < 64 ? a1 - base : 64);
+        uint32_t my_pos = 0;
+        float my_am = 0.f;
+        if (i < n) {
+            my_pos = b.aux_pos[base + i];
+            my_am = b.aux_mass[base + i];
+        }
+        for (int j = 0; j < n; j++) {
+            const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)my_pos, j);
+            const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_am), j));
+            const int idx = pos > 0 ? (int)pos - 1 : 0;
+            if (idx == i) {
+                m0 += am;
+                m1 += am;
+                if (cfg->nl_lower[li]) nl0 = cfg->nl_lower[li];
+            }
         }
     }
     r.m0 = m0;

@@ -33,14 +33,11 @@ void pya_score_table_extend(float mz_error, uint32_t n_top, uint32_t n_to, std::
                             std::vector<uint32_t> &off);
 extern "C" {
 size_t pya_bin_lds_bytes(uint32_t cap);
-size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix);
+size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl);
 size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
-size_t pya_fused_lds_bytes(uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
-int pya_launch_fused_small(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
-                           uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t prefix,
-                     hipStream_t stream);
+                     uint32_t with_nl, hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
                         hipStream_t stream);
@@ -269,7 +266,6 @@ struct pya_plan {
     DevBuf<uint8_t> d_ret_rank;
     DevBuf<uint16_t> d_grid;
     Bucket buckets[kNumBuckets];
-    Bucket fused;                       /* C(n,k) <= 64: whole path in one kernel */
     Bucket all_ids;                     /* every PSM (bin_spectra launch) */
     /* owned copies of inputs/outputs (pya_score_batch path) */
     DevBuf<double> d_mz, d_inten;
@@ -283,7 +279,7 @@ struct pya_plan {
     size_t o_status = 0, d2h_bytes = 0, o_best_score = 0, o_best_sig = 0, o_n_sig_out = 0, o_ascores = 0, o_alt = 0;
     uint32_t io_max_k = 0;
     BatchDev dev;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t last_stream = nullptr;
     bool ran = false;
 
@@ -685,10 +681,6 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     p->sig_off.resize(n + 1);
     const uint32_t n_uniq = (uint32_t)h->cfg.n_uniq, n_types = (uint32_t)h->cfg.n_types;
     uint32_t max_P = 1, lut_need = 0, max_k = 1;
-    /* The fused score+localize kernel for C(n,k) <= 64 is parity-tested but measures slower than
-     * score_signatures + localize (it runs the walk at localize's occupancy):
-     * opt-in with PYA_FUSE=1. */
-    const bool use_fused = !(flags & PYA_FLAG_KEEP) && std::getenv("PYA_FUSE") != nullptr;
     int64_t sig_total = 0;
     /* Pass A (threaded for big batches): the per-letter work -- validate every PSM and count its
      * modifiable residues.  It only finds the first offending PSM; the detailed message comes from
@@ -796,16 +788,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                            (unsigned long long)i, per_type, PYA_MAX_LIST);
         lut_need = std::max(lut_need, per_type * n_types);
         if ((uint32_t)k > max_k) max_k = (uint32_t)k;
-        const bool fuse = use_fused && N <= 64;
-        if (fuse) {
-            Bucket &bk = p->fused;
-            bk.ids.push_back((uint32_t)i);
-            bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
-            bk.list_cap = std::max<uint32_t>(bk.list_cap, next_pow2(std::max<uint32_t>(per_type, 1)));
-            bk.pos_cap = std::max<uint32_t>(bk.pos_cap, (uint32_t)std::max<int64_t>(L - 1, 1));
-            bk.n_types = n_types;
-            bk.k_max = std::max<uint32_t>(bk.k_max, (uint32_t)k);
-        } else if (N > 0 && (uint32_t)k < ns) {
+        if (N > 0 && (uint32_t)k < ns) {
             int bi = 0;
             while (N > kBucketLimits[bi]) bi++;
             Bucket &bk = p->buckets[bi];
@@ -835,11 +818,6 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     }
     if (io && io->max_k < max_k)
         return h->fail(PYA_ERR_ARG, -1, "results.max_k (%u) is smaller than the largest n_of_mod (%u)", io->max_k, max_k);
-    if (!p->fused.ids.empty()) {
-        size_t need = pya_fused_lds_bytes(p->peak_cap, p->fused.pos_cap, p->fused.pool_cap(), p->fused.sb());
-        if (need > kMaxLds)
-            return h->fail(PYA_ERR_LIMIT, (int64_t)p->fused.ids[0], "LDS budget exceeded (%zu bytes) on the fused path", need);
-    }
     for (Bucket &bk : p->buckets) {
         if (bk.ids.empty()) continue;
         size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb());
@@ -871,8 +849,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_n_sig = meta(p->n_sig.data(), n * 4), o_order_off = meta(p->order_off.data(), n * 4),
                      o_aux_pos = meta(has_aux ? b->aux_pos + aux_base : nullptr, (size_t)total_aux * 4),
                      o_aux_mass = meta(has_aux ? b->aux_mass + aux_base : nullptr, (size_t)total_aux * 4),
-                     o_all_ids = meta(p->all_ids.ids.data(), p->all_ids.ids.size() * 4),
-                     o_fused_ids = meta(p->fused.ids.data(), p->fused.ids.size() * 4);
+                     o_all_ids = meta(p->all_ids.ids.data(), p->all_ids.ids.size() * 4);
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
             o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
@@ -910,7 +887,6 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_aux_pos.adopt(base + o_aux_pos, (size_t)total_aux);
         p->d_aux_mass.adopt(base + o_aux_mass, (size_t)total_aux);
         p->all_ids.d_ids.adopt(base + o_all_ids, p->all_ids.ids.size());
-        p->fused.d_ids.adopt(base + o_fused_ids, p->fused.ids.size());
         for (int i = 0; i < kNumBuckets; i++)
             p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
         if (io) {
@@ -982,7 +958,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     for (Bucket &bk : p->buckets) {
         /* buckets with C(n,k) > 64 share the walk over the first sites between signatures */
         const uint32_t prefix = (bk.n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
-        e = pya_launch_score(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, prefix, st);
+        e = pya_launch_score(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
@@ -991,22 +967,18 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
-    e = pya_launch_fused_small(&d, p->fused.d_ids.p, (uint32_t)p->fused.ids.size(), p->peak_cap, p->fused.pos_cap,
-                               p->fused.pool_cap(), p->fused.sb(), p->fused.gtp(), st);
-    if (e) return h->hip_fail((hipError_t)e, "fused_small launch");
-    if (timing) HIPCHK(h, hipEventRecord(p->ev[4], st));
     p->last_stream = st;
     p->ran = true;
     p->dev = d;
     return PYA_OK;
 }
 
-int pya_plan_timings(pya_plan *p, float ms[4]) {
+int pya_plan_timings(pya_plan *p, float ms[3]) {
     if (!p || !ms) return PYA_ERR_ARG;
     pya_handle *h = p->h;
     if (!(p->flags & PYA_FLAG_TIMING) || !p->ran) return h->fail(PYA_ERR_STATE, -1, "plan has no timing events");
-    HIPCHK(h, hipEventSynchronize(p->ev[4]));
-    for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
+    HIPCHK(h, hipEventSynchronize(p->ev[3]));
+    for (int i = 0; i < 3; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
     return PYA_OK;
 }
 

@@ -1,4 +1,4 @@
-/* localize_core.hip.h -- device code shared by rank_and_localize.hip and fused_small.hip:
+/* localize_core.hip.h -- device code of rank_and_localize.hip:
  * the std::sort emulation, the per-signature fragment machinery and the batched Ascore
  * computation.  See rank_and_localize.hip for the algorithm notes and reference citations. */
 #ifndef PYA_LOCALIZE_CORE_H
@@ -514,6 +514,8 @@ struct LocCtx {
     uint32_t pos_cap, pool_cap;
     int sb;                   /* signatures per batch (winner included), <= PYA_LOC_SB_MAX */
     int gtp;                  /* log2 of the ion types localised per pass                  */
+    bool presorted;           /* charge 1, no neutral losses, all residue masses positive:  */
+                              /* every fragment list comes out ascending, no check needed   */
 };
 
 DEV void loc_prefix_tables(const LocCtx &c, int S) {
@@ -625,6 +627,49 @@ DEV uint32_t fastdiv(uint32_t e, const FastDiv &f) {
 
 #define LOC_STAGE 128          /* surviving ions collected before they are looked up together */
 
+/* Surviving ions are few and scattered: they are collected into a dense staging buffer and looked
+ * up a full wave at a time.  `kept` lanes append (val, tag = competitor*2 + side); once 64 are
+ * staged -- or at the last call, whatever is there -- one wave-wide lookup updates the
+ * competitor's trial / match counts. */
+DEV void loc_stage_flush(const LocCtx &c, int &staged) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    wave_lds_sync();
+    const int take = staged < 64 ? staged : 64;
+    if (lane < take) {
+        const uint32_t tg = w.stage_tag[lane];
+        atomicAdd(&w.c_tr[tg], 1u);
+        if (match_rank(c.tab, w.stage_val[lane]) <= w.c_depth[tg >> 1]) atomicAdd(&w.c_cnt[tg], 1u);
+    }
+    wave_lds_sync();
+    /* move the overflow (at most 63 entries) to the front */
+    const int rem = staged - take;
+    float mv = 0.f;
+    uint32_t mt = 0;
+    if (lane < rem) {
+        mv = w.stage_val[take + lane];
+        mt = w.stage_tag[take + lane];
+    }
+    wave_lds_sync();
+    if (lane < rem) {
+        w.stage_val[lane] = mv;
+        w.stage_tag[lane] = mt;
+    }
+    staged = rem;
+    wave_lds_sync();
+}
+DEV void loc_stage_push(const LocCtx &c, bool kept, float val, uint32_t tag, int &staged) {
+    const LocLds &w = c.w;
+    const uint64_t km = __ballot(kept);
+    if (kept) {
+        const int slot = staged + __popcll(km & lanemask_lt());
+        w.stage_val[slot] = val;
+        w.stage_tag[slot] = tag;
+    }
+    staged += __popcll(km);
+    if (staged >= 64) loc_stage_flush(c, staged);
+}
+
 /* Site-determining ions of competitors 1..S-1 against the winner (entry 0): fills w.c_cnt /
  * w.c_tr and the depth in w.c_depth.
  *
@@ -708,7 +753,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
         const int nlists = nsl << gt;
         const int dense = nlists * (int)mmax;
         int unsorted = 0;
-        for (int e = lane; e < dense; e += 64) {
+        for (int e = lane; !c.presorted && e < dense; e += 64) {
             const uint32_t lid = fastdiv((uint32_t)e, divM);
             const int i = e - (int)lid * (int)mmax;
             const int t = (int)lid & ((1 << gt) - 1), slot = (int)lid >> gt;
@@ -758,9 +803,20 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
         const int ntask = ncomp << gt;
         const int pair_items = ntask * 2 * (int)mmax;
         uint64_t bad_tasks = 0;
+        /* Optimistic: an ion without a partner is staged for its lookup right here.  Should a task
+         * turn out to need the serial replay (rare), the counts are put back and the round is
+         * redone from the keep flags. */
+        uint32_t snap_tr = 0, snap_cnt = 0;
+        if (lane < S * 2) {
+            snap_tr = w.c_tr[lane];
+            snap_cnt = w.c_cnt[lane];
+        }
+        int staged = 0;
         for (int base = 0; base < pair_items; base += 64) {      /* wave-uniform trip count */
             const int e = base + lane;
-            bool multi = false;
+            bool multi = false, kept = false;
+            float me = 0.f;
+            uint32_t tag = 0;
             if (e < pair_items) {
                 const uint32_t ts = fastdiv((uint32_t)e, divM);     /* task*2 + side */
                 const int i = e - (int)ts * (int)mmax;
@@ -774,7 +830,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                     if (i < M) {
                         const float *mine = w.pool + ((size_t)(((side ? cj + 1 : 0) << gt) + t) << g2);
                         const float *other = w.pool + ((size_t)(((side ? 0 : cj + 1) << gt) + t) << g2);
-                        const float me = mine[i];
+                        me = mine[i];
                         /* diff is always (list A) - (list B), as the reference computes it.  Seen
                          * from an A ion the B list ascends, so diff descends: skip B ions with
                          * diff >= err.  Seen from a B ion diff ascends: skip A ions with diff <= -err. */
@@ -792,8 +848,10 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                             const float diff = side ? (o - me) : (me - o);
                             cnt += (__builtin_fabsf(diff) < err) ? 1 : 0;
                         }
-                        w.keep[((size_t)ts << g2) + i] = cnt == 0 ? 1 : 0;
+                        kept = cnt == 0;
+                        w.keep[((size_t)ts << g2) + i] = kept ? 1 : 0;
                         multi = cnt > 1;
+                        tag = (uint32_t)(cc * 2 + side);
                     }
                 }
             }
@@ -803,10 +861,23 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                 rest &= rest - 1;
                 bad_tasks |= 1ull << (fastdiv((uint32_t)(base + src), divM) >> 1);
             }
+            if (!bad_tasks) loc_stage_push(c, kept, me, tag, staged);
+        }
+        if (!bad_tasks) {
+            while (staged > 0) loc_stage_flush(c, staged);
+            wave_lds_sync();
+            STAMP(*c.b, 33);
+            continue;
+        }
+        /* ---- a task needs the reference's serial walk: undo the optimistic counts ---- */
+        wave_lds_sync();
+        if (lane < S * 2) {
+            w.c_tr[lane] = snap_tr;
+            w.c_cnt[lane] = snap_cnt;
         }
         wave_lds_sync();
         STAMP(*c.b, 33);
-        if (bad_tasks) {
+        {
             const int task = lane;                               /* ntask <= 64 */
             if (task < ntask && ((bad_tasks >> task) & 1ull)) {
                 const int t = task & ((1 << gt) - 1), cj = task >> gt;
@@ -839,10 +910,9 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             wave_lds_sync();
         }
         STAMP(*c.b, 37);
-        /* ---- match the surviving ions: they are few and scattered, so they are first collected
-         * into a dense staging buffer and then looked up a full wave at a time ---- */
-        int staged = 0;
-        for (int base = 0; base < pair_items || staged > 0; base += 64) {
+        /* ---- match the surviving ions from the keep flags ---- */
+        staged = 0;
+        for (int base = 0; base < pair_items; base += 64) {
             const int e = base + lane;
             bool kept = false;
             float val = 0.f;
@@ -862,41 +932,9 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                     }
                 }
             }
-            const uint64_t km = __ballot(kept);
-            if (kept) {
-                const int slot = staged + __popcll(km & lanemask_lt());
-                w.stage_val[slot] = val;
-                w.stage_tag[slot] = tag;
-            }
-            staged += __popcll(km);
-            const bool last = base + 64 >= pair_items;
-            if (staged >= 64 || (last && staged > 0)) {
-                wave_lds_sync();
-                const int take = staged < 64 ? staged : 64;
-                if (lane < take) {
-                    const uint32_t tg = w.stage_tag[lane];
-                    atomicAdd(&w.c_tr[tg], 1u);
-                    if (match_rank(c.tab, w.stage_val[lane]) <= w.c_depth[tg >> 1]) atomicAdd(&w.c_cnt[tg], 1u);
-                }
-                wave_lds_sync();
-                /* move the overflow (at most 63 entries) to the front */
-                const int rem = staged - take;
-                float mv = 0.f;
-                uint32_t mt = 0;
-                if (lane < rem) {
-                    mv = w.stage_val[take + lane];
-                    mt = w.stage_tag[take + lane];
-                }
-                wave_lds_sync();
-                if (lane < rem) {
-                    w.stage_val[lane] = mv;
-                    w.stage_tag[lane] = mt;
-                }
-                staged = rem;
-                wave_lds_sync();
-            }
-            if (last && staged == 0) break;
+            loc_stage_push(c, kept, val, tag, staged);
         }
+        while (staged > 0) loc_stage_flush(c, staged);
         wave_lds_sync();
         STAMP(*c.b, 34);
     }

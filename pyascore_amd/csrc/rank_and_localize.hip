@@ -177,6 +177,9 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
     ctx.gtp = (int)gtp;
     ctx.L = res.L;
     ctx.zmax = b.max_charge[psm];
+    /* positive residue masses make the float32 running sum, hence every m/z list, ascending */
+    ctx.presorted = ctx.zmax == 1 && ctx.nl.n_nl == 0 &&
+                    !__any(lane < res.L && !(res.m0 > 0.f && res.m1 > 0.f));
     ctx.pos_cap = pos_cap;
     ctx.pool_cap = pool_cap;
     const LocLds &w = ctx.w;

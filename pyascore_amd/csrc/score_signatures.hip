@@ -9,10 +9,11 @@
  * loop over the signatures.  A walker keeps the reference's float32 running sum in a register,
  * derives every (neutral-loss variant, ion type, charge) m/z in the reference's double/float
  * order, looks it up in the wave's LDS copy of the retained-peak table (m/z grid + short scan)
- * and bumps a packed rank histogram.  Per-residue data sits in one register per lane and is
- * broadcast with v_readlane (no LDS).  The binomial tail is a host-built table (float32 chain in
- * the reference's order), so the device does integer counting + table reads + the
- * exactly-rounded weighted sum.
+ * and bumps its column of an LDS rank histogram (ds_add_u32).  Per-residue masses are staged in
+ * LDS once per direction of travel.  All three kernels of the path are VALU-issue bound
+ * (profiles/r01_d), so the walker is written for instruction count: ~40 VALU per fragment.  The
+ * binomial tail is a host-built table (float32 chain in the reference's order), so the device
+ * does integer counting + table reads + the exactly-rounded weighted sum.
  *
  * HBM traffic per PSM: retained table (5 B x R) + peptide bytes + 8 B x C(n,k) signature
  * table (L2 resident, shared by all PSMs of a shape) in; 4 B x C(n,k) weighted scores out.
@@ -38,51 +39,68 @@ struct PrefixState {
     uint32_t nl_state;
     uint32_t nfrag;
     uint32_t pad;
-    uint64_t ha, hb, hc;
+    uint64_t ha, hb, hc;        /* rank counts of the prefix, 16-bit fields */
 };
 
 /* PREFIX is a template parameter so that the small-C(n,k) instantiation does not carry the
  * registers of the shared-prefix path (60 vs 77 VGPRs = 8 vs 6 waves per SIMD). */
 template <bool PREFIX>
 __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
-                                                                  uint32_t n_ids, uint32_t cap) {
+                                                                  uint32_t n_ids, uint32_t cap, uint32_t with_nl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[blockIdx.x];
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
 
-    uint16_t *nl_present = (uint16_t *)lds_raw;             /* [256] */
-    uint16_t *grid = nl_present + 256;                      /* [PYA_GRID_CELLS] */
-    float *nl_uniq = (float *)(grid + PYA_GRID_CELLS);      /* [PYA_MAX_UNIQ] */
-    PeakEntry *t_e = (PeakEntry *)(nl_uniq + PYA_MAX_UNIQ); /* [cap + PYA_TABLE_PAD] */
-    PrefixState *pre = (PrefixState *)(t_e + cap + PYA_TABLE_PAD);   /* [2][64], only if `prefix` */
+    uint16_t *grid = (uint16_t *)lds_raw;                       /* [PYA_GRID_CELLS] */
+    uint32_t *cnt = (uint32_t *)(grid + PYA_GRID_CELLS);        /* [PYA_NTOP / 2][64] */
+    float2 *resd = (float2 *)(cnt + PYA_NTOP / 2 * 64);         /* [64] */
+    PeakEntry *t_e = (PeakEntry *)(resd + 64);                  /* [cap + PYA_TABLE_PAD] */
+    unsigned char *tail = (unsigned char *)(t_e + cap + PYA_TABLE_PAD);
+    uint16_t *nl_present = nullptr;                             /* [256]          } only with */
+    float *nl_uniq = nullptr;                                   /* [PYA_MAX_UNIQ] } neutral   */
+    uint8_t *resn = nullptr;                                    /* [64]           } losses    */
+    if (with_nl) {
+        nl_present = (uint16_t *)tail;
+        nl_uniq = (float *)(nl_present + 256);
+        resn = (uint8_t *)(nl_uniq + PYA_MAX_UNIQ);
+        tail = resn + 64;
+    }
+    PrefixState *pre = (PrefixState *)tail;                     /* [2][64], only if PREFIX */
 
     if (b.status[psm] != PYA_ST_OK) return;
     const uint32_t N = b.n_sig[psm];
     if (N == 0) return;
 
-    /* stage the retained-peak table */
+    /* every global read the prologue needs is issued before the first LDS hand-off, so that the
+     * memory round trips of the peptide, the fixed modifications and the peak table overlap */
+    const Residues res = load_residues(b, cfg, psm);
+    const int zmax = b.max_charge[psm];
+    const uint64_t *order = b.order_tab + b.order_off[psm];
+    const int64_t s0 = b.sig_off[psm];
     PeakTable tab;
     stage_peak_table(b, psm, t_e, &tab);
     WalkEnv env;
     env.cfg = cfg;
-    env.n_nl = cfg->n_nl;
+    env.n_nl = with_nl ? cfg->n_nl : 0;
     env.nl_present = nl_present;
     env.nl_uniq = nl_uniq;
+    env.resd = resd;
+    env.resn = resn;
+    env.cnt = cnt;
     if (env.n_nl) {
         for (int i = lane; i < 256; i += 64) nl_present[i] = cfg->present[i];
         if (lane < PYA_MAX_UNIQ) nl_uniq[lane] = cfg->uniq[lane];
     }
+    stage_residues(res, resd, resn);
     wave_lds_sync();
     grid_build(&tab, grid);
 
-    const Residues res = load_residues(b, cfg, psm);
     env.L = res.L;
-    env.zmax = b.max_charge[psm];
-    const uint64_t *order = b.order_tab + b.order_off[psm];
-    const int64_t s0 = b.sig_off[psm];
-    const bool both_dirs = cfg->n_fwd > 0 && cfg->n_fwd < cfg->n_types;
+    env.zmax = zmax;
+    const bool has_f = cfg->n_fwd > 0, has_b = cfg->n_fwd < cfg->n_types;
+    const bool both_dirs = has_f && has_b;
     wave_lds_sync();
     /* localize looks up its few ions in the global table: leave it the grid (one 512-byte store) */
     ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)grid)[lane];
@@ -90,6 +108,7 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
     int lut_fail = 0;
     const bool split = N <= 32 && both_dirs;     /* lanes 0..31 forward, 32..63 backward */
     const bool simple = walk_is_simple(env);
+    const uint32_t simple_nfrag = (uint32_t)((has_f ? 1 : 0) + (has_b ? 1 : 0)) * (uint32_t)(res.L - 1);
     const int n_sites = __popcll(res.site_mask);
     const bool shared = PREFIX && N >= 128 && n_sites >= PREFIX_SITES + 2;
     int stop[2] = {0, 0};
@@ -98,23 +117,26 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
         stop[0] = nth_set_bit(res.site_mask, PREFIX_SITES);
         stop[1] = res.L - 1 - nth_set_bit(res.site_mask, n_sites - 1 - PREFIX_SITES);
         for (int dir = 0; dir < 2; dir++) {
-            if (dir == 0 ? cfg->n_fwd == 0 : cfg->n_fwd == cfg->n_types) continue;
+            if (dir == 0 ? !has_f : !has_b) continue;
             if (stop[dir] > res.L - 1) stop[dir] = res.L - 1;
             const uint64_t pbits = dir == 0 ? (uint64_t)lane : (__brevll((uint64_t)lane) >> (64 - n_sites));
             const uint64_t pmask = deposit_sites(pbits, res.site_mask);
             WalkState st = {0.f, 0u};
-            Hist h = {0ull, 0ull, 0ull};
             uint32_t nf = 0;
-            if (simple) walk_simple_range(env, res, tab, pmask, dir, true, 0, stop[dir], st, h, nf);
-            else walk_range(env, res, tab, pmask, dir, true, 0, stop[dir], st, h, nf);
+            hist_clear(env);
+            if (simple) walk_simple_range(env, tab, pmask, dir, true, 0, stop[dir], st);
+            else walk_range(env, tab, pmask, dir, true, 0, stop[dir], st, nf);
             PrefixState ps;
             ps.running = st.running;
             ps.nl_state = st.nl_state;
-            ps.nfrag = nf;
+            ps.nfrag = nf;                                  /* simple mode counts steps instead */
             ps.pad = 0;
-            ps.ha = h.a;
-            ps.hb = h.b;
-            ps.hc = h.c;
+            uint64_t hw[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+            for (int d = 0; d < PYA_NTOP; d++) hw[d >> 2] |= (uint64_t)hist_count(cnt, lane, d) << ((d & 3) * 16);
+            ps.ha = hw[0];
+            ps.hb = hw[1];
+            ps.hc = hw[2];
             pre[dir * 64 + lane] = ps;
         }
         wave_lds_sync();
@@ -124,37 +146,41 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
         const bool active = s < N;
         const uint64_t bits = active ? order[s] : 0ull;
         const uint64_t resmask = deposit_sites(bits, res.site_mask);
-        Hist h = {0ull, 0ull, 0ull};
+        Hist ph = {0ull, 0ull, 0ull};                       /* counts inherited from the prefix table */
         uint32_t nfrag = 0;
+        hist_clear(env);
         if (shared) {
             for (int dir = 0; dir < 2; dir++) {
-                if (dir == 0 ? cfg->n_fwd == 0 : cfg->n_fwd == cfg->n_types) continue;
+                if (dir == 0 ? !has_f : !has_b) continue;
                 const uint32_t pat = dir == 0 ? (uint32_t)(bits & 63ull)
                                               : (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 63ull);
                 const PrefixState ps = pre[dir * 64 + pat];
                 WalkState st = {ps.running, ps.nl_state};
-                h.a += ps.ha;
-                h.b += ps.hb;
-                h.c += ps.hc;
+                ph.a += ps.ha;
+                ph.b += ps.hb;
+                ph.c += ps.hc;
                 nfrag += ps.nfrag;
-                if (simple) walk_simple_range(env, res, tab, resmask, dir, active, stop[dir], res.L - 1, st, h, nfrag);
-                else walk_range(env, res, tab, resmask, dir, active, stop[dir], res.L - 1, st, h, nfrag);
+                if (simple) walk_simple_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, st);
+                else walk_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, st, nfrag);
             }
-        } else if (simple) {
-            if (split) {
-                walk_simple(env, res, tab, resmask, lane >> 5, active, h, nfrag);
-                fold_upper_half(h, nfrag);
-            } else {
-                if (cfg->n_fwd > 0) walk_simple(env, res, tab, resmask, 0, active, h, nfrag);
-                if (cfg->n_fwd < cfg->n_types) walk_simple(env, res, tab, resmask, 1, active, h, nfrag);
-            }
-        } else if (split) {
-            walk(env, res, tab, resmask, lane >> 5, active, h, nfrag);
-            fold_upper_half(h, nfrag);
         } else {
-            if (cfg->n_fwd > 0) walk(env, res, tab, resmask, 0, active, h, nfrag);
-            if (cfg->n_fwd < cfg->n_types) walk(env, res, tab, resmask, 1, active, h, nfrag);
+            WalkState st = {0.f, 0u};
+            if (split) {
+                if (simple) walk_simple_range(env, tab, resmask, lane >> 5, active, 0, res.L - 1, st);
+                else walk_range(env, tab, resmask, lane >> 5, active, 0, res.L - 1, st, nfrag);
+            } else {
+                for (int dir = 0; dir < 2; dir++) {
+                    if (dir == 0 ? !has_f : !has_b) continue;
+                    st.running = 0.f;
+                    st.nl_state = 0u;
+                    if (simple) walk_simple_range(env, tab, resmask, dir, active, 0, res.L - 1, st);
+                    else walk_range(env, tab, resmask, dir, active, 0, res.L - 1, st, nfrag);
+                }
+            }
         }
+        if (split) nfrag += (uint32_t)__shfl_down((int)nfrag, 32, 64);   /* the backward walker sits 32 lanes up */
+        if (simple) nfrag = simple_nfrag;
+        wave_lds_sync();
 
         if (active && (!split || lane < 32)) {
             /* cumulative counts over rank (Ascore.cpp:115-118) and scores (Ascore.cpp:123-139) */
@@ -162,7 +188,7 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
             uint32_t acc = 0;
 #pragma unroll
             for (int d = 0; d < PYA_NTOP; d++) {
-                acc += hist_get(h, d);
+                acc += hist_count(cnt, lane, d) + (split ? hist_count(cnt, lane + 32, d) : 0u) + hist_get(ph, d);
                 cum[d] = acc;
             }
             float ws = -1.f;
@@ -186,31 +212,31 @@ __global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, co
                 rec[5] = nfrag;
             }
         }
+        wave_lds_sync();                                    /* columns are cleared again next round */
     }
     if (__any(lut_fail) && lane == 0) b.status[psm] = PYA_ST_LUT_RANGE;
 }
 
-extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix) {
-    return ((size_t)cap + PYA_TABLE_PAD) * 8 + 512 + PYA_GRID_CELLS * 2 + PYA_MAX_UNIQ * 4 + 64 +
-           (prefix ? 2 * 64 * sizeof(PrefixState) : 0);
+extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl) {
+    return PYA_GRID_CELLS * 2 + PYA_NTOP / 2 * 64 * 4 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8 +
+           (with_nl ? 512 + PYA_MAX_UNIQ * 4 + 64 : 0) + (prefix ? 2 * 64 * sizeof(PrefixState) : 0) + 64;
 }
 
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
-                                uint32_t prefix, hipStream_t stream) {
+                                uint32_t prefix, uint32_t with_nl, hipStream_t stream) {
     if (n_ids == 0) return 0;
     /* spectra near the 8192-peak limit need more than the default 64 KB of dynamic LDS */
+    const size_t lds = pya_score_lds_bytes(cap, prefix, with_nl);
     hipError_t e = prefix ? hipFuncSetAttribute((const void *)pya_score_signatures_kernel<true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)pya_score_lds_bytes(cap, 1))
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                           : hipFuncSetAttribute((const void *)pya_score_signatures_kernel<false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)pya_score_lds_bytes(cap, 0));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     if (prefix)
-        hipLaunchKernelGGL(pya_score_signatures_kernel<true>, dim3(n_ids), dim3(64), pya_score_lds_bytes(cap, 1),
-                           stream, *b, d_ids, n_ids, cap);
+        hipLaunchKernelGGL(pya_score_signatures_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
+                           cap, with_nl);
     else
-        hipLaunchKernelGGL(pya_score_signatures_kernel<false>, dim3(n_ids), dim3(64), pya_score_lds_bytes(cap, 0),
-                           stream, *b, d_ids, n_ids, cap);
+        hipLaunchKernelGGL(pya_score_signatures_kernel<false>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
+                           cap, with_nl);
     return (int)hipGetLastError();
 }

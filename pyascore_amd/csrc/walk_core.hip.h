@@ -1,26 +1,60 @@
-/* walk_core.hip.h -- the per-(signature, direction) fragment walker shared by
- * score_signatures.hip and fused_small.hip.  See score_signatures.hip for the notes. */
+/* walk_core.hip.h -- the per-(signature, direction) fragment walker of score_signatures.hip.
+ * See score_signatures.hip for the notes. */
 #ifndef PYA_WALK_CORE_H
 #define PYA_WALK_CORE_H
 #include "device_common.hip.h"
 
+/* Per-wave LDS the walkers work on:
+ *   resd [64] {m0, m1}: unmodified / modified mass of every residue, so a lane reads the residue
+ *        that enters its fragment (index step, or L-1-step when it travels from the C-terminus)
+ *        with one ds_read_b64 instead of four v_readlane and selects;
+ *   resn [64]: the residues' neutral-loss classes (only staged when the scorer has neutral losses);
+ *   cnt  [PYA_NTOP/2][64]: rank histogram, one column per lane, two 16-bit counters per word,
+ *        bumped with ds_add_u32 -- a handful of VALU instructions per fragment where a register
+ *        histogram of packed fields took ~20.  The score kernel's speed follows its occupancy,
+ *        which LDS decides, hence the packing. */
 struct WalkEnv {
     const DevConfig *cfg;
     const uint16_t *nl_present;
     const float *nl_uniq;
+    const float2 *resd;
+    const uint8_t *resn;
+    uint32_t *cnt;
     int n_nl, L, zmax;
 };
 
-/* Walks one direction per lane (`dir` may differ between lanes: the residue of a step is read
- * for both directions with two v_readlane and selected).  Adds to h / nfrag. */
+DEV void hist_clear(const WalkEnv &e) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 0; d < PYA_NTOP / 2; d++) e.cnt[d * 64 + lane] = 0u;
+}
+DEV void hist_bump(uint32_t *col, bool active, int rank) {
+    if (active && rank < PYA_NTOP) atomicAdd(col + (rank >> 1) * 64, 1u << ((rank & 1) * 16));
+}
+/* count of rank d in column `lane` */
+DEV uint32_t hist_count(const uint32_t *cnt, int lane, int d) {
+    return (cnt[(d >> 1) * 64 + lane] >> ((d & 1) * 16)) & 0xffffu;
+}
+
+/* stages resd / resn from the one-residue-per-lane registers (caller syncs afterwards) */
+DEV void stage_residues(const Residues &res, float2 *resd, uint8_t *resn) {
+    const int i = lane_id();
+    if (i < res.L) {
+        resd[i] = make_float2(res.m0, res.m1);
+        if (resn) resn[i] = (uint8_t)res.nl;
+    }
+}
+
 /* resumable state of a walker: float32 running sum and neutral-loss stack state */
 struct WalkState {
     float running;
     uint32_t nl_state;
 };
 
-DEV void walk_range(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
-                    bool active, int step_begin, int step_end, WalkState &st, Hist &h, uint32_t &nfrag) {
+/* General walker: one direction per lane (`dir` may differ between lanes).  Bumps the lane's
+ * histogram column and adds to nfrag. */
+DEV void walk_range(const WalkEnv &e, const PeakTable &tab, uint64_t resmask, int dir, bool active,
+                    int step_begin, int step_end, WalkState &st, uint32_t &nfrag) {
     const DevConfig *cfg = e.cfg;
     const int n_f = cfg->n_fwd, n_b = cfg->n_types - cfg->n_fwd;
     const int my_types = dir == 0 ? n_f : n_b;
@@ -28,31 +62,19 @@ DEV void walk_range(const WalkEnv &e, const Residues &res, const PeakTable &tab,
     const bool any_f = __any(active && dir == 0), any_b = __any(active && dir == 1);
     const int t_max = (any_f && any_b) ? (n_f > n_b ? n_f : n_b) : (any_f ? n_f : n_b);
     const uint64_t types64 = load_types64(cfg);
+    const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - e.L)) : resmask;
+    uint32_t *col = e.cnt + lane_id();
     float running = st.running;                            /* 0 at the start: 0 + r == r exactly */
     uint32_t nl_state = st.nl_state;
     for (int step = step_begin; step < step_end; step++) {
-        const int i_f = step, i_b = e.L - 1 - step;                      /* wave-uniform */
-        float m0 = 0.f, m1 = 0.f;
-        uint32_t nlp = 0;
-        if (any_f) {
-            m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i_f));
-            m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i_f));
-            nlp = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, i_f);
-        }
-        if (any_b) {
-            const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i_b));
-            const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i_b));
-            const uint32_t bn = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, i_b);
-            m0 = dir ? b0 : m0;
-            m1 = dir ? b1 : m1;
-            nlp = dir ? bn : nlp;
-        }
-        const int i = dir ? i_b : i_f;
-        const bool mod = (resmask >> i) & 1ull;
-        const float r = mod ? m1 : m0;
+        const int ri = dir ? e.L - 1 - step : step;
+        const float2 mm = e.resd[ri];
+        const bool mod = (tmask >> step) & 1ull;
+        const float r = mod ? mm.y : mm.x;
         running = r + running;                                           /* ModifiedPeptide.cpp:385-389 */
         uint32_t pm = active ? 1u : 0u;
         if (e.n_nl) {
+            const uint32_t nlp = e.resn[ri];
             const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
             if (cls) nl_state = nl_bump(nl_state, cls);
             pm = active ? (uint32_t)e.nl_present[nl_state & 255u] : 0u;
@@ -71,7 +93,7 @@ DEV void walk_range(const WalkEnv &e, const Residues &res, const PeakTable &tab,
                 for (int z = 1; z <= e.zmax; z++) {
                     const float f = charge_mz(m, z);
                     if (on_t) {
-                        hist_add(h, match_rank_lds(tab, f));
+                        hist_bump(col, true, match_rank_lds(tab, f));
                         nfrag++;
                     }
                 }
@@ -82,18 +104,11 @@ DEV void walk_range(const WalkEnv &e, const Residues &res, const PeakTable &tab,
     st.nl_state = nl_state;
 }
 
-DEV void walk(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
-              bool active, Hist &h, uint32_t &nfrag) {
-    WalkState st = {0.f, 0u};
-    walk_range(e, res, tab, resmask, dir, active, 0, e.L - 1, st, h, nfrag);
-}
-
-/* Fast path of `walk` for the common scorer settings -- no neutral losses, charge 1, at most
- * one ion type per direction (BASELINE cfg1/2/3/5): straight-line code per residue step.
- * `tmask` bit t = "the t-th residue in THIS lane's travel direction is modified". */
-DEV void walk_simple_range(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask,
-                           int dir, bool active, int step_begin, int step_end, WalkState &st, Hist &h,
-                           uint32_t &nfrag) {
+/* Fast path for the common scorer settings -- no neutral losses, charge 1, at most one ion type
+ * per direction (BASELINE cfg1/2/3/5): straight-line code per residue step; the number of
+ * fragments is the number of steps, so the caller counts them. */
+DEV void walk_simple_range(const WalkEnv &e, const PeakTable &tab, uint64_t resmask, int dir, bool active,
+                           int step_begin, int step_end, WalkState &st) {
     const DevConfig *cfg = e.cfg;
     const int L = e.L;
     /* per-lane ion-type constants (the type letters are wave-uniform scalars) */
@@ -101,47 +116,31 @@ DEV void walk_simple_range(const WalkEnv &e, const Residues &res, const PeakTabl
     if (cfg->n_fwd > 0) type_constants(cfg->types[0], &Af, &Bf);
     if (cfg->n_fwd < cfg->n_types) type_constants(cfg->types[cfg->n_fwd], &Ab, &Bb);
     const double A = dir ? Ab : Af, B = dir ? Bb : Bf;
+    /* bit t = "the t-th residue in THIS lane's travel direction is modified" */
     const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
     const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
+    /* the lane's residue pointer moves one entry per step, up or down */
+    const float2 *rp = e.resd + (dir ? L - 1 - step_begin : step_begin);
+    const int stride = dir ? -1 : 1;
+    uint32_t *col = e.cnt + lane_id();
     float running = st.running;                            /* 0 at the start: 0 + r == r exactly */
-    for (int step = step_begin; step < step_end; step++) {
-        const int i_b = L - 1 - step;
-        const float f0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), step));
-        const float f1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), step));
-        const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), i_b));
-        const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), i_b));
+    for (int step = step_begin; step < step_end; step++, rp += stride) {
+        const float2 mm = *rp;
         const uint32_t word = step < 32 ? tlo : thi;       /* wave-uniform choice */
         const bool mod = (word >> (step & 31)) & 1u;
-        const float m0 = dir ? b0 : f0, m1 = dir ? b1 : f1;
-        const float r = mod ? m1 : m0;
+        const float r = mod ? mm.y : mm.x;
         running = r + running;                             /* ModifiedPeptide.cpp:385-389 */
         const double m = ((double)running + A) - B;
         const float f = (float)(m + 1.007825);
         const int rk = match_rank_lds(tab, f);
-        if (active) hist_add(h, rk);
+        hist_bump(col, active, rk);
     }
-    if (active && step_end > step_begin) nfrag += (uint32_t)(step_end - step_begin);
     st.running = running;
-}
-
-DEV void walk_simple(const WalkEnv &e, const Residues &res, const PeakTable &tab, uint64_t resmask, int dir,
-                     bool active, Hist &h, uint32_t &nfrag) {
-    WalkState st = {0.f, 0u};
-    walk_simple_range(e, res, tab, resmask, dir, active, 0, e.L - 1, st, h, nfrag);
 }
 
 DEV bool walk_is_simple(const WalkEnv &e) {
     const int n_f = e.cfg->n_fwd, n_b = e.cfg->n_types - e.cfg->n_fwd;
     return e.n_nl == 0 && e.zmax == 1 && n_f <= 1 && n_b <= 1;
 }
-
-/* walker of the opposite direction sits 32 lanes up: fold it into lanes 0..31 */
-DEV void fold_upper_half(Hist &h, uint32_t &nfrag) {
-    h.a += __shfl_down(h.a, 32, 64);
-    h.b += __shfl_down(h.b, 32, 64);
-    h.c += __shfl_down(h.c, 32, 64);
-    nfrag += (uint32_t)__shfl_down((int)nfrag, 32, 64);
-}
-
 
 #endif

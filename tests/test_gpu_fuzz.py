@@ -13,10 +13,8 @@ from fuzzcase import random_case as _random_case
 
 
 @pytest.mark.parametrize("seed", range(40))
-def test_random_settings_and_batches(seed, monkeypatch):
+def test_random_settings_and_batches(seed):
     rng = np.random.default_rng(9000 + seed)
-    if seed % 4 == 3:
-        monkeypatch.setenv("PYA_FUSE", "1")
     settings, batch = _random_case(rng)
     if batch["n_psm"] == 0:
         pytest.skip("empty draw")

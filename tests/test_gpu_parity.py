@@ -14,15 +14,11 @@ from pyascore_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["fused", "three_kernel"])
-def path(request, monkeypatch):
-    """Batches run twice: on bin_spectra / score_signatures / localize (default) and with PSMs of
-    C(n,k) <= 64 on the fused score+localize kernel (PYA_FUSE=1)."""
-    if request.param == "fused":
-        monkeypatch.setenv("PYA_FUSE", "1")
-    else:
-        monkeypatch.delenv("PYA_FUSE", raising=False)
-    return request.param
+@pytest.fixture
+def path():
+    """bin_spectra -> score_signatures -> localize (the only path; the name is kept for the tests
+    that were parametrised over an experimental fused kernel, removed because it was slower)."""
+    return "three_kernel"
 
 
 def _gpu(settings):
@@ -122,6 +118,30 @@ def test_equal_intensities_take_the_exact_sweep(monkeypatch):
     want = _checker(settings).score_batch(tied, got["ascores"].shape[1])
     for key in want:
         assert np.array_equal(got[key], want[key]), key
+
+
+def test_negative_residue_mass_and_crowded_lists():
+    """Fragment lists are ascending only while every residue mass is positive (localize then skips
+    its order check): a fixed modification heavier than its residue, negative, must still take
+    the sorting route.  A wide tolerance makes ions find several partners, which sends tasks
+    through the serial replay of the reference's greedy walk after the optimistic pass."""
+    batch, settings = synth.make_batch("cfg2", n_psm=300, seed=91)
+    rng = np.random.default_rng(3)
+    aux_pos, aux_mass, aux_off = [], [], [0]
+    for i in range(batch["n_psm"]):
+        L = int(batch["pep_off"][i + 1] - batch["pep_off"][i])
+        pos = rng.choice(np.arange(1, L + 1), size=2, replace=False)
+        aux_pos += [int(p) for p in pos]
+        aux_mass += [-250.0, 15.994915]
+        aux_off.append(len(aux_pos))
+    neg = dict(batch, aux_pos=np.array(aux_pos, np.uint32), aux_mass=np.array(aux_mass, np.float32),
+               aux_off=np.array(aux_off, np.int64))
+    for mz_error in (settings["mz_error"], 4.0):
+        st = dict(settings, mz_error=mz_error)
+        got = _gpu(st).score_batch(neg)
+        want = _checker(st).score_batch(neg, got["ascores"].shape[1])
+        for key in want:
+            assert np.array_equal(got[key], want[key]), (key, mz_error)
 
 
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 20, 33, 64, 65, 200, 495, 1000, 3003, 4097, 15000])
