@@ -524,24 +524,44 @@ DEV void loc_prefix_tables(const LocCtx &c, int S) {
     if (lane < 2 * S) {
         const int s = lane >> 1, d = lane & 1;
         const uint64_t mask = w.sig_mask[s];
-        float running = 0.f;
-        uint32_t st = 0, cnt = 0;
         const size_t base = (size_t)(s * 2 + d) * c.pos_cap;
-        for (int step = 0; step + 1 < c.L; step++) {
-            const int ri = d == 0 ? step : c.L - 1 - step;
-            const bool mod = (mask >> ri) & 1ull;
-            const float r = mod ? w.m1[ri] : w.m0[ri];
-            running = step == 0 ? r : r + running;
-            const uint32_t nlp = w.nlp[ri];
-            const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
-            if (cls) st = nl_bump(st, cls);
-            const uint32_t pm = c.nl.n_nl ? (uint32_t)c.nl.present[st & 255u] : 1u;
-            w.run[base + step] = running;
-            w.pmk[base + step] = (uint16_t)pm;
-            w.cpre[base + step] = (uint16_t)cnt;
-            cnt += __popc(pm);
+        if (c.nl.n_nl == 0) {
+            /* no neutral losses: one ion per prefix, so only the running sums are tabulated
+             * (loc_site_ions knows pmk = 1 and cpre = step without reading them) */
+            const uint64_t tmask = d ? (__brevll(mask) >> (64 - c.L)) : mask;   /* travel order */
+            const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
+            const float *p0 = w.m0 + (d ? c.L - 1 : 0), *p1 = w.m1 + (d ? c.L - 1 : 0);
+            const int stride = d ? -1 : 1;
+            float *dst = w.run + base;
+            float running = 0.f;
+            for (int step = 0; step + 1 < c.L; step++, p0 += stride, p1 += stride) {
+                const uint32_t word = step < 32 ? tlo : thi;
+                const bool mod = (word >> (step & 31)) & 1u;
+                const float a = *p0, bmass = *p1;
+                const float r = mod ? bmass : a;
+                running = step == 0 ? r : r + running;
+                dst[step] = running;
+            }
+            w.tot[s * 2 + d] = (uint32_t)(c.L - 1);
+        } else {
+            float running = 0.f;
+            uint32_t st = 0, cnt = 0;
+            for (int step = 0; step + 1 < c.L; step++) {
+                const int ri = d == 0 ? step : c.L - 1 - step;
+                const bool mod = (mask >> ri) & 1ull;
+                const float r = mod ? w.m1[ri] : w.m0[ri];
+                running = step == 0 ? r : r + running;
+                const uint32_t nlp = w.nlp[ri];
+                const uint32_t cls = mod ? (nlp >> 4) : (nlp & 15u);
+                if (cls) st = nl_bump(st, cls);
+                const uint32_t pm = (uint32_t)c.nl.present[st & 255u];
+                w.run[base + step] = running;
+                w.pmk[base + step] = (uint16_t)pm;
+                w.cpre[base + step] = (uint16_t)cnt;
+                cnt += __popc(pm);
+            }
+            w.tot[s * 2 + d] = cnt;
         }
-        w.tot[s * 2 + d] = cnt;
     }
 }
 
@@ -549,64 +569,6 @@ DEV int ilog2_ceil(int v) {                     /* smallest g with (1 << g) >= v
     int g = 0;
     while ((1 << g) < v) g++;
     return g;
-}
-
-/* rank histograms + total fragments of signatures [s_lo, S).  Work items are (signature,
- * direction, prefix) with the prefix index padded to a power of two so that decoding an item is
- * shifts and masks only (integer division is tens of instructions on this hardware). */
-DEV void loc_counts(const LocCtx &c, int s_lo, int S) {
-    const int lane = lane_id();
-    const LocLds &w = c.w;
-    const DevConfig *cfg = c.cfg;
-    const int Lm1 = c.L - 1;
-    const int gp = ilog2_ceil(Lm1 > 0 ? Lm1 : 1);
-    const uint64_t types64 = load_types64(cfg);
-    for (int i = s_lo * 11 + lane; i < S * 11; i += 64) w.hist[i] = 0;
-    wave_lds_sync();
-    const int E = ((S - s_lo) * 2) << gp;
-    for (int e = lane; e < E; e += 64) {
-        const int pos = e & ((1 << gp) - 1);
-        const int sd = e >> gp;
-        const int s = s_lo + (sd >> 1), d = sd & 1;
-        const int t0 = d == 0 ? 0 : cfg->n_fwd, t1 = d == 0 ? cfg->n_fwd : cfg->n_types;
-        if (t0 == t1 || pos >= Lm1) continue;
-        const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
-        const float running = w.run[idx];
-        uint32_t pm = w.pmk[idx];
-        atomicAdd(&w.hist[s * 11 + 10], (uint32_t)(__popc(pm) * (t1 - t0) * c.zmax));
-        while (pm) {
-            const int v = __builtin_ctz(pm);
-            pm &= pm - 1;
-            const float x = running - (c.nl.n_nl ? c.nl.uniq[v] : 0.f);
-            const double xd = (double)x;
-            for (int t = t0; t < t1; t++) {
-                double A, B;
-                type_constants(type_at(types64, t), &A, &B);
-                const double m = (xd + A) - B;
-                for (int z = 1; z <= c.zmax; z++) {
-                    const int rk = match_rank(c.tab, charge_mz(m, z));
-                    if (rk < PYA_NTOP) atomicAdd(&w.hist[s * 11 + rk], 1u);
-                }
-            }
-        }
-    }
-    wave_lds_sync();
-}
-
-DEV void loc_scores(const LocCtx &c, int s_lo, int S, int *fail) {
-    const int lane = lane_id();
-    const LocLds &w = c.w;
-    for (int i = s_lo * 10 + lane; i < S * 10; i += 64) {
-        const int s = i / 10, d = i % 10;
-        uint32_t cum = 0;
-        for (int r = 0; r <= d; r++) cum += w.hist[s * 11 + r];
-        const uint32_t nf = w.hist[s * 11 + 10];
-        float sc = 0.f;
-        if (nf <= c.b->lut_n_max) sc = c.b->lut[lut_row(nf) + (uint32_t)d * (nf + 1) + cum];
-        else *fail = 1;
-        w.scores[i] = sc;
-    }
-    wave_lds_sync();
 }
 
 /* e / d for e*d < 2^32 with a precomputed multiplier (integer division is ~40 instructions) */
@@ -736,15 +698,21 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             type_constants(type_at(types64, tb + t), &A, &B);
             const int d = tb + t < cfg->n_fwd ? 0 : 1;
             const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
-            uint32_t pm = w.pmk[idx];
             const float running = w.run[idx];
-            float *dst = w.pool + ((size_t)((slot << gt) + t) << g2) + (size_t)w.cpre[idx] * c.zmax;
-            while (pm) {
-                const int v = __builtin_ctz(pm);
-                pm &= pm - 1;
-                const float x = running - (c.nl.n_nl ? c.nl.uniq[v] : 0.f);
-                const double m = ((double)x + A) - B;
+            if (c.nl.n_nl == 0) {
+                float *dst = w.pool + ((size_t)((slot << gt) + t) << g2) + (size_t)pos * c.zmax;
+                const double m = ((double)running + A) - B;
                 for (int z = 1; z <= c.zmax; z++) *dst++ = charge_mz(m, z);
+            } else {
+                uint32_t pm = w.pmk[idx];
+                float *dst = w.pool + ((size_t)((slot << gt) + t) << g2) + (size_t)w.cpre[idx] * c.zmax;
+                while (pm) {
+                    const int v = __builtin_ctz(pm);
+                    pm &= pm - 1;
+                    const float x = running - c.nl.uniq[v];
+                    const double m = ((double)x + A) - B;
+                    for (int z = 1; z <= c.zmax; z++) *dst++ = charge_mz(m, z);
+                }
             }
         }
         wave_lds_sync();
@@ -1004,11 +972,6 @@ DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, con
             }
             wave_lds_sync();
             STAMP(b, 28);
-        } else if (!scores_all && !(b.debug & 2)) {
-            loc_counts(ctx, have_best ? 1 : 0, S);
-            STAMP(b, 28);
-            loc_scores(ctx, have_best ? 1 : 0, S, &fail);
-            STAMP(b, 29);
         }
         have_best = true;
         if (!(b.debug & 1)) loc_site_ions(ctx, S);
