@@ -26,11 +26,25 @@ HOST_FLAGS = ["-O2", "-fPIC", "-pthread", "-std=c++17", "-ffp-contract=off", "-W
               "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")]
 
 
-def _stale(target, deps):
+def _stale(target, deps, flags=None):
+    """Older than a dependency, or built with other flags (kept in <target>.flags)."""
     if not os.path.exists(target):
         return True
+    if flags is not None:
+        try:
+            with open(target + ".flags") as f:
+                if f.read() != " ".join(flags):
+                    return True
+        except OSError:
+            return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(cmd, flags, src, obj):
+    _run(cmd + flags + ["-c", src, "-o", obj])
+    with open(obj + ".flags", "w") as f:
+        f.write(" ".join(flags))
 
 
 def _run(cmd):
@@ -39,23 +53,24 @@ def _run(cmd):
 
 
 def build(force=False):
+    dflags = list(DEVICE_FLAGS)
     if os.environ.get("PYA_LOC_WAVES"):         # A/B experiments on the localize kernel's occupancy target
-        DEVICE_FLAGS.append("-DLOC_WAVES=" + os.environ["PYA_LOC_WAVES"])
-        force = True
+        dflags.append("-DLOC_WAVES=" + os.environ["PYA_LOC_WAVES"])
+    if os.environ.get("PYA_DEFS"):              # other -D switches for A/B builds
+        dflags += os.environ["PYA_DEFS"].split()
     if os.environ.get("PYA_BUILD_STAMPS"):      # diagnostic build with in-kernel phase stamps
-        DEVICE_FLAGS.append("-DPYA_STAMPS")
-        force = True
+        dflags.append("-DPYA_STAMPS")
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     for src in DEVICE_SRC:
         s, o = os.path.join(CSRC, src), os.path.join(CSRC, src + ".o")
-        if force or _stale(o, [s] + hdrs):
-            _run([HIPCC] + DEVICE_FLAGS + ["-c", s, "-o", o])
+        if force or _stale(o, [s] + hdrs, dflags):
+            _compile([HIPCC], dflags, s, o)
         objs.append(o)
     for src in HOST_SRC:
         s, o = os.path.join(CSRC, src), os.path.join(CSRC, src + ".o")
-        if force or _stale(o, [s] + hdrs):
-            _run(["g++"] + HOST_FLAGS + ["-c", s, "-o", o])
+        if force or _stale(o, [s] + hdrs, HOST_FLAGS):
+            _compile(["g++"], HOST_FLAGS, s, o)
         objs.append(o)
     if force or _stale(LIB, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)

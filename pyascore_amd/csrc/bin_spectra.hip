@@ -11,7 +11,9 @@
  */
 #include "bin_core.hip.h"
 
+#ifndef BIN_WAVES
 #define BIN_WAVES 4     /* independent spectra per workgroup when LDS allows (no cross-wave sync) */
+#endif
 
 __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDev b, const uint32_t *psm_ids,
                                                                          uint32_t n_ids, uint32_t cap) {

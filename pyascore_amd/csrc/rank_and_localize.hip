@@ -31,7 +31,7 @@ extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint
 }
 
 #ifndef LOC_WAVES
-#define LOC_WAVES 5
+#define LOC_WAVES 4
 #endif
 __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
                                                           uint32_t n_ids, uint32_t peak_cap,

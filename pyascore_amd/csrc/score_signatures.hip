@@ -44,8 +44,11 @@ struct PrefixState {
 
 /* PREFIX is a template parameter so that the small-C(n,k) instantiation does not carry the
  * registers of the shared-prefix path (60 vs 77 VGPRs = 8 vs 6 waves per SIMD). */
+#ifndef SCORE_WAVES
+#define SCORE_WAVES 6
+#endif
 template <bool PREFIX>
-__global__ __launch_bounds__(64) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
+__global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
                                                                   uint32_t n_ids, uint32_t cap, uint32_t with_nl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
