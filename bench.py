@@ -39,6 +39,33 @@ def algorithmic_bytes(batch, max_k):
     return 16 * peaks + res + 8 * n + 8 * aux + 16 * n + 64 * n
 
 
+def profiled_traffic(cfg, kernel, default_size):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary of this config
+    (profiles/*_rocprof_<cfg>/pmc_summary.csv, collected by scripts/profile.sh in separate --pmc
+    passes).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 128-byte requests as
+    64 bytes, hence the factor 2 (MI355X_MICROARCH.md, HBM section).  None when the run is not the
+    profiled workload."""
+    import csv
+    import glob
+    if not default_size:
+        return None, None
+    dirs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_" + cfg)))
+    if not dirs:
+        return None, None
+    path = os.path.join(dirs[-1], "pmc_summary.csv")
+    vals = {}
+    try:
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row["kernel"] == kernel:
+                    vals[row["counter"]] = float(row["mean_value"])
+    except OSError:
+        return None, None
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None, None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+
+
 def cpu_baseline(batch, settings, target_seconds=12.0):
     from oracle import harness, orc
     import subprocess
@@ -139,6 +166,8 @@ def main():
         t = time.perf_counter()
         scorer.score_batch(batch)
         host_rate = batch["n_psm"] / (time.perf_counter() - t)
+        default_size = args.psms is None and args.config != "cfg3"
+        traffic, traffic_src = profiled_traffic(args.config, names[dom], default_size)
         line = {
             "metric": METRIC, "value": world * batch["n_psm"] * args.steps / elapsed, "unit": "PSMs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +181,8 @@ def main():
                        "max_fragment_charge": int(batch["max_charge"].max()),
                        "neutral_losses": settings["neutral_losses"], "parallelism": "psm-shard x%d + 1 gather" % world},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg,
                          "kernel_ms": {n: float(m) for n, m in zip(names, kern_ms)}},
             "host_api": {"value": host_rate, "unit": "PSMs/s",
