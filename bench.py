@@ -112,8 +112,12 @@ def main():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PYA_BENCH_FORCE_DIST=1 runs the collective path with a world of one (the only way to exercise
+    # RCCL on a single-GPU box)
+    use_dist = world > 1 or bool(os.environ.get("PYA_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_psm = args.psms or synth.CONFIGS[args.config]["n_psm"]
@@ -129,30 +133,42 @@ def main():
     d_int = torch.from_numpy(batch["intensity"]).to(dev)
     plan = DevicePlan(scorer, batch, timing=True)
 
+    in_flight = []
+
     def step():
         plan.run(d_mz, d_int)
-        if world > 1:
-            dist_gather(plan.packed_summary(), 0)          # the single RCCL gather of the path
+        if use_dist:
+            # the single RCCL gather of the path, asynchronous: the gather of this batch's packed
+            # records overlaps the kernels of the next batch (at most one gather behind)
+            in_flight.append(dist_gather(plan.packed_summary(), 0, async_op=True))
+            if len(in_flight) > 1:
+                in_flight.pop(0)[0].wait()
+
+    def drain():
+        while in_flight:
+            in_flight.pop(0)[0].wait()
 
     for _ in range(args.warmup):
         step()
+    drain()
     plan.check()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     kern_ms = np.zeros(3)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         kern_ms += np.asarray(plan.timings_ms())           # HIP events on the launch stream
+    drain()                                                # every gather of the timed steps has landed
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     plan.check()
     kern_ms /= max(args.steps, 1)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -192,7 +208,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, settings)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -69,14 +69,16 @@ def score_sharded(score_fn, batch, rank, world_size, gather_fn, mod_group="STY",
     return out, ranges
 
 
-def dist_gather(tensor, dst=0):
-    """One torch.distributed.gather (RCCL on GPU tensors, gloo on CPU tensors)."""
+def dist_gather(tensor, dst=0, async_op=False):
+    """One torch.distributed.gather (RCCL on GPU tensors, gloo on CPU tensors).
+
+    With async_op=True returns (work, parts): the collective runs on the backend's own stream and
+    the caller's stream only waits when work.wait() is called -- a pipeline of batches calls it
+    after enqueuing the next batch's kernels, so the gather of batch i overlaps the scoring of
+    batch i+1 (the gathered tensor is a packed copy, the scorer's own buffers are free again)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    if dist.get_rank() == dst:
-        parts = [torch.empty_like(tensor) for _ in range(world)]
-        dist.gather(tensor, parts, dst=dst)
-        return parts
-    dist.gather(tensor, None, dst=dst)
-    return None
+    parts = [torch.empty_like(tensor) for _ in range(world)] if dist.get_rank() == dst else None
+    work = dist.gather(tensor, parts, dst=dst, async_op=async_op)
+    return (work, parts) if async_op else parts

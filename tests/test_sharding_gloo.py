@@ -52,6 +52,15 @@ def _worker(rank, world, port, out_path):
 
     rec, ranges = shard.score_sharded(score_fn, batch, rank, world, gather_fn)
     assert calls["gather"] == 1                       # exactly one collective on the path
+    # the pipelined form bench.py uses: asynchronous gathers, waited for one batch later
+    flights = [shard.dist_gather(torch.full((5, 3), 10 * step + rank, dtype=torch.int32), 0, async_op=True)
+               for step in range(3)]
+    for step, (work, parts) in enumerate(flights):
+        work.wait()
+        if rank == 0:
+            assert [int(p[0, 0]) for p in parts] == [10 * step + r for r in range(world)]
+        else:
+            assert parts is None
     if rank == 0:
         np.save(out_path, rec.numpy())
     else:
