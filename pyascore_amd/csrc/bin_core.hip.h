@@ -7,6 +7,133 @@
 /* LDS bytes the binning stage needs for a spectrum of up to `cap` peaks (cap multiple of 64) */
 DEV size_t bin_lds_bytes(uint32_t cap) { return (size_t)cap * (8 + 4 + 2 + 1); }
 
+/* ---------------------------------------------------------------------------------------
+ * Exact top-n_top selection of one window when intensities tie (Spectra.cpp:24-41): libstdc++'s
+ * std::nth_element (introselect: median-of-3 partitions, heap select at depth 0, closing insertion
+ * sort of <= 3) followed by resize and std::sort (<= 16 elements: a stable insertion sort), run
+ * serially by one lane on an index array; keys are read through the indices.  comp(a, b) =
+ * intensity[a] > intensity[b].
+ * ------------------------------------------------------------------------------------- */
+struct RunArr {
+    uint16_t *idx;          /* [len] permutation of 0..len-1 */
+    const double *key;      /* [len] intensities of the window's peaks in input order */
+};
+DEV double run_key(const RunArr &r, int pos) { return r.key[r.idx[pos]]; }
+DEV void run_swap(const RunArr &r, int a, int b) {
+    const uint16_t t = r.idx[a];
+    r.idx[a] = r.idx[b];
+    r.idx[b] = t;
+}
+/* __adjust_heap + __push_heap on [first, first+len), value = element index v */
+DEV void run_heap_adjust(const RunArr &r, int first, int hole, int len, uint16_t v) {
+    const double vk = r.key[v];
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (run_key(r, first + child) > run_key(r, first + child - 1)) child--;
+        r.idx[first + hole] = r.idx[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        r.idx[first + hole] = r.idx[first + child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && run_key(r, first + parent) > vk) {
+        r.idx[first + hole] = r.idx[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    r.idx[first + hole] = v;
+}
+/* __heap_select(first, middle, last) */
+DEV void run_heap_select(const RunArr &r, int first, int middle, int last) {
+    const int len = middle - first;
+    if (len >= 2) {
+        for (int parent = (len - 2) / 2;; parent--) {
+            run_heap_adjust(r, first, parent, len, r.idx[first + parent]);
+            if (parent == 0) break;
+        }
+    }
+    for (int i = middle; i < last; i++) {
+        if (run_key(r, i) > run_key(r, first)) {             /* __pop_heap(first, middle, i) */
+            const uint16_t v = r.idx[i];
+            r.idx[i] = r.idx[first];
+            run_heap_adjust(r, first, 0, len, v);
+        }
+    }
+}
+/* __unguarded_partition_pivot(f, l) */
+DEV int run_partition(const RunArr &r, int f, int l) {
+    const int mid = f + (l - f) / 2;
+    const double a = run_key(r, f + 1), b = run_key(r, mid), c = run_key(r, l - 1);
+    int pick;
+    if (a > b) {
+        if (b > c) pick = mid;
+        else if (a > c) pick = l - 1;
+        else pick = f + 1;
+    } else if (a > c) pick = f + 1;
+    else if (b > c) pick = l - 1;
+    else pick = mid;
+    run_swap(r, f, pick);
+    const double pv = run_key(r, f);
+    int lo = f + 1, hi = l;
+    for (;;) {
+        while (run_key(r, lo) > pv) lo++;
+        hi--;
+        while (pv > run_key(r, hi)) hi--;
+        if (!(lo < hi)) return lo;
+        run_swap(r, lo, hi);
+        lo++;
+    }
+}
+/* stable insertion sort of positions [first, last): what __insertion_sort leaves */
+DEV void run_insertion_sort(const RunArr &r, int first, int last) {
+    for (int i = first + 1; i < last; i++) {
+        const uint16_t v = r.idx[i];
+        const double vk = r.key[v];
+        int j = i - 1;
+        while (j >= first && vk > run_key(r, j)) {
+            r.idx[j + 1] = r.idx[j];
+            j--;
+        }
+        r.idx[j + 1] = v;
+    }
+}
+/* ranks of one window: rank_out[e] for the e-th peak of the window in input order */
+DEV void run_exact_ranks(const RunArr &r, int len, uint8_t *rank_out) {
+    for (int e = 0; e < len; e++) {
+        r.idx[e] = (uint16_t)e;
+        rank_out[e] = PYA_NO_MATCH;
+    }
+    if (len > PYA_NTOP) {                                      /* std::nth_element(begin, begin + 9, end) */
+        int first = 0, last = len;
+        const int nth = PYA_NTOP - 1;
+        int depth = 0;
+        for (int t = len; t > 1; t >>= 1) depth++;
+        depth *= 2;
+        bool done = false;
+        while (last - first > 3) {
+            if (depth == 0) {
+                run_heap_select(r, first, nth + 1, last);
+                run_swap(r, first, nth);
+                done = true;
+                break;
+            }
+            depth--;
+            const int cut = run_partition(r, first, last);
+            if (cut <= nth) first = cut;
+            else last = cut;
+        }
+        if (!done) run_insertion_sort(r, first, last);
+    }
+    const int n = len < PYA_NTOP ? len : PYA_NTOP;             /* resize(n_top); std::sort */
+    run_insertion_sort(r, 0, n);
+    for (int q = 0; q < n; q++) rank_out[r.idx[q]] = (uint8_t)q;
+}
+
 /* Bins the spectrum of `psm` (Spectra.cpp:43-68, :24-41).  On return *out_mz / *out_rank point
  * into `lds` and hold the retained peaks (ascending float32 m/z, rank inside their window);
  * returns their count, or -1 with *status set.  Ends with an LDS sync. */
@@ -144,16 +271,18 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
         }
         if (!exact) {
         } else if (!unsorted) {
-            int carry_lo = 0;
+            /* equal intensities in some window: which of them are retained, and in which rank
+             * order, is whatever std::nth_element + std::sort leave.  The lane of a window's first
+             * peak emulates them serially on the window's slice of s_bin (constant inside a run,
+             * so it doubles as the index array and is put back afterwards). */
             for (int base = 0; base < P; base += 64) {
                 const int i = base + lane;
                 const bool in = i < P;
                 const uint32_t w = in ? (uint32_t)s_bin[i] : 0x10000u;
                 const uint32_t pw = (in && i > 0) ? (uint32_t)s_bin[i - 1] : 0x10001u;
-                const double me = s_inten[in ? i : 0];
-                const uint64_t starts = __ballot(in && pw != w);
-                const uint64_t upto = lanemask_lt() | (1ull << lane);
-                const uint64_t le = starts & upto, gt = starts & ~upto;
+                const bool start = in && pw != w;
+                const uint64_t starts = __ballot(start);
+                const uint64_t gt = starts & ~(lanemask_lt() | (1ull << lane));
                 int run_end = P - 1;
                 for (int nb = base + 64; nb < P; nb += 64) {
                     const int j = nb + lane;
@@ -163,19 +292,17 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                         break;
                     }
                 }
-                const int lo = le ? base + 63 - __builtin_clzll(le) : carry_lo;
                 const int hi = gt ? base + __builtin_ctzll(gt) - 1 : run_end;
-                const int len = in ? hi - lo + 1 : 0;
-                const int t_max = (int)wave_max_u32((uint32_t)len);
-                carry_lo = __builtin_amdgcn_readlane(lo, 63);
-                int cnt = 0;
-#pragma unroll 2
-                for (int t = 0; t < t_max; t++) {
-                    const int j = t < len ? lo + t : i;
-                    const double o = s_inten[j];
-                    cnt += (o > me || (o == me && j < i)) ? 1 : 0;
+                wave_lds_sync();
+                if (start) {
+                    const int len = hi - i + 1;
+                    RunArr r;
+                    r.idx = s_bin + i;
+                    r.key = s_inten + i;
+                    run_exact_ranks(r, len, s_rank + i);
+                    for (int e = 0; e < len; e++) s_bin[i + e] = (uint16_t)w;
                 }
-                if (in) s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
+                wave_lds_sync();
             }
         } else {
             for (int base = 0; base < P; base += 64) {

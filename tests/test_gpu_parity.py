@@ -89,35 +89,40 @@ def test_unsorted_spectrum_and_ties(path):
         assert np.array_equal(got[key], want[key]), key
 
 
-def test_equal_intensities_take_the_exact_sweep(monkeypatch):
-    """bin_spectra ranks with a strict-compare sweep and redoes a spectrum with the exact
-    (intensity, then index) sweep when the counts show equal intensities inside a window: both
-    routes must agree (PYA_DEBUG=128 forces the exact sweep), and ties that sit below the top ten
-    of their window must not change the result the reference gives."""
+def test_equal_intensities_follow_nth_element(monkeypatch):
+    """Which of several equally intense peaks of a window are retained, and their rank order, is
+    whatever std::nth_element + std::sort leave in the reference (Spectra.cpp:24-41).  bin_spectra
+    ranks with a strict-compare sweep, notices equal intensities through a count identity and then
+    emulates the two library calls window by window: results must equal the reference's on spectra
+    full of ties, and forcing that route for every spectrum (PYA_DEBUG=128) must change nothing."""
     batch, settings = synth.make_batch("cfg2", n_psm=400, seed=77)
-    rng = np.random.default_rng(5)
-    it = batch["intensity"].copy()
-    heavy = dict(batch, intensity=np.floor(it / np.median(it) * 3.0) + 1.0)       # many ties everywhere
+    it = batch["intensity"]
+    cases = {
+        "coarse": np.floor(it / np.median(it) * 3.0) + 1.0,           # a handful of levels: ties everywhere
+        "counts": np.floor(it / np.median(it) * 40.0) + 1.0,          # count-like: ties among weak peaks
+        "flat": np.ones_like(it),                                     # every peak ties with every other
+    }
     gpu = _gpu(settings)
-    monkeypatch.delenv("PYA_DEBUG", raising=False)
-    fast = gpu.score_batch(heavy)
+    chk = _checker(settings)
+    for name, inten in cases.items():
+        tied = dict(batch, intensity=inten)
+        monkeypatch.delenv("PYA_DEBUG", raising=False)
+        got = gpu.score_batch(tied)
+        want = chk.score_batch(tied, got["ascores"].shape[1])
+        for key in want:
+            assert np.array_equal(got[key], want[key]), (name, key)
+        monkeypatch.setenv("PYA_DEBUG", "128")
+        forced = gpu.score_batch(tied)
+        monkeypatch.delenv("PYA_DEBUG", raising=False)
+        for key in got:
+            assert np.array_equal(got[key], forced[key]), (name, key)
+    # no ties at all: the forced route must still agree with the fast one
     monkeypatch.setenv("PYA_DEBUG", "128")
-    exact = gpu.score_batch(heavy)
+    forced = gpu.score_batch(batch)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
-    for key in fast:
-        assert np.array_equal(fast[key], exact[key]), key
-    # ties only among weak peaks: give the weakest peak of each spectrum a twin of equal
-    # intensity -- never retained, so the reference's unspecified tie order cannot matter
-    low = it.copy()
-    for i in range(batch["n_psm"]):
-        a, b = batch["peak_off"][i], batch["peak_off"][i + 1]
-        order = np.argsort(low[a:b])
-        low[a + order[1]] = low[a + order[0]]
-    tied = dict(batch, intensity=low)
-    got = gpu.score_batch(tied)
-    want = _checker(settings).score_batch(tied, got["ascores"].shape[1])
-    for key in want:
-        assert np.array_equal(got[key], want[key]), key
+    plain = gpu.score_batch(batch)
+    for key in plain:
+        assert np.array_equal(plain[key], forced[key]), key
 
 
 def test_negative_residue_mass_and_crowded_lists():
