@@ -106,7 +106,12 @@ def edge_psms(rng, err):
     return P
 
 
+ONLY = sys.argv[1:]          # optional: regenerate only the cases whose names start with these
+
+
 def run_case(name, st, psms):
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
     batch = synth.pack_batch(psms) if isinstance(psms, list) else psms
     ref = harness.make_scorer(orc.OracleAscore, st, kind="ref")
     exp = harness.collect(ref, batch, synth.unpack_psm)
@@ -142,6 +147,13 @@ def main():
                                       nl=[("sty", 97.9769)]), edge_psms(rng, 0.02))
     run_case("edge_Zc", settings(mz_error=0.1, fragment_types="Zc", nl=[("m", 63.998)]),
              edge_psms(rng, 0.1))
+    # equal intensities inside the windows: the reference keeps what std::nth_element + std::sort
+    # leave (Spectra.cpp:24-41).  First half: three intensity levels, second half: count-like.
+    s, b = synth_case("cfg2", 48, 16)
+    it = b["intensity"]
+    half = int(b["peak_off"][24])
+    q = np.concatenate([np.floor(it[:half] / np.median(it) * 3.0), np.floor(it[half:] / np.median(it) * 40.0)]) + 1.0
+    run_case("ties_cfg2", s, dict(b, intensity=q))
 
 
 if __name__ == "__main__":
