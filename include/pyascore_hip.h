@@ -15,6 +15,7 @@
  *   pya_results fields            best_score / ascores / alt_sites / best signature
  *                                                                     Ascore.pyx:232-288
  *   pya_get_pep_scores            PyAscore.pep_scores                 Ascore.pyx:241-252
+ *   pya_get_pep_scores_range      the same for a range of PSMs of a retained batch (bulk export)
  *   pya_calculate_ambiguity       PyAscore.calculate_ambiguity        Ascore.pyx:208-230
  *   pya_format_peptide            ModifiedPeptide::getPeptide         cpp/ModifiedPeptide.cpp:199-253
  *   pya_plan_*                    (new) device-resident variant of pya_score_batch for callers
@@ -127,6 +128,14 @@ void pya_plan_destroy(pya_plan *plan);
 int pya_get_pep_scores(pya_handle *h, uint64_t psm, uint64_t cap, uint64_t *n, uint64_t *sig_bits,
                        int32_t *counts /* cap x 10 */, float *scores /* cap x 10 */,
                        float *weighted_score, int32_t *total_fragments);
+/* the same for PSMs [psm_begin, psm_end) in one call (three device copies for the whole range):
+ * rec_off[psm_end - psm_begin + 1] receives the CSR offsets of the PSMs' records; with cap == 0 only
+ * rec_off is filled (size query), otherwise the arrays must hold rec_off[last] records.
+ * (pep_scores of a whole batch, Ascore.pyx:241-252 at scale) */
+int pya_get_pep_scores_range(pya_handle *h, uint64_t psm_begin, uint64_t psm_end, uint64_t cap,
+                             int64_t *rec_off, uint64_t *sig_bits, int32_t *counts /* cap x 10 */,
+                             float *scores /* cap x 10 */, float *weighted_score,
+                             int32_t *total_fragments);
 int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits,
                             const float *ref_scores, float ref_weighted, uint64_t other_bits,
                             const float *other_scores, float other_weighted, float *out);

@@ -50,6 +50,7 @@ SYMBOLS = {
     "pya_plan_destroy": (None, [_vp]),
     "pya_get_pep_scores": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), _vp, _vp,
                                      _vp, _vp, _vp]),
+    "pya_get_pep_scores_range": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pya_calculate_ambiguity": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_float, C.c_uint64,
                                           _vp, C.c_float, C.POINTER(C.c_float)]),
     "pya_format_peptide": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int32, _vp, _vp, C.c_uint64,

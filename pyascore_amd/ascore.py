@@ -87,6 +87,7 @@ class PyAscore:
             self._raise(rc)
         self.device = int(device)
         self._last = None            # summary of the last score() call
+        self._batch_n = None         # PSMs of the batch retained by score_batch(keep=True)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -180,6 +181,7 @@ class PyAscore:
                                        _lib.PYA_FLAG_KEEP if keep else 0, C.byref(r))
         if rc:
             self._raise(rc)
+        self._batch_n = n if keep else None
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -232,6 +234,35 @@ class PyAscore:
                             counts=counts[i].copy(), scores=scores[i].copy(),
                             weighted_score=float(ws[i]), total_fragments=int(nfrag[i]),
                             sequence=self._format(last, b, ns)))
+        return out
+
+    def batch_pep_scores(self, begin=0, end=None):
+        """All localisations of PSMs [begin, end) of the last ``score_batch(..., keep=True)``, in the
+        reference's sorted order, as CSR arrays (bulk form of ``pep_scores``, Ascore.pyx:241-252):
+        dict(rec_off i64[n+1], sig_bits u64[R] (bit j = j-th modifiable residue), counts i32[R, 10],
+        scores f32[R, 10], weighted_score f32[R], total_fragments i32[R]); records of PSM i are
+        rows rec_off[i - begin] : rec_off[i - begin + 1]."""
+        if self._batch_n is None:
+            raise RuntimeError("no batch retained: call score_batch(batch, keep=True) first")
+        end = self._batch_n if end is None else int(end)
+        begin = int(begin)
+        if not 0 <= begin <= end <= self._batch_n:
+            raise ValueError("PSM range outside the retained batch")
+        off = np.zeros(end - begin + 1, np.int64)
+        rc = self._lib.pya_get_pep_scores_range(self._h, begin, end, 0, _as_ptr(off), None, None, None, None, None)
+        if rc:
+            self._raise(rc)
+        total = int(off[-1])
+        out = dict(rec_off=off, sig_bits=np.zeros(total, np.uint64), counts=np.zeros((total, 10), np.int32),
+                   scores=np.zeros((total, 10), np.float32), weighted_score=np.zeros(total, np.float32),
+                   total_fragments=np.zeros(total, np.int32))
+        if total:
+            rc = self._lib.pya_get_pep_scores_range(self._h, begin, end, total, _as_ptr(off),
+                                                    _as_ptr(out["sig_bits"]), _as_ptr(out["counts"]),
+                                                    _as_ptr(out["scores"]), _as_ptr(out["weighted_score"]),
+                                                    _as_ptr(out["total_fragments"]))
+            if rc:
+                self._raise(rc)
         return out
 
     @property

@@ -1092,41 +1092,61 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
     return PYA_OK;
 }
 
-int pya_get_pep_scores(pya_handle *h, uint64_t psm, uint64_t cap, uint64_t *n_out, uint64_t *sig_bits,
-                       int32_t *counts, float *scores, float *ws_out, int32_t *nfrag_out) {
-    if (!h || !n_out) return PYA_ERR_ARG;
+int pya_get_pep_scores_range(pya_handle *h, uint64_t psm_begin, uint64_t psm_end, uint64_t cap, int64_t *rec_off,
+                             uint64_t *sig_bits, int32_t *counts, float *scores, float *ws_out,
+                             int32_t *nfrag_out) {
+    if (!h || !rec_off) return PYA_ERR_ARG;
     pya_plan *p = h->kept;
     if (!p) return h->fail(PYA_ERR_STATE, -1, "no batch retained: call pya_score_batch with PYA_FLAG_KEEP first");
-    if (psm >= p->n_psm) return h->fail(PYA_ERR_ARG, -1, "PSM index out of range");
-    const uint32_t N = p->n_sig[psm];
-    *n_out = N;
-    if (N == 0 || cap == 0) return PYA_OK;
-    if (cap < N) return h->fail(PYA_ERR_ARG, -1, "capacity %llu < %u records", (unsigned long long)cap, N);
+    if (psm_begin > psm_end || psm_end > p->n_psm) return h->fail(PYA_ERR_ARG, -1, "PSM index out of range");
+    const int64_t s_begin = p->sig_off[psm_begin], s_end = p->sig_off[psm_end];
+    const uint64_t total = (uint64_t)(s_end - s_begin);
+    for (uint64_t i = psm_begin; i <= psm_end; i++) rec_off[i - psm_begin] = p->sig_off[i] - s_begin;
+    if (total == 0 || cap == 0) return PYA_OK;
+    if (cap < total)
+        return h->fail(PYA_ERR_ARG, -1, "capacity %llu < %llu records", (unsigned long long)cap,
+                       (unsigned long long)total);
+    if (!sig_bits || !counts || !scores || !ws_out || !nfrag_out) return h->fail(PYA_ERR_ARG, -1, "NULL output array");
     HIPCHK(h, hipSetDevice(h->device));
-    const int64_t s0 = p->sig_off[psm];
-    std::vector<uint32_t> rec((size_t)N * PYA_REC_WORDS), sorted(N);
-    std::vector<float> ws(N);
-    HIPCHK(h, hipMemcpy(rec.data(), p->d_rec.p + s0 * PYA_REC_WORDS, rec.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(sorted.data(), p->d_sorted.p + s0, (size_t)N * 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(ws.data(), p->d_ws.p + s0, (size_t)N * 4, hipMemcpyDeviceToHost));
-    const uint64_t *order = h->order_tab.data() + p->order_off[psm];
-    for (uint32_t r = 0; r < N; r++) {
-        const uint32_t i = sorted[r];
-        if (i >= N) return h->fail(PYA_ERR_HIP, (int64_t)psm, "corrupt sort permutation");
-        const uint32_t *w = &rec[(size_t)i * PYA_REC_WORDS];
-        const uint32_t nf = w[5];
-        sig_bits[r] = order[i];
-        ws_out[r] = ws[i];
-        nfrag_out[r] = (int32_t)nf;
-        for (int d = 0; d < PYA_NTOP; d++) {
-            uint32_t c = (w[d >> 1] >> ((d & 1) * 16)) & 0xffffu;
-            counts[(size_t)r * PYA_NTOP + d] = (int32_t)c;
-            /* same table the kernels read (score_table.cpp) */
-            scores[(size_t)r * PYA_NTOP + d] =
-                nf < h->lut_off.size() ? h->lut[h->lut_off[nf] + (uint32_t)d * (nf + 1) + c] : 0.f;
+    /* one copy per workspace array for the whole range, then the permutation on the host */
+    std::vector<uint32_t> rec((size_t)total * PYA_REC_WORDS), sorted(total);
+    std::vector<float> ws(total);
+    HIPCHK(h, hipMemcpy(rec.data(), p->d_rec.p + s_begin * PYA_REC_WORDS, rec.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(sorted.data(), p->d_sorted.p + s_begin, (size_t)total * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(ws.data(), p->d_ws.p + s_begin, (size_t)total * 4, hipMemcpyDeviceToHost));
+    for (uint64_t psm = psm_begin; psm < psm_end; psm++) {
+        const uint32_t N = p->n_sig[psm];
+        const size_t o = (size_t)(p->sig_off[psm] - s_begin);
+        const uint64_t *order = h->order_tab.data() + p->order_off[psm];
+        for (uint32_t r = 0; r < N; r++) {
+            const uint32_t i = sorted[o + r];
+            if (i >= N) return h->fail(PYA_ERR_HIP, (int64_t)psm, "corrupt sort permutation");
+            const uint32_t *w = &rec[(o + i) * PYA_REC_WORDS];
+            const uint32_t nf = w[5];
+            sig_bits[o + r] = order[i];
+            ws_out[o + r] = ws[o + i];
+            nfrag_out[o + r] = (int32_t)nf;
+            for (int d = 0; d < PYA_NTOP; d++) {
+                const uint32_t c = (w[d >> 1] >> ((d & 1) * 16)) & 0xffffu;
+                counts[(o + r) * PYA_NTOP + d] = (int32_t)c;
+                /* same table the kernels read (score_table.cpp) */
+                scores[(o + r) * PYA_NTOP + d] =
+                    nf < h->lut_off.size() ? h->lut[h->lut_off[nf] + (uint32_t)d * (nf + 1) + c] : 0.f;
+            }
         }
     }
     return PYA_OK;
+}
+
+int pya_get_pep_scores(pya_handle *h, uint64_t psm, uint64_t cap, uint64_t *n_out, uint64_t *sig_bits,
+                       int32_t *counts, float *scores, float *ws_out, int32_t *nfrag_out) {
+    if (!h || !n_out) return PYA_ERR_ARG;
+    int64_t off[2] = {0, 0};
+    const int rc = pya_get_pep_scores_range(h, psm, psm + 1, 0, off, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    *n_out = (uint64_t)off[1];
+    if (off[1] == 0 || cap == 0) return PYA_OK;
+    return pya_get_pep_scores_range(h, psm, psm + 1, cap, off, sig_bits, counts, scores, ws_out, nfrag_out);
 }
 
 int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits, const float *ref_scores,

@@ -125,6 +125,35 @@ def test_equal_intensities_follow_nth_element(monkeypatch):
         assert np.array_equal(plain[key], forced[key]), key
 
 
+@pytest.mark.parametrize("case", ["synth_cfg3", "edge_nl", "velos_zprec", "ties_cfg2"])
+def test_bulk_pep_scores_match_golden(case):
+    """pya_get_pep_scores_range: every localisation of every PSM of a retained batch
+    in one call, in the reference's sorted order -- against the reference's pep_scores."""
+    settings, batch, expected = harness.load_case(os.path.join(GOLDEN, case + ".npz"))
+    gpu = _gpu(settings)
+    gpu.score_batch(batch, keep=True)
+    got = gpu.batch_pep_scores()
+    assert np.array_equal(got["rec_off"], expected["ps_off"])
+    assert np.array_equal(got["sig_bits"], expected["ps_bits"])
+    assert np.array_equal(got["counts"], expected["ps_counts"])
+    assert np.array_equal(got["total_fragments"], expected["ps_nfrag"])
+    assert np.array_equal(got["scores"], expected["ps_scores"])
+    assert np.array_equal(got["weighted_score"], expected["ps_ws"])
+    # a sub-range carries the same rows
+    n = batch["n_psm"]
+    lo, hi = n // 3, max(n // 3 + 1, 2 * n // 3)
+    part = gpu.batch_pep_scores(lo, hi)
+    a, b = int(expected["ps_off"][lo]), int(expected["ps_off"][hi])
+    assert np.array_equal(part["rec_off"], expected["ps_off"][lo:hi + 1] - a)
+    assert np.array_equal(part["sig_bits"], expected["ps_bits"][a:b])
+    assert np.array_equal(part["weighted_score"], expected["ps_ws"][a:b])
+    with pytest.raises(ValueError):
+        gpu.batch_pep_scores(0, n + 1)
+    gpu.score_batch(batch)                     # not retained any more
+    with pytest.raises(RuntimeError):
+        gpu.batch_pep_scores()
+
+
 def test_negative_residue_mass_and_crowded_lists():
     """Fragment lists are ascending only while every residue mass is positive (localize then skips
     its order check): a fixed modification heavier than its residue, negative, must still take
