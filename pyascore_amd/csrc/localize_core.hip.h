@@ -909,11 +909,10 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
 }
 
 /* Ascores of every modified site of the winner (cpp/Ascore.cpp:212-254): walks the pushed
- * competitors LOC_SB-1 at a time.  `scores_all`, when
- * given, holds the 10 depth scores of every signature (pre-sort index); otherwise `rec` holds the
- * cumulative counts score_signatures wrote, from which the depth scores are read off the score
- * table (the same reads score_signatures made).  Lane a accumulates site a in *my_asc / *my_alt. */
-DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, const float *scores_all,
+ * competitors sb-1 at a time.  `rec` holds the cumulative counts score_signatures wrote, from which
+ * the depth scores are read off the score table (the same reads score_signatures made).  Lane a
+ * accumulates site a in *my_asc; alternative sites go to site_alt[a] (LDS). */
+DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, unsigned long long *site_alt,
                         const uint32_t *rec, uint64_t best_bits, float best_ws,
                         uint32_t best_i, uint64_t site_mask, float *my_asc_io, uint64_t *my_alt_io,
                         int *fail_io) {
@@ -927,38 +926,29 @@ DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, con
     uint32_t e = 0;
     STAMP_BEGIN();
     while (e < np) {
-        /* gather the next competitors that are not exact PepScore ties of the winner */
-        int S = 1;
-        while (e < np && S < ctx.sb) {
-            const PushedEntry pe = pushed[e++];               /* LDS, wave-uniform */
-            const uint32_t ci = pe.idx;
+        /* the next sb-1 competitors, one per lane (the scan pushed no exact tie of the winner:
+         * those were settled there, Ascore.cpp:159-161) */
+        const int take = (int)(np - e) < ctx.sb - 1 ? (int)(np - e) : ctx.sb - 1;
+        const int S = 1 + take;
+        if (lane >= 1 && lane < S) {
+            const PushedEntry pe = pushed[e + lane - 1];
             const uint64_t c = pe.bits;
-            const float c_ws = pe.ws;
             const uint64_t gone = best_bits & ~c, came = c & ~best_bits;
             const int a = __popcll(best_bits & (gone - 1));
-            const int q = __builtin_ctzll(came);
-            if (lane == a) my_alt |= 1ull << nth_set_bit(site_mask, q);
-            if ((double)__builtin_fabsf(best_ws - c_ws) < 1e-6) {       /* Ascore.cpp:159-161 */
-                if (lane == a) my_asc = 0.f < my_asc ? 0.f : my_asc;
-                continue;
-            }
-            if (lane == 0) {
-                w.sig_mask[S] = deposit_sites(c, site_mask);
-                w.c_idx[S] = (uint32_t)a;
-                w.c_pre[S] = ci;
-            }
-            if (scores_all && lane < PYA_NTOP) w.scores[S * 10 + lane] = scores_all[ci * 10 + lane];
-            S++;
+            atomicOr(&site_alt[a], 1ull << nth_set_bit(site_mask, __builtin_ctzll(came)));
+            w.sig_mask[lane] = deposit_sites(c, site_mask);
+            w.c_idx[lane] = (uint32_t)a;
+            w.c_pre[lane] = pe.idx;
         }
+        e += (uint32_t)take;
         STAMP(b, 26);
         if (S == 1) continue;
-        if (scores_all && !have_best && lane < PYA_NTOP) w.scores[lane] = scores_all[best_i * 10 + lane];
         if (lane == 0) w.c_pre[0] = best_i;
         wave_lds_sync();
         if (!(b.debug & 4)) loc_prefix_tables(ctx, S);
         wave_lds_sync();
         STAMP(b, 27);
-        if (!scores_all && rec) {
+        {
             /* depth scores of signatures [have_best, S) from the recorded cumulative counts */
             for (int i = (have_best ? 10 : 0) + lane; i < S * 10; i += 64) {
                 const int s = i / 10, d = i % 10;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
     STAMP(b, 25);
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
-    loc_ascore_all(ctx, lds.pushed, np, nullptr, b.rec ? b.rec + s0 * PYA_REC_WORDS : nullptr,
+    loc_ascore_all(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
                    best_bits, best_ws, best_i, res.site_mask,
                    &my_asc, &my_alt, &fail);
     STAMP(b, 36);
