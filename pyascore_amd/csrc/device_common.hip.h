@@ -409,22 +409,29 @@ DEV Residues load_residues(const BatchDev &b, const DevConfig *cfg, int64_t psm)
     return r;
 }
 
-/* sig bits (bit j = j-th modifiable residue) -> residue mask (bit i = residue i modified) */
+/* sig bits (bit j = j-th modifiable residue) -> residue mask (bit i = residue i modified).
+ * `site_mask` is wave-uniform everywhere this is called, so the loop runs over the sites on the
+ * scalar unit (s_ff1 / s_bitset) and each lane spends a handful of VALU instructions per site,
+ * where a per-lane "while (bits)" costs a divergent loop of 64-bit updates. */
 DEV uint64_t deposit_sites(uint64_t bits, uint64_t site_mask) {
     uint64_t out = 0, m = site_mask;
-    while (bits) {
-        uint64_t low = m & (0 - m);
-        if (bits & 1) out |= low;
+    for (int j = 0; m; j++) {
+        const int pos = __builtin_ctzll(m);
         m &= m - 1;
-        bits >>= 1;
+        out |= ((bits >> j) & 1ull) << pos;
     }
     return out;
 }
 
-/* position of the n-th (0-based) set bit */
+/* position of the n-th (0-based) set bit of the wave-uniform mask m (n may differ per lane) */
 DEV int nth_set_bit(uint64_t m, int n) {
-    for (int i = 0; i < n; i++) m &= m - 1;
-    return __builtin_ctzll(m);
+    int res = 64;
+    for (int j = 0; m; j++) {
+        const int pos = __builtin_ctzll(m);
+        m &= m - 1;
+        res = j == n ? pos : res;
+    }
+    return res;
 }
 
 DEV uint32_t nl_bump(uint32_t state, uint32_t cls) {
