@@ -802,19 +802,44 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                         /* diff is always (list A) - (list B), as the reference computes it.  Seen
                          * from an A ion the B list ascends, so diff descends: skip B ions with
                          * diff >= err.  Seen from a B ion diff ascends: skip A ions with diff <= -err. */
-                        int j = 0;
-                        for (int step = P2 >> 1; step > 0; step >>= 1) {
-                            const int probe = j + step;
-                            const float o = probe - 1 < Mo ? other[probe - 1] : __builtin_huge_valf();
-                            const float diff = side ? (o - me) : (me - o);
-                            const bool skip = side ? (diff <= -err) : (diff >= err);
-                            if (skip) j = probe;
+                        int cnt = -1;
+                        if (c.presorted) {
+                            /* position-indexed ascending lists: the first candidate partner sits at
+                             * the ion's own index or one above.  Four neighbours fetched together
+                             * decide it without the dependent probes of a binary search: index q is
+                             * the search result iff other[q-1] is skipped and other[q] is not
+                             * (the skip test is monotone along an ascending list). */
+                            float d[4];
+                            bool ok[4], sk[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const int q = i - 1 + u;
+                                ok[u] = q >= 0 && q < Mo;
+                                const float o = ok[u] ? other[q] : (q < 0 ? -__builtin_huge_valf() : __builtin_huge_valf());
+                                d[u] = side ? (o - me) : (me - o);
+                                sk[u] = side ? (d[u] <= -err) : (d[u] >= err);
+                            }
+                            const int w1 = (ok[1] && __builtin_fabsf(d[1]) < err) ? 1 : 0;
+                            const int w2 = (ok[2] && __builtin_fabsf(d[2]) < err) ? 1 : 0;
+                            const int w3 = (ok[3] && __builtin_fabsf(d[3]) < err) ? 1 : 0;
+                            if (sk[0] && !sk[1]) cnt = w1 + w2;            /* search result = i     */
+                            else if (sk[1] && !sk[2]) cnt = w2 + w3;       /* search result = i + 1 */
                         }
-                        int cnt = 0;
-                        for (int q = j; q < j + 2 && q < Mo; q++) {
-                            const float o = other[q];
-                            const float diff = side ? (o - me) : (me - o);
-                            cnt += (__builtin_fabsf(diff) < err) ? 1 : 0;
+                        if (cnt < 0) {
+                            int j = 0;
+                            for (int step = P2 >> 1; step > 0; step >>= 1) {
+                                const int probe = j + step;
+                                const float o = probe - 1 < Mo ? other[probe - 1] : __builtin_huge_valf();
+                                const float diff = side ? (o - me) : (me - o);
+                                const bool skip = side ? (diff <= -err) : (diff >= err);
+                                if (skip) j = probe;
+                            }
+                            cnt = 0;
+                            for (int q = j; q < j + 2 && q < Mo; q++) {
+                                const float o = other[q];
+                                const float diff = side ? (o - me) : (me - o);
+                                cnt += (__builtin_fabsf(diff) < err) ? 1 : 0;
+                            }
                         }
                         kept = cnt == 0;
                         w.keep[((size_t)ts << g2) + i] = kept ? 1 : 0;
