@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDe
                                                                          uint32_t n_ids, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave;
+    const uint32_t slot = xcd_slot(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
     if (slot >= n_ids) return;
     unsigned char *lds_raw = lds_all + (size_t)wave * (((size_t)cap * 15 + 63) & ~(size_t)63);
     const uint32_t psm = psm_ids[slot];

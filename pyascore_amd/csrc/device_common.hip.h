@@ -92,6 +92,19 @@ DEV int wave_excl_scan_i32(int v, int *total) {
     return x - v;
 }
 
+/* Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Remapping
+ * block b to slot (b % 8) * ceil(n / 8) + b / 8 gives every XCD one contiguous range of PSMs, so
+ * the per-PSM metadata lines (offsets, counts, status: 8-16 PSMs per 64-byte line) are fetched by
+ * one L2 instead of eight. */
+DEV uint32_t xcd_slot(uint32_t b, uint32_t n) {
+#ifdef PYA_NO_XCD_REMAP
+    return b;
+#else
+    const uint32_t q = n >> 3, r = n & 7u, x = b & 7u, k = b >> 3;
+    return x * q + (x < r ? x : r) + k;                   /* XCD x owns q + (x < r) consecutive slots */
+#endif
+}
+
 /* LDS traffic of one wave is in order, but the compiler must not move accesses across the
  * points where lanes exchange data through LDS. */
 DEV void wave_lds_sync() {

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
                                                           uint32_t gtp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
-    const uint32_t psm = psm_ids[blockIdx.x];
+    const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int k = b.n_of_mod[psm];

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(B
                                                                   uint32_t n_ids, uint32_t cap, uint32_t with_nl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
-    const uint32_t psm = psm_ids[blockIdx.x];
+    const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
 
