@@ -66,6 +66,22 @@ def profiled_traffic(cfg, kernel, default_size):
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
 
 
+def achievable_hbm_gbs(torch, dev, nbytes=1 << 30, reps=5):
+    """Read + write rate of a plain device copy of 1 GiB (the "trivial kernel" of SURVEY 8(d)): the
+    HBM bandwidth a streaming kernel reaches on this box, reported beside the 8 TB/s spec."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    t1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (t0.elapsed_time(t1) * 1e-3) / 1e9
+
+
 def cpu_baseline(batch, settings, target_seconds=12.0):
     """The reference's C++ core (oracle/_ref; the CPU restatement if that library did not travel)
     on the host cores of this box: one scorer per thread (ctypes releases the GIL), every thread a
@@ -89,15 +105,25 @@ def cpu_baseline(batch, settings, target_seconds=12.0):
     t = time.perf_counter()
     scorers[0].score_batch(slice_batch(batch, 0, n1), k)
     dt1 = time.perf_counter() - t
-    n = int(min(batch["n_psm"], max(probe, rate1 * cores * target_seconds * 2 / 3)))
+    want = rate1 * cores * target_seconds * 2 / 3            # PSMs for the all-core leg
+    n = int(min(batch["n_psm"], max(probe, want)))
+    reps = max(1, int(round(want / n)))                      # small batches are scored several times over
     cuts = [n * i // cores for i in range(cores + 1)]
+
+    def work(i):
+        part = slice_batch(batch, cuts[i], cuts[i + 1])
+        for _ in range(reps):
+            scorers[i].score_batch(part, k)
+
     t = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda i: scorers[i].score_batch(slice_batch(batch, cuts[i], cuts[i + 1]), k), range(cores)))
+        list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t
+    n *= reps
     return {"value": n / dt, "unit": "PSMs/s", "cores": cores,
             "kind": "reference" if kind == "ref" else "port",
-            "sample": "first %d PSMs of rank 0's batch in %d slices, one thread each, %.1f s" % (n, cores, dt),
+            "sample": "%d PSMs (first %d of rank 0's batch x %d) in %d slices, one thread each, %.1f s"
+                      % (n, n // reps, reps, cores, dt),
             "one_core": {"value": n1 / dt1, "sample": "first %d PSMs, one thread, %.1f s" % (n1, dt1)}}
 
 
@@ -196,6 +222,7 @@ def main():
         t = time.perf_counter()
         scorer.score_batch(batch)
         host_rate = batch["n_psm"] / (time.perf_counter() - t)
+        copy_gbs = achievable_hbm_gbs(torch, dev)
         default_size = args.psms is None and args.config != "cfg3"
         traffic, traffic_src = profiled_traffic(args.config, names[dom], default_size)
         line = {
@@ -214,6 +241,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg,
+                         "achievable_peak": copy_gbs, "frac_of_achievable": achieved / copy_gbs,
+                         "whole_path_gbs": alg / (float(kern_ms.sum()) * 1e-3) / 1e9 if kern_ms.sum() > 0 else 0.0,
                          "kernel_ms": {n: float(m) for n, m in zip(names, kern_ms)}},
             "host_api": {"value": host_rate, "unit": "PSMs/s",
                          "note": "PyAscore.score_batch: host arrays in, host results out (PCIe + host pre-pass)"},
