@@ -1,6 +1,8 @@
 """Randomised parity: random scorer settings (mod groups incl. termini, ion types, neutral-loss
 groups, tolerances) x random small batches (lengths, site counts, charges, fixed mods incl. the
 n-terminus, sorted and unsorted peaks), HIP path vs the CPU checker on this box, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +14,11 @@ pytestmark = pytest.mark.gpu
 from fuzzcase import random_case as _random_case
 
 
-@pytest.mark.parametrize("seed", range(40))
+# PYA_FUZZ_SEEDS=a:b widens the sweep for a one-off soak (default: 40 seeds)
+_LO, _HI = (int(x) for x in os.environ.get("PYA_FUZZ_SEEDS", "0:40").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_LO, _HI))
 def test_random_settings_and_batches(seed):
     rng = np.random.default_rng(9000 + seed)
     settings, batch = _random_case(rng)
