@@ -102,11 +102,12 @@ DEV void run_insertion_sort(const RunArr &r, int first, int last) {
         r.idx[j + 1] = v;
     }
 }
-/* ranks of one window: rank_out[e] for the e-th peak of the window in input order */
-DEV void run_exact_ranks(const RunArr &r, int len, uint8_t *rank_out) {
+/* Ranks of one window.  r.idx holds the window's peaks in input order as indices into r.key /
+ * rank_out (`identity`: they are simply 0..len-1 and are filled in here). */
+DEV void run_exact_ranks(const RunArr &r, int len, uint8_t *rank_out, bool identity) {
     for (int e = 0; e < len; e++) {
-        r.idx[e] = (uint16_t)e;
-        rank_out[e] = PYA_NO_MATCH;
+        if (identity) r.idx[e] = (uint16_t)e;
+        rank_out[r.idx[e]] = PYA_NO_MATCH;
     }
     if (len > PYA_NTOP) {                                      /* std::nth_element(begin, begin + 9, end) */
         int first = 0, last = len;
@@ -136,7 +137,14 @@ DEV void run_exact_ranks(const RunArr &r, int len, uint8_t *rank_out) {
 
 /* Bins the spectrum of `psm` (Spectra.cpp:43-68, :24-41).  On return *out_mz / *out_rank point
  * into `lds` and hold the retained peaks (ascending float32 m/z, rank inside their window);
- * returns their count, or -1 with *status set.  Ends with an LDS sync. */
+ * returns their count, or -1 with *status set.  Ends with an LDS sync.
+ *
+ * EXACT = false is the common case -- peaks in m/z order, no two equal intensities inside a
+ * window -- and returns PYA_BIN_REDO for everything else; EXACT = true handles everything (any
+ * peak order, ties resolved as std::nth_element + std::sort do).  Two instantiations in two
+ * kernels, because the rare paths would otherwise double the registers of the common one. */
+#define PYA_BIN_REDO (-2)
+template <bool EXACT>
 DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
                  const uint8_t **out_rank, int *status) {
     const int lane = lane_id();
@@ -213,6 +221,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             if (!redo) break;
         }
     }
+    if (!EXACT && (unsorted || (b.debug & 128))) return PYA_BIN_REDO;
     wave_lds_sync();
 
     /* pass 3: intensity rank inside the window = number of window mates that are more intense
@@ -226,8 +235,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
          * add-with-carry per mate).  Without equal intensities inside a window that IS the rank;
          * with them the counts of a window no longer add up to len*(len-1)/2, which the check
          * after the sweep notices, and the exact sweep below redoes the spectrum. */
-        bool exact = unsorted || (b.debug & 128);
-        if (!exact) {
+        if (!EXACT) {
             int carry_lo = 0, deficit = 0;
             for (int base = 0; base < P; base += 64) {
                 const int i = base + lane;
@@ -266,10 +274,9 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                 deficit += in ? (len - 1) - 2 * cnt : 0;
                 if (in) s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
             }
-            exact = wave_sum_i32(deficit) != 0;
-            if (exact) wave_lds_sync();
+            if (wave_sum_i32(deficit) != 0) return PYA_BIN_REDO;   /* equal intensities somewhere */
         }
-        if (!exact) {
+        if (!EXACT) {
         } else if (!unsorted) {
             /* equal intensities in some window: which of them are retained, and in which rank
              * order, is whatever std::nth_element + std::sort leave.  The lane of a window's first
@@ -299,25 +306,75 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                     RunArr r;
                     r.idx = s_bin + i;
                     r.key = s_inten + i;
-                    run_exact_ranks(r, len, s_rank + i);
+                    run_exact_ranks(r, len, s_rank + i, true);
                     for (int e = 0; e < len; e++) s_bin[i + e] = (uint16_t)w;
                 }
                 wave_lds_sync();
             }
         } else {
+            /* peaks out of m/z order: a window's peaks are scattered, every pair is compared */
+            int tie = 0;
             for (int base = 0; base < P; base += 64) {
                 const int i = base + lane;
                 if (i < P) {
                     const uint16_t w = s_bin[i];
                     const double me = s_inten[i];
                     int cnt = 0;
-                    for (int j = 0; j < P && cnt < PYA_NTOP; j++) {
+                    for (int j = 0; j < P; j++) {
                         if (s_bin[j] != w || j == i) continue;
                         const double o = s_inten[j];
                         cnt += (o > me || (o == me && j < i)) ? 1 : 0;
+                        tie |= (o == me) ? 1 : 0;
                     }
                     s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
                 }
+            }
+            if (__any(tie)) {
+                /* Equal intensities in a window: std::nth_element + std::sort work on the window's
+                 * peaks in input order.  A stable counting sort by window id lists them (peak
+                 * indices, in the PSM's still unused slice of the retained-m/z output as scratch),
+                 * then every window is emulated by the lane of its first list entry. */
+                uint16_t *list = (uint16_t *)(b.ret_mz + p0);
+                for (int base = 0; base < P; base += 64) {
+                    const int i = base + lane;
+                    if (i < P) {
+                        const uint16_t w = s_bin[i];
+                        int pos = 0;
+                        for (int j = 0; j < P; j++) {
+                            const uint16_t wj = s_bin[j];
+                            pos += (wj < w || (wj == w && j < i)) ? 1 : 0;
+                        }
+                        list[pos] = (uint16_t)i;
+                    }
+                }
+                __threadfence();
+                wave_lds_sync();
+                for (int base = 0; base < P; base += 64) {
+                    const int q = base + lane;
+                    const bool in = q < P;
+                    const uint32_t w = in ? (uint32_t)s_bin[list[q]] : 0x10000u;
+                    const uint32_t pw = (in && q > 0) ? (uint32_t)s_bin[list[q - 1]] : 0x10001u;
+                    const bool start = in && pw != w;
+                    const uint64_t starts = __ballot(start);
+                    const uint64_t gt = starts & ~(lanemask_lt() | (1ull << lane));
+                    int run_end = P - 1;
+                    for (int nb = base + 64; nb < P; nb += 64) {
+                        const int j = nb + lane;
+                        const uint64_t m2 = __ballot(j < P && s_bin[list[j]] != s_bin[list[j - 1]]);
+                        if (m2) {
+                            run_end = nb + __builtin_ctzll(m2) - 1;
+                            break;
+                        }
+                    }
+                    const int hi = gt ? base + __builtin_ctzll(gt) - 1 : run_end;
+                    if (start) {
+                        RunArr r;
+                        r.idx = list + q;
+                        r.key = s_inten;
+                        run_exact_ranks(r, hi - q + 1, s_rank, false);
+                    }
+                }
+                __threadfence();
             }
         }
     }
@@ -341,7 +398,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             }
             total += __popcll(m);
         }
-    } else {
+    } else if (EXACT) {
         /* general order: position = number of retained peaks with a smaller (m/z, index) */
         for (int base = 0; base < P; base += 64) {
             int i = base + lane;

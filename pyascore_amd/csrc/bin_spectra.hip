@@ -8,6 +8,11 @@
  *
  * HBM traffic: reads 16 B per raw peak once (coalesced, 8 B per lane), writes 5 B per retained
  * peak.  Everything else lives in LDS: intensity (f64) and window id (u16) per peak.
+ *
+ * Two kernels: pya_bin_spectra_kernel takes the common case (peaks in m/z order, no two equal
+ * intensities inside a window) and appends every other spectrum to a list that
+ * pya_bin_exact_kernel works off -- any peak order, ties resolved as std::nth_element + std::sort
+ * resolve them.  The rare paths stay out of the hot kernel's register budget that way.
  */
 #include "bin_core.hip.h"
 
@@ -15,19 +20,8 @@
 #define BIN_WAVES 4     /* independent spectra per workgroup when LDS allows (no cross-wave sync) */
 #endif
 
-__global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDev b, const uint32_t *psm_ids,
-                                                                         uint32_t n_ids, uint32_t cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t slot = xcd_slot(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
-    if (slot >= n_ids) return;
-    unsigned char *lds_raw = lds_all + (size_t)wave * (((size_t)cap * 15 + 63) & ~(size_t)63);
-    const uint32_t psm = psm_ids[slot];
+DEV void bin_store(const BatchDev &b, uint32_t psm, int R, int status, const float *r_mz, const uint8_t *r_rank) {
     const int lane = lane_id();
-    const float *r_mz;
-    const uint8_t *r_rank;
-    int status;
-    const int R = bin_core(b, psm, lds_raw, cap, &r_mz, &r_rank, &status);
     if (R < 0) {
         if (lane == 0) {
             b.status[psm] = status;
@@ -46,6 +40,41 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDe
     }
 }
 
+__global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDev b, const uint32_t *psm_ids,
+                                                                         uint32_t n_ids, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t slot = xcd_slot(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
+    if (slot >= n_ids) return;
+    unsigned char *lds_raw = lds_all + (size_t)wave * (((size_t)cap * 15 + 63) & ~(size_t)63);
+    const uint32_t psm = psm_ids[slot];
+    const float *r_mz;
+    const uint8_t *r_rank;
+    int status;
+    const int R = bin_core<false>(b, psm, lds_raw, cap, &r_mz, &r_rank, &status);
+    if (R == PYA_BIN_REDO) {
+        /* peaks out of m/z order or equal intensities in a window: left to pya_bin_exact_kernel */
+        if (lane_id() == 0) b.redo_ids[atomicAdd(b.redo_count, 1u)] = psm;
+        return;
+    }
+    bin_store(b, psm, R, status, r_mz, r_rank);
+}
+
+/* the spectra the kernel above declined, one per wavefront, a fixed grid striding over the list */
+__global__ __launch_bounds__(64) void pya_bin_exact_kernel(BatchDev b, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    const uint32_t n = *b.redo_count;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const uint32_t psm = b.redo_ids[k];
+        const float *r_mz;
+        const uint8_t *r_rank;
+        int status;
+        const int R = bin_core<true>(b, psm, lds_all, cap, &r_mz, &r_rank, &status);
+        bin_store(b, psm, R, status, r_mz, r_rank);
+        wave_lds_sync();
+    }
+}
+
 extern "C" size_t pya_bin_lds_bytes(uint32_t cap) { return (size_t)cap * (8 + 4 + 2 + 1) + 64; }
 
 extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
@@ -57,7 +86,16 @@ extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t
     hipError_t e = hipFuncSetAttribute((const void *)pya_bin_spectra_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(b->redo_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_bin_spectra_kernel, dim3((n_ids + nw - 1) / nw), dim3(64 * nw), lds, stream, *b, d_ids,
                        n_ids, cap);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void *)pya_bin_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)per_wave);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t grid = n_ids < 1024u ? n_ids : 1024u;
+    hipLaunchKernelGGL(pya_bin_exact_kernel, dim3(grid), dim3(64), per_wave, stream, *b, cap);
     return (int)hipGetLastError();
 }

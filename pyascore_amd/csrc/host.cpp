@@ -265,6 +265,7 @@ struct pya_plan {
     DevBuf<float> d_aux_mass, d_ret_mz, d_ws;
     DevBuf<uint8_t> d_ret_rank;
     DevBuf<uint16_t> d_grid;
+    DevBuf<uint32_t> d_redo;             /* [1 + n_psm]: count, then the ids bin_spectra hands to its exact variant */
     Bucket buckets[kNumBuckets];
     Bucket all_ids;                     /* every PSM (bin_spectra launch) */
     /* owned copies of inputs/outputs (pya_score_batch path) */
@@ -486,6 +487,8 @@ void fill_dev(pya_plan *p) {
     d.ret_rank = p->d_ret_rank.p;
     d.ret_n = p->d_ret_n.p;
     d.grid = p->d_grid.p;
+    d.redo_count = p->d_redo.p;
+    d.redo_ids = p->d_redo.p + 64;
     d.ws = p->d_ws.p;
     d.rec = p->d_rec.p;
     d.sorted_idx = p->d_sorted.p;
@@ -869,7 +872,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
                      o_ret_mz = reserve((size_t)p->total_peaks * 4), o_ret_rank = reserve((size_t)p->total_peaks),
-                     o_grid = reserve(n * PYA_GRID_CELLS * 2),
+                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         if (!p->arena.take_if_fits(h->spare_arena, total)) HIPCHK(h, p->arena.alloc(total));
@@ -903,6 +906,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_ret_mz.adopt(base + o_ret_mz, (size_t)p->total_peaks);
         p->d_ret_rank.adopt(base + o_ret_rank, (size_t)p->total_peaks);
         p->d_grid.adopt(base + o_grid, n * PYA_GRID_CELLS);
+        p->d_redo.adopt(base + o_redo, n + 64);
         p->d_ws.adopt(base + o_ws, (size_t)sig_total);
         p->d_rec.adopt(base + o_rec, (size_t)sig_total * PYA_REC_WORDS);
         if (flags & PYA_FLAG_KEEP) p->d_sorted.adopt(base + o_sorted, (size_t)sig_total);

@@ -116,6 +116,18 @@ def test_equal_intensities_follow_nth_element(monkeypatch):
         monkeypatch.delenv("PYA_DEBUG", raising=False)
         for key in got:
             assert np.array_equal(got[key], forced[key]), (name, key)
+    # peaks out of m/z order AND equal intensities: the windows' input order decides
+    rng = np.random.default_rng(11)
+    mz, inten = batch["mz"].copy(), cases["counts"].copy()
+    for i in range(batch["n_psm"]):
+        a, b = batch["peak_off"][i], batch["peak_off"][i + 1]
+        p = rng.permutation(b - a)
+        mz[a:b], inten[a:b] = mz[a:b][p], inten[a:b][p]
+    shuffled = dict(batch, mz=mz, intensity=inten)
+    got = gpu.score_batch(shuffled)
+    want = chk.score_batch(shuffled, got["ascores"].shape[1])
+    for key in want:
+        assert np.array_equal(got[key], want[key]), ("shuffled", key)
     # no ties at all: the forced route must still agree with the fast one
     monkeypatch.setenv("PYA_DEBUG", "128")
     forced = gpu.score_batch(batch)
