@@ -75,6 +75,8 @@ struct BatchDev {
     uint16_t *grid;                 /* [n_psm][PYA_GRID_CELLS] m/z grid over the retained peaks (score_signatures) */
     uint32_t *redo_count;           /* spectra bin_spectra hands to its exact variant (peaks out of */
     uint32_t *redo_ids;             /* [n_psm] m/z order, or equal intensities inside a window)     */
+    uint32_t *redo3_count;          /* PSMs the lean localize instantiation hands to the general one */
+    uint32_t *redo3_ids;            /* [n_psm]                                                       */
     float *ws;                      /* weighted score per signature, pre-sort order         */
     uint32_t *rec;                  /* optional per-signature records: 6 words each         */
     uint32_t *sorted_idx;           /* optional sorted permutation, at sig_off              */

@@ -40,7 +40,7 @@ int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, u
                      uint32_t with_nl, hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
-                        hipStream_t stream);
+                        uint32_t plain, hipStream_t stream);
 int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
@@ -210,7 +210,9 @@ struct pya_handle {
     } while (0)
 
 struct Bucket {
-    std::vector<uint32_t> ids;
+    std::vector<uint32_t> ids;          /* every PSM of the bucket (score_signatures launch), plain ones first */
+    std::vector<uint32_t> general_ids;  /* filled while scanning; appended to ids afterwards */
+    uint32_t n_plain = 0;               /* ids[0, n_plain): localised by the lean kernel instantiation */
     DevBuf<uint32_t> d_ids;
     uint32_t n_cap = 0, list_cap = 1, pos_cap = 1;
     /* Signatures localised together (winner included) -- LDS per wave decides the occupancy of
@@ -265,6 +267,7 @@ struct pya_plan {
     DevBuf<float> d_aux_mass, d_ret_mz, d_ws;
     DevBuf<uint8_t> d_ret_rank;
     DevBuf<uint16_t> d_grid;
+    DevBuf<uint32_t> d_redo3;            /* the same for localize's lean instantiation */
     DevBuf<uint32_t> d_redo;             /* [1 + n_psm]: count, then the ids bin_spectra hands to its exact variant */
     Bucket buckets[kNumBuckets];
     Bucket all_ids;                     /* every PSM (bin_spectra launch) */
@@ -489,6 +492,8 @@ void fill_dev(pya_plan *p) {
     d.grid = p->d_grid.p;
     d.redo_count = p->d_redo.p;
     d.redo_ids = p->d_redo.p + 64;
+    d.redo3_count = p->d_redo3.p;
+    d.redo3_ids = p->d_redo3.p + 64;
     d.ws = p->d_ws.p;
     d.rec = p->d_rec.p;
     d.sorted_idx = p->d_sorted.p;
@@ -685,6 +690,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     const uint32_t n_uniq = (uint32_t)h->cfg.n_uniq, n_types = (uint32_t)h->cfg.n_types;
     uint32_t max_P = 1, lut_need = 0, max_k = 1;
     int64_t sig_total = 0;
+    const bool plain_on = h->cfg.n_nl == 0 && !(flags & PYA_FLAG_KEEP) && !std::getenv("PYA_NO_PLAIN");
     /* Pass A (threaded for big batches): the per-letter work -- validate every PSM and count its
      * modifiable residues.  It only finds the first offending PSM; the detailed message comes from
      * the serial checks below, run for that PSM alone. */
@@ -795,7 +801,10 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             int bi = 0;
             while (N > kBucketLimits[bi]) bi++;
             Bucket &bk = p->buckets[bi];
-            bk.ids.push_back((uint32_t)i);
+            /* lean localize instantiation: no neutral losses, charge 1, summary mode (it checks the
+             * residue masses itself and hands back what it cannot do) */
+            if (plain_on && z == 1) bk.ids.push_back((uint32_t)i);
+            else bk.general_ids.push_back((uint32_t)i);
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
             bk.list_cap = std::max<uint32_t>(bk.list_cap, next_pow2(std::max<uint32_t>(per_type, 1)));
             bk.pos_cap = std::max<uint32_t>(bk.pos_cap, (uint32_t)std::max<int64_t>(L - 1, 1));
@@ -803,10 +812,16 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             bk.k_max = std::max<uint32_t>(bk.k_max, (uint32_t)k);
         } else {
             Bucket &bk = p->buckets[0];                 /* unambiguous / empty: cheapest launch */
-            bk.ids.push_back((uint32_t)i);
+            bk.general_ids.push_back((uint32_t)i);
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
         }
         p->all_ids.ids.push_back((uint32_t)i);
+    }
+    for (Bucket &bk : p->buckets) {
+        bk.n_plain = (uint32_t)bk.ids.size();
+        bk.ids.insert(bk.ids.end(), bk.general_ids.begin(), bk.general_ids.end());
+        bk.general_ids.clear();
+        bk.general_ids.shrink_to_fit();
     }
     lap("psm loop");
     p->sig_off[n] = sig_total;
@@ -872,7 +887,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
                      o_ret_mz = reserve((size_t)p->total_peaks * 4), o_ret_rank = reserve((size_t)p->total_peaks),
-                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4),
+                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((n + 64) * 4),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         if (!p->arena.take_if_fits(h->spare_arena, total)) HIPCHK(h, p->arena.alloc(total));
@@ -907,6 +922,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_ret_rank.adopt(base + o_ret_rank, (size_t)p->total_peaks);
         p->d_grid.adopt(base + o_grid, n * PYA_GRID_CELLS);
         p->d_redo.adopt(base + o_redo, n + 64);
+        p->d_redo3.adopt(base + o_redo3, n + 64);
         p->d_ws.adopt(base + o_ws, (size_t)sig_total);
         p->d_rec.adopt(base + o_rec, (size_t)sig_total * PYA_REC_WORDS);
         if (flags & PYA_FLAG_KEEP) p->d_sorted.adopt(base + o_sorted, (size_t)sig_total);
@@ -967,7 +983,11 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
     for (Bucket &bk : p->buckets) {
-        e = pya_launch_localize(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), st);
+        e = pya_launch_localize(&d, bk.d_ids.p, bk.n_plain, p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(),
+                                bk.gtp(), 1u, st);
+        if (e) return h->hip_fail((hipError_t)e, "localize launch");
+        e = pya_launch_localize(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, p->peak_cap, bk.n_cap,
+                                bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));

@@ -135,8 +135,11 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
 
 /* Runs the introsort phase in place.  Afterwards the array is partitioned into runs of <= 16
  * (or heap-sorted runs) exactly as libstdc++ leaves it before __final_insertion_sort. */
-DEV void sort_introsort_loop(const SortLds &s, int N, bool spine_only) {
-    if (N <= 16) return;
+/* PLAIN (the lean instantiation of the localize kernel, see rank_and_localize.hip) gives up --
+ * returns true -- where the depth limit would call for the serial heap sort. */
+template <bool PLAIN>
+DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only) {
+    if (N <= 16) return false;
     const int lane = lane_id();
     int depth0 = 0;
     for (int t = N; t > 1; t >>= 1) depth0++;
@@ -151,6 +154,7 @@ DEV void sort_introsort_loop(const SortLds &s, int N, bool spine_only) {
         int f = __shfl(st_f, sp, 64), l = __shfl(st_l, sp, 64), d = __shfl(st_d, sp, 64);
         while (l - f > 16) {
             if (d == 0) {
+                if (PLAIN) return true;
                 wave_lds_sync();
                 if (lane == 0) heap_sort_serial(s, f, l);
                 wave_lds_sync();
@@ -166,6 +170,7 @@ DEV void sort_introsort_loop(const SortLds &s, int N, bool spine_only) {
         }
     }
     wave_lds_sync();
+    return false;
 }
 
 /* final position of element i after the closing (stable) insertion sort */
@@ -518,6 +523,7 @@ struct LocCtx {
                               /* every fragment list comes out ascending, no check needed   */
 };
 
+template <bool PLAIN>
 DEV void loc_prefix_tables(const LocCtx &c, int S) {
     const int lane = lane_id();
     const LocLds &w = c.w;
@@ -525,7 +531,7 @@ DEV void loc_prefix_tables(const LocCtx &c, int S) {
         const int s = lane >> 1, d = lane & 1;
         const uint64_t mask = w.sig_mask[s];
         const size_t base = (size_t)(s * 2 + d) * c.pos_cap;
-        if (c.nl.n_nl == 0) {
+        if (PLAIN || c.nl.n_nl == 0) {
             /* no neutral losses: one ion per prefix, so only the running sums are tabulated
              * (loc_site_ions knows pmk = 1 and cpre = step without reading them) */
             const uint64_t tmask = d ? (__brevll(mask) >> (64 - c.L)) : mask;   /* travel order */
@@ -543,7 +549,7 @@ DEV void loc_prefix_tables(const LocCtx &c, int S) {
                 dst[step] = running;
             }
             w.tot[s * 2 + d] = (uint32_t)(c.L - 1);
-        } else {
+        } else if (!PLAIN) {
             float running = 0.f;
             uint32_t st = 0, cnt = 0;
             for (int step = 0; step + 1 < c.L; step++) {
@@ -639,7 +645,10 @@ DEV void loc_stage_push(const LocCtx &c, bool kept, float val, uint32_t tag, int
  * powers of two; slot 0 = the winner, generated once and shared by every task).  A "task" is one
  * (competitor, ion type): list A = winner, list B = competitor; its keep flags are
  * [task][side][P2]. */
-DEV void loc_site_ions(const LocCtx &c, int S) {
+/* PLAIN: returns true when the PSM needs a route only the general instantiation has (an ion with
+ * two partners within mz_error: the reference's serial walk has to be replayed). */
+template <bool PLAIN>
+DEV bool loc_site_ions(const LocCtx &c, int S) {
     const int lane = lane_id();
     const LocLds &w = c.w;
     const DevConfig *cfg = c.cfg;
@@ -699,11 +708,11 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             const int d = tb + t < cfg->n_fwd ? 0 : 1;
             const size_t idx = (size_t)(s * 2 + d) * c.pos_cap + pos;
             const float running = w.run[idx];
-            if (c.nl.n_nl == 0) {
+            if (PLAIN || c.nl.n_nl == 0) {
                 float *dst = w.pool + ((size_t)((slot << gt) + t) << g2) + (size_t)pos * c.zmax;
                 const double m = ((double)running + A) - B;
                 for (int z = 1; z <= c.zmax; z++) *dst++ = charge_mz(m, z);
-            } else {
+            } else if (!PLAIN) {
                 uint32_t pm = w.pmk[idx];
                 float *dst = w.pool + ((size_t)((slot << gt) + t) << g2) + (size_t)w.cpre[idx] * c.zmax;
                 while (pm) {
@@ -717,6 +726,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
         }
         wave_lds_sync();
         STAMP(*c.b, 30);
+        if (!PLAIN) {
         /* ---- out of order anywhere?  then pad to the stride and run the bitonic network ---- */
         const int nlists = nsl << gt;
         const int dense = nlists * (int)mmax;
@@ -759,6 +769,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                     wave_lds_sync();
                 }
             }
+        }
         }
         STAMP(*c.b, 32);
         /* ---- cancel.  Site-determining ions = what the reference's greedy two-pointer walk
@@ -803,7 +814,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                          * from an A ion the B list ascends, so diff descends: skip B ions with
                          * diff >= err.  Seen from a B ion diff ascends: skip A ions with diff <= -err. */
                         int cnt = -1;
-                        if (c.presorted) {
+                        if (PLAIN || c.presorted) {
                             /* position-indexed ascending lists: the first candidate partner sits at
                              * the ion's own index or one above.  Four neighbours fetched together
                              * decide it without the dependent probes of a binary search: index q is
@@ -848,7 +859,8 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
                     }
                 }
             }
-            uint64_t rest = __ballot(multi);
+            if (PLAIN && __any(multi)) return true;
+            uint64_t rest = PLAIN ? 0ull : __ballot(multi);
             while (rest) {
                 const int src = __builtin_ctzll(rest);
                 rest &= rest - 1;
@@ -862,6 +874,7 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
             STAMP(*c.b, 33);
             continue;
         }
+        if (PLAIN) continue;                               /* (unreachable: bad_tasks is empty) */
         /* ---- a task needs the reference's serial walk: undo the optimistic counts ---- */
         wave_lds_sync();
         if (lane < S * 2) {
@@ -931,13 +944,15 @@ DEV void loc_site_ions(const LocCtx &c, int S) {
         wave_lds_sync();
         STAMP(*c.b, 34);
     }
+    return false;
 }
 
 /* Ascores of every modified site of the winner (cpp/Ascore.cpp:212-254): walks the pushed
  * competitors sb-1 at a time.  `rec` holds the cumulative counts score_signatures wrote, from which
  * the depth scores are read off the score table (the same reads score_signatures made).  Lane a
  * accumulates site a in *my_asc; alternative sites go to site_alt[a] (LDS). */
-DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, unsigned long long *site_alt,
+template <bool PLAIN>
+DEV bool loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, unsigned long long *site_alt,
                         const uint32_t *rec, uint64_t best_bits, float best_ws,
                         uint32_t best_i, uint64_t site_mask, float *my_asc_io, uint64_t *my_alt_io,
                         int *fail_io) {
@@ -970,7 +985,7 @@ DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, uns
         if (S == 1) continue;
         if (lane == 0) w.c_pre[0] = best_i;
         wave_lds_sync();
-        if (!(b.debug & 4)) loc_prefix_tables(ctx, S);
+        if (!(b.debug & 4)) loc_prefix_tables<PLAIN>(ctx, S);
         wave_lds_sync();
         STAMP(b, 27);
         {
@@ -989,7 +1004,9 @@ DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, uns
             STAMP(b, 28);
         }
         have_best = true;
-        if (!(b.debug & 1)) loc_site_ions(ctx, S);
+        if (!(b.debug & 1)) {
+            if (loc_site_ions<PLAIN>(ctx, S)) return true;
+        }
         STAMP(b, 35);
         /* one competitor per lane: the table reads of all of them are in flight together */
         float asc_l = 0.f;
@@ -1014,6 +1031,7 @@ DEV void loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, uns
     *my_asc_io = my_asc;
     *my_alt_io = my_alt;
     *fail_io = fail;
+    return false;
 }
 
 #endif

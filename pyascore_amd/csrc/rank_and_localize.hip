@@ -31,15 +31,25 @@ extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint
 }
 
 #ifndef LOC_WAVES
-#define LOC_WAVES 4
+#define LOC_WAVES 4            /* general instantiation: 128 VGPRs */
 #endif
-__global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b, const uint32_t *psm_ids,
-                                                          uint32_t n_ids, uint32_t peak_cap,
-                                                          uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
-                                                          uint32_t gtp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    if (blockIdx.x >= n_ids) return;
-    const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
+#ifndef LOC_WAVES_PLAIN
+#define LOC_WAVES_PLAIN 5      /* lean instantiation: fits 102 VGPRs without scratch */
+#endif
+
+/* One PSM, one wavefront.  Two instantiations:
+ *   PLAIN = true  -- no neutral losses, fragment charge 1, every residue mass positive (so every
+ *                    fragment list is ascending and position-indexed), summary mode.  Everything
+ *                    only other PSMs need is compiled out, which takes the kernel from 128 to
+ *                    under 102 VGPRs = 5 instead of 4 waves per SIMD (this kernel's speed follows
+ *                    its occupancy).  Returns true -- nothing written -- when the PSM turns out to
+ *                    need a route it does not have: an ion with two partners within mz_error,
+ *                    introsort running out of depth, a non-positive residue mass.  Such PSMs are appended to a list and redone by
+ *                    the general instantiation.
+ *   PLAIN = false -- everything. */
+template <bool PLAIN>
+DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t peak_cap, uint32_t pos_cap,
+                       uint32_t pool_cap, uint32_t sb, uint32_t gtp) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int k = b.n_of_mod[psm];
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
             b.best_sig[psm] = 0ull;
             b.n_sig_out[psm] = -1;
         }
-        return;
+        return false;
     }
 
     const int N = (int)b.n_sig[psm];
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
             b.n_sig_out[psm] = N;
             if (b.keep && N > 0) b.sorted_idx[s0] = 0;
         }
-        return;
+        return false;
     }
 
     STAMP_BEGIN();
@@ -88,6 +98,11 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
     stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, false);
     const Residues res = load_residues(b, cfg, psm);
     const uint64_t site_mask_u = res.site_mask;
+    /* positive residue masses make the float32 running sum, hence every m/z list, ascending */
+    const int zmax = b.max_charge[psm];
+    const bool presorted = zmax == 1 && cfg->n_nl == 0 &&
+                           !__any(lane < res.L && !(res.m0 > 0.f && res.m1 > 0.f));
+    if (PLAIN && (!presorted || b.keep || (b.debug & 512))) return true;   /* not this kernel's PSM */
     STAMP(b, 20);
 
     /* ---- sort (cpp/Ascore.cpp:141-146) ---- */
@@ -108,7 +123,9 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
     /* only the left spine of the partition tree decides the front element; the full sort is
      * needed when the caller wants the whole ordering */
     STAMP(b, 21);
-    if (!(b.debug & 8)) sort_introsort_loop(srt, N, b.keep == 0);
+    if (!(b.debug & 8)) {
+        if (sort_introsort_loop<PLAIN>(srt, N, b.keep == 0)) return true;
+    }
     STAMP(b, 22);
 
     /* front of the sorted list = left-most maximum of the partitioned array */
@@ -176,10 +193,8 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
     ctx.sb = (int)sb;
     ctx.gtp = (int)gtp;
     ctx.L = res.L;
-    ctx.zmax = b.max_charge[psm];
-    /* positive residue masses make the float32 running sum, hence every m/z list, ascending */
-    ctx.presorted = ctx.zmax == 1 && ctx.nl.n_nl == 0 &&
-                    !__any(lane < res.L && !(res.m0 > 0.f && res.m1 > 0.f));
+    ctx.zmax = zmax;
+    ctx.presorted = presorted;
     ctx.pos_cap = pos_cap;
     ctx.pool_cap = pool_cap;
     const LocLds &w = ctx.w;
@@ -192,9 +207,10 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
     STAMP(b, 25);
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
-    loc_ascore_all(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
+    const bool declined = loc_ascore_all<PLAIN>(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
                    best_bits, best_ws, best_i, res.site_mask,
                    &my_asc, &my_alt, &fail);
+    if (PLAIN && declined) return true;
     STAMP(b, 36);
     if (lane < k && lds.site_tie[lane]) my_asc = 0.f < my_asc ? 0.f : my_asc;
     if (lane < k) my_alt |= lds.site_alt[lane];
@@ -208,6 +224,30 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_kernel(BatchDev b,
         b.best_sig[psm] = best_bits;
         b.n_sig_out[psm] = N;
         if (any_fail) b.status[psm] = overflow ? PYA_ST_PUSHED_OVERFLOW : PYA_ST_LUT_RANGE;
+    }
+    return false;
+}
+
+template <bool PLAIN>
+__global__ __launch_bounds__(64, PLAIN ? LOC_WAVES_PLAIN : LOC_WAVES) void pya_localize_kernel(
+    BatchDev b, const uint32_t *psm_ids, uint32_t n_ids, uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap,
+    uint32_t sb, uint32_t gtp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (blockIdx.x >= n_ids) return;
+    const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
+    const bool declined = localize_body<PLAIN>(b, psm, lds_raw, peak_cap, pos_cap, pool_cap, sb, gtp);
+    if (PLAIN && declined && lane_id() == 0) b.redo3_ids[atomicAdd(b.redo3_count, 1u)] = psm;
+}
+
+/* the PSMs the lean instantiation declined, on the general one: a small grid strides over the list */
+__global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_redo_kernel(BatchDev b, uint32_t peak_cap,
+                                                                        uint32_t pos_cap, uint32_t pool_cap,
+                                                                        uint32_t sb, uint32_t gtp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t n = *b.redo3_count;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        localize_body<false>(b, b.redo3_ids[k], lds_raw, peak_cap, pos_cap, pool_cap, sb, gtp);
+        wave_lds_sync();
     }
 }
 
@@ -260,20 +300,40 @@ __global__ __launch_bounds__(64) void pya_debug_sort_kernel(const float *keys, u
         srt.idx[i] = (uint16_t)i;
     }
     wave_lds_sync();
-    sort_introsort_loop(srt, N, false);
+    sort_introsort_loop<false>(srt, N, false);
     for (int i = lane; i < N; i += 64) perm[sort_final_pos(srt, i, N)] = srt.idx[i];
 }
 
 extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids,
                                    uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
-                                   uint32_t sb, uint32_t gtp, hipStream_t stream) {
+                                   uint32_t sb, uint32_t gtp, uint32_t plain, hipStream_t stream) {
     if (n_ids == 0) return 0;
-    size_t lds = pya_localize_lds_bytes(peak_cap, n_cap, pos_cap, pool_cap, sb);
-    hipError_t e = hipFuncSetAttribute((const void *)pya_localize_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = pya_localize_lds_bytes(peak_cap, n_cap, pos_cap, pool_cap, sb);
+    hipError_t e;
+    if (!plain) {
+        e = hipFuncSetAttribute((const void *)pya_localize_kernel<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(pya_localize_kernel<false>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, peak_cap,
+                           pos_cap, pool_cap, sb, gtp);
+        return (int)hipGetLastError();
+    }
+    /* lean instantiation first, then whatever it declined on the general one */
+    e = hipMemsetAsync(b->redo3_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pya_localize_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                       peak_cap, pos_cap, pool_cap, sb, gtp);
+    e = hipFuncSetAttribute((const void *)pya_localize_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, peak_cap,
+                       pos_cap, pool_cap, sb, gtp);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void *)pya_localize_redo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t grid = n_ids < 1024u ? n_ids : 1024u;
+    hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, peak_cap, pos_cap, pool_cap,
+                       sb, gtp);
     return (int)hipGetLastError();
 }
 

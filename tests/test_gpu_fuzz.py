@@ -19,8 +19,12 @@ _LO, _HI = (int(x) for x in os.environ.get("PYA_FUZZ_SEEDS", "0:40").split(":"))
 
 
 @pytest.mark.parametrize("seed", range(_LO, _HI))
-def test_random_settings_and_batches(seed):
+def test_random_settings_and_batches(seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
+    if seed % 4 == 3:
+        monkeypatch.setenv("PYA_NO_PLAIN", "1")      # every PSM on the general localize instantiation
+    elif seed % 4 == 2:
+        monkeypatch.setenv("PYA_DEBUG", "512")        # the lean instantiation declines everything
     settings, batch = _random_case(rng)
     if batch["n_psm"] == 0:
         pytest.skip("empty draw")

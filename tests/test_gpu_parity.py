@@ -14,11 +14,19 @@ from pyascore_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def path():
-    """bin_spectra -> score_signatures -> localize (the only path; the name is kept for the tests
-    that were parametrised over an experimental fused kernel, removed because it was slower)."""
-    return "three_kernel"
+@pytest.fixture(params=["lean_localize", "general_localize", "lean_declines"])
+def path(request, monkeypatch):
+    """Batches run three times: plain PSMs (no neutral losses, fragment charge 1) on the lean
+    instantiation of the localize kernel (default); every PSM on the general instantiation
+    (PYA_NO_PLAIN=1); and with the lean instantiation declining every PSM (PYA_DEBUG=512), which
+    sends them through its hand-over list to the general one."""
+    monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
+    monkeypatch.delenv("PYA_DEBUG", raising=False)
+    if request.param == "general_localize":
+        monkeypatch.setenv("PYA_NO_PLAIN", "1")
+    elif request.param == "lean_declines":
+        monkeypatch.setenv("PYA_DEBUG", "512")
+    return request.param
 
 
 def _gpu(settings):
