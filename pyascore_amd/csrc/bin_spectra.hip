@@ -86,16 +86,20 @@ extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t
     hipError_t e = hipFuncSetAttribute((const void *)pya_bin_spectra_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(b->redo_count, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_bin_spectra_kernel, dim3((n_ids + nw - 1) / nw), dim3(64 * nw), lds, stream, *b, d_ids,
                        n_ids, cap);
-    e = hipGetLastError();
+    return (int)hipGetLastError();
+}
+
+/* after every pya_launch_bin of a batch: the spectra they declined (b->redo_count must have been
+ * zeroed before the first of them) */
+extern "C" int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream) {
+    if (n_total == 0) return 0;
+    const size_t per_wave = (((size_t)cap * 15 + 63) & ~(size_t)63);
+    hipError_t e = hipFuncSetAttribute((const void *)pya_bin_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)per_wave);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void *)pya_bin_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)per_wave);
-    if (e != hipSuccess) return (int)e;
-    const uint32_t grid = n_ids < 1024u ? n_ids : 1024u;
+    const uint32_t grid = n_total < 1024u ? n_total : 1024u;
     hipLaunchKernelGGL(pya_bin_exact_kernel, dim3(grid), dim3(64), per_wave, stream, *b, cap);
     return (int)hipGetLastError();
 }

@@ -36,6 +36,7 @@ size_t pya_bin_lds_bytes(uint32_t cap);
 size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl);
 size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
+int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t prefix,
                      uint32_t with_nl, hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
@@ -270,7 +271,17 @@ struct pya_plan {
     DevBuf<uint32_t> d_redo3;            /* the same for localize's lean instantiation */
     DevBuf<uint32_t> d_redo;             /* [1 + n_psm]: count, then the ids bin_spectra hands to its exact variant */
     Bucket buckets[kNumBuckets];
-    Bucket all_ids;                     /* every PSM (bin_spectra launch) */
+    /* bin_spectra and score_signatures size their LDS by the peak count, so they are launched per
+     * peak class (caps = a few quantiles of the batch's peak counts): one 8 000-peak spectrum must
+     * not set the occupancy of a batch of 300-peak spectra.  score lists are additionally split by
+     * the C(n,k) class (prefix sharing on / off). */
+    struct IdList {
+        uint32_t off, n, cap, ncls;
+    };
+    std::vector<uint32_t> bin_ids, score_ids;
+    std::vector<IdList> bin_lists, score_lists;
+    std::vector<uint8_t> ncls;          /* [n_psm] C(n,k) class of the PSM */
+    DevBuf<uint32_t> d_bin_ids, d_score_ids;
     /* owned copies of inputs/outputs (pya_score_batch path) */
     DevBuf<double> d_mz, d_inten;
     DevBuf<float> d_best_score, d_ascores;
@@ -687,6 +698,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     p->n_sig.resize(n);
     p->order_off.resize(n);
     p->sig_off.resize(n + 1);
+    p->ncls.assign(n, 0);
     const uint32_t n_uniq = (uint32_t)h->cfg.n_uniq, n_types = (uint32_t)h->cfg.n_types;
     uint32_t max_P = 1, lut_need = 0, max_k = 1;
     int64_t sig_total = 0;
@@ -797,9 +809,11 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                            (unsigned long long)i, per_type, PYA_MAX_LIST);
         lut_need = std::max(lut_need, per_type * n_types);
         if ((uint32_t)k > max_k) max_k = (uint32_t)k;
+        int cls_of_i = 0;
         if (N > 0 && (uint32_t)k < ns) {
             int bi = 0;
             while (N > kBucketLimits[bi]) bi++;
+            cls_of_i = bi;
             Bucket &bk = p->buckets[bi];
             /* lean localize instantiation: no neutral losses, charge 1, summary mode (it checks the
              * residue masses itself and hands back what it cannot do) */
@@ -815,7 +829,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             bk.general_ids.push_back((uint32_t)i);
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
         }
-        p->all_ids.ids.push_back((uint32_t)i);
+        p->ncls[i] = (uint8_t)cls_of_i;
     }
     for (Bucket &bk : p->buckets) {
         bk.n_plain = (uint32_t)bk.ids.size();
@@ -828,6 +842,54 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     p->total_sigs = sig_total;
     p->max_k = max_k;
     p->peak_cap = (max_P + 63u) & ~63u;
+    {
+        /* peak classes: the median, 90th and 99th percentile and the maximum of the peak counts,
+         * rounded up to 32 (one class for small batches) */
+        std::vector<uint32_t> caps;
+        if (n >= 2048 && !std::getenv("PYA_ONE_PEAK_CLASS")) {
+            std::vector<uint32_t> pk(n);
+            for (uint64_t i = 0; i < n; i++) pk[i] = (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
+            for (double q : {0.5, 0.9, 0.99}) {
+                const size_t at = (size_t)(q * (double)(n - 1));
+                std::nth_element(pk.begin(), pk.begin() + at, pk.end());
+                caps.push_back((pk[at] + 31u) & ~31u);
+            }
+        }
+        /* classes only pay when the tail is long: every extra launch has its own ramp-up and tail */
+        if (!caps.empty() && p->peak_cap < 2 * caps[0] && !std::getenv("PYA_PEAK_CLASSES")) caps.clear();
+        caps.push_back(p->peak_cap);
+        std::sort(caps.begin(), caps.end());
+        caps.erase(std::unique(caps.begin(), caps.end()), caps.end());
+        const size_t nc = caps.size();
+        std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0);
+        std::vector<uint8_t> pcls(n);
+        for (uint64_t i = 0; i < n; i++) {
+            const uint32_t P = (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
+            size_t c = 0;
+            while (caps[c] < P) c++;
+            pcls[i] = (uint8_t)c;
+            cnt_bin[c]++;
+            cnt_score[p->ncls[i] * nc + c]++;
+        }
+        uint32_t off = 0;
+        for (size_t c = 0; c < nc; c++) {
+            p->bin_lists.push_back({off, 0u, caps[c], 0u});
+            off += cnt_bin[c];
+        }
+        off = 0;
+        for (size_t g = 0; g < nc * kNumBuckets; g++) {
+            p->score_lists.push_back({off, 0u, caps[g % nc], (uint32_t)(g / nc)});
+            off += cnt_score[g];
+        }
+        p->bin_ids.resize(n);
+        p->score_ids.resize(n);
+        for (uint64_t i = 0; i < n; i++) {
+            pya_plan::IdList &bl = p->bin_lists[pcls[i]];
+            p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
+            pya_plan::IdList &sl = p->score_lists[p->ncls[i] * nc + pcls[i]];
+            p->score_ids[sl.off + sl.n++] = (uint32_t)i;
+        }
+    }
     rc = ensure_lut(h, lut_need);
     if (rc) return rc;
     if (h->order_uploaded != h->order_tab.size() || !h->d_order.p) {
@@ -867,7 +929,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_n_sig = meta(p->n_sig.data(), n * 4), o_order_off = meta(p->order_off.data(), n * 4),
                      o_aux_pos = meta(has_aux ? b->aux_pos + aux_base : nullptr, (size_t)total_aux * 4),
                      o_aux_mass = meta(has_aux ? b->aux_mass + aux_base : nullptr, (size_t)total_aux * 4),
-                     o_all_ids = meta(p->all_ids.ids.data(), p->all_ids.ids.size() * 4);
+                     o_bin_ids = meta(p->bin_ids.data(), p->bin_ids.size() * 4),
+                     o_score_ids = meta(p->score_ids.data(), p->score_ids.size() * 4);
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
             o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
@@ -904,7 +967,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_order_off.adopt(base + o_order_off, n);
         p->d_aux_pos.adopt(base + o_aux_pos, (size_t)total_aux);
         p->d_aux_mass.adopt(base + o_aux_mass, (size_t)total_aux);
-        p->all_ids.d_ids.adopt(base + o_all_ids, p->all_ids.ids.size());
+        p->d_bin_ids.adopt(base + o_bin_ids, p->bin_ids.size());
+        p->d_score_ids.adopt(base + o_score_ids, p->score_ids.size());
         for (int i = 0; i < kNumBuckets; i++)
             p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
         if (io) {
@@ -972,13 +1036,19 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     d.max_k = o->max_k;
     const bool timing = p->flags & PYA_FLAG_TIMING;
     if (timing) HIPCHK(h, hipEventRecord(p->ev[0], st));
-    int e = pya_launch_bin(&d, p->all_ids.d_ids.p, (uint32_t)p->all_ids.ids.size(), p->peak_cap, st);
-    if (e) return h->hip_fail((hipError_t)e, "bin_spectra launch");
+    HIPCHK(h, hipMemsetAsync(d.redo_count, 0, sizeof(uint32_t), st));
+    int e = 0;
+    for (const pya_plan::IdList &l : p->bin_lists) {
+        e = pya_launch_bin(&d, p->d_bin_ids.p + l.off, l.n, l.cap, st);
+        if (e) return h->hip_fail((hipError_t)e, "bin_spectra launch");
+    }
+    e = pya_launch_bin_exact(&d, (uint32_t)p->n_psm, p->peak_cap, st);
+    if (e) return h->hip_fail((hipError_t)e, "bin_spectra (exact) launch");
     if (timing) HIPCHK(h, hipEventRecord(p->ev[1], st));
-    for (Bucket &bk : p->buckets) {
-        /* buckets with C(n,k) > 64 share the walk over the first sites between signatures */
-        const uint32_t prefix = (bk.n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
-        e = pya_launch_score(&d, bk.d_ids.p, (uint32_t)bk.ids.size(), p->peak_cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, st);
+    for (const pya_plan::IdList &l : p->score_lists) {
+        /* classes with C(n,k) > 64 share the walk over the first sites between signatures */
+        const uint32_t prefix = (p->buckets[l.ncls].n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
+        e = pya_launch_score(&d, p->d_score_ids.p + l.off, l.n, l.cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
