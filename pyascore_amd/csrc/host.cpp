@@ -702,7 +702,10 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     const uint32_t n_uniq = (uint32_t)h->cfg.n_uniq, n_types = (uint32_t)h->cfg.n_types;
     uint32_t max_P = 1, lut_need = 0, max_k = 1;
     int64_t sig_total = 0;
-    const bool plain_on = h->cfg.n_nl == 0 && !(flags & PYA_FLAG_KEEP) && !std::getenv("PYA_NO_PLAIN");
+    /* (tiny batches are launch-bound: the lean instantiation's extra memset + hand-over launch cost
+     * more than its occupancy gains there) */
+    const bool plain_on = h->cfg.n_nl == 0 && !(flags & PYA_FLAG_KEEP) && !std::getenv("PYA_NO_PLAIN") &&
+                          n >= (uint64_t)(std::getenv("PYA_PLAIN_MIN") ? std::atoi(std::getenv("PYA_PLAIN_MIN")) : 512);
     /* Pass A (threaded for big batches): the per-letter work -- validate every PSM and count its
      * modifiable residues.  It only finds the first offending PSM; the detailed message comes from
      * the serial checks below, run for that PSM alone. */

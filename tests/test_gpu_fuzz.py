@@ -21,6 +21,7 @@ _LO, _HI = (int(x) for x in os.environ.get("PYA_FUZZ_SEEDS", "0:40").split(":"))
 @pytest.mark.parametrize("seed", range(_LO, _HI))
 def test_random_settings_and_batches(seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
+    monkeypatch.setenv("PYA_PLAIN_MIN", "0")          # small batches skip the lean localize kernel by default
     if seed % 4 == 3:
         monkeypatch.setenv("PYA_NO_PLAIN", "1")      # every PSM on the general localize instantiation
     elif seed % 4 == 2:

@@ -22,6 +22,7 @@ def path(request, monkeypatch):
     sends them through its hand-over list to the general one."""
     monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
+    monkeypatch.setenv("PYA_PLAIN_MIN", "0")       # batches under 512 PSMs skip the lean kernel by default
     if request.param == "general_localize":
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
     elif request.param == "lean_declines":
