@@ -223,46 +223,6 @@ DEV Prefix prefix_state(const Residues &res, uint64_t resmask, int dir, const Nl
     return p;
 }
 
-/* PepScore ingredients of one signature: cumulative counts and total fragments (wave-uniform) */
-DEV void signature_counts(const Residues &res, const DevConfig *cfg, const NlTables &nl,
-                          const PeakTable &tab, uint64_t resmask, int zmax, uint32_t cum[PYA_NTOP],
-                          uint32_t *nfrag_out) {
-    Hist h = {0ull, 0ull, 0ull};
-    int nfrag = 0;
-    for (int dir = 0; dir < 2; dir++) {
-        const int t0 = dir == 0 ? 0 : cfg->n_fwd;
-        const int t1 = dir == 0 ? cfg->n_fwd : cfg->n_types;
-        if (t0 == t1) continue;
-        Prefix p = prefix_state(res, resmask, dir, nl);
-        uint32_t pm = p.pm;
-        while (__any(pm != 0)) {
-            const bool on = pm != 0;
-            const int v = on ? __builtin_ctz(pm) : 0;
-            pm &= pm - 1;
-            const float x = p.running - (nl.n_nl ? nl.uniq[v] : 0.f);
-            const double xd = (double)x;
-            for (int t = t0; t < t1; t++) {
-                const double m = type_offset(xd, cfg->types[t]);
-                for (int z = 1; z <= zmax; z++) {
-                    const float fmz = charge_mz(m, z);
-                    if (on) {
-                        hist_add(h, match_rank(tab, fmz));
-                        nfrag++;
-                    }
-                }
-            }
-        }
-    }
-    h = hist_wave_sum(h);
-    *nfrag_out = (uint32_t)wave_sum_i32(nfrag);
-    uint32_t acc = 0;
-#pragma unroll
-    for (int d = 0; d < PYA_NTOP; d++) {
-        acc += hist_get(h, d);
-        cum[d] = acc;
-    }
-}
-
 /* all fragments of (signature, type) over charges 1..zmax into list[]; returns the count */
 DEV int fragment_list(const Residues &res, const DevConfig *cfg, const NlTables &nl, uint64_t resmask,
                       uint8_t type, int zmax, float *list) {
@@ -389,20 +349,6 @@ DEV float ambiguity(const BatchDev &b, const Residues &res, const DevConfig *cfg
     return s0 - s1;
 }
 
-DEV void scores_from_counts(const BatchDev &b, const uint32_t cum[PYA_NTOP], uint32_t nfrag,
-                            float out[PYA_NTOP], int *fail) {
-    if (nfrag > b.lut_n_max) {
-        *fail = 1;
-#pragma unroll
-        for (int d = 0; d < PYA_NTOP; d++) out[d] = 0.f;
-        return;
-    }
-    const uint32_t off = lut_row(nfrag);
-#pragma unroll
-    for (int d = 0; d < PYA_NTOP; d++) out[d] = b.lut[off + (uint32_t)d * (nfrag + 1) + cum[d]];
-}
-
-
 /* LDS carve-up shared by the localisation and the ambiguity kernels */
 struct K3Lds {
     uint16_t *nl_present;
@@ -442,7 +388,6 @@ struct LocLds {
     uint16_t *pmk;            /* same shape: neutral-loss sums present                    */
     uint16_t *cpre;           /* same shape: exclusive count of variants before prefix    */
     uint32_t *tot;            /* [sb*2] variants per (sig, dir)                        */
-    uint32_t *hist;           /* [sb*11] rank histogram + total fragments             */
     float *scores;            /* [sb*10]                                              */
     uint32_t *c_idx;          /* [sb] which modified site of the winner the competitor moves */
     uint32_t *c_pre;          /* [sb] pre-sort index of the signature (entry 0 = winner)     */
@@ -466,8 +411,7 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, ui
     w.stage_val = w.pool + pool_cap;
     w.stage_tag = (uint32_t *)(w.stage_val + 128);
     w.tot = w.stage_tag + 128;
-    w.hist = w.tot + LOC_SB * 2;
-    w.c_idx = w.hist + LOC_SB * 11;
+    w.c_idx = w.tot + LOC_SB * 2;
     w.c_pre = w.c_idx + LOC_SB;
     w.c_depth = (int32_t *)(w.c_pre + LOC_SB);
     w.c_cnt = (uint32_t *)(w.c_depth + LOC_SB);
@@ -501,13 +445,14 @@ DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, u
 /* ---------------------------------------------------------------------------------------
  * Batched localisation: the winner and up to sb-1 competitors at a time.
  *   1. one lane per (signature, direction) walks the residues and tabulates, per prefix
- *      length, the float32 running sum and the neutral-loss sums that exist;
- *   2. every (signature, direction, prefix) entry expands to its fragment m/z, looks them up
- *      and bumps the signature's rank histogram (LDS atomics) -> the 10 depth scores;
- *   3. per (competitor, ion type) task the two fragment lists are written to an LDS pool,
- *      sorted if they are not already, cancelled against each other by the reference's
- *      greedy walk -- one TASK per lane, so all walks of the batch run side by side -- and
- *      the surviving ions are matched in parallel.
+ *      length, the float32 running sum (and, with neutral losses, the loss sums that exist);
+ *   2. the 10 depth scores of every signature of the batch are read off the score table from
+ *      the cumulative counts score_signatures recorded;
+ *   3. per (competitor, ion type) task the two fragment lists are written to an LDS pool and
+ *      sorted if they can be out of order; every ion looks for partners within mz_error in the
+ *      other list (its neighbours for position-indexed lists, a binary search otherwise), ions
+ *      without a partner are staged and looked up a wave at a time; a task with a doubly
+ *      partnered ion is replayed with the reference's serial greedy walk.
  * ------------------------------------------------------------------------------------- */
 struct LocCtx {
     const BatchDev *b;
