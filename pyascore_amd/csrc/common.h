@@ -13,7 +13,8 @@
 #define PYA_MAX_UNIQ 16            /* distinct sums of <= 2 neutral losses (incl. 0)       */
 #define PYA_MAX_LIST 2048          /* fragments of one signature and one ion type          */
 #define PYA_MAX_LUT_N 4096         /* largest trial count the score table covers           */
-#define PYA_MAX_PUSHED 64          /* tied best competitors kept per PSM                   */
+#define PYA_MAX_PUSHED 128         /* single-move competitors of one PSM: k * (n_sites - k) <= 126 */
+                                   /* for every shape with C(n,k) <= PYA_MAX_SIGNATURES             */
 
 /* per-PSM status written by the kernels */
 #define PYA_ST_OK 0

@@ -34,12 +34,12 @@ void pya_score_table_extend(float mz_error, uint32_t n_top, uint32_t n_to, std::
 extern "C" {
 size_t pya_bin_lds_bytes(uint32_t cap);
 size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl);
-size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
+size_t pya_localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
 int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t prefix,
                      uint32_t with_nl, hipStream_t stream);
-int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t peak_cap,
+int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap,
                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
                         uint32_t plain, hipStream_t stream);
 int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,
@@ -246,6 +246,11 @@ struct Bucket {
         return 2u * per_sig > want ? 2u * per_sig : want;
     }
     uint32_t n_types = 1, k_max = 1;
+    uint32_t push_max = 1;              /* largest k * (n_sites - k): single-move competitors of one PSM */
+    uint32_t push_cap() const {
+        uint32_t v = (push_max + 7u) & ~7u;
+        return v > PYA_MAX_PUSHED ? PYA_MAX_PUSHED : v;
+    }
 };
 
 struct pya_plan {
@@ -827,6 +832,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             bk.pos_cap = std::max<uint32_t>(bk.pos_cap, (uint32_t)std::max<int64_t>(L - 1, 1));
             bk.n_types = n_types;
             bk.k_max = std::max<uint32_t>(bk.k_max, (uint32_t)k);
+            bk.push_max = std::max<uint32_t>(bk.push_max, (uint32_t)k * (ns - (uint32_t)k));
         } else {
             Bucket &bk = p->buckets[0];                 /* unambiguous / empty: cheapest launch */
             bk.general_ids.push_back((uint32_t)i);
@@ -903,7 +909,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         return h->fail(PYA_ERR_ARG, -1, "results.max_k (%u) is smaller than the largest n_of_mod (%u)", io->max_k, max_k);
     for (Bucket &bk : p->buckets) {
         if (bk.ids.empty()) continue;
-        size_t need = pya_localize_lds_bytes(p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb());
+        size_t need = pya_localize_lds_bytes(bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb());
         if (need > kMaxLds)
             return h->fail(PYA_ERR_LIMIT, (int64_t)bk.ids[0], "LDS budget exceeded (%zu bytes) for the bucket of PSM %u",
                            need, bk.ids[0]);
@@ -1056,10 +1062,10 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
     for (Bucket &bk : p->buckets) {
-        e = pya_launch_localize(&d, bk.d_ids.p, bk.n_plain, p->peak_cap, bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(),
+        e = pya_launch_localize(&d, bk.d_ids.p, bk.n_plain, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(),
                                 bk.gtp(), 1u, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
-        e = pya_launch_localize(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, p->peak_cap, bk.n_cap,
+        e = pya_launch_localize(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
                                 bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }

@@ -354,7 +354,7 @@ struct K3Lds {
     uint16_t *nl_present;
     float *nl_uniq;
     PeakEntry *t_e;          /* [peak_cap + PYA_TABLE_PAD] */
-    PushedEntry *pushed;     /* [PYA_MAX_PUSHED] */
+    PushedEntry *pushed;     /* [push_cap]: at most k * (n_sites - k) single-move competitors exist */
     uint32_t *site_max;      /* [64] best competitor PepScore (bits) per modified site */
     uint32_t *site_tie;      /* [64] some best competitor ties the winner (Ascore 0)   */
     unsigned long long *site_alt;  /* [64] positions of competitors that tie the winner */
@@ -363,12 +363,12 @@ struct K3Lds {
     unsigned char *scratch;  /* sort arrays, later the localisation work area */
 };
 
-DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap, bool with_table = true) {
+DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap, bool with_table = true, uint32_t push_cap = PYA_MAX_PUSHED) {
     K3Lds k;
     k.nl_present = (uint16_t *)raw;
     k.nl_uniq = (float *)(k.nl_present + 256);
     k.pushed = (PushedEntry *)(k.nl_uniq + PYA_MAX_UNIQ);
-    k.site_alt = (unsigned long long *)(k.pushed + PYA_MAX_PUSHED);
+    k.site_alt = (unsigned long long *)(k.pushed + push_cap);
     k.site_max = (uint32_t *)(k.site_alt + 64);
     k.site_tie = k.site_max + 64;
     k.n_pushed = k.site_tie + 64;

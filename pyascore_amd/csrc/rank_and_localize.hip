@@ -21,10 +21,10 @@
 #include "device_common.hip.h"
 #include "localize_core.hip.h"
 
-extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap,
+extern "C" size_t pya_localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap,
                                          uint32_t pool_cap, uint32_t sb) {
-    (void)peak_cap;                 /* the localize kernel looks peaks up in global memory */
-    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + PYA_MAX_PUSHED * 16 + 64 * 16 + 16;
+    /* (the localize kernel looks peaks up in global memory: no peak table here) */
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + 64 * 16 + 16;
     size_t srt = (size_t)n_cap * 10 + 64;
     size_t lst = pya_loc_lds_bytes(pos_cap, pool_cap, sb);
     return fixed + (srt > lst ? srt : lst) + 64;
@@ -48,7 +48,7 @@ extern "C" size_t pya_localize_lds_bytes(uint32_t peak_cap, uint32_t n_cap, uint
  *                    the general instantiation.
  *   PLAIN = false -- everything. */
 template <bool PLAIN>
-DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t peak_cap, uint32_t pos_cap,
+DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t push_cap, uint32_t pos_cap,
                        uint32_t pool_cap, uint32_t sb, uint32_t gtp) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
@@ -91,7 +91,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     STAMP_BEGIN();
     /* only a handful of ions are matched here, so the retained-peak table is not staged in LDS:
      * that keeps this kernel's LDS small (occupancy) and saves the staging + grid build */
-    K3Lds lds = carve(lds_raw, peak_cap, false);
+    K3Lds lds = carve(lds_raw, 0, false, push_cap);
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
@@ -168,7 +168,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
                             continue;
                         }
                         const uint32_t slot = atomicAdd(lds.n_pushed, 1u);
-                        if (slot < PYA_MAX_PUSHED) {
+                        if (slot < push_cap) {
                             PushedEntry pe;
                             pe.bits = c;
                             pe.ws = __uint_as_float(u);
@@ -183,8 +183,8 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     }
     const uint32_t n_pushed = *lds.n_pushed;
     int fail = 0;
-    if (n_pushed > PYA_MAX_PUSHED) fail = 2;
-    uint32_t np = n_pushed < PYA_MAX_PUSHED ? n_pushed : PYA_MAX_PUSHED;
+    if (n_pushed > push_cap) fail = 2;                    /* cannot happen: push_cap >= k * (n_sites - k) */
+    uint32_t np = n_pushed < push_cap ? n_pushed : push_cap;
     if (b.debug & 16) np = 0;
 
     STAMP(b, 24);
@@ -230,23 +230,23 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
 
 template <bool PLAIN>
 __global__ __launch_bounds__(64, PLAIN ? LOC_WAVES_PLAIN : LOC_WAVES) void pya_localize_kernel(
-    BatchDev b, const uint32_t *psm_ids, uint32_t n_ids, uint32_t peak_cap, uint32_t pos_cap, uint32_t pool_cap,
+    BatchDev b, const uint32_t *psm_ids, uint32_t n_ids, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap,
     uint32_t sb, uint32_t gtp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
-    const bool declined = localize_body<PLAIN>(b, psm, lds_raw, peak_cap, pos_cap, pool_cap, sb, gtp);
+    const bool declined = localize_body<PLAIN>(b, psm, lds_raw, push_cap, pos_cap, pool_cap, sb, gtp);
     if (PLAIN && declined && lane_id() == 0) b.redo3_ids[atomicAdd(b.redo3_count, 1u)] = psm;
 }
 
 /* the PSMs the lean instantiation declined, on the general one: a small grid strides over the list */
-__global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_redo_kernel(BatchDev b, uint32_t peak_cap,
+__global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_redo_kernel(BatchDev b, uint32_t push_cap,
                                                                         uint32_t pos_cap, uint32_t pool_cap,
                                                                         uint32_t sb, uint32_t gtp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t n = *b.redo3_count;
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        localize_body<false>(b, b.redo3_ids[k], lds_raw, peak_cap, pos_cap, pool_cap, sb, gtp);
+        localize_body<false>(b, b.redo3_ids[k], lds_raw, push_cap, pos_cap, pool_cap, sb, gtp);
         wave_lds_sync();
     }
 }
@@ -305,16 +305,16 @@ __global__ __launch_bounds__(64) void pya_debug_sort_kernel(const float *keys, u
 }
 
 extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids,
-                                   uint32_t peak_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
+                                   uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
                                    uint32_t sb, uint32_t gtp, uint32_t plain, hipStream_t stream) {
     if (n_ids == 0) return 0;
-    const size_t lds = pya_localize_lds_bytes(peak_cap, n_cap, pos_cap, pool_cap, sb);
+    const size_t lds = pya_localize_lds_bytes(push_cap, n_cap, pos_cap, pool_cap, sb);
     hipError_t e;
     if (!plain) {
         e = hipFuncSetAttribute((const void *)pya_localize_kernel<false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(pya_localize_kernel<false>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, peak_cap,
+        hipLaunchKernelGGL(pya_localize_kernel<false>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, push_cap,
                            pos_cap, pool_cap, sb, gtp);
         return (int)hipGetLastError();
     }
@@ -324,7 +324,7 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     e = hipFuncSetAttribute((const void *)pya_localize_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, peak_cap,
+    hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, push_cap,
                        pos_cap, pool_cap, sb, gtp);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -332,7 +332,7 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
                             (int)lds);
     if (e != hipSuccess) return (int)e;
     const uint32_t grid = n_ids < 1024u ? n_ids : 1024u;
-    hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, peak_cap, pos_cap, pool_cap,
+    hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, push_cap, pos_cap, pool_cap,
                        sb, gtp);
     return (int)hipGetLastError();
 }

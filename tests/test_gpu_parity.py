@@ -175,6 +175,23 @@ def test_bulk_pep_scores_match_golden(case):
         gpu.batch_pep_scores()
 
 
+def test_many_tied_competitors():
+    """Shapes with many single-move competitors (k * (n_sites - k) up to 126 for C(n,k) <= 15 000):
+    at noise level most of them tie for the best score of their site and all of them have to be
+    carried into the Ascore stage."""
+    for n_sites, n_mod, L in ((17, 6, 24), (45, 3, 50), (14, 7, 20)):
+        batch, settings = synth.make_batch("cfg5", n_psm=12, seed=300 + n_sites, L=L, n_sites=n_sites, n_mod=n_mod)
+        # weak evidence: keep the noise, drop most signal peaks, so that many assignments tie
+        rng = np.random.default_rng(n_sites)
+        keep = rng.random(batch["mz"].size) < 0.85
+        off = np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(np.int64), batch["peak_off"][:-1]))])
+        thin = dict(batch, mz=batch["mz"][keep], intensity=batch["intensity"][keep], peak_off=off.astype(np.int64))
+        got = _gpu(settings).score_batch(thin)
+        want = _checker(settings).score_batch(thin, got["ascores"].shape[1])
+        for key in want:
+            assert np.array_equal(got[key], want[key]), (n_sites, n_mod, key)
+
+
 def test_negative_residue_mass_and_crowded_lists():
     """Fragment lists are ascending only while every residue mass is positive (localize then skips
     its order check): a fixed modification heavier than its residue, negative, must still take
