@@ -130,8 +130,8 @@ def cpu_baseline(batch, settings, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--psms", type=int, default=None, help="PSMs per GPU (default: the config's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
