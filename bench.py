@@ -120,7 +120,16 @@ def cpu_baseline(batch, settings, target_seconds=12.0):
         list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t
     n *= reps
-    return {"value": n / dt, "unit": "PSMs/s", "cores": cores,
+    cpu_model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for row in f:
+                if row.startswith("model name"):
+                    cpu_model = row.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "PSMs/s", "cores": cores, "cpu": cpu_model,
             "kind": "reference" if kind == "ref" else "port",
             "sample": "%d PSMs (first %d of rank 0's batch x %d) in %d slices, one thread each, %.1f s"
                       % (n, n // reps, reps, cores, dt),
