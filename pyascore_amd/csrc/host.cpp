@@ -33,12 +33,12 @@ void pya_score_table_extend(float mz_error, uint32_t n_top, uint32_t n_to, std::
                             std::vector<uint32_t> &off);
 extern "C" {
 size_t pya_bin_lds_bytes(uint32_t cap);
-size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl);
+size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact);
 size_t pya_localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
 int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t prefix,
-                     uint32_t with_nl, hipStream_t stream);
+                     uint32_t with_nl, uint32_t compact, hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap,
                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
                         uint32_t plain, hipStream_t stream);
@@ -246,6 +246,7 @@ struct Bucket {
         return 2u * per_sig > want ? 2u * per_sig : want;
     }
     uint32_t n_types = 1, k_max = 1;
+    uint32_t z_max = 1;                 /* largest fragment charge in the bucket */
     uint32_t push_max = 1;              /* largest k * (n_sites - k): single-move competitors of one PSM */
     uint32_t push_cap() const {
         uint32_t v = (push_max + 7u) & ~7u;
@@ -833,6 +834,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             bk.n_types = n_types;
             bk.k_max = std::max<uint32_t>(bk.k_max, (uint32_t)k);
             bk.push_max = std::max<uint32_t>(bk.push_max, (uint32_t)k * (ns - (uint32_t)k));
+            bk.z_max = std::max<uint32_t>(bk.z_max, (uint32_t)z);
         } else {
             Bucket &bk = p->buckets[0];                 /* unambiguous / empty: cheapest launch */
             bk.general_ids.push_back((uint32_t)i);
@@ -1057,7 +1059,10 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     for (const pya_plan::IdList &l : p->score_lists) {
         /* classes with C(n,k) > 64 share the walk over the first sites between signatures */
         const uint32_t prefix = (p->buckets[l.ncls].n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
-        e = pya_launch_score(&d, p->d_score_ids.p + l.off, l.n, l.cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, st);
+        /* every PSM of the class on the straight-line walker: compact prefix entries */
+        const uint32_t compact = (h->cfg.n_nl == 0 && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 &&
+                                  p->buckets[l.ncls].z_max == 1) ? 1u : 0u;
+        e = pya_launch_score(&d, p->d_score_ids.p + l.off, l.n, l.cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact, st);
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));

@@ -42,6 +42,16 @@ struct PrefixState {
     uint64_t ha, hb, hc;        /* rank counts of the prefix, 16-bit fields */
 };
 
+/* the same for the straight-line walker (no neutral losses, charge 1, one ion type per direction):
+ * a direction's prefix has at most 63 fragments, so the ten rank counts fit 8-bit fields that add
+ * without unpacking, and the entry shrinks from 40 to 16 bytes -- this kernel's speed follows its
+ * occupancy, and with 2 x 64 entries per wave LDS is what limits it */
+struct PrefixCompact {
+    float running;
+    uint32_t hi;                /* ranks 8, 9 */
+    uint64_t lo;                /* ranks 0..7 */
+};
+
 /* PREFIX is a template parameter so that the small-C(n,k) instantiation does not carry the
  * registers of the shared-prefix path (60 vs 77 VGPRs = 8 vs 6 waves per SIMD). */
 #ifndef SCORE_WAVES
@@ -49,7 +59,8 @@ struct PrefixState {
 #endif
 template <bool PREFIX>
 __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
-                                                                  uint32_t n_ids, uint32_t cap, uint32_t with_nl) {
+                                                                  uint32_t n_ids, uint32_t cap, uint32_t with_nl,
+                                                                  uint32_t compact) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
@@ -70,7 +81,8 @@ __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(B
         resn = (uint8_t *)(nl_uniq + PYA_MAX_UNIQ);
         tail = resn + 64;
     }
-    PrefixState *pre = (PrefixState *)tail;                     /* [2][64], only if PREFIX */
+    PrefixState *pre = (PrefixState *)tail;                     /* [2][64], only if PREFIX ... */
+    PrefixCompact *prc = (PrefixCompact *)tail;                 /* ... or this when `compact`  */
 
     if (b.status[psm] != PYA_ST_OK) return;
     const uint32_t N = b.n_sig[psm];
@@ -129,18 +141,29 @@ __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(B
             hist_clear(env);
             if (simple) walk_simple_range(env, tab, pmask, dir, true, 0, stop[dir], st);
             else walk_range(env, tab, pmask, dir, true, 0, stop[dir], st, nf);
-            PrefixState ps;
-            ps.running = st.running;
-            ps.nl_state = st.nl_state;
-            ps.nfrag = nf;                                  /* simple mode counts steps instead */
-            ps.pad = 0;
-            uint64_t hw[3] = {0ull, 0ull, 0ull};
+            if (compact) {
+                PrefixCompact pc;
+                pc.running = st.running;
+                uint64_t lo = 0ull;
 #pragma unroll
-            for (int d = 0; d < PYA_NTOP; d++) hw[d >> 2] |= (uint64_t)hist_count(cnt, lane, d) << ((d & 3) * 16);
-            ps.ha = hw[0];
-            ps.hb = hw[1];
-            ps.hc = hw[2];
-            pre[dir * 64 + lane] = ps;
+                for (int d = 0; d < 8; d++) lo |= (uint64_t)hist_count(cnt, lane, d) << (d * 8);
+                pc.lo = lo;
+                pc.hi = hist_count(cnt, lane, 8) | (hist_count(cnt, lane, 9) << 8);
+                prc[dir * 64 + lane] = pc;
+            } else {
+                PrefixState ps;
+                ps.running = st.running;
+                ps.nl_state = st.nl_state;
+                ps.nfrag = nf;                              /* simple mode counts steps instead */
+                ps.pad = 0;
+                uint64_t hw[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+                for (int d = 0; d < PYA_NTOP; d++) hw[d >> 2] |= (uint64_t)hist_count(cnt, lane, d) << ((d & 3) * 16);
+                ps.ha = hw[0];
+                ps.hb = hw[1];
+                ps.hc = hw[2];
+                pre[dir * 64 + lane] = ps;
+            }
         }
         wave_lds_sync();
     }
@@ -150,6 +173,8 @@ __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(B
         const uint64_t bits = active ? order[s] : 0ull;
         const uint64_t resmask = deposit_sites(bits, res.site_mask);
         Hist ph = {0ull, 0ull, 0ull};                       /* counts inherited from the prefix table */
+        uint64_t p8lo = 0ull;                               /* (compact form: 8-bit fields) */
+        uint32_t p8hi = 0u;
         uint32_t nfrag = 0;
         hist_clear(env);
         if (shared) {
@@ -157,12 +182,21 @@ __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(B
                 if (dir == 0 ? !has_f : !has_b) continue;
                 const uint32_t pat = dir == 0 ? (uint32_t)(bits & 63ull)
                                               : (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 63ull);
-                const PrefixState ps = pre[dir * 64 + pat];
-                WalkState st = {ps.running, ps.nl_state};
-                ph.a += ps.ha;
-                ph.b += ps.hb;
-                ph.c += ps.hc;
-                nfrag += ps.nfrag;
+                WalkState st = {0.f, 0u};
+                if (compact) {
+                    const PrefixCompact pc = prc[dir * 64 + pat];
+                    st.running = pc.running;
+                    p8lo += pc.lo;                           /* fields stay below 256: <= 63 per direction */
+                    p8hi += pc.hi;
+                } else {
+                    const PrefixState ps = pre[dir * 64 + pat];
+                    st.running = ps.running;
+                    st.nl_state = ps.nl_state;
+                    ph.a += ps.ha;
+                    ph.b += ps.hb;
+                    ph.c += ps.hc;
+                    nfrag += ps.nfrag;
+                }
                 if (simple) walk_simple_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, st);
                 else walk_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, st, nfrag);
             }
@@ -191,7 +225,8 @@ __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(B
             uint32_t acc = 0;
 #pragma unroll
             for (int d = 0; d < PYA_NTOP; d++) {
-                acc += hist_count(cnt, lane, d) + (split ? hist_count(cnt, lane + 32, d) : 0u) + hist_get(ph, d);
+                acc += hist_count(cnt, lane, d) + (split ? hist_count(cnt, lane + 32, d) : 0u) + hist_get(ph, d) +
+                       (d < 8 ? (uint32_t)(p8lo >> (d * 8)) & 0xffu : (p8hi >> ((d - 8) * 8)) & 0xffu);
                 cum[d] = acc;
             }
             float ws = -1.f;
@@ -220,16 +255,17 @@ __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(B
     if (__any(lut_fail) && lane == 0) b.status[psm] = PYA_ST_LUT_RANGE;
 }
 
-extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl) {
+extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact) {
     return PYA_GRID_CELLS * 2 + PYA_NTOP / 2 * 64 * 4 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8 +
-           (with_nl ? 512 + PYA_MAX_UNIQ * 4 + 64 : 0) + (prefix ? 2 * 64 * sizeof(PrefixState) : 0) + 64;
+           (with_nl ? 512 + PYA_MAX_UNIQ * 4 + 64 : 0) + (prefix ? 2 * 64 * (compact ? sizeof(PrefixCompact) : sizeof(PrefixState)) : 0) + 64;
 }
 
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
-                                uint32_t prefix, uint32_t with_nl, hipStream_t stream) {
+                                uint32_t prefix, uint32_t with_nl, uint32_t compact, hipStream_t stream) {
     if (n_ids == 0) return 0;
     /* spectra near the 8192-peak limit need more than the default 64 KB of dynamic LDS */
-    const size_t lds = pya_score_lds_bytes(cap, prefix, with_nl);
+    if (!prefix) compact = 0;
+    const size_t lds = pya_score_lds_bytes(cap, prefix, with_nl, compact);
     hipError_t e = prefix ? hipFuncSetAttribute((const void *)pya_score_signatures_kernel<true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                           : hipFuncSetAttribute((const void *)pya_score_signatures_kernel<false>,
@@ -237,9 +273,9 @@ extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32
     if (e != hipSuccess) return (int)e;
     if (prefix)
         hipLaunchKernelGGL(pya_score_signatures_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                           cap, with_nl);
+                           cap, with_nl, compact);
     else
         hipLaunchKernelGGL(pya_score_signatures_kernel<false>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                           cap, with_nl);
+                           cap, with_nl, compact);
     return (int)hipGetLastError();
 }
