@@ -106,45 +106,61 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     STAMP(b, 20);
 
     /* ---- sort (cpp/Ascore.cpp:141-146) ---- */
-    SortLds srt;
-    srt.key = (float *)lds.scratch;
-    srt.idx = (uint16_t *)(srt.key + N);
-    srt.lpos = srt.idx + N;
-    srt.rpos = srt.lpos + N;
-    for (int i = lane; i < N; i += 64) {
-        srt.key[i] = ws[i];
-        srt.idx[i] = (uint16_t)i;
-    }
     if (lane == 0) *lds.n_pushed = 0;
     lds.site_max[lane] = 0;
     lds.site_tie[lane] = 0;
     lds.site_alt[lane] = 0ull;
-    wave_lds_sync();
-    /* only the left spine of the partition tree decides the front element; the full sort is
-     * needed when the caller wants the whole ordering */
-    STAMP(b, 21);
-    if (!(b.debug & 8)) {
-        if (sort_introsort_loop<PLAIN>(srt, N, b.keep == 0)) return true;
-    }
-    STAMP(b, 22);
-
-    /* front of the sorted list = left-most maximum of the partitioned array */
+    /* The winner is the front of the sorted list: the largest PepScore, and among equal ones
+     * whichever std::sort leaves first.  When the maximum is unique (4 PSMs in 5) no emulation is
+     * needed to name it. */
+    const float ws_lane = lane < N ? ws[lane] : 0.f;       /* the first 64 scores stay in a register */
     uint32_t kmax = 0;
     for (int i = lane; i < N; i += 64) {
-        uint32_t u = __float_as_uint(srt.key[i]);          /* scores are >= 0: bit order = value order */
+        const uint32_t u = __float_as_uint(i < 64 ? ws_lane : ws[i]);   /* scores are >= 0: bit order = value order */
         kmax = u > kmax ? u : kmax;
     }
     kmax = wave_max_u32(kmax);
-    uint32_t first_pos = 0xffffffffu;
-    for (int i = lane; i < N; i += 64)
-        if (__float_as_uint(srt.key[i]) == kmax) first_pos = first_pos < (uint32_t)i ? first_pos : (uint32_t)i;
-    first_pos = wave_min_u32(first_pos);
-    const uint32_t best_i = srt.idx[first_pos];
+    int n_max = 0;
+    uint32_t first_max = 0xffffffffu;
+    for (int i = lane; i < N; i += 64) {
+        if (__float_as_uint(i < 64 ? ws_lane : ws[i]) == kmax) {
+            n_max++;
+            first_max = first_max < (uint32_t)i ? first_max : (uint32_t)i;
+        }
+    }
+    n_max = wave_sum_i32(n_max);
+    first_max = wave_min_u32(first_max);
+    uint32_t best_i = first_max;
+    STAMP(b, 21);
+    if (n_max != 1 || b.keep || (b.debug & 1024)) {
+        SortLds srt;
+        srt.key = (float *)lds.scratch;
+        srt.idx = (uint16_t *)(srt.key + N);
+        srt.lpos = srt.idx + N;
+        srt.rpos = srt.lpos + N;
+        for (int i = lane; i < N; i += 64) {
+            srt.key[i] = i < 64 ? ws_lane : ws[i];
+            srt.idx[i] = (uint16_t)i;
+        }
+        wave_lds_sync();
+        /* only the left spine of the partition tree decides the front element; the full sort is
+         * needed when the caller wants the whole ordering */
+        if (!(b.debug & 8)) {
+            if (sort_introsort_loop<PLAIN>(srt, N, b.keep == 0)) return true;
+        }
+        /* front of the sorted list = left-most maximum of the partitioned array */
+        uint32_t first_pos = 0xffffffffu;
+        for (int i = lane; i < N; i += 64)
+            if (__float_as_uint(srt.key[i]) == kmax) first_pos = first_pos < (uint32_t)i ? first_pos : (uint32_t)i;
+        first_pos = wave_min_u32(first_pos);
+        best_i = srt.idx[first_pos];
+        if (b.keep) {
+            for (int i = lane; i < N; i += 64) b.sorted_idx[s0 + sort_final_pos(srt, i, N)] = srt.idx[i];
+        }
+    }
+    STAMP(b, 22);
     const float best_ws = __uint_as_float(kmax);
     const uint64_t best_bits = order[best_i];
-    if (b.keep) {
-        for (int i = lane; i < N; i += 64) b.sorted_idx[s0 + sort_final_pos(srt, i, N)] = srt.idx[i];
-    }
     wave_lds_sync();
 
     STAMP(b, 23);

@@ -14,12 +14,13 @@ from pyascore_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["lean_localize", "general_localize", "lean_declines"])
+@pytest.fixture(params=["lean_localize", "general_localize", "lean_declines", "always_sort"])
 def path(request, monkeypatch):
-    """Batches run three times: plain PSMs (no neutral losses, fragment charge 1) on the lean
+    """Batches run four times: plain PSMs (no neutral losses, fragment charge 1) on the lean
     instantiation of the localize kernel (default); every PSM on the general instantiation
-    (PYA_NO_PLAIN=1); and with the lean instantiation declining every PSM (PYA_DEBUG=512), which
-    sends them through its hand-over list to the general one."""
+    (PYA_NO_PLAIN=1); with the lean instantiation declining every PSM (PYA_DEBUG=512), which
+    sends them through its hand-over list to the general one; and with the std::sort emulation
+    run even where a unique best PepScore makes it unnecessary (PYA_DEBUG=1024)."""
     monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
     monkeypatch.setenv("PYA_PLAIN_MIN", "0")       # batches under 512 PSMs skip the lean kernel by default
@@ -27,6 +28,8 @@ def path(request, monkeypatch):
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
     elif request.param == "lean_declines":
         monkeypatch.setenv("PYA_DEBUG", "512")
+    elif request.param == "always_sort":
+        monkeypatch.setenv("PYA_DEBUG", "1024")
     return request.param
 
 
