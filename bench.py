@@ -105,7 +105,15 @@ def cpu_baseline(batch, settings, target_seconds=12.0):
     t = time.perf_counter()
     scorers[0].score_batch(slice_batch(batch, 0, n1), k)
     dt1 = time.perf_counter() - t
-    want = rate1 * cores * target_seconds * 2 / 3            # PSMs for the all-core leg
+    # all-core rate from a short probe first (64 threads rarely scale 64x: memory-bound slices)
+    probe_all = int(min(batch["n_psm"], cores * 64))
+    pc = [probe_all * i // cores for i in range(cores + 1)]
+    t = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda i: scorers[i].score_batch(slice_batch(batch, pc[i], pc[i + 1]), k) if pc[i + 1] > pc[i]
+                    else None, range(cores)))
+    rate_all = probe_all / max(time.perf_counter() - t, 1e-9)
+    want = max(rate_all, rate1) * target_seconds * 2 / 3     # PSMs for the all-core leg
     n = int(min(batch["n_psm"], max(probe, want)))
     reps = max(1, int(round(want / n)))                      # small batches are scored several times over
     cuts = [n * i // cores for i in range(cores + 1)]
