@@ -4,7 +4,7 @@
 #define PYA_BIN_CORE_H
 #include "device_common.hip.h"
 
-/* LDS bytes the binning stage needs for a spectrum of up to `cap` peaks (cap multiple of 64) */
+/* LDS bytes the binning stage needs for a spectrum of up to `cap` peaks (cap multiple of 32) */
 DEV size_t bin_lds_bytes(uint32_t cap) { return (size_t)cap * (8 + 4 + 2 + 1); }
 
 /* ---------------------------------------------------------------------------------------

@@ -852,7 +852,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     p->sig_off[n] = sig_total;
     p->total_sigs = sig_total;
     p->max_k = max_k;
-    p->peak_cap = (max_P + 63u) & ~63u;
+    p->peak_cap = (max_P + 31u) & ~31u;
     {
         /* peak classes: the median, 90th and 99th percentile and the maximum of the peak counts,
          * rounded up to 32 (one class for small batches) */
