@@ -167,6 +167,7 @@ struct pya_handle {
     /* device allocations recycled between pya_score_batch calls (hipMalloc/hipFree of a few
      * hundred MB cost milliseconds) */
     DevBuf<unsigned char> spare_arena;
+    DevBuf<double> io_buf;                     /* spectra of big pya_score_batch calls (uploaded by a helper thread) */
     std::vector<unsigned char> stage;          /* host staging of small batches: one copy each way */
 
     std::string err;
@@ -654,6 +655,7 @@ namespace {
 struct IoReq {                       /* pya_score_batch: spectra and results live in the plan's arena too */
     const double *mz, *inten;
     uint32_t max_k;
+    double *d_mz_ext, *d_inten_ext;  /* ... unless the caller uploads the spectra itself (big batches) */
 };
 }
 
@@ -945,8 +947,9 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
             o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
-        const size_t o_mz = io ? meta(io->mz + peak_base, (size_t)p->total_peaks * 8) : 0,
-                     o_inten = io ? meta(io->inten + peak_base, (size_t)p->total_peaks * 8) : 0;
+        const bool own_spectra = io && !io->d_mz_ext;
+        const size_t o_mz = own_spectra ? meta(io->mz + peak_base, (size_t)p->total_peaks * 8) : 0,
+                     o_inten = own_spectra ? meta(io->inten + peak_base, (size_t)p->total_peaks * 8) : 0;
         const size_t h2d_bytes = total;
         p->o_status = reserve(n * 4);
         if (io) {
@@ -983,8 +986,13 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         for (int i = 0; i < kNumBuckets; i++)
             p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
         if (io) {
-            p->d_mz.adopt(base + o_mz, (size_t)p->total_peaks);
-            p->d_inten.adopt(base + o_inten, (size_t)p->total_peaks);
+            if (own_spectra) {
+                p->d_mz.adopt(base + o_mz, (size_t)p->total_peaks);
+                p->d_inten.adopt(base + o_inten, (size_t)p->total_peaks);
+            } else {
+                p->d_mz.adopt(io->d_mz_ext, (size_t)p->total_peaks);
+                p->d_inten.adopt(io->d_inten_ext, (size_t)p->total_peaks);
+            }
             p->d_best_score.adopt(base + p->o_best_score, n);
             p->d_best_sig.adopt(base + p->o_best_sig, n);
             p->d_n_sig_out.adopt(base + p->o_n_sig_out, n);
@@ -1158,9 +1166,33 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
         t0 = t1;
     };
     pya_plan *p = nullptr;
-    const IoReq io = {mz, inten, out->max_k};
+    IoReq io = {mz, inten, out->max_k, nullptr, nullptr};
+    /* Big batches: the spectra (16 bytes per peak, PCIe-bound) go up on a helper thread while this
+     * one runs the host pre-pass of the plan; small ones ride in the plan's single staged copy. */
+    const int64_t peaks_lo = b->peak_off[0], n_peaks = b->peak_off[b->n_psm] - peaks_lo;
+    std::thread uploader;
+    hipError_t up_err = hipSuccess;
+    if (n_peaks > 0 && (size_t)n_peaks * 16 > kStageLimit && !std::getenv("PYA_NO_UPLOAD_THREAD")) {
+        HIPCHK(h, hipSetDevice(h->device));
+        if (h->io_buf.n < (size_t)n_peaks * 2) HIPCHK(h, h->io_buf.alloc((size_t)n_peaks * 2));
+        io.d_mz_ext = h->io_buf.p;
+        io.d_inten_ext = h->io_buf.p + n_peaks;
+        const int device = h->device;
+        uploader = std::thread([&, device]() {
+            up_err = hipSetDevice(device);
+            if (up_err == hipSuccess)
+                up_err = hipMemcpy(io.d_mz_ext, mz + peaks_lo, (size_t)n_peaks * 8, hipMemcpyHostToDevice);
+            if (up_err == hipSuccess)
+                up_err = hipMemcpy(io.d_inten_ext, inten + peaks_lo, (size_t)n_peaks * 8, hipMemcpyHostToDevice);
+        });
+    }
     int rc = plan_create_impl(h, b, flags & ~PYA_FLAG_TIMING, &io, &p);
+    if (uploader.joinable()) uploader.join();
     if (rc) return rc;
+    if (up_err != hipSuccess) {
+        pya_plan_destroy(p);
+        return h->hip_fail(up_err, "spectrum upload");
+    }
     std::unique_ptr<pya_plan, void (*)(pya_plan *)> guard(p, pya_plan_destroy);
     lap("plan + h2d");
     const uint64_t n = b->n_psm;
