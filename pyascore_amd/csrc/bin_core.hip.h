@@ -14,61 +14,90 @@ DEV size_t bin_lds_bytes(uint32_t cap) { return (size_t)cap * (8 + 4 + 2 + 1); }
  * serially by one lane on an index array; keys are read through the indices.  comp(a, b) =
  * intensity[a] > intensity[b].
  * ------------------------------------------------------------------------------------- */
-struct RunArr {
-    uint16_t *idx;          /* [len] permutation of 0..len-1 */
-    const double *key;      /* [len] intensities of the window's peaks in input order */
+/* Two element stores:
+ *   RunDirect   -- (intensity, index) pairs permuted in place (the window's slice of the LDS
+ *                  intensity array plus a parallel index array): one LDS read per key;
+ *   RunIndirect -- only an index list is permuted, keys are read through it (windows whose peaks
+ *                  are scattered over the spectrum: unordered input). */
+struct RunElem {
+    double k;
+    uint16_t i;
 };
-DEV double run_key(const RunArr &r, int pos) { return r.key[r.idx[pos]]; }
-DEV void run_swap(const RunArr &r, int a, int b) {
-    const uint16_t t = r.idx[a];
-    r.idx[a] = r.idx[b];
-    r.idx[b] = t;
+struct RunDirect {
+    double *key;            /* [len] */
+    uint16_t *idx;          /* [len] */
+    DEV double k(int pos) const { return key[pos]; }
+    DEV RunElem get(int pos) const { return {key[pos], idx[pos]}; }
+    DEV void put(int pos, const RunElem &e) const {
+        key[pos] = e.k;
+        idx[pos] = e.i;
+    }
+    DEV uint16_t id(int pos) const { return idx[pos]; }
+};
+struct RunIndirect {
+    uint16_t *idx;          /* [len] peak indices */
+    const double *key;      /* the spectrum's intensities */
+    DEV double k(int pos) const { return key[idx[pos]]; }
+    DEV RunElem get(int pos) const {
+        const uint16_t i = idx[pos];
+        return {key[i], i};
+    }
+    DEV void put(int pos, const RunElem &e) const { idx[pos] = e.i; }
+    DEV uint16_t id(int pos) const { return idx[pos]; }
+};
+template <class R>
+DEV void run_swap(const R &r, int a, int b) {
+    const RunElem x = r.get(a), y = r.get(b);
+    r.put(a, y);
+    r.put(b, x);
 }
-/* __adjust_heap + __push_heap on [first, first+len), value = element index v */
-DEV void run_heap_adjust(const RunArr &r, int first, int hole, int len, uint16_t v) {
-    const double vk = r.key[v];
+/* __adjust_heap + __push_heap on [first, first+len) */
+template <class R>
+DEV void run_heap_adjust(const R &r, int first, int hole, int len, const RunElem &v) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (run_key(r, first + child) > run_key(r, first + child - 1)) child--;
-        r.idx[first + hole] = r.idx[first + child];
+        if (r.k(first + child) > r.k(first + child - 1)) child--;
+        r.put(first + hole, r.get(first + child));
         hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2) {
         child = 2 * (child + 1);
-        r.idx[first + hole] = r.idx[first + child - 1];
+        r.put(first + hole, r.get(first + child - 1));
         hole = child - 1;
     }
     int parent = (hole - 1) / 2;
-    while (hole > top && run_key(r, first + parent) > vk) {
-        r.idx[first + hole] = r.idx[first + parent];
+    while (hole > top && r.k(first + parent) > v.k) {
+        r.put(first + hole, r.get(first + parent));
         hole = parent;
         parent = (hole - 1) / 2;
     }
-    r.idx[first + hole] = v;
+    r.put(first + hole, v);
 }
 /* __heap_select(first, middle, last) */
-DEV void run_heap_select(const RunArr &r, int first, int middle, int last) {
+template <class R>
+DEV void run_heap_select(const R &r, int first, int middle, int last) {
     const int len = middle - first;
     if (len >= 2) {
         for (int parent = (len - 2) / 2;; parent--) {
-            run_heap_adjust(r, first, parent, len, r.idx[first + parent]);
+            run_heap_adjust(r, first, parent, len, r.get(first + parent));
             if (parent == 0) break;
         }
     }
     for (int i = middle; i < last; i++) {
-        if (run_key(r, i) > run_key(r, first)) {             /* __pop_heap(first, middle, i) */
-            const uint16_t v = r.idx[i];
-            r.idx[i] = r.idx[first];
+        if (r.k(i) > r.k(first)) {                            /* __pop_heap(first, middle, i) */
+            const RunElem v = r.get(i);
+            r.put(i, r.get(first));
             run_heap_adjust(r, first, 0, len, v);
         }
     }
 }
 /* __unguarded_partition_pivot(f, l) */
-DEV int run_partition(const RunArr &r, int f, int l) {
+template <class R>
+DEV int run_partition(const R &r, int f, int l) {
     const int mid = f + (l - f) / 2;
-    const double a = run_key(r, f + 1), b = run_key(r, mid), c = run_key(r, l - 1);
+    const double a = r.k(f + 1), b = r.k(mid), c = r.k(l - 1);
     int pick;
     if (a > b) {
         if (b > c) pick = mid;
@@ -78,37 +107,35 @@ DEV int run_partition(const RunArr &r, int f, int l) {
     else if (b > c) pick = l - 1;
     else pick = mid;
     run_swap(r, f, pick);
-    const double pv = run_key(r, f);
+    const double pv = r.k(f);
     int lo = f + 1, hi = l;
     for (;;) {
-        while (run_key(r, lo) > pv) lo++;
+        while (r.k(lo) > pv) lo++;
         hi--;
-        while (pv > run_key(r, hi)) hi--;
+        while (pv > r.k(hi)) hi--;
         if (!(lo < hi)) return lo;
         run_swap(r, lo, hi);
         lo++;
     }
 }
 /* stable insertion sort of positions [first, last): what __insertion_sort leaves */
-DEV void run_insertion_sort(const RunArr &r, int first, int last) {
+template <class R>
+DEV void run_insertion_sort(const R &r, int first, int last) {
     for (int i = first + 1; i < last; i++) {
-        const uint16_t v = r.idx[i];
-        const double vk = r.key[v];
+        const RunElem v = r.get(i);
         int j = i - 1;
-        while (j >= first && vk > run_key(r, j)) {
-            r.idx[j + 1] = r.idx[j];
+        while (j >= first && v.k > r.k(j)) {
+            r.put(j + 1, r.get(j));
             j--;
         }
-        r.idx[j + 1] = v;
+        r.put(j + 1, v);
     }
 }
-/* Ranks of one window.  r.idx holds the window's peaks in input order as indices into r.key /
- * rank_out (`identity`: they are simply 0..len-1 and are filled in here). */
-DEV void run_exact_ranks(const RunArr &r, int len, uint8_t *rank_out, bool identity) {
-    for (int e = 0; e < len; e++) {
-        if (identity) r.idx[e] = (uint16_t)e;
-        rank_out[r.idx[e]] = PYA_NO_MATCH;
-    }
+/* Ranks of one window whose len elements sit in r in input order: rank_out[element id] = rank
+ * inside the window, PYA_NO_MATCH for the ones that are not retained. */
+template <class R>
+DEV void run_exact_ranks(const R &r, int len, uint8_t *rank_out) {
+    for (int e = 0; e < len; e++) rank_out[r.id(e)] = PYA_NO_MATCH;
     if (len > PYA_NTOP) {                                      /* std::nth_element(begin, begin + 9, end) */
         int first = 0, last = len;
         const int nth = PYA_NTOP - 1;
@@ -132,7 +159,7 @@ DEV void run_exact_ranks(const RunArr &r, int len, uint8_t *rank_out, bool ident
     }
     const int n = len < PYA_NTOP ? len : PYA_NTOP;             /* resize(n_top); std::sort */
     run_insertion_sort(r, 0, n);
-    for (int q = 0; q < n; q++) rank_out[r.idx[q]] = (uint8_t)q;
+    for (int q = 0; q < n; q++) rank_out[r.id(q)] = (uint8_t)q;
 }
 
 /* Bins the spectrum of `psm` (Spectra.cpp:43-68, :24-41).  On return *out_mz / *out_rank point
@@ -236,6 +263,13 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
          * with them the counts of a window no longer add up to len*(len-1)/2, which the check
          * after the sweep notices, and the exact sweep below redoes the spectrum. */
         if (!EXACT) {
+          /* Sweep 0 ranks (strictly-more-intense mates).  Only if its counts reveal equal intensities
+           * somewhere does sweep 1 look where: equal peaks that all rank below the top n_top of
+           * their window are dropped whatever the library calls do with them, so the spectrum is
+           * handed over only when a peak ranked inside the top n_top has an equal (count-like
+           * intensities tie all the time among the weak peaks, hardly ever at the top). */
+          bool hot = false;
+          for (int sweep = 0; sweep < 2; sweep++) {
             int carry_lo = 0, deficit = 0;
             for (int base = 0; base < P; base += 64) {
                 const int i = base + lane;
@@ -266,48 +300,74 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                 const double *src = s_inten + (in ? lo : 0);
                 int cnt = 0;
                 const int t_end = __builtin_amdgcn_readfirstlane(t_max);
+                if (sweep == 0) {
 #pragma unroll 4
-                for (int t = 0; t < t_end; t++) {
-                    const double o = src[t];                      /* unconditional: no branch around the read */
-                    cnt += (int)((t < len) & (o > me));
+                    for (int t = 0; t < t_end; t++) {
+                        const double o = src[t];                  /* unconditional: no branch around the read */
+                        cnt += (int)((t < len) & (o > me));
+                    }
+                    deficit += in ? (len - 1) - 2 * cnt : 0;
+                    if (in) s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
+                } else {
+#pragma unroll 4
+                    for (int t = 0; t < t_end; t++) {
+                        const double o = src[t];
+                        cnt += (int)((t < len) & (o == me));      /* counts the peak itself too */
+                    }
+                    hot = hot || (in && s_rank[i] < PYA_NTOP && cnt > 1);
                 }
-                deficit += in ? (len - 1) - 2 * cnt : 0;
-                if (in) s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
             }
-            if (wave_sum_i32(deficit) != 0) return PYA_BIN_REDO;   /* equal intensities somewhere */
+            if (sweep == 0) {
+                if (wave_sum_i32(deficit) == 0) break;            /* no two equal intensities in any window */
+            } else if (__any(hot)) {
+                return PYA_BIN_REDO;                              /* a tie inside some window's top n_top */
+            }
+          }
         }
         if (!EXACT) {
         } else if (!unsorted) {
-            /* equal intensities in some window: which of them are retained, and in which rank
-             * order, is whatever std::nth_element + std::sort leave.  The lane of a window's first
-             * peak emulates them serially on the window's slice of s_bin (constant inside a run,
-             * so it doubles as the index array and is put back afterwards). */
-            for (int base = 0; base < P; base += 64) {
-                const int i = base + lane;
-                const bool in = i < P;
-                const uint32_t w = in ? (uint32_t)s_bin[i] : 0x10000u;
-                const uint32_t pw = (in && i > 0) ? (uint32_t)s_bin[i - 1] : 0x10001u;
-                const bool start = in && pw != w;
-                const uint64_t starts = __ballot(start);
-                const uint64_t gt = starts & ~(lanemask_lt() | (1ull << lane));
-                int run_end = P - 1;
-                for (int nb = base + 64; nb < P; nb += 64) {
-                    const int j = nb + lane;
-                    const uint64_t m2 = __ballot(j < P && s_bin[j] != s_bin[j - 1]);
-                    if (m2) {
-                        run_end = nb + __builtin_ctzll(m2) - 1;
+            /* Which equally intense peaks of a window are retained, and in which rank order, is
+             * whatever std::nth_element + std::sort leave: one lane per window emulates them
+             * serially on the window's (intensity, index) pairs in place -- up to 64 windows at a
+             * time, so the serial chains of a spectrum's windows run side by side. */
+            uint16_t *run_lo = (uint16_t *)(lds + (size_t)cap * 15);   /* [66] window starts of a round */
+            int scan = 0;
+            while (scan < P) {
+                int cnt = 0;
+                const int first = scan;
+                while (scan < P && cnt <= 64) {                  /* 64 windows and the start of the 65th */
+                    const int i = scan + lane;
+                    const bool start = i < P && (i == first || s_bin[i] != s_bin[i - 1]);
+                    const uint64_t m = __ballot(start);
+                    const int here = __popcll(m);
+                    if (start) {
+                        const int r = cnt + __popcll(m & lanemask_lt());
+                        if (r <= 64) run_lo[r] = (uint16_t)i;
+                    }
+                    if (cnt + here > 64) {
+                        /* the 65th start (rank 64) closes the round: the next one resumes there */
+                        uint64_t mm = m;
+                        for (int q = 0; q < 64 - cnt; q++) mm &= mm - 1;
+                        scan += __builtin_ctzll(mm);
+                        cnt = 64;
                         break;
                     }
+                    cnt += here;
+                    scan += 64;
                 }
-                const int hi = gt ? base + __builtin_ctzll(gt) - 1 : run_end;
+                if (scan >= P) {
+                    scan = P;
+                    if (lane == 0 && cnt <= 64) run_lo[cnt] = (uint16_t)P;   /* the last window ends with the spectrum */
+                }
+                if (cnt > 64) cnt = 64;
                 wave_lds_sync();
-                if (start) {
-                    const int len = hi - i + 1;
-                    RunArr r;
-                    r.idx = s_bin + i;
-                    r.key = s_inten + i;
-                    run_exact_ranks(r, len, s_rank + i, true);
-                    for (int e = 0; e < len; e++) s_bin[i + e] = (uint16_t)w;
+                if (lane < cnt) {
+                    const int lo = run_lo[lane], len = (int)run_lo[lane + 1] - lo;
+                    RunDirect r;
+                    r.key = s_inten + lo;
+                    r.idx = s_bin + lo;
+                    for (int e = 0; e < len; e++) r.idx[e] = (uint16_t)e;
+                    run_exact_ranks(r, len, s_rank + lo);
                 }
                 wave_lds_sync();
             }
@@ -368,10 +428,10 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                     }
                     const int hi = gt ? base + __builtin_ctzll(gt) - 1 : run_end;
                     if (start) {
-                        RunArr r;
+                        RunIndirect r;
                         r.idx = list + q;
                         r.key = s_inten;
-                        run_exact_ranks(r, hi - q + 1, s_rank, false);
+                        run_exact_ranks(r, hi - q + 1, s_rank);
                     }
                 }
                 __threadfence();

@@ -95,11 +95,11 @@ extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t
  * zeroed before the first of them) */
 extern "C" int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream) {
     if (n_total == 0) return 0;
-    const size_t per_wave = (((size_t)cap * 15 + 63) & ~(size_t)63);
+    const size_t per_wave = (((size_t)cap * 15 + 63) & ~(size_t)63) + 192;      /* + the round's window starts */
     hipError_t e = hipFuncSetAttribute((const void *)pya_bin_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)per_wave);
     if (e != hipSuccess) return (int)e;
-    const uint32_t grid = n_total < 1024u ? n_total : 1024u;
+    const uint32_t grid = n_total < 16384u ? n_total : 16384u;   /* all spectra may need it (count-like intensities) */
     hipLaunchKernelGGL(pya_bin_exact_kernel, dim3(grid), dim3(64), per_wave, stream, *b, cap);
     return (int)hipGetLastError();
 }

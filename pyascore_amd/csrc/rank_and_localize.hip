@@ -347,7 +347,7 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     e = hipFuncSetAttribute((const void *)pya_localize_redo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
     if (e != hipSuccess) return (int)e;
-    const uint32_t grid = n_ids < 1024u ? n_ids : 1024u;
+    const uint32_t grid = n_ids < 8192u ? n_ids : 8192u;
     hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, push_cap, pos_cap, pool_cap,
                        sb, gtp);
     return (int)hipGetLastError();
