@@ -90,7 +90,12 @@ struct BatchDev {
     uint64_t *alt_mask;
     uint32_t max_k;
     uint32_t keep;                  /* write rec / sorted_idx                               */
-    uint32_t debug;                 /* PYA_DEBUG ablation bits (timing experiments only)    */
+    /* PYA_DEBUG bits.  Ablation, results become meaningless: 1 no site-determining ions, 4 no prefix
+     * tables, 8 no sort emulation, 16 no competitors, 32 no window ranking, 64 no compaction.
+     * Route selection, results stay exact (used by the tests): 128 every spectrum through
+     * pya_bin_exact_kernel, 512 the lean localize instantiation declines every PSM, 1024 the
+     * std::sort emulation runs even for a unique best PepScore. */
+    uint32_t debug;
     unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */
 };
 
