@@ -48,10 +48,10 @@ def profiled_traffic(cfg, kernel, default_size):
     import csv
     import glob
     if not default_size:
-        return None, None
+        return None, None, None
     dirs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_" + cfg)))
     if not dirs:
-        return None, None
+        return None, None, None
     path = os.path.join(dirs[-1], "pmc_summary.csv")
     vals = {}
     try:
@@ -60,10 +60,14 @@ def profiled_traffic(cfg, kernel, default_size):
                 if row["kernel"] == kernel:
                     vals[row["counter"]] = float(row["mean_value"])
     except OSError:
-        return None, None
+        return None, None, None
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None, None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+        return None, None, None
+    valu = None
+    if vals.get("SQ_BUSY_CYCLES") and "SQ_INSTS_VALU" in vals:
+        # a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; 1024 SIMDs, 32 shader engines
+        valu = vals["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (vals["SQ_BUSY_CYCLES"] / 32.0)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT), valu
 
 
 def achievable_hbm_gbs(torch, dev, nbytes=1 << 30, reps=5):
@@ -242,7 +246,7 @@ def main():
         host_rate = batch["n_psm"] / (time.perf_counter() - t)
         copy_gbs = achievable_hbm_gbs(torch, dev)
         default_size = args.psms is None and args.config != "cfg3"
-        traffic, traffic_src = profiled_traffic(args.config, names[dom], default_size)
+        traffic, traffic_src, valu_share = profiled_traffic(args.config, names[dom], default_size)
         line = {
             "metric": METRIC, "value": world * batch["n_psm"] * args.steps / elapsed, "unit": "PSMs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -258,6 +262,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
+                         # what actually bounds the kernel: share of its cycles in which the vector ALUs issue
+                         "valu_issue_share": valu_share,
                          "algorithmic_bytes_per_launch": alg,
                          "achievable_peak": copy_gbs, "frac_of_achievable": achieved / copy_gbs,
                          "whole_path_gbs": alg / (float(kern_ms.sum()) * 1e-3) / 1e9 if kern_ms.sum() > 0 else 0.0,
