@@ -88,6 +88,7 @@ class PyAscore:
         self.device = int(device)
         self._last = None            # summary of the last score() call
         self._batch_n = None         # PSMs of the batch retained by score_batch(keep=True)
+        self._one = None             # preallocated batch-of-one scaffolding of score()
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -133,16 +134,43 @@ class PyAscore:
         else:
             ap = np.zeros(0, np.uint32)
             am = np.zeros(0, np.float32)
-        batch = dict(
-            n_psm=1, mz=mz_arr, intensity=int_arr, peak_off=np.array([0, mz_arr.size], np.int64),
-            pep=pep, pep_off=np.array([0, pep.size], np.int64),
-            n_of_mod=np.array([n_of_mod], np.int32), max_charge=np.array([max_fragment_charge], np.int32),
-            aux_pos=ap, aux_mass=am, aux_off=np.array([0, ap.size], np.int64))
-        res = self.score_batch(batch, keep=True)
+        # A batch of one through preallocated CSR scaffolding: a per-PSM loop calls this 10^5 times,
+        # and rebuilding a dozen small arrays and two ctypes structures per call costs as much as
+        # the device work.
+        one = self._one
+        k = max(1, int(n_of_mod))
+        if one is None or one["k"] < k:
+            one = dict(k=k, peak_off=np.zeros(2, np.int64), pep_off=np.zeros(2, np.int64),
+                       aux_off=np.zeros(2, np.int64), n_of_mod=np.zeros(1, np.int32),
+                       max_charge=np.zeros(1, np.int32), best_score=np.zeros(1, np.float32),
+                       best_sig=np.zeros(1, np.uint64), n_sig=np.zeros(1, np.int32),
+                       ascores=np.zeros((1, k), np.float32), alt_mask=np.zeros((1, k), np.uint64))
+            one["batch"] = _lib.Batch(1, _as_ptr(one["peak_off"]), None, _as_ptr(one["pep_off"]),
+                                      _as_ptr(one["n_of_mod"]), _as_ptr(one["max_charge"]), None, None,
+                                      _as_ptr(one["aux_off"]))
+            one["results"] = _lib.Results(k, _as_ptr(one["best_score"]), _as_ptr(one["best_sig"]),
+                                          _as_ptr(one["n_sig"]), _as_ptr(one["ascores"]), _as_ptr(one["alt_mask"]))
+            self._one = one
+        one["peak_off"][1] = mz_arr.size
+        one["pep_off"][1] = pep.size
+        one["aux_off"][1] = ap.size
+        one["n_of_mod"][0] = n_of_mod
+        one["max_charge"][0] = max_fragment_charge
+        b = one["batch"]
+        b.pep = pep.ctypes.data
+        b.aux_pos = ap.ctypes.data
+        b.aux_mass = am.ctypes.data
+        one["ascores"][:] = 0
+        one["alt_mask"][:] = 0
+        rc = self._lib.pya_score_batch(self._h, C.byref(b), mz_arr.ctypes.data, int_arr.ctypes.data,
+                                       _lib.PYA_FLAG_KEEP, C.byref(one["results"]))
+        if rc:
+            self._raise(rc)
+        self._batch_n = 1
         self._last = dict(pep=pep, peptide=peptide, k=int(n_of_mod), aux_pos=ap.copy(), aux_mass=am.copy(),
-                          best_score=float(res["best_score"][0]), best_sig=int(res["best_sig"][0]),
-                          n_sig=int(res["n_sig"][0]), ascores=res["ascores"][0].copy(),
-                          alt_mask=res["alt_mask"][0].copy())
+                          best_score=float(one["best_score"][0]), best_sig=int(one["best_sig"][0]),
+                          n_sig=int(one["n_sig"][0]), ascores=one["ascores"][0].copy(),
+                          alt_mask=one["alt_mask"][0].copy())
 
     def score_batch(self, batch, keep=False):
         """Scores a CSR batch (see pyascore_amd.synth) in one call.

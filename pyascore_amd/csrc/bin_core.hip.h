@@ -483,4 +483,25 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     return total;
 }
 
+/* retained table of one spectrum (or its error status) to global memory */
+DEV void bin_store(const BatchDev &b, uint32_t psm, int R, int status, const float *r_mz, const uint8_t *r_rank) {
+    const int lane = lane_id();
+    if (R < 0) {
+        if (lane == 0) {
+            b.status[psm] = status;
+            b.ret_n[psm] = 0;
+        }
+        return;
+    }
+    const int64_t p0 = b.peak_off[psm];
+    for (int i = lane; i < R; i += 64) {
+        b.ret_mz[p0 + i] = r_mz[i];
+        b.ret_rank[p0 + i] = r_rank[i];
+    }
+    if (lane == 0) {
+        b.ret_n[psm] = (uint32_t)R;
+        b.status[psm] = PYA_ST_OK;
+    }
+}
+
 #endif

@@ -20,26 +20,6 @@
 #define BIN_WAVES 4     /* independent spectra per workgroup when LDS allows (no cross-wave sync) */
 #endif
 
-DEV void bin_store(const BatchDev &b, uint32_t psm, int R, int status, const float *r_mz, const uint8_t *r_rank) {
-    const int lane = lane_id();
-    if (R < 0) {
-        if (lane == 0) {
-            b.status[psm] = status;
-            b.ret_n[psm] = 0;
-        }
-        return;
-    }
-    const int64_t p0 = b.peak_off[psm];
-    for (int i = lane; i < R; i += 64) {
-        b.ret_mz[p0 + i] = r_mz[i];
-        b.ret_rank[p0 + i] = r_rank[i];
-    }
-    if (lane == 0) {
-        b.ret_n[psm] = (uint32_t)R;
-        b.status[psm] = PYA_ST_OK;
-    }
-}
-
 __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDev b, const uint32_t *psm_ids,
                                                                          uint32_t n_ids, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];

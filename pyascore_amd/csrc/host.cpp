@@ -42,6 +42,11 @@ int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, u
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap,
                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
                         uint32_t plain, hipStream_t stream);
+size_t pya_tiny_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact, uint32_t push_cap,
+                          uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
+int pya_launch_tiny(const BatchDev *b, uint32_t n_psm, uint32_t cap, uint32_t prefix, uint32_t with_nl,
+                    uint32_t compact, uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
+                    uint32_t sb, uint32_t gtp, hipStream_t stream);
 int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
@@ -53,6 +58,7 @@ namespace {
 const size_t kMaxLds = 160 * 1024;
 const uint32_t kBucketLimits[] = {64, 512, 4096, PYA_MAX_SIGNATURES};
 const int kNumBuckets = 4;
+const uint64_t kTinyBatch = 8;          /* up to this many PSMs go through the fused single-launch kernel */
 const size_t kStageLimit = 1u << 20;   /* batches whose transfers are smaller than this go through one staged copy */
 
 template <typename T>
@@ -1054,6 +1060,31 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     d.alt_mask = o->alt_mask;
     d.max_k = o->max_k;
     const bool timing = p->flags & PYA_FLAG_TIMING;
+    /* a handful of PSMs (PyAscore.score is a batch of one) is launch-bound: one fused launch, one
+     * wavefront per PSM, instead of the five of the three-kernel path (tiny_batch.hip) */
+    if (!timing && p->n_psm <= kTinyBatch && !std::getenv("PYA_NO_TINY")) {
+        Bucket m;                                           /* caps that cover every PSM of the batch */
+        for (const Bucket &bk : p->buckets) {
+            if (bk.ids.empty()) continue;
+            m.n_cap = std::max(m.n_cap, bk.n_cap);
+            m.list_cap = std::max(m.list_cap, bk.list_cap);
+            m.pos_cap = std::max(m.pos_cap, bk.pos_cap);
+            m.n_types = std::max(m.n_types, bk.n_types);
+            m.k_max = std::max(m.k_max, bk.k_max);
+            m.push_max = std::max(m.push_max, bk.push_max);
+            m.z_max = std::max(m.z_max, bk.z_max);
+        }
+        const uint32_t prefix = (m.n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
+        const uint32_t compact = (h->cfg.n_nl == 0 && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 &&
+                                  m.z_max == 1) ? 1u : 0u;
+        int e = pya_launch_tiny(&d, (uint32_t)p->n_psm, p->peak_cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact,
+                                m.push_cap(), m.n_cap, m.pos_cap, m.pool_cap(), m.sb(), m.gtp(), st);
+        if (e) return h->hip_fail((hipError_t)e, "tiny_batch launch");
+        p->last_stream = st;
+        p->ran = true;
+        p->dev = d;
+        return PYA_OK;
+    }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[0], st));
     HIPCHK(h, hipMemsetAsync(d.redo_count, 0, sizeof(uint32_t), st));
     int e = 0;

@@ -18,42 +18,8 @@
  * HBM traffic per PSM: retained table (5 B x R) + peptide bytes + 8 B x C(n,k) signature
  * table (L2 resident, shared by all PSMs of a shape) in; 4 B x C(n,k) weighted scores out.
  */
-#include "device_common.hip.h"
+#include "score_core.hip.h"
 
-DEV float lut_score(const BatchDev &b, uint32_t depth, uint32_t k, uint32_t n) {
-    return b.lut[lut_row(n) + depth * (n + 1) + k];
-}
-
-#include "walk_core.hip.h"
-
-/* With many site assignments most of them agree on the first modifiable residues of a
- * direction, and a fragment's m/z depends only on the pattern of the residues it contains.  So
- * the first PREFIX_SITES sites of each direction are walked once per PATTERN (2^6 = 64 patterns,
- * one per lane) and every signature resumes from its pattern's state (float32 running sum,
- * neutral-loss stack, rank histogram) -- bit-identical to walking from the start, because it IS
- * the same sequence of float additions.  This is the first level of the reference's prefix-
- * sharing fragment tree (cpp/Ascore.cpp:69-109) laid out for a wavefront. */
-#define PREFIX_SITES 6
-struct PrefixState {
-    float running;
-    uint32_t nl_state;
-    uint32_t nfrag;
-    uint32_t pad;
-    uint64_t ha, hb, hc;        /* rank counts of the prefix, 16-bit fields */
-};
-
-/* the same for the straight-line walker (no neutral losses, charge 1, one ion type per direction):
- * a direction's prefix has at most 63 fragments, so the ten rank counts fit 8-bit fields that add
- * without unpacking, and the entry shrinks from 40 to 16 bytes -- this kernel's speed follows its
- * occupancy, and with 2 x 64 entries per wave LDS is what limits it */
-struct PrefixCompact {
-    float running;
-    uint32_t hi;                /* ranks 8, 9 */
-    uint64_t lo;                /* ranks 0..7 */
-};
-
-/* PREFIX is a template parameter so that the small-C(n,k) instantiation does not carry the
- * registers of the shared-prefix path (60 vs 77 VGPRs = 8 vs 6 waves per SIMD). */
 #ifndef SCORE_WAVES
 #define SCORE_WAVES 6
 #endif
@@ -63,201 +29,11 @@ __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(B
                                                                   uint32_t compact) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
-    const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
-    const int lane = lane_id();
-    const DevConfig *cfg = b.cfg;
-
-    uint16_t *grid = (uint16_t *)lds_raw;                       /* [PYA_GRID_CELLS] */
-    uint32_t *cnt = (uint32_t *)(grid + PYA_GRID_CELLS);        /* [PYA_NTOP / 2][64] */
-    float2 *resd = (float2 *)(cnt + PYA_NTOP / 2 * 64);         /* [64] */
-    PeakEntry *t_e = (PeakEntry *)(resd + 64);                  /* [cap + PYA_TABLE_PAD] */
-    unsigned char *tail = (unsigned char *)(t_e + cap + PYA_TABLE_PAD);
-    uint16_t *nl_present = nullptr;                             /* [256]          } only with */
-    float *nl_uniq = nullptr;                                   /* [PYA_MAX_UNIQ] } neutral   */
-    uint8_t *resn = nullptr;                                    /* [64]           } losses    */
-    if (with_nl) {
-        nl_present = (uint16_t *)tail;
-        nl_uniq = (float *)(nl_present + 256);
-        resn = (uint8_t *)(nl_uniq + PYA_MAX_UNIQ);
-        tail = resn + 64;
-    }
-    PrefixState *pre = (PrefixState *)tail;                     /* [2][64], only if PREFIX ... */
-    PrefixCompact *prc = (PrefixCompact *)tail;                 /* ... or this when `compact`  */
-
-    if (b.status[psm] != PYA_ST_OK) return;
-    const uint32_t N = b.n_sig[psm];
-    if (N == 0) return;
-
-    /* every global read the prologue needs is issued before the first LDS hand-off, so that the
-     * memory round trips of the peptide, the fixed modifications and the peak table overlap */
-    const Residues res = load_residues(b, cfg, psm);
-    const int zmax = b.max_charge[psm];
-    const uint64_t *order = b.order_tab + b.order_off[psm];
-    const int64_t s0 = b.sig_off[psm];
-    PeakTable tab;
-    stage_peak_table(b, psm, t_e, &tab);
-    WalkEnv env;
-    env.cfg = cfg;
-    env.n_nl = with_nl ? cfg->n_nl : 0;
-    env.nl_present = nl_present;
-    env.nl_uniq = nl_uniq;
-    env.resd = resd;
-    env.resn = resn;
-    env.cnt = cnt;
-    if (env.n_nl) {
-        for (int i = lane; i < 256; i += 64) nl_present[i] = cfg->present[i];
-        if (lane < PYA_MAX_UNIQ) nl_uniq[lane] = cfg->uniq[lane];
-    }
-    stage_residues(res, resd, resn);
-    wave_lds_sync();
-    grid_build(&tab, grid);
-
-    env.L = res.L;
-    env.zmax = zmax;
-    const bool has_f = cfg->n_fwd > 0, has_b = cfg->n_fwd < cfg->n_types;
-    const bool both_dirs = has_f && has_b;
-    wave_lds_sync();
-    /* localize looks up its few ions in the global table: leave it the grid (one 512-byte store) */
-    ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)grid)[lane];
-
-    int lut_fail = 0;
-    const bool split = N <= 32 && both_dirs;     /* lanes 0..31 forward, 32..63 backward */
-    const bool simple = walk_is_simple(env);
-    const uint32_t simple_nfrag = (uint32_t)((has_f ? 1 : 0) + (has_b ? 1 : 0)) * (uint32_t)(res.L - 1);
-    const int n_sites = __popcll(res.site_mask);
-    const bool shared = PREFIX && N >= 128 && n_sites >= PREFIX_SITES + 2;
-    int stop[2] = {0, 0};
-    if (shared) {
-        /* steps [0, stop) of a direction cover exactly its first PREFIX_SITES sites */
-        stop[0] = nth_set_bit(res.site_mask, PREFIX_SITES);
-        stop[1] = res.L - 1 - nth_set_bit(res.site_mask, n_sites - 1 - PREFIX_SITES);
-        for (int dir = 0; dir < 2; dir++) {
-            if (dir == 0 ? !has_f : !has_b) continue;
-            if (stop[dir] > res.L - 1) stop[dir] = res.L - 1;
-            const uint64_t pbits = dir == 0 ? (uint64_t)lane : (__brevll((uint64_t)lane) >> (64 - n_sites));
-            const uint64_t pmask = deposit_sites(pbits, res.site_mask);
-            WalkState st = {0.f, 0u};
-            uint32_t nf = 0;
-            hist_clear(env);
-            if (simple) walk_simple_range(env, tab, pmask, dir, true, 0, stop[dir], st);
-            else walk_range(env, tab, pmask, dir, true, 0, stop[dir], st, nf);
-            if (compact) {
-                PrefixCompact pc;
-                pc.running = st.running;
-                uint64_t lo = 0ull;
-#pragma unroll
-                for (int d = 0; d < 8; d++) lo |= (uint64_t)hist_count(cnt, lane, d) << (d * 8);
-                pc.lo = lo;
-                pc.hi = hist_count(cnt, lane, 8) | (hist_count(cnt, lane, 9) << 8);
-                prc[dir * 64 + lane] = pc;
-            } else {
-                PrefixState ps;
-                ps.running = st.running;
-                ps.nl_state = st.nl_state;
-                ps.nfrag = nf;                              /* simple mode counts steps instead */
-                ps.pad = 0;
-                uint64_t hw[3] = {0ull, 0ull, 0ull};
-#pragma unroll
-                for (int d = 0; d < PYA_NTOP; d++) hw[d >> 2] |= (uint64_t)hist_count(cnt, lane, d) << ((d & 3) * 16);
-                ps.ha = hw[0];
-                ps.hb = hw[1];
-                ps.hc = hw[2];
-                pre[dir * 64 + lane] = ps;
-            }
-        }
-        wave_lds_sync();
-    }
-    for (uint32_t sbase = 0; sbase < N; sbase += 64) {
-        const uint32_t s = split ? (uint32_t)(lane & 31) : sbase + lane;
-        const bool active = s < N;
-        const uint64_t bits = active ? order[s] : 0ull;
-        const uint64_t resmask = deposit_sites(bits, res.site_mask);
-        Hist ph = {0ull, 0ull, 0ull};                       /* counts inherited from the prefix table */
-        uint64_t p8lo = 0ull;                               /* (compact form: 8-bit fields) */
-        uint32_t p8hi = 0u;
-        uint32_t nfrag = 0;
-        hist_clear(env);
-        if (shared) {
-            for (int dir = 0; dir < 2; dir++) {
-                if (dir == 0 ? !has_f : !has_b) continue;
-                const uint32_t pat = dir == 0 ? (uint32_t)(bits & 63ull)
-                                              : (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 63ull);
-                WalkState st = {0.f, 0u};
-                if (compact) {
-                    const PrefixCompact pc = prc[dir * 64 + pat];
-                    st.running = pc.running;
-                    p8lo += pc.lo;                           /* fields stay below 256: <= 63 per direction */
-                    p8hi += pc.hi;
-                } else {
-                    const PrefixState ps = pre[dir * 64 + pat];
-                    st.running = ps.running;
-                    st.nl_state = ps.nl_state;
-                    ph.a += ps.ha;
-                    ph.b += ps.hb;
-                    ph.c += ps.hc;
-                    nfrag += ps.nfrag;
-                }
-                if (simple) walk_simple_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, st);
-                else walk_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, st, nfrag);
-            }
-        } else {
-            WalkState st = {0.f, 0u};
-            if (split) {
-                if (simple) walk_simple_range(env, tab, resmask, lane >> 5, active, 0, res.L - 1, st);
-                else walk_range(env, tab, resmask, lane >> 5, active, 0, res.L - 1, st, nfrag);
-            } else {
-                for (int dir = 0; dir < 2; dir++) {
-                    if (dir == 0 ? !has_f : !has_b) continue;
-                    st.running = 0.f;
-                    st.nl_state = 0u;
-                    if (simple) walk_simple_range(env, tab, resmask, dir, active, 0, res.L - 1, st);
-                    else walk_range(env, tab, resmask, dir, active, 0, res.L - 1, st, nfrag);
-                }
-            }
-        }
-        if (split) nfrag += (uint32_t)__shfl_down((int)nfrag, 32, 64);   /* the backward walker sits 32 lanes up */
-        if (simple) nfrag = simple_nfrag;
-        wave_lds_sync();
-
-        if (active && (!split || lane < 32)) {
-            /* cumulative counts over rank (Ascore.cpp:115-118) and scores (Ascore.cpp:123-139) */
-            uint32_t cum[PYA_NTOP];
-            uint32_t acc = 0;
-#pragma unroll
-            for (int d = 0; d < PYA_NTOP; d++) {
-                acc += hist_count(cnt, lane, d) + (split ? hist_count(cnt, lane + 32, d) : 0u) + hist_get(ph, d) +
-                       (d < 8 ? (uint32_t)(p8lo >> (d * 8)) & 0xffu : (p8hi >> ((d - 8) * 8)) & 0xffu);
-                cum[d] = acc;
-            }
-            float ws = -1.f;
-            if (nfrag <= b.lut_n_max) {
-                double sum = 0.;
-#pragma unroll
-                for (int d = 0; d < PYA_NTOP; d++) {
-                    float sc = lut_score(b, (uint32_t)d, cum[d], nfrag);
-                    float prod = cfg->weights[d] * sc;                    /* float product ...   */
-                    sum = sum + (double)prod;                             /* ... double sum      */
-                }
-                ws = (float)sum;
-            } else {
-                lut_fail = 1;
-            }
-            b.ws[s0 + s] = ws;
-            if (b.rec) {
-                uint32_t *rec = b.rec + (s0 + s) * PYA_REC_WORDS;
-#pragma unroll
-                for (int d = 0; d < PYA_NTOP; d += 2) rec[d >> 1] = cum[d] | (cum[d + 1] << 16);
-                rec[5] = nfrag;
-            }
-        }
-        wave_lds_sync();                                    /* columns are cleared again next round */
-    }
-    if (__any(lut_fail) && lane == 0) b.status[psm] = PYA_ST_LUT_RANGE;
+    score_body<PREFIX>(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, with_nl, compact);
 }
 
 extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact) {
-    return PYA_GRID_CELLS * 2 + PYA_NTOP / 2 * 64 * 4 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8 +
-           (with_nl ? 512 + PYA_MAX_UNIQ * 4 + 64 : 0) + (prefix ? 2 * 64 * (compact ? sizeof(PrefixCompact) : sizeof(PrefixState)) : 0) + 64;
+    return score_lds_bytes(cap, prefix, with_nl, compact);
 }
 
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,

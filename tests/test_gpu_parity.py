@@ -43,9 +43,16 @@ def _checker(settings):
     return harness.make_scorer(orc.OracleAscore, settings, kind=kind)
 
 
+@pytest.mark.parametrize("route", ["single_launch", "three_kernels"])
 @pytest.mark.parametrize("case", golden_cases())
-def test_public_api_matches_golden(case):
-    """score() + every property of PyAscore, PSM by PSM, against the reference's outputs."""
+def test_public_api_matches_golden(case, route, monkeypatch):
+    """score() + every property of PyAscore, PSM by PSM, against the reference's outputs -- on the
+    fused single-launch kernel batches of a few PSMs take by default, and on the three-kernel path
+    (PYA_NO_TINY=1)."""
+    if route == "three_kernels":
+        monkeypatch.setenv("PYA_NO_TINY", "1")
+    else:
+        monkeypatch.delenv("PYA_NO_TINY", raising=False)
     settings, batch, expected = harness.load_case(os.path.join(GOLDEN, case + ".npz"))
     got = harness.collect(_gpu(settings), batch, synth.unpack_psm)
     assert harness.compare(got, expected, exact_float=False, rtol=1e-6, atol=1e-6) == []
