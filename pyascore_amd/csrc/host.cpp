@@ -58,7 +58,7 @@ namespace {
 const size_t kMaxLds = 160 * 1024;
 const uint32_t kBucketLimits[] = {64, 512, 4096, PYA_MAX_SIGNATURES};
 const int kNumBuckets = 4;
-const uint64_t kTinyBatch = 8;          /* up to this many PSMs go through the fused single-launch kernel */
+const uint64_t kTinyBatch = 64;         /* up to this many PSMs go through the fused single-launch kernel */
 const size_t kStageLimit = 1u << 20;   /* batches whose transfers are smaller than this go through one staged copy */
 
 template <typename T>

@@ -21,11 +21,19 @@ _LO, _HI = (int(x) for x in os.environ.get("PYA_FUZZ_SEEDS", "0:40").split(":"))
 @pytest.mark.parametrize("seed", range(_LO, _HI))
 def test_random_settings_and_batches(seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
-    monkeypatch.setenv("PYA_PLAIN_MIN", "0")          # small batches skip the lean localize kernel by default
-    if seed % 4 == 3:
-        monkeypatch.setenv("PYA_NO_PLAIN", "1")      # every PSM on the general localize instantiation
-    elif seed % 4 == 2:
-        monkeypatch.setenv("PYA_DEBUG", "512")        # the lean instantiation declines everything
+    # the routes a batch can take: fused single launch (small batches, default), or the three-kernel
+    # path with the lean localize instantiation / with it declining everything / general only /
+    # with the sort emulation forced
+    route = seed % 5
+    monkeypatch.setenv("PYA_PLAIN_MIN", "0")
+    if route != 0:
+        monkeypatch.setenv("PYA_NO_TINY", "1")
+    if route == 2:
+        monkeypatch.setenv("PYA_DEBUG", "512")
+    elif route == 3:
+        monkeypatch.setenv("PYA_NO_PLAIN", "1")
+    elif route == 4:
+        monkeypatch.setenv("PYA_DEBUG", "1024")
     settings, batch = _random_case(rng)
     if batch["n_psm"] == 0:
         pytest.skip("empty draw")

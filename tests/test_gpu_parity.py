@@ -24,6 +24,7 @@ def path(request, monkeypatch):
     monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
     monkeypatch.setenv("PYA_PLAIN_MIN", "0")       # batches under 512 PSMs skip the lean kernel by default
+    monkeypatch.setenv("PYA_NO_TINY", "1")         # ... and those of up to 64 the three kernels altogether
     if request.param == "general_localize":
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
     elif request.param == "lean_declines":
