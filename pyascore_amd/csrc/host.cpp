@@ -1062,7 +1062,8 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     const bool timing = p->flags & PYA_FLAG_TIMING;
     /* a handful of PSMs (PyAscore.score is a batch of one) is launch-bound: one fused launch, one
      * wavefront per PSM, instead of the five of the three-kernel path (tiny_batch.hip) */
-    if (!timing && p->n_psm <= kTinyBatch && !std::getenv("PYA_NO_TINY")) {
+    const uint64_t tiny_max = std::getenv("PYA_TINY_MAX") ? (uint64_t)std::atoll(std::getenv("PYA_TINY_MAX")) : kTinyBatch;
+    if (!timing && p->n_psm <= tiny_max && !std::getenv("PYA_NO_TINY")) {
         Bucket m;                                           /* caps that cover every PSM of the batch */
         for (const Bucket &bk : p->buckets) {
             if (bk.ids.empty()) continue;
