@@ -186,6 +186,17 @@ def test_bulk_pep_scores_match_golden(case):
         gpu.batch_pep_scores()
 
 
+def test_largest_shapes_end_to_end(path):
+    """C(16,8) = 12 870 and C(45,3) = 14 190 site assignments per PSM (the limit is 15 000): the
+    buckets with prefix sharing, multi-chunk sorting and the largest LDS footprints."""
+    for n_sites, n_mod, L in ((16, 8, 30), (45, 3, 50)):
+        batch, settings = synth.make_batch("cfg5", n_psm=3, seed=500 + n_sites, L=L, n_sites=n_sites, n_mod=n_mod)
+        got = _gpu(settings).score_batch(batch)
+        want = _checker(settings).score_batch(batch, got["ascores"].shape[1])
+        for key in want:
+            assert np.array_equal(got[key], want[key]), (n_sites, n_mod, key)
+
+
 def test_many_tied_competitors():
     """Shapes with many single-move competitors (k * (n_sites - k) up to 126 for C(n,k) <= 15 000):
     at noise level most of them tie for the best score of their site and all of them have to be
