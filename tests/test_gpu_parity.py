@@ -197,6 +197,27 @@ def test_largest_shapes_end_to_end(path):
             assert np.array_equal(got[key], want[key]), (n_sites, n_mod, key)
 
 
+def test_longest_peptide_and_most_sites(path):
+    """64 residues with 63 modifiable ones (the limits), one and two modifications, all ion types,
+    charge 2: every 64-bit mask is full."""
+    rng = np.random.default_rng(64)
+    from pyascore_amd.synth import pack_batch
+    psms = []
+    for pep, k in (("S" * 63 + "K", 1), ("ST" * 31 + "YK", 2), ("K" + "Y" * 63, 1)):
+        mass = np.array([synth.RESIDUE_MASS[c] for c in pep])
+        frag = np.concatenate([np.cumsum(mass)[:-1] + synth.PROTON, np.cumsum(mass[::-1])[:-1] + synth.WATER + synth.PROTON])
+        mz = np.sort(np.concatenate([frag[rng.random(frag.size) < 0.5] + rng.uniform(-0.01, 0.01), rng.uniform(100, 6000, 400)]))
+        psms.append(dict(mz=mz, intensity=rng.lognormal(5.0, 1.0, mz.size), peptide=pep, n_of_mod=k, max_charge=2,
+                         aux_pos=np.array([64], np.uint32), aux_mass=np.array([42.010565], np.float32)))
+    batch = pack_batch(psms)
+    settings = dict(bin_size=100.0, n_top=10, mod_group="STY", mod_mass=79.966331, mz_error=0.05,
+                    fragment_types="bycz", neutral_losses=[])
+    got = _gpu(settings).score_batch(batch)
+    want = _checker(settings).score_batch(batch, got["ascores"].shape[1])
+    for key in want:
+        assert np.array_equal(got[key], want[key]), key
+
+
 def test_many_tied_competitors():
     """Shapes with many single-move competitors (k * (n_sites - k) up to 126 for C(n,k) <= 15 000):
     at noise level most of them tie for the best score of their site and all of them have to be
