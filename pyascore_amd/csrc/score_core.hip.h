@@ -100,7 +100,7 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     int lut_fail = 0;
     const bool split = N <= 32 && both_dirs;     /* lanes 0..31 forward, 32..63 backward */
     const bool simple = walk_is_simple(env);
-    const uint32_t simple_nfrag = (uint32_t)((has_f ? 1 : 0) + (has_b ? 1 : 0)) * (uint32_t)(res.L - 1);
+    const uint32_t simple_nfrag = (uint32_t)((has_f ? 1 : 0) + (has_b ? 1 : 0)) * (uint32_t)(res.L - 1) * (uint32_t)zmax;
     const int n_sites = __popcll(res.site_mask);
     const bool shared = PREFIX && N >= 128 && n_sites >= PREFIX_SITES + 2;
     int stop[2] = {0, 0};

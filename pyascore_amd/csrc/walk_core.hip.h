@@ -104,9 +104,9 @@ DEV void walk_range(const WalkEnv &e, const PeakTable &tab, uint64_t resmask, in
     st.nl_state = nl_state;
 }
 
-/* Fast path for the common scorer settings -- no neutral losses, charge 1, at most one ion type
- * per direction (BASELINE cfg1/2/3/5): straight-line code per residue step; the number of
- * fragments is the number of steps, so the caller counts them. */
+/* Fast path for the common scorer settings -- no neutral losses, at most one ion type per
+ * direction (BASELINE cfg1/2/3/5): straight-line code per residue step plus a short loop over the
+ * higher charges; the number of fragments is steps x charges, so the caller counts them. */
 DEV void walk_simple_range(const WalkEnv &e, const PeakTable &tab, uint64_t resmask, int dir, bool active,
                            int step_begin, int step_end, WalkState &st) {
     const DevConfig *cfg = e.cfg;
@@ -131,16 +131,16 @@ DEV void walk_simple_range(const WalkEnv &e, const PeakTable &tab, uint64_t resm
         const float r = mod ? mm.y : mm.x;
         running = r + running;                             /* ModifiedPeptide.cpp:385-389 */
         const double m = ((double)running + A) - B;
-        const float f = (float)(m + 1.007825);
-        const int rk = match_rank_lds(tab, f);
+        const int rk = match_rank_lds(tab, (float)(m + 1.007825));
         hist_bump(col, active, rk);
+        for (int z = 2; z <= e.zmax; z++) hist_bump(col, active, match_rank_lds(tab, charge_mz(m, z)));
     }
     st.running = running;
 }
 
 DEV bool walk_is_simple(const WalkEnv &e) {
     const int n_f = e.cfg->n_fwd, n_b = e.cfg->n_types - e.cfg->n_fwd;
-    return e.n_nl == 0 && e.zmax == 1 && n_f <= 1 && n_b <= 1;
+    return e.n_nl == 0 && n_f <= 1 && n_b <= 1;
 }
 
 #endif
