@@ -5,6 +5,8 @@ per-PSM loop over the CPU checker written the way the reference's loop is."""
 import numpy as np
 import pytest
 
+from conftest import checker_kind
+
 from pyascore_amd import batch_cli
 
 PHOSPHO = 79.966331
@@ -79,7 +81,7 @@ def test_rows_match_per_psm_reference_loop(tmp_path):
     spectra, psms = _toy_inputs()
     gpu = PyAscore(100.0, 10, "STY", PHOSPHO, 0.05, "by")
     rows = batch_cli.localize(gpu, psms, spectra, "STY", PHOSPHO, hit_depth=2, max_fragment_charge=3)
-    kind = "ref" if orc.available("ref") else "oracle"
+    kind = checker_kind()
     chk = orc.OracleAscore(100.0, 10, "STY", PHOSPHO, 0.05, "by", kind=kind)
     want = []
     for match in psms:                                        # the reference's loop, PSM by PSM

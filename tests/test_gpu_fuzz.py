@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import checker_kind
+
 from oracle import harness, orc
 from pyascore_amd import synth
 
@@ -39,7 +41,7 @@ def test_random_settings_and_batches(seed, monkeypatch):
         pytest.skip("empty draw")
     from pyascore_amd import PyAscore
     gpu = harness.make_scorer(PyAscore, settings)
-    kind = "ref" if orc.available("ref") else "oracle"
+    kind = checker_kind()
     chk = harness.make_scorer(orc.OracleAscore, settings, kind=kind)
     got = gpu.score_batch(batch)
     want = chk.score_batch(batch, got["ascores"].shape[1])

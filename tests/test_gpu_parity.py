@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases
+from conftest import GOLDEN, golden_cases, checker_kind
 from oracle import harness, orc
 from pyascore_amd import synth
 
@@ -40,7 +40,7 @@ def _gpu(settings):
 
 
 def _checker(settings):
-    kind = "ref" if orc.available("ref") else "oracle"
+    kind = checker_kind()
     return harness.make_scorer(orc.OracleAscore, settings, kind=kind)
 
 
@@ -352,10 +352,17 @@ def _same(a, b, keys=("n_sig", "best_sig", "best_score", "ascores", "alt_mask"))
         assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("cfg,n", [("cfg2", 100_000), ("cfg3", 125_000)])
-def test_full_size_properties(cfg, n):
-    """(1) determinism, (2) a batch scores exactly like its two halves, (3) PSM order does not
-    matter, (4) a random sample agrees bit for bit with the CPU checker."""
+@pytest.mark.parametrize("cfg,n,n_sample", [
+    ("cfg2", 100_000, 1500),
+    ("cfg3", 1_000_000, 1500),       # the whole 8-GPU config on one GPU
+    ("cfg4", 250_000, 1000),         # general localize route: neutral losses, four ion types, charge 4
+    ("cfg5", 50_000, 120),           # 3003 site assignments per PSM: prefix-shared walker, multi-chunk sort
+])
+def test_full_size_properties(cfg, n, n_sample):
+    """Every BASELINE config at its full size (the reference's test/test_ascore.py:10-61 likewise runs
+    every fixture in every setting): (1) determinism, (2) a batch scores exactly like its two halves,
+    (3) PSM order does not matter, (4) a random sample agrees bit for bit with the reference's C++
+    core on this box."""
     batch, settings = synth.make_batch(cfg, n_psm=n, seed=4242)
     gpu = _gpu(settings)
     full = gpu.score_batch(batch)
@@ -366,9 +373,12 @@ def test_full_size_properties(cfg, n):
     for key in ("n_sig", "best_sig", "best_score"):
         assert np.array_equal(np.concatenate([lo[key], hi[key]]), full[key]), key
     for key in ("ascores", "alt_mask"):
-        assert np.array_equal(np.concatenate([lo[key][:, :k], hi[key][:, :k]]), full[key][:, :k]), key
+        kl, kh = lo[key].shape[1], hi[key].shape[1]
+        assert np.array_equal(lo[key], full[key][:half, :kl]) and not full[key][:half, kl:].any(), key
+        assert np.array_equal(hi[key], full[key][half:, :kh]) and not full[key][half:, kh:].any(), key
+    del lo, hi
     rng = np.random.default_rng(7)
-    pick = np.sort(rng.choice(n, 1500, replace=False))
+    pick = np.sort(rng.choice(n, n_sample, replace=False))
     sub = synth.pack_batch([dict(mz=kw["mz_arr"], intensity=kw["int_arr"], peptide=kw["peptide"],
                                  n_of_mod=kw["n_of_mod"], max_charge=kw["max_fragment_charge"])
                             for kw in (synth.unpack_psm(batch, int(i)) for i in pick[::-1])])   # reversed order
@@ -379,6 +389,7 @@ def test_full_size_properties(cfg, n):
     for key in ("n_sig", "best_sig", "best_score"):
         assert np.array_equal(got[key][::-1], full[key][pick]), key
     assert np.array_equal(got["ascores"][::-1][:, :kk], full["ascores"][pick][:, :kk])
+    assert np.array_equal(got["alt_mask"][::-1][:, :kk], full["alt_mask"][pick][:, :kk])
 
 
 def test_peak_order_invariance_at_scale():
