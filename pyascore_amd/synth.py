@@ -100,20 +100,27 @@ def make_batch(config="cfg2", n_psm=None, seed=0, **override):
         order = np.argsort(key, kind="stable")
         uniq, starts = np.unique(key[order], return_index=True)
         ends = np.append(starts[1:], n)
-        peps, mzs, ints, cnts = [None] * n, [None] * n, [None] * n, np.zeros(n, np.int64)
+        # one vectorised generator call per (L, n_sites, n_mod) shape, then scattered back into input
+        # order with index arithmetic (no per-PSM Python work: 1M PSMs in seconds)
+        groups, cnts = [], np.zeros(n, np.int64)
         for s, e in zip(starts, ends):
             idx = order[s:e]
             L, nsit, k = int(Ls[idx[0]]), int(ns[idx[0]]), int(ks[idx[0]])
             p, m, it, c = _fixed_shape(rng, e - s, L, nsit, k, err)
-            off = np.concatenate([[0], np.cumsum(c)])
-            for j, i in enumerate(idx):
-                peps[i] = p[j]
-                mzs[i] = m[off[j]:off[j + 1]]
-                ints[i] = it[off[j]:off[j + 1]]
-                cnts[i] = c[j]
-        pep_flat = np.concatenate(peps)
-        mz = np.concatenate(mzs)
-        inten = np.concatenate(ints)
+            cnts[idx] = c
+            groups.append((idx, p, m, it, c))
+        peak_off = np.concatenate([[0], np.cumsum(cnts)])
+        pep_off = np.concatenate([[0], np.cumsum(Ls)])
+        mz = np.empty(peak_off[-1], np.float64)
+        inten = np.empty(peak_off[-1], np.float64)
+        pep_flat = np.empty(pep_off[-1], np.uint8)
+        for idx, p, m, it, c in groups:
+            src_start = np.concatenate([[0], np.cumsum(c)[:-1]])
+            dest = np.repeat(peak_off[idx] - src_start, c) + np.arange(m.size)
+            mz[dest] = m
+            inten[dest] = it
+            pep_flat[(pep_off[idx][:, None] + np.arange(p.shape[1])[None, :]).ravel()] = p.ravel()
+        del groups
         counts = cnts
         pep_len = Ls.astype(np.int64)
         n_of_mod = ks.astype(np.int32)
@@ -134,6 +141,131 @@ def make_batch(config="cfg2", n_psm=None, seed=0, **override):
                     fragment_types=cfg["fragment_types"],
                     neutral_losses=[list(cfg["neutral_loss"])] if cfg["neutral_loss"] else [])
     return batch, settings
+
+
+# ---------------------------------------------------------------------------------------------
+# Batch *descriptions* and slices: what the multi-GPU path needs.  A description holds only the
+# per-PSM shape (L, n_sites, n_mod, max_charge) of a whole job -- a few bytes per PSM, so every rank
+# can hold it and cut the same work-balanced partition -- and spectra are generated per fixed block
+# of BLOCK PSMs from a seed that depends only on (seed, block).  A rank generates just the blocks
+# its slice touches, and the job's data do not depend on the number of ranks.
+# ---------------------------------------------------------------------------------------------
+BLOCK = 16384
+
+
+def describe(config="cfg2", n_psm=None, seed=0, **override):
+    """Per-PSM shapes of a synthetic job of one BASELINE config (no spectra)."""
+    cfg = dict(CONFIGS[config])
+    cfg.update(override)
+    n = int(n_psm if n_psm is not None else cfg["n_psm"])
+    if cfg["L"] is not None:
+        Ls = np.full(n, cfg["L"], np.int64)
+        ns = np.full(n, cfg["n_sites"], np.int64)
+        ks = np.full(n, cfg["n_mod"], np.int64)
+    else:
+        rng = np.random.default_rng([int(seed), 0xD35C])
+        Ls = rng.integers(8, 41, size=n)
+        ks = rng.integers(1, 5, size=n)
+        hi = np.minimum(12, Ls - 1)
+        ns = np.minimum(ks + 1 + (rng.random(n) * (hi - ks)).astype(np.int64), hi)
+    settings = dict(bin_size=100.0, n_top=10, mod_group="STY", mod_mass=PHOSPHO, mz_error=cfg["mz_error"],
+                    fragment_types=cfg["fragment_types"],
+                    neutral_losses=[list(cfg["neutral_loss"])] if cfg["neutral_loss"] else [])
+    return dict(config=config, n_psm=n, seed=int(seed), L=Ls, n_sites=ns, n_mod=ks,
+                max_charge=np.full(n, cfg["max_charge"], np.int64), settings=settings)
+
+
+def _var_shape(rng, Ls, ns, ks, mz_error, n_noise=300, keep_p=0.6):
+    """The generator of _fixed_shape for PSMs of mixed shapes in one vectorised pass (rows padded to
+    the longest peptide and masked): -> (pep uint8 flat, mz flat, intensity flat, peak counts)."""
+    n, Lmax = Ls.size, int(Ls.max())
+    col = np.arange(Lmax)[None, :]
+    inside = col < Ls[:, None]
+    base = np.frombuffer(BASE_ALPHABET.encode(), dtype=np.uint8)
+    pep = base[rng.integers(0, len(base), size=(n, Lmax))]
+    key = rng.random((n, Lmax))
+    key[~inside] = 2.0
+    is_site = np.argsort(np.argsort(key, axis=1), axis=1) < ns[:, None]
+    sty = np.frombuffer(b"STY", dtype=np.uint8)[rng.choice(3, size=(n, Lmax), p=(0.5, 0.35, 0.15))]
+    pep = np.where(is_site, sty, pep)
+    key = rng.random((n, Lmax))
+    key[~is_site] = 2.0
+    is_mod = np.argsort(np.argsort(key, axis=1), axis=1) < ks[:, None]
+    mass = np.where(inside, _MASS_LUT[pep] + PHOSPHO * is_mod, 0.0)
+    rev_idx = np.clip(Ls[:, None] - 1 - col, 0, Lmax - 1)
+    mass_rev = np.where(inside, np.take_along_axis(mass, rev_idx, axis=1), 0.0)
+    frag_ok = (col < (Ls[:, None] - 1))[:, : Lmax - 1]
+    fwd = np.cumsum(mass, axis=1)[:, : Lmax - 1]
+    rev = np.cumsum(mass_rev, axis=1)[:, : Lmax - 1]
+    sig = np.concatenate([fwd + PROTON, rev + WATER + PROTON], axis=1)
+    keep = (rng.random(sig.shape) < keep_p) & np.concatenate([frag_ok, frag_ok], axis=1)
+    sig = sig + rng.uniform(-0.4 * mz_error, 0.4 * mz_error, size=sig.shape)
+    sig_int = rng.lognormal(6.0, 1.2, size=sig.shape)
+    noise = rng.uniform(100.0, 2000.0, size=(n, n_noise))
+    noise_int = rng.lognormal(4.5, 1.0, size=(n, n_noise))
+    mz = np.concatenate([np.where(keep, sig, np.inf), noise], axis=1)
+    inten = np.concatenate([sig_int, noise_int], axis=1)
+    order = np.argsort(mz, axis=1, kind="stable")
+    mz = np.take_along_axis(mz, order, axis=1)
+    inten = np.take_along_axis(inten, order, axis=1)
+    counts = (keep.sum(axis=1) + n_noise).astype(np.int64)
+    valid = np.arange(mz.shape[1])[None, :] < counts[:, None]
+    return pep[inside], mz[valid], inten[valid], counts
+
+
+def _make_block(desc, b):
+    """PSMs [b * BLOCK, min((b + 1) * BLOCK, n)) of a described job."""
+    i0, i1 = b * BLOCK, min((b + 1) * BLOCK, desc["n_psm"])
+    n = i1 - i0
+    rng = np.random.default_rng([desc["seed"], 0xB10C, b])
+    Ls, ns, ks = desc["L"][i0:i1], desc["n_sites"][i0:i1], desc["n_mod"][i0:i1]
+    pep, mz, inten, counts = _var_shape(rng, Ls, ns, ks, desc["settings"]["mz_error"])
+    return dict(n_psm=n, mz=mz, intensity=inten, peak_off=np.concatenate([[0], np.cumsum(counts)]).astype(np.int64),
+                pep=pep, pep_off=np.concatenate([[0], np.cumsum(Ls)]).astype(np.int64),
+                n_of_mod=ks.astype(np.int32), max_charge=desc["max_charge"][i0:i1].astype(np.int32),
+                aux_pos=np.zeros(0, np.uint32), aux_mass=np.zeros(0, np.float32), aux_off=np.zeros(n + 1, np.int64))
+
+
+def concat_batches(parts):
+    """CSR batches back to back."""
+    out = dict(n_psm=int(sum(p["n_psm"] for p in parts)))
+    for key in ("mz", "intensity", "pep", "n_of_mod", "max_charge", "aux_pos", "aux_mass"):
+        out[key] = np.concatenate([p[key] for p in parts]) if parts else np.zeros(0)
+    for key, data in (("peak_off", "mz"), ("pep_off", "pep"), ("aux_off", "aux_pos")):
+        offs, base = [np.zeros(1, np.int64)], 0
+        for p in parts:
+            offs.append(np.asarray(p[key][1:], np.int64) - int(p[key][0]) + base)
+            base += int(p[key][-1]) - int(p[key][0])
+        out[key] = np.concatenate(offs)
+    return out
+
+
+def make_slice(desc, lo=0, hi=None, threads=None):
+    """PSMs [lo, hi) of a described job as a CSR batch (blocks generated on a thread pool: numpy's
+    sorts and generators release the GIL)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    hi = desc["n_psm"] if hi is None else int(hi)
+    lo = int(lo)
+    if not 0 <= lo <= hi <= desc["n_psm"]:
+        raise ValueError("slice outside the job")
+    if hi == lo:
+        return concat_batches([])
+    blocks = list(range(lo // BLOCK, (hi - 1) // BLOCK + 1))
+    nt = max(1, min(len(blocks), threads or min(8, os.cpu_count() or 1)))
+
+    def one(b):
+        part = _make_block(desc, b)
+        b0 = b * BLOCK
+        a, z = max(lo, b0) - b0, min(hi, b0 + part["n_psm"]) - b0
+        return part if (a == 0 and z == part["n_psm"]) else slice_batch(part, a, z)
+
+    if nt == 1:
+        parts = [one(b) for b in blocks]
+    else:
+        with ThreadPoolExecutor(nt) as ex:
+            parts = list(ex.map(one, blocks))
+    return concat_batches(parts)
 
 
 def pack_batch(psms):

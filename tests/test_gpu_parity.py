@@ -363,7 +363,8 @@ def test_full_size_properties(cfg, n, n_sample):
     every fixture in every setting): (1) determinism, (2) a batch scores exactly like its two halves,
     (3) PSM order does not matter, (4) a random sample agrees bit for bit with the reference's C++
     core on this box."""
-    batch, settings = synth.make_batch(cfg, n_psm=n, seed=4242)
+    desc = synth.describe(cfg, n_psm=n, seed=4242)
+    batch, settings = synth.make_slice(desc), desc["settings"]
     gpu = _gpu(settings)
     full = gpu.score_batch(batch)
     _same(gpu.score_batch(batch), full)
