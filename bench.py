@@ -7,6 +7,9 @@ A *step* is one pass of the hot path (bin_spectra -> score_signatures -> rank_an
 over one batch of synthetic PSMs of the named BASELINE config whose spectra are already
 resident in HBM; for N > 1 every rank scores its own batch of the same size (weak scaling)
 and every step ends with the single RCCL gather of the fixed-size result records to rank 0.
+The job is ONE seeded description (per-PSM shapes) cut by pyascore_amd.shard.partition into
+work-balanced contiguous ranges; a rank generates and scores its own range only.  --scaling strong
+keeps the job size fixed as N grows (e.g. --config cfg3 --scaling strong: 1M PSMs over N GPUs).
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline     : the dominant kernel's achieved algorithmic GB/s vs the 8 TB/s HBM peak,
@@ -155,12 +158,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--psms", type=int, default=None, help="PSMs per GPU (default: the config's size)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every GPU gets --psms PSMs' worth of work; strong: the job (--total) is fixed")
+    ap.add_argument("--total", type=int, default=None, help="PSMs of the whole job with --scaling strong "
+                    "(default: the config's size, e.g. 1M for cfg3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from pyascore_amd import PyAscore, synth
+    from pyascore_amd import PyAscore, shard, synth
     from pyascore_amd.device import DevicePlan
     from pyascore_amd.shard import dist_gather
 
@@ -181,10 +188,25 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    n_psm = args.psms or synth.CONFIGS[args.config]["n_psm"]
+    # ONE job description (per-PSM shapes only) that every rank derives from the same seed; the job is
+    # cut into contiguous ranges balanced by C(n,k) x (L-1) x types x charges (shard.partition) and
+    # every rank generates the spectra of its own range only.
+    n_per_gpu = args.psms or synth.CONFIGS[args.config]["n_psm"]
     if args.config == "cfg3" and args.psms is None:
-        n_psm = synth.CONFIGS["cfg3"]["n_psm"] // 8          # the config is quoted on 8 GPUs
-    batch, settings = synth.make_batch(args.config, n_psm=n_psm, seed=1000 + rank)
+        n_per_gpu = synth.CONFIGS["cfg3"]["n_psm"] // 8      # the config is quoted on 8 GPUs
+    if args.scaling == "strong":
+        total = args.total or (world * args.psms if args.psms else synth.CONFIGS[args.config]["n_psm"])
+    else:
+        total = world * n_per_gpu
+    desc = synth.describe(args.config, n_psm=total, seed=1000)
+    settings = desc["settings"]
+    weights = shard.work_estimate_shapes(desc["n_sites"], desc["n_mod"], desc["L"], desc["max_charge"],
+                                         n_types=len(settings["fragment_types"]))
+    ranges = shard.partition(weights, world)
+    lo, hi = ranges[rank]
+    batch = synth.make_slice(desc, lo, hi)
+    job_max_k = max(1, int(desc["n_mod"].max()))
+    longest = max(h - l for l, h in ranges)
     scorer = PyAscore(settings["bin_size"], settings["n_top"], settings["mod_group"], settings["mod_mass"],
                       settings["mz_error"], settings["fragment_types"], device=local_rank)
     for g, m in settings["neutral_losses"]:
@@ -192,16 +214,22 @@ def main():
 
     d_mz = torch.from_numpy(batch["mz"]).to(dev)
     d_int = torch.from_numpy(batch["intensity"]).to(dev)
-    plan = DevicePlan(scorer, batch, timing=True)
+    plan = DevicePlan(scorer, batch, timing=True, max_k=job_max_k)
 
     in_flight = []
+    # two send buffers of the job-wide record shape (longest shard x width): equal on every rank
+    send = [torch.zeros((longest, shard.record_width(job_max_k)), dtype=torch.int32, device=dev) for _ in range(2)]
+    flip = [0]
 
     def step():
         plan.run(d_mz, d_int)
         if use_dist:
             # the single RCCL gather of the path, asynchronous: the gather of this batch's packed
             # records overlaps the kernels of the next batch (at most one gather behind)
-            in_flight.append(dist_gather(plan.packed_summary(), 0, async_op=True))
+            buf = send[flip[0]]
+            flip[0] ^= 1
+            buf[: hi - lo] = plan.packed_summary()
+            in_flight.append(dist_gather(buf, 0, async_op=True))
             if len(in_flight) > 1:
                 in_flight.pop(0)[0].wait()
 
@@ -248,13 +276,13 @@ def main():
         default_size = args.psms is None and args.config != "cfg3"
         traffic, traffic_src, valu_share = profiled_traffic(args.config, names[dom], default_size)
         line = {
-            "metric": METRIC, "value": world * batch["n_psm"] * args.steps / elapsed, "unit": "PSMs/s",
+            "metric": METRIC, "value": total * args.steps / elapsed, "unit": "PSMs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64 scalar + i32 counts",
-            "data": "synthetic (SURVEY.md 8(d) generator, seed 1000+rank)",
-            "config": {"workload": "%s: %d PSMs/GPU" % (args.config, batch["n_psm"]),
-                       "psms_per_gpu": batch["n_psm"], "peaks_per_spectrum": float(batch["peak_off"][-1]) / batch["n_psm"],
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32/f64 scalar + i32 counts",
+            "data": "synthetic (SURVEY.md 8(d) generator, job seed 1000, spectra per 16k-PSM block)",
+            "config": {"workload": "%s: %d PSMs over %d GPU(s), work-balanced contiguous shards" % (args.config, total, world),
+                       "psms_total": total, "psms_rank0": batch["n_psm"], "shard_sizes": [h - l for l, h in ranges], "peaks_per_spectrum": float(batch["peak_off"][-1]) / batch["n_psm"],
                        "signatures_total_per_gpu": plan.total_signatures, "mz_error": settings["mz_error"],
                        "fragment_types": settings["fragment_types"],
                        "max_fragment_charge": int(batch["max_charge"].max()),

@@ -62,6 +62,18 @@ extern "C" {
 #define PYA_FLAG_KEEP 1u    /* retain per-signature records for pya_get_pep_scores /     */
                             /* pya_calculate_ambiguity                                    */
 #define PYA_FLAG_TIMING 2u  /* record HIP events around every kernel of pya_plan_run     */
+#define PYA_FLAG_SKIP_INVALID 4u /* a PSM that is invalid, exceeds a limit or is rejected by a  */
+                            /* kernel does not fail the call: it gets best_score -1, n_sig -1, */
+                            /* and its code in pya_last_batch_status(); the rest is scored      */
+
+/* per-PSM codes of pya_last_batch_status */
+#define PYA_PSM_OK 0
+#define PYA_PSM_NO_WINDOWS 1       /* all peaks on one multiple of 100 m/z (reference: UB)      */
+#define PYA_PSM_TOO_MANY_WINDOWS 2
+#define PYA_PSM_TABLE_RANGE 3      /* trial count outside the score table                        */
+#define PYA_PSM_TIED_OVERFLOW 4
+#define PYA_PSM_INVALID 16         /* unknown residue, empty spectrum, bad charge, ...           */
+#define PYA_PSM_OVER_LIMIT 17      /* beyond a documented limit (length, sites, C(n,k), peaks)   */
 
 typedef struct pya_handle pya_handle;
 typedef struct pya_plan pya_plan;
@@ -109,6 +121,10 @@ int64_t pya_error_index(const pya_handle *h);
 /* host buffers in, host buffers out: H2D copy + kernels + D2H copy, synchronous */
 int pya_score_batch(pya_handle *h, const pya_batch *batch, const double *mz,
                     const double *intensity, uint32_t flags, const pya_results *out);
+
+/* per-PSM status codes (PYA_PSM_*) of the last pya_score_batch call on this handle; n must equal
+ * that batch's n_psm.  All zeros unless PYA_FLAG_SKIP_INVALID let PSMs be set aside. */
+int pya_last_batch_status(pya_handle *h, int32_t *status, uint64_t n);
 
 /* device-resident path: plan once (host pre-pass, tables, workspace), run many times */
 int pya_plan_create(pya_handle *h, const pya_batch *batch, uint32_t flags, pya_plan **out);

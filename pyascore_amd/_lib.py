@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYA_LIB") or os.path.join(_HERE, "libpyascore_hip.so")   # PYA_LIB: A/B builds
 
 PYA_OK, PYA_ERR_ARG, PYA_ERR_HIP, PYA_ERR_PSM, PYA_ERR_LIMIT, PYA_ERR_STATE = 0, -1, -2, -3, -4, -5
-PYA_FLAG_KEEP, PYA_FLAG_TIMING = 1, 2
+PYA_FLAG_KEEP, PYA_FLAG_TIMING, PYA_FLAG_SKIP_INVALID = 1, 2, 4
 PYA_MAX_PEPTIDE_LEN = 64
 
 _vp = C.c_void_p
@@ -41,6 +41,7 @@ SYMBOLS = {
     "pya_last_error": (C.c_char_p, [_vp]),
     "pya_error_index": (C.c_int64, [_vp]),
     "pya_score_batch": (C.c_int, [_vp, C.POINTER(Batch), _vp, _vp, C.c_uint32, C.POINTER(Results)]),
+    "pya_last_batch_status": (C.c_int, [_vp, _vp, C.c_uint64]),
     "pya_plan_create": (C.c_int, [_vp, C.POINTER(Batch), C.c_uint32, C.POINTER(_vp)]),
     "pya_plan_run": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(Results)]),
     "pya_plan_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 3)]),

@@ -172,12 +172,17 @@ class PyAscore:
                           n_sig=int(one["n_sig"][0]), ascores=one["ascores"][0].copy(),
                           alt_mask=one["alt_mask"][0].copy())
 
-    def score_batch(self, batch, keep=False):
+    def score_batch(self, batch, keep=False, skip_invalid=False):
         """Scores a CSR batch (see pyascore_amd.synth) in one call.
 
         Returns dict(best_score f32[n], best_sig u64[n], n_sig i32[n], ascores f32[n, max_k],
         alt_mask u64[n, max_k]); row i holds what the reference's properties would hold after
-        ``score()`` of PSM i (ascores beyond n_of_mod[i] are 0)."""
+        ``score()`` of PSM i (ascores beyond n_of_mod[i] are 0).
+
+        ``skip_invalid=True``: a PSM that is invalid (unknown residue, empty spectrum, ...) or beyond
+        a documented limit of this implementation does not fail the call; it gets best_score -1,
+        n_sig -1 and a non-zero code in the extra ``status`` array (include/pyascore_hip.h PYA_PSM_*),
+        and ``status_message`` describes the first such PSM."""
         n = int(batch["n_psm"])
         mz = np.ascontiguousarray(batch["mz"], np.float64)
         it = np.ascontiguousarray(batch["intensity"], np.float64)
@@ -205,11 +210,20 @@ class PyAscore:
                        _as_ptr(arrs["aux_mass"]), _as_ptr(arrs["aux_off"]))
         r = _lib.Results(max_k, _as_ptr(out["best_score"]), _as_ptr(out["best_sig"]), _as_ptr(out["n_sig"]),
                          _as_ptr(out["ascores"]), _as_ptr(out["alt_mask"]))
-        rc = self._lib.pya_score_batch(self._h, C.byref(b), _as_ptr(mz), _as_ptr(it),
-                                       _lib.PYA_FLAG_KEEP if keep else 0, C.byref(r))
+        flags = (_lib.PYA_FLAG_KEEP if keep else 0) | (_lib.PYA_FLAG_SKIP_INVALID if skip_invalid else 0)
+        rc = self._lib.pya_score_batch(self._h, C.byref(b), _as_ptr(mz), _as_ptr(it), flags, C.byref(r))
         if rc:
             self._raise(rc)
         self._batch_n = n if keep else None
+        if keep:
+            self._last = None        # the handle's retained plan now belongs to this batch, not to score()'s PSM
+        if skip_invalid:
+            out["status"] = np.zeros(n, np.int32)
+            rc = self._lib.pya_last_batch_status(self._h, _as_ptr(out["status"]), n)
+            if rc:
+                self._raise(rc)
+            out["status_message"] = (self._lib.pya_last_error(self._h).decode("utf8", "replace")
+                                     if out["status"].any() else "")
         return out
 
     # ------------------------------------------------------------------------------------------

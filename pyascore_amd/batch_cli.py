@@ -92,10 +92,21 @@ def localize(ascore, psms, spectra_map, residues, mod_mass, hit_depth=1, max_fra
     if not picked:
         return []
     batch = pack_batch(picked)
-    res = ascore.score_batch(batch)
+    # One PSM the kernels cannot take (longer than 64 residues, more than 15 000 site assignments,
+    # an unknown residue, ...) must not cost the whole run its output: such PSMs are set aside by the
+    # library, reported here, and written as rows without a localisation.
+    res = ascore.score_batch(batch, skip_invalid=True)
+    bad = np.flatnonzero(res["status"])
+    if bad.size:
+        import warnings
+        warnings.warn("%d of %d PSMs were not scored (first: %s); their rows carry no localisation"
+                      % (bad.size, len(picked), res["status_message"]), RuntimeWarning)
     rows = []
     buf = C.create_string_buffer(1024)
     for i, psm in enumerate(picked):
+        if res["status"][i]:
+            rows.append([scans[i], "", float("nan"), "", ""])
+            continue
         k = psm["n_of_mod"]
         pep = np.frombuffer(psm["peptide"].encode("utf8"), dtype=np.uint8)
         ns = C.c_int32()

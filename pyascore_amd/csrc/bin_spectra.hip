@@ -63,8 +63,7 @@ extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t
     const size_t per_wave = (((size_t)cap * 15 + 63) & ~(size_t)63);
     const uint32_t nw = per_wave * BIN_WAVES <= 64 * 1024 ? BIN_WAVES : 1;
     size_t lds = nw * per_wave;
-    hipError_t e = hipFuncSetAttribute((const void *)pya_bin_spectra_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_bin_spectra_kernel);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_bin_spectra_kernel, dim3((n_ids + nw - 1) / nw), dim3(64 * nw), lds, stream, *b, d_ids,
                        n_ids, cap);
@@ -76,8 +75,7 @@ extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t
 extern "C" int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream) {
     if (n_total == 0) return 0;
     const size_t per_wave = (((size_t)cap * 15 + 63) & ~(size_t)63) + 192;      /* + the round's window starts */
-    hipError_t e = hipFuncSetAttribute((const void *)pya_bin_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)per_wave);
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_bin_exact_kernel);
     if (e != hipSuccess) return (int)e;
     const uint32_t grid = n_total < 16384u ? n_total : 16384u;   /* all spectra may need it (count-like intensities) */
     hipLaunchKernelGGL(pya_bin_exact_kernel, dim3(grid), dim3(64), per_wave, stream, *b, cap);

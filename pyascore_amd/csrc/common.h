@@ -22,6 +22,8 @@
 #define PYA_ST_TOO_MANY_BINS 2
 #define PYA_ST_LUT_RANGE 3         /* trial count outside the uploaded score table          */
 #define PYA_ST_PUSHED_OVERFLOW 4
+#define PYA_ST_INVALID 16          /* set aside by the host pre-pass (PYA_FLAG_SKIP_INVALID): invalid PSM    */
+#define PYA_ST_OVER_LIMIT 17       /* ... or one that exceeds a documented limit of this implementation     */
 
 /* Scorer configuration as the kernels see it (one copy in device memory per handle).
  * Residue tables are indexed by (letter - 'A') & 31.                                      */

@@ -9,7 +9,27 @@
 #define PYA_DEVICE_COMMON_H
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "common.h"
+
+/* Dynamic LDS above 64 KB has to be allowed per kernel.  The allowance is raised ONCE per kernel
+ * and device to the CU's 160 KB (it does not influence occupancy; the launch's own size does), so
+ * host threads driving different handles never lower each other's limit between the call and the
+ * launch. */
+static inline hipError_t pya_set_max_lds(const void *fn, std::atomic<uint32_t> &done_mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint32_t bit = 1u << (dev & 31);
+    if (done_mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done_mask.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+#define PYA_ENSURE_MAX_LDS(kernel)                            \
+    ([]() -> hipError_t {                                     \
+        static std::atomic<uint32_t> done_mask_{0};           \
+        return pya_set_max_lds((const void *)(kernel), done_mask_); \
+    }())
 
 #define DEV __device__ __forceinline__
 

@@ -178,6 +178,7 @@ struct pya_handle {
 
     std::string err;
     int64_t err_index = -1;
+    std::vector<int32_t> last_status;         /* per-PSM codes of the last pya_score_batch */
     pya_plan *kept = nullptr;                 /* plan of the last PYA_FLAG_KEEP batch */
 
     int fail(int code, int64_t index, const char *fmt, ...) {
@@ -294,6 +295,8 @@ struct pya_plan {
     std::vector<uint32_t> bin_ids, score_ids;
     std::vector<IdList> bin_lists, score_lists;
     std::vector<uint8_t> ncls;          /* [n_psm] C(n,k) class of the PSM */
+    std::vector<int32_t> pre_status;    /* [n_psm] PSMs the host pre-pass set aside (PYA_FLAG_SKIP_INVALID) */
+    uint64_t n_skipped = 0;
     DevBuf<uint32_t> d_bin_ids, d_score_ids;
     /* owned copies of inputs/outputs (pya_score_batch path) */
     DevBuf<double> d_mz, d_inten;
@@ -701,6 +704,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     p->total_peaks = n ? p->peak_off[n] - peak_base : 0;
     const int64_t total_pep = n ? p->pep_off[n] - pep_base : 0;
     const int64_t total_aux = n ? p->aux_off[n] - aux_base : 0;
+    if (p->total_peaks < 0 || total_pep < 0 || total_aux < 0)
+        return h->fail(PYA_ERR_ARG, -1, "offset arrays are not monotone (the last offset is below the first)");
     p->pep.assign(b->pep + pep_base, b->pep + pep_base + total_pep);
     for (uint64_t i = 0; i <= n; i++) {
         p->peak_off[i] -= peak_base;
@@ -723,14 +728,16 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     /* Pass A (threaded for big batches): the per-letter work -- validate every PSM and count its
      * modifiable residues.  It only finds the first offending PSM; the detailed message comes from
      * the serial checks below, run for that PSM alone. */
-    uint64_t first_bad = n;
+    const bool skip_invalid = (flags & PYA_FLAG_SKIP_INVALID) != 0;
+    std::vector<uint8_t> bad(n, 0);
     {
-        auto scan = [&](uint64_t lo, uint64_t hi, uint64_t *bad) {
+        auto scan = [&](uint64_t lo, uint64_t hi) {
             for (uint64_t i = lo; i < hi; i++) {
                 const int64_t P = p->peak_off[i + 1] - p->peak_off[i];
                 const int64_t L = p->pep_off[i + 1] - p->pep_off[i];
                 const int32_t k = p->n_of_mod[i], z = p->max_charge[i];
-                bool ok = P > 0 && P <= PYA_MAX_PEAKS && L >= 1 && L <= PYA_MAX_PEPTIDE_LEN && k >= 0 && z >= 1 && z <= 16;
+                bool ok = P > 0 && P <= PYA_MAX_PEAKS && L >= 1 && L <= PYA_MAX_PEPTIDE_LEN && k >= 0 && z >= 1 && z <= 16 &&
+                          p->aux_off[i + 1] >= p->aux_off[i];
                 uint32_t ns = 0;
                 if (ok) {
                     const uint8_t *s = p->pep.data() + p->pep_off[i];
@@ -742,62 +749,84 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                         ok = ok && b->aux_pos[aux_base + a] <= (uint32_t)L;
                     ok = ok && ns <= PYA_MAX_SITES;
                 }
-                if (!ok) {
-                    *bad = i;
-                    return;
-                }
-                p->n_sites[i] = (uint8_t)ns;
+                bad[i] = ok ? 0 : 1;
+                p->n_sites[i] = ok ? (uint8_t)ns : 0;
             }
         };
         unsigned nt = n >= 20000 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-        std::vector<uint64_t> bad(nt, n);
         if (nt == 1) {
-            scan(0, n, &bad[0]);
+            scan(0, n);
         } else {
             std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; t++)
-                th.emplace_back(scan, n * t / nt, n * (t + 1) / nt, &bad[t]);
+            for (unsigned t = 0; t < nt; t++) th.emplace_back(scan, n * t / nt, n * (t + 1) / nt);
             for (auto &x : th) x.join();
         }
-        for (uint64_t v : bad) first_bad = std::min(first_bad, v);
     }
+    /* an invalid PSM ends the call with its message -- or, with PYA_FLAG_SKIP_INVALID, is set aside
+     * (status PYA_ST_INVALID / PYA_ST_OVER_LIMIT, best_score -1, n_sig -1) while the rest is scored */
+    p->pre_status.assign(n, 0);
+    uint64_t n_skipped = 0;
+    auto reject = [&](int code, uint64_t i, const char *fmt, ...) -> int {
+        char buf[400];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        if (!skip_invalid) return h->fail(code, (int64_t)i, "%s", buf);
+        if (n_skipped == 0) (void)h->fail(code, (int64_t)i, "%s", buf);       /* first message is kept */
+        n_skipped++;
+        p->pre_status[i] = code == PYA_ERR_LIMIT ? PYA_ST_OVER_LIMIT : PYA_ST_INVALID;
+        p->n_sites[i] = 0;
+        p->n_sig[i] = 0;
+        p->order_off[i] = 0;
+        p->sig_off[i] = sig_total;
+        p->buckets[0].general_ids.push_back((uint32_t)i);     /* localize writes the "no result" record */
+        return PYA_OK;
+    };
     for (uint64_t i = 0; i < n; i++) {
         const int64_t P = p->peak_off[i + 1] - p->peak_off[i];
         const int64_t L = p->pep_off[i + 1] - p->pep_off[i];
         const int32_t k = p->n_of_mod[i], z = p->max_charge[i];
         uint32_t ns = p->n_sites[i];
-        if (i == first_bad) {
-        ns = 0;
-        if (P <= 0) return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: empty spectrum", (unsigned long long)i);
-        if (P > PYA_MAX_PEAKS)
-            return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: %lld peaks exceed the limit of %d",
-                           (unsigned long long)i, (long long)P, PYA_MAX_PEAKS);
-        if (L < 1 || L > PYA_MAX_PEPTIDE_LEN)
-            return h->fail(L < 1 ? PYA_ERR_PSM : PYA_ERR_LIMIT, (int64_t)i,
-                           "PSM %llu: peptide length %lld outside 1..%d", (unsigned long long)i, (long long)L,
-                           PYA_MAX_PEPTIDE_LEN);
-        if (k < 0) return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: negative n_of_mod", (unsigned long long)i);
-        if (z < 1 || z > 16)
-            return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: max_fragment_charge %d outside 1..16",
-                           (unsigned long long)i, z);
-        const uint8_t *s = p->pep.data() + p->pep_off[i];
-        for (int64_t j = 0; j < L; j++) {
-            char c = (char)s[j];
-            if (!h->is_residue[(unsigned char)c])
-                return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: unknown residue '%c' at position %lld",
-                               (unsigned long long)i, c, (long long)(j + 1));
-            if (h->letter_modifiable(c, (size_t)j, (size_t)L)) ns++;
-        }
-        for (int64_t a = p->aux_off[i]; has_aux && a < p->aux_off[i + 1]; a++) {
-            uint32_t pos = b->aux_pos[aux_base + a];
-            if (pos > (uint32_t)L)
-                return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: aux_mod_pos %u beyond the peptide",
-                               (unsigned long long)i, pos);
-        }
-        if (ns > PYA_MAX_SITES)
-            return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: %u modifiable residues exceed %d",
-                           (unsigned long long)i, ns, PYA_MAX_SITES);
-        return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: rejected by the batch scan", (unsigned long long)i);
+        if (bad[i]) {
+            int rc2 = PYA_OK;
+            const uint64_t iu = i;
+            if (P <= 0) rc2 = reject(PYA_ERR_PSM, i, "PSM %llu: empty spectrum", (unsigned long long)iu);
+            else if (P > PYA_MAX_PEAKS)
+                rc2 = reject(PYA_ERR_LIMIT, i, "PSM %llu: %lld peaks exceed the limit of %d", (unsigned long long)iu,
+                             (long long)P, PYA_MAX_PEAKS);
+            else if (L < 1 || L > PYA_MAX_PEPTIDE_LEN)
+                rc2 = reject(L < 1 ? PYA_ERR_PSM : PYA_ERR_LIMIT, i, "PSM %llu: peptide length %lld outside 1..%d",
+                             (unsigned long long)iu, (long long)L, PYA_MAX_PEPTIDE_LEN);
+            else if (k < 0) rc2 = reject(PYA_ERR_PSM, i, "PSM %llu: negative n_of_mod", (unsigned long long)iu);
+            else if (z < 1 || z > 16)
+                rc2 = reject(PYA_ERR_PSM, i, "PSM %llu: max_fragment_charge %d outside 1..16", (unsigned long long)iu, z);
+            else if (p->aux_off[i + 1] < p->aux_off[i])
+                rc2 = reject(PYA_ERR_ARG, i, "PSM %llu: aux_off is not monotone", (unsigned long long)iu);
+            else {
+                const uint8_t *s = p->pep.data() + p->pep_off[i];
+                uint32_t cnt = 0;
+                int64_t bad_j = -1;
+                for (int64_t j = 0; j < L; j++) {
+                    if (!h->is_residue[s[j]] && bad_j < 0) bad_j = j;
+                    if (h->letter_modifiable((char)s[j], (size_t)j, (size_t)L)) cnt++;
+                }
+                int64_t bad_a = -1;
+                for (int64_t a = p->aux_off[i]; has_aux && a < p->aux_off[i + 1]; a++)
+                    if (b->aux_pos[aux_base + a] > (uint32_t)L && bad_a < 0) bad_a = a;
+                if (bad_j >= 0)
+                    rc2 = reject(PYA_ERR_PSM, i, "PSM %llu: unknown residue '%c' at position %lld", (unsigned long long)iu,
+                                 (char)s[bad_j], (long long)(bad_j + 1));
+                else if (bad_a >= 0)
+                    rc2 = reject(PYA_ERR_PSM, i, "PSM %llu: aux_mod_pos %u beyond the peptide", (unsigned long long)iu,
+                                 b->aux_pos[aux_base + bad_a]);
+                else if (cnt > PYA_MAX_SITES)
+                    rc2 = reject(PYA_ERR_LIMIT, i, "PSM %llu: %u modifiable residues exceed %d", (unsigned long long)iu, cnt,
+                                 PYA_MAX_SITES);
+                else rc2 = reject(PYA_ERR_PSM, i, "PSM %llu: rejected by the batch scan", (unsigned long long)iu);
+            }
+            if (rc2) return rc2;
+            continue;
         }
         uint64_t N = 0;
         if ((uint32_t)k <= ns) {
@@ -805,9 +834,19 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             if (cached == 0) cached = binom(ns, (uint32_t)k);
             N = cached;
         }
-        if (N > PYA_MAX_SIGNATURES)
-            return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: C(%u,%d) site assignments exceed the limit of %d",
-                           (unsigned long long)i, ns, k, PYA_MAX_SIGNATURES);
+        if (N > PYA_MAX_SIGNATURES) {
+            int rc2 = reject(PYA_ERR_LIMIT, i, "PSM %llu: C(%u,%d) site assignments exceed the limit of %d",
+                             (unsigned long long)i, ns, k, PYA_MAX_SIGNATURES);
+            if (rc2) return rc2;
+            continue;
+        }
+        const uint32_t per_type = (uint32_t)(L - 1) * (uint32_t)z * n_uniq;
+        if (per_type > PYA_MAX_LIST) {
+            int rc2 = reject(PYA_ERR_LIMIT, i, "PSM %llu: %u fragments per ion type exceed %d", (unsigned long long)i,
+                             per_type, PYA_MAX_LIST);
+            if (rc2) return rc2;
+            continue;
+        }
         p->n_sites[i] = (uint8_t)ns;
         p->n_sig[i] = (uint32_t)N;
         uint32_t ooff = 0;
@@ -820,10 +859,6 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->sig_off[i] = sig_total;
         sig_total += (int64_t)N;
         max_P = std::max<uint32_t>(max_P, (uint32_t)P);
-        const uint32_t per_type = (uint32_t)(L - 1) * (uint32_t)z * n_uniq;
-        if (per_type > PYA_MAX_LIST)
-            return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: %u fragments per ion type exceed %d",
-                           (unsigned long long)i, per_type, PYA_MAX_LIST);
         lut_need = std::max(lut_need, per_type * n_types);
         if ((uint32_t)k > max_k) max_k = (uint32_t)k;
         int cls_of_i = 0;
@@ -857,6 +892,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         bk.general_ids.shrink_to_fit();
     }
     lap("psm loop");
+    p->n_skipped = n_skipped;
     p->sig_off[n] = sig_total;
     p->total_sigs = sig_total;
     p->max_k = max_k;
@@ -867,7 +903,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         std::vector<uint32_t> caps;
         if (n >= 2048 && !std::getenv("PYA_ONE_PEAK_CLASS")) {
             std::vector<uint32_t> pk(n);
-            for (uint64_t i = 0; i < n; i++) pk[i] = (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
+            for (uint64_t i = 0; i < n; i++)
+                pk[i] = p->pre_status[i] ? 1u : (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
             for (double q : {0.5, 0.9, 0.99}) {
                 const size_t at = (size_t)(q * (double)(n - 1));
                 std::nth_element(pk.begin(), pk.begin() + at, pk.end());
@@ -883,6 +920,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0);
         std::vector<uint8_t> pcls(n);
         for (uint64_t i = 0; i < n; i++) {
+            if (p->pre_status[i]) continue;                  /* set aside: neither binned nor scored */
             const uint32_t P = (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
             size_t c = 0;
             while (caps[c] < P) c++;
@@ -900,9 +938,10 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             p->score_lists.push_back({off, 0u, caps[g % nc], (uint32_t)(g / nc)});
             off += cnt_score[g];
         }
-        p->bin_ids.resize(n);
-        p->score_ids.resize(n);
+        p->bin_ids.resize(n - n_skipped);
+        p->score_ids.resize(n - n_skipped);
         for (uint64_t i = 0; i < n; i++) {
+            if (p->pre_status[i]) continue;
             pya_plan::IdList &bl = p->bin_lists[pcls[i]];
             p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
             pya_plan::IdList &sl = p->score_lists[p->ncls[i] * nc + pcls[i]];
@@ -1025,6 +1064,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             HIPCHK(h, hipDeviceSynchronize());
         }
     }
+    if (n_skipped)      /* bin_spectra never touches these entries, so they keep their code for every run */
+        HIPCHK(h, hipMemcpy(p->d_status.p, p->pre_status.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
     lap("arena+upload");
     if (flags & PYA_FLAG_TIMING)
         for (auto &e : p->ev) HIPCHK(h, hipEventCreate(&e));
@@ -1063,8 +1104,10 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     /* a handful of PSMs (PyAscore.score is a batch of one) is launch-bound: one fused launch, one
      * wavefront per PSM, instead of the five of the three-kernel path (tiny_batch.hip) */
     const uint64_t tiny_max = std::getenv("PYA_TINY_MAX") ? (uint64_t)std::atoll(std::getenv("PYA_TINY_MAX")) : kTinyBatch;
-    if (!timing && p->n_psm <= tiny_max && !std::getenv("PYA_NO_TINY")) {
-        Bucket m;                                           /* caps that cover every PSM of the batch */
+    bool tiny = !timing && p->n_psm <= tiny_max && p->n_skipped == 0 && !std::getenv("PYA_NO_TINY");
+    Bucket m;                                               /* caps that cover every PSM of the batch */
+    uint32_t prefix = 0, compact = 0;
+    if (tiny) {
         for (const Bucket &bk : p->buckets) {
             if (bk.ids.empty()) continue;
             m.n_cap = std::max(m.n_cap, bk.n_cap);
@@ -1075,9 +1118,15 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
             m.push_max = std::max(m.push_max, bk.push_max);
             m.z_max = std::max(m.z_max, bk.z_max);
         }
-        const uint32_t prefix = (m.n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
-        const uint32_t compact = (h->cfg.n_nl == 0 && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 &&
-                                  m.z_max == 1) ? 1u : 0u;
+        prefix = (m.n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
+        compact = (h->cfg.n_nl == 0 && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 && m.z_max == 1) ? 1u : 0u;
+        /* the merged caps (maxima over the buckets) can ask for more LDS than any single bucket does:
+         * such a batch takes the three-kernel path, whose launches are sized per bucket */
+        if (pya_tiny_lds_bytes(p->peak_cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact, m.push_cap(), m.n_cap, m.pos_cap,
+                               m.pool_cap(), m.sb()) > kMaxLds)
+            tiny = false;
+    }
+    if (tiny) {
         int e = pya_launch_tiny(&d, (uint32_t)p->n_psm, p->peak_cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact,
                                 m.push_cap(), m.n_cap, m.pos_cap, m.pool_cap(), m.sb(), m.gtp(), st);
         if (e) return h->hip_fail((hipError_t)e, "tiny_batch launch");
@@ -1130,10 +1179,15 @@ int pya_plan_timings(pya_plan *p, float ms[3]) {
     return PYA_OK;
 }
 
-static int check_status(pya_handle *h, const int32_t *st, uint64_t n) {
+static int check_status(pya_handle *h, const int32_t *st, uint64_t n, bool skip_invalid = false) {
+    if (skip_invalid) return PYA_OK;                    /* codes are reported per PSM instead */
     for (uint64_t i = 0; i < n; i++) {
         switch (st[i]) {
             case PYA_ST_OK: break;
+            case PYA_ST_INVALID:
+            case PYA_ST_OVER_LIMIT:
+                return h->fail(st[i] == PYA_ST_INVALID ? PYA_ERR_PSM : PYA_ERR_LIMIT, (int64_t)i,
+                               "PSM %llu was set aside by the host pre-pass", (unsigned long long)i);
             case PYA_ST_NO_BINS:
                 return h->fail(PYA_ERR_PSM, (int64_t)i, "PSM %llu: all peaks sit on one multiple of 100 m/z; the "
                                "spectrum has no windows", (unsigned long long)i);
@@ -1158,7 +1212,9 @@ int pya_plan_check(pya_plan *p) {
     HIPCHK(h, hipStreamSynchronize(p->last_stream));
     std::vector<int32_t> st(p->n_psm);
     HIPCHK(h, hipMemcpy(st.data(), p->d_status.p, p->n_psm * sizeof(int32_t), hipMemcpyDeviceToHost));
-    return check_status(h, st.data(), p->n_psm);
+    const bool skip = (p->flags & PYA_FLAG_SKIP_INVALID) != 0;
+    if (skip) h->last_status = st;
+    return check_status(h, st.data(), p->n_psm, skip);
 }
 
 uint64_t pya_plan_workspace_bytes(const pya_plan *p) { return p ? p->workspace_bytes() : 0; }
@@ -1186,8 +1242,14 @@ void pya_plan_destroy(pya_plan *p) {
 int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const double *inten, uint32_t flags,
                     const pya_results *out) {
     if (!h || !b || !out) return PYA_ERR_ARG;
+    h->last_status.clear();
     if (b->n_psm == 0) return PYA_OK;
     if (!mz || !inten) return h->fail(PYA_ERR_ARG, -1, "NULL spectrum arrays");
+    if (!b->peak_off || !b->pep || !b->pep_off || !b->n_of_mod || !b->max_charge)
+        return h->fail(PYA_ERR_ARG, -1, "NULL array in batch");
+    if (!out->best_score || !out->best_sig || !out->n_sig || !out->ascores || !out->alt_mask)
+        return h->fail(PYA_ERR_ARG, -1, "NULL array in results");
+    if (b->peak_off[b->n_psm] < b->peak_off[0]) return h->fail(PYA_ERR_ARG, -1, "peak_off is not monotone");
     const bool host_timing = std::getenv("PYA_HOST_TIMING") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -1238,7 +1300,9 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
         unsigned char *sg = h->stage.data();
         HIPCHK(h, hipMemcpy(sg, p->arena.p + p->o_status, p->d2h_bytes, hipMemcpyDeviceToHost));
         lap("kernels + d2h");
-        rc = check_status(h, (const int32_t *)sg, n);
+        const bool skip = (flags & PYA_FLAG_SKIP_INVALID) != 0;
+        if (skip) h->last_status.assign((const int32_t *)sg, (const int32_t *)sg + n);
+        rc = check_status(h, (const int32_t *)sg, n, skip);
         if (rc) return rc;
         const size_t o = p->o_status;
         std::memcpy(out->best_score, sg + (p->o_best_score - o), n * sizeof(float));
@@ -1261,6 +1325,17 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
         if (h->kept) pya_plan_destroy(h->kept);
         h->kept = guard.release();
     }
+    return PYA_OK;
+}
+
+int pya_last_batch_status(pya_handle *h, int32_t *status, uint64_t n) {
+    if (!h || !status) return PYA_ERR_ARG;
+    if (h->last_status.empty()) {                       /* nothing was set aside (or the flag was not given) */
+        std::memset(status, 0, n * sizeof(int32_t));
+        return PYA_OK;
+    }
+    if (n != h->last_status.size()) return h->fail(PYA_ERR_ARG, -1, "the last batch had %zu PSMs", h->last_status.size());
+    std::memcpy(status, h->last_status.data(), n * sizeof(int32_t));
     return PYA_OK;
 }
 

@@ -108,8 +108,7 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     const size_t lds = pya_localize_lds_bytes(push_cap, n_cap, pos_cap, pool_cap, sb);
     hipError_t e;
     if (!plain) {
-        e = hipFuncSetAttribute((const void *)pya_localize_kernel<false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = PYA_ENSURE_MAX_LDS(pya_localize_kernel<false>);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(pya_localize_kernel<false>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, push_cap,
                            pos_cap, pool_cap, sb, gtp);
@@ -118,15 +117,13 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     /* lean instantiation first, then whatever it declined on the general one */
     e = hipMemsetAsync(b->redo3_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void *)pya_localize_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+    e = PYA_ENSURE_MAX_LDS(pya_localize_kernel<true>);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, push_cap,
                        pos_cap, pool_cap, sb, gtp);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void *)pya_localize_redo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+    e = PYA_ENSURE_MAX_LDS(pya_localize_redo_kernel);
     if (e != hipSuccess) return (int)e;
     const uint32_t grid = n_ids < 8192u ? n_ids : 8192u;
     hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, push_cap, pos_cap, pool_cap,
@@ -143,8 +140,7 @@ extern "C" int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t pe
                                     uint64_t ref_bits, uint64_t oth_bits, const float *d_scores,
                                     float ref_ws, float oth_ws, float *d_out, hipStream_t stream) {
     size_t lds = pya_amb_lds_bytes(peak_cap, list_cap);
-    hipError_t e = hipFuncSetAttribute((const void *)pya_ambiguity_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_ambiguity_kernel);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_ambiguity_kernel, dim3(1), dim3(64), lds, stream, *b, psm, peak_cap, list_cap,
                        ref_bits, oth_bits, d_scores, ref_ws, oth_ws, d_out);
@@ -153,8 +149,7 @@ extern "C" int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t pe
 
 extern "C" int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream) {
     size_t lds = (size_t)n * 10 + 64;
-    hipError_t e = hipFuncSetAttribute((const void *)pya_debug_sort_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_debug_sort_kernel);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_debug_sort_kernel, dim3(1), dim3(64), lds, stream, d_keys, n, d_perm);
     return (int)hipGetLastError();

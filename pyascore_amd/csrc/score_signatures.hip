@@ -42,10 +42,8 @@ extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32
     /* spectra near the 8192-peak limit need more than the default 64 KB of dynamic LDS */
     if (!prefix) compact = 0;
     const size_t lds = pya_score_lds_bytes(cap, prefix, with_nl, compact);
-    hipError_t e = prefix ? hipFuncSetAttribute((const void *)pya_score_signatures_kernel<true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                          : hipFuncSetAttribute((const void *)pya_score_signatures_kernel<false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = prefix ? PYA_ENSURE_MAX_LDS(pya_score_signatures_kernel<true>)
+                          : PYA_ENSURE_MAX_LDS(pya_score_signatures_kernel<false>);
     if (e != hipSuccess) return (int)e;
     if (prefix)
         hipLaunchKernelGGL(pya_score_signatures_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,

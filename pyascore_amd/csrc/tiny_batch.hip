@@ -55,8 +55,7 @@ extern "C" int pya_launch_tiny(const BatchDev *b, uint32_t n_psm, uint32_t cap, 
                                uint32_t pool_cap, uint32_t sb, uint32_t gtp, hipStream_t stream) {
     if (n_psm == 0) return 0;
     const size_t lds = pya_tiny_lds_bytes(cap, prefix, with_nl, compact, push_cap, n_cap, pos_cap, pool_cap, sb);
-    hipError_t e = hipFuncSetAttribute((const void *)pya_tiny_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_tiny_batch_kernel);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_tiny_batch_kernel, dim3(n_psm), dim3(64), lds, stream, *b, n_psm, cap, prefix, with_nl,
                        compact, push_cap, pos_cap, pool_cap, sb, gtp);

@@ -17,9 +17,10 @@ class DevicePlan:
 
     ``spectra`` are two float64 CUDA/HIP tensors (m/z, intensity) laid out as the batch's
     ``peak_off`` says.  ``run()`` enqueues the three kernels on torch's current stream and
-    returns the result tensors (device)."""
+    returns the result tensors (device).  ``max_k`` widens the per-site result rows beyond this
+    batch's own largest n_of_mod: ranks that gather fixed-size records pass the job-wide value."""
 
-    def __init__(self, scorer, batch, timing=False):
+    def __init__(self, scorer, batch, timing=False, max_k=None):
         import torch
         if not isinstance(scorer, PyAscore):
             raise TypeError("scorer must be a pyascore_amd.PyAscore")
@@ -28,6 +29,10 @@ class DevicePlan:
         self._lib = scorer._lib
         self.n_psm = int(batch["n_psm"])
         self.max_k = max(1, int(np.max(batch["n_of_mod"]))) if self.n_psm else 1
+        if max_k is not None:
+            if int(max_k) < self.max_k:
+                raise ValueError("max_k=%d is smaller than the batch's largest n_of_mod (%d)" % (max_k, self.max_k))
+            self.max_k = int(max_k)
         self.device = torch.device("cuda", scorer.device)
         self._meta = dict(
             peak_off=np.ascontiguousarray(batch["peak_off"], np.int64),
@@ -46,6 +51,7 @@ class DevicePlan:
         rc = self._lib.pya_plan_create(scorer._h, C.byref(b), _lib.PYA_FLAG_TIMING if timing else 0,
                                        C.byref(self._plan))
         if rc:
+            self._plan = None
             scorer._raise(rc)
         self.timing = timing
         n, k = self.n_psm, self.max_k

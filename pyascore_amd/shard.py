@@ -5,30 +5,54 @@ per GPU), balanced by the estimated work  C(n_sites, n_mods) x (L - 1) x ion typ
 There is no collective on the data path; the only exchange is ONE gather of fixed-size summary
 records to rank 0 at the end (RCCL when the tensors are on the GPU, gloo in the CPU tests).
 """
-from math import comb
-
 import numpy as np
 
 from .synth import slice_batch
 
+_COMB = None
+
+
+def comb_table():
+    """C(n, k) for n, k < 65 as float64 (exact up to 2^53; only used as a weight)."""
+    global _COMB
+    if _COMB is None:
+        t = np.zeros((65, 65), np.float64)
+        t[:, 0] = 1.0
+        for n in range(1, 65):
+            t[n, 1:] = t[n - 1, 1:] + t[n - 1, :-1]
+        _COMB = t
+    return _COMB
+
+
+def work_estimate_shapes(n_sites, n_mod, L, max_charge, n_types=2):
+    """Per-PSM work  max(1, C(n_sites, n_mod)) x (L - 1) x ion types x charges  from shape arrays
+    (SURVEY.md section 8(e)); vectorised, so a million PSMs cost milliseconds."""
+    n_sites = np.clip(np.asarray(n_sites, np.int64), 0, 64)
+    k = np.asarray(n_mod, np.int64)
+    c = np.where((k >= 0) & (k <= n_sites), comb_table()[n_sites, np.clip(k, 0, 64)], 0.0)
+    return (np.maximum(c, 1.0) * np.maximum(np.asarray(L, np.int64) - 1, 1) * float(n_types) *
+            np.maximum(np.asarray(max_charge, np.int64), 1))
+
+
+def count_sites(batch, mod_group="STY"):
+    """Modifiable residues per PSM of a CSR batch ('n' / 'c' in the group admit the termini)."""
+    pep, off = np.asarray(batch["pep"]), np.asarray(batch["pep_off"], np.int64)
+    letters = np.frombuffer(mod_group.replace("n", "").replace("c", "").encode(), dtype=np.uint8)
+    is_site = np.isin(pep, letters)
+    nonempty = off[1:] > off[:-1]
+    if "n" in mod_group:
+        is_site[off[:-1][nonempty]] = True
+    if "c" in mod_group:
+        is_site[off[1:][nonempty] - 1] = True
+    csum = np.concatenate([[0], np.cumsum(is_site)])
+    return csum[off[1:]] - csum[off[:-1]]
+
 
 def work_estimate(batch, mod_group="STY", n_types=2):
-    """Per-PSM work estimate used for balancing."""
-    n = int(batch["n_psm"])
-    pep, off = batch["pep"], batch["pep_off"]
-    is_site = np.isin(pep, np.frombuffer(mod_group.encode(), dtype=np.uint8))
-    csum = np.concatenate([[0], np.cumsum(is_site)])
-    n_sites = csum[off[1:]] - csum[off[:-1]]
-    L = (off[1:] - off[:-1]).astype(np.int64)
-    k = batch["n_of_mod"].astype(np.int64)
-    table = {}
-    w = np.empty(n, np.float64)
-    for i in range(n):
-        key = (int(n_sites[i]), int(k[i]))
-        if key not in table:
-            table[key] = comb(*key) if key[1] <= key[0] else 0
-        w[i] = max(1, table[key]) * max(1, L[i] - 1) * n_types * max(1, int(batch["max_charge"][i]))
-    return w
+    """Per-PSM work estimate of a CSR batch used for balancing."""
+    off = np.asarray(batch["pep_off"], np.int64)
+    return work_estimate_shapes(count_sites(batch, mod_group), batch["n_of_mod"], off[1:] - off[:-1],
+                                batch["max_charge"], n_types)
 
 
 def partition(weights, world_size):
@@ -46,27 +70,43 @@ def partition(weights, world_size):
     return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
 
 
-def score_sharded(score_fn, batch, rank, world_size, gather_fn, mod_group="STY", n_types=2):
-    """Scores rank's shard with ``score_fn(shard_batch) -> int32 [n, width] records`` (a torch
-    tensor on whatever device the process group communicates on) and gathers all records to
-    rank 0 with ONE call of ``gather_fn(tensor, dst=0) -> list of tensors or None``.
+def record_width(max_k):
+    """int32 words of one gathered summary record (device.DevicePlan.packed_summary)."""
+    return 4 + 3 * int(max_k)
 
+
+def score_sharded(score_fn, batch, rank, world_size, gather_fn, mod_group="STY", n_types=2):
+    """Scores rank's shard with ``score_fn(shard_batch, max_k) -> int32 [n, 4 + 3 * max_k] records``
+    (a torch tensor on whatever device the process group communicates on) and gathers all records
+    to rank 0 with ONE call of ``gather_fn(tensor, dst=0) -> list of tensors or None``.
+
+    ``max_k`` is the JOB-wide largest n_of_mod: every rank packs at that width, whatever its own
+    shard holds (an empty shard included), so the fixed-size gather sees equal shapes on all ranks.
     Returns (records of the whole batch in input order, ranges) on rank 0, (None, ranges)
     elsewhere.  Shards are padded to the largest shard so one fixed-size gather suffices."""
-    import torch
     ranges = partition(work_estimate(batch, mod_group, n_types), world_size)
+    max_k = max(1, int(np.max(batch["n_of_mod"]))) if int(batch["n_psm"]) else 1
     lo, hi = ranges[rank]
-    shard = slice_batch(batch, lo, hi)
-    rec = score_fn(shard)
+    rec = score_fn(slice_batch(batch, lo, hi), max_k)
+    return gather_records(rec, ranges, rank, max_k, gather_fn), ranges
+
+
+def gather_records(rec, ranges, rank, max_k, gather_fn):
+    """The single collective of the path: pads this rank's records to the longest shard and gathers
+    them to rank 0, which returns them in input order (None elsewhere)."""
+    import torch
+    lo, hi = ranges[rank]
+    width = record_width(max_k)
+    if tuple(rec.shape) != (hi - lo, width):
+        raise ValueError("rank %d packed records of shape %s; the job-wide shape is (%d, %d)"
+                         % (rank, tuple(rec.shape), hi - lo, width))
     longest = max(h - l for l, h in ranges)
-    width = rec.shape[1]
     padded = torch.zeros((longest, width), dtype=rec.dtype, device=rec.device)
     padded[: hi - lo] = rec
     parts = gather_fn(padded, 0)
     if rank != 0:
-        return None, ranges
-    out = torch.cat([parts[r][: h - l] for r, (l, h) in enumerate(ranges)], dim=0)
-    return out, ranges
+        return None
+    return torch.cat([parts[r][: h - l] for r, (l, h) in enumerate(ranges)], dim=0)
 
 
 def dist_gather(tensor, dst=0, async_op=False):

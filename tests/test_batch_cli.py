@@ -99,3 +99,21 @@ def test_rows_match_per_psm_reference_loop(tmp_path):
     batch_cli.write_tsv(rows, str(out))
     lines = out.read_text().splitlines()
     assert lines[0].split("\t") == list(batch_cli.COLUMNS) and len(lines) == len(rows) + 1
+
+
+@pytest.mark.gpu
+def test_one_unscorable_psm_does_not_cost_the_run_its_output():
+    """A PSM beyond a limit the reference does not have (here: 70 residues) is written as a row
+    without a localisation, with a warning; the other rows are unchanged."""
+    from pyascore_amd import PyAscore
+    spectra, psms = _toy_inputs()
+    gpu = PyAscore(100.0, 10, "STY", PHOSPHO, 0.05, "by")
+    want = batch_cli.localize(gpu, psms, spectra, "STY", PHOSPHO, hit_depth=2, max_fragment_charge=3)
+    long_psm = dict(psms[0], scan=psms[-1]["scan"] + 1, peptide="A" * 60 + "STSTSTSTSK",
+                    mod_positions=np.array([61], np.int32), mod_masses=np.array([PHOSPHO]))
+    spectra2 = dict(spectra)
+    spectra2[long_psm["scan"]] = spectra[psms[0]["scan"]]
+    with pytest.warns(RuntimeWarning, match="not scored"):
+        rows = batch_cli.localize(gpu, psms + [long_psm], spectra2, "STY", PHOSPHO, hit_depth=2, max_fragment_charge=3)
+    assert rows[:-1] == want
+    assert rows[-1][0] == long_psm["scan"] and rows[-1][1] == "" and np.isnan(rows[-1][2]) and rows[-1][3:] == ["", ""]

@@ -418,21 +418,12 @@ def test_device_plan_and_shard_path_on_one_gpu():
     want = gpu.score_batch(batch)
     k = int(batch["n_of_mod"].max())
 
-    def score_fn(sh):
+    def score_fn(sh, max_k):
         dev = torch.device("cuda", gpu.device)
-        plan = DevicePlan(gpu, sh)
+        plan = DevicePlan(gpu, sh, max_k=max_k)
         plan.run(torch.from_numpy(sh["mz"]).to(dev), torch.from_numpy(sh["intensity"]).to(dev))
         plan.check()
-        assert plan.max_k <= k
-        rec = plan.packed_summary()
-        if plan.max_k < k:          # pad to the batch-wide record width
-            n = rec.shape[0]
-            pad = torch.zeros((n, 4 + 3 * k), dtype=rec.dtype, device=rec.device)
-            mk = plan.max_k
-            pad[:, :4 + mk] = rec[:, :4 + mk]
-            pad[:, 4 + k:4 + k + 2 * mk] = rec[:, 4 + mk:]
-            rec = pad
-        return rec
+        return plan.packed_summary()
 
     rec, ranges = shard.score_sharded(score_fn, batch, 0, 1, lambda t, dst: [t])
     got = unpack_summary(rec.cpu().numpy(), k)
@@ -491,3 +482,71 @@ def test_rccl_gather_path_single_rank():
         _same(got, gpu.score_batch(batch))
     finally:
         dist.destroy_process_group()
+
+
+def test_skip_invalid_sets_psms_aside():
+    """PYA_FLAG_SKIP_INVALID: PSMs the library cannot take (a limit the reference does not have, an
+    unknown residue, an empty spectrum, a spectrum without m/z windows) get a status code and
+    "no result" rows; every other PSM of the batch scores exactly as it does alone."""
+    good, settings = synth.make_batch("cfg3", n_psm=40, seed=8)
+    rng = np.random.default_rng(4)
+    mzs = np.sort(rng.uniform(150.0, 1500.0, 200))
+    its = rng.lognormal(5, 1, 200)
+    odd = [
+        dict(mz=mzs, intensity=its, peptide="A" * 30 + "STY" * 14, n_of_mod=2, max_charge=1),          # 72 residues
+        dict(mz=mzs, intensity=its, peptide="PEPTIXDESK", n_of_mod=1, max_charge=1),                     # unknown residue
+        dict(mz=np.zeros(0), intensity=np.zeros(0), peptide="PEPTIDESK", n_of_mod=1, max_charge=1),      # empty spectrum
+        dict(mz=mzs, intensity=its, peptide="ST" * 20, n_of_mod=12, max_charge=1),                       # C(40,12) assignments
+        dict(mz=np.array([500.0]), intensity=np.array([1.0]), peptide="PEPTIDESK", n_of_mod=1, max_charge=1),   # no window
+        dict(mz=mzs, intensity=its, peptide="PEPTIDESK", n_of_mod=1, max_charge=0),                      # charge 0
+    ]
+    psms = [dict(mz=kw["mz_arr"], intensity=kw["int_arr"], peptide=kw["peptide"], n_of_mod=kw["n_of_mod"],
+                 max_charge=kw["max_fragment_charge"]) for kw in (synth.unpack_psm(good, i) for i in range(40))]
+    where = [3, 11, 12, 25, 33, 45]
+    for w, o in zip(where, odd):
+        psms.insert(w, o)
+    batch = synth.pack_batch(psms)
+    gpu = _gpu(settings)
+    with pytest.raises(ValueError):
+        gpu.score_batch(batch)
+    got = gpu.score_batch(batch, skip_invalid=True)
+    keep = np.setdiff1d(np.arange(batch["n_psm"]), where)
+    assert list(got["status"][where]) == [17, 16, 16, 17, 1, 16] and not got["status"][keep].any()
+    assert "PSM 3" in got["status_message"]
+    assert np.all(got["best_score"][where] == -1.0) and np.all(got["n_sig"][where] == -1)
+    assert not got["ascores"][where].any() and not got["alt_mask"][where].any()
+    alone = gpu.score_batch(good)
+    k = alone["ascores"].shape[1]
+    for key in ("n_sig", "best_sig", "best_score"):
+        assert np.array_equal(got[key][keep], alone[key]), key
+    assert np.array_equal(got["ascores"][keep][:, :k], alone["ascores"]) and not got["ascores"][keep][:, k:].any()
+    assert np.array_equal(got["alt_mask"][keep][:, :k], alone["alt_mask"])
+    # a clean batch reports all zeros
+    assert not gpu.score_batch(good, skip_invalid=True)["status"].any()
+
+
+def test_retained_batch_invalidates_single_psm_state():
+    """score() then score_batch(keep=True): the handle's retained records now belong to the batch, so
+    the per-PSM properties go back to their initial state instead of mixing the two."""
+    batch, settings = synth.make_batch("cfg2", n_psm=8, seed=12)
+    gpu = _gpu(settings)
+    gpu.score(**synth.unpack_psm(batch, 5))
+    assert gpu.best_sequence and len(gpu.pep_scores) == 20
+    gpu.score_batch(batch, keep=True)
+    assert gpu.best_sequence == "" and gpu.best_score == -1.0 and gpu.pep_scores == [] and gpu.ascores.size == 0
+    with pytest.raises(RuntimeError):
+        gpu.calculate_ambiguity({}, {})
+    assert gpu.batch_pep_scores()["rec_off"][-1] == 8 * 20
+    gpu.score(**synth.unpack_psm(batch, 5))
+    assert len(gpu.pep_scores) == 20
+
+
+def test_drop_in_import_name():
+    """`from pyascore import PyAscore` (reference pyascore/__init__.py:17) gives the HIP scorer."""
+    import pyascore
+    import pyascore_amd
+    assert pyascore.PyAscore is pyascore_amd.PyAscore
+    s = pyascore.PyAscore(bin_size=100., n_top=10, mod_group="STY", mod_mass=79.966331, mz_error=0.05)
+    mz = np.array([150.0, 300.5, 420.25]); it = np.array([1.0, 2.0, 3.0])
+    s.score(mz, it, "PEPTIDE", 1)
+    assert s.best_sequence == "PEPT[80]IDE"
