@@ -17,7 +17,7 @@
  *   pya_get_pep_scores            PyAscore.pep_scores                 Ascore.pyx:241-252
  *   pya_get_pep_scores_range      the same for a range of PSMs of a retained batch (bulk export)
  *   pya_calculate_ambiguity       PyAscore.calculate_ambiguity        Ascore.pyx:208-230
- *   pya_format_peptide            ModifiedPeptide::getPeptide         cpp/ModifiedPeptide.cpp:199-253
+ *   pya_format_peptide(s)         ModifiedPeptide::getPeptide         cpp/ModifiedPeptide.cpp:199-253
  *   pya_plan_*                    (new) device-resident variant of pya_score_batch for callers
  *                                 that keep spectra in HBM and own a HIP stream
  *
@@ -160,6 +160,15 @@ int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits,
 int pya_format_peptide(const pya_handle *h, const uint8_t *pep, uint64_t pep_len, int32_t n_of_mod,
                        const uint32_t *aux_pos, const float *aux_mass, uint64_t n_aux,
                        uint64_t sig_bits, int32_t sig_len, char *buf, uint64_t cap);
+/* pya_format_peptide for many records in ONE call: record r is the localisation sig_bits[r] of PSM
+ * rec_psm[r] of `batch` (rec_psm NULL: record r belongs to PSM r -- the best sequences of a scored
+ * batch; with rec_psm -- the sequence column of a bulk pep_scores export).  rec_valid (optional): a
+ * record with rec_valid[r] <= 0 (n_sig of a PSM without localisation, a set-aside PSM) gets the empty
+ * string.  Strings come back as CSR bytes without terminators: str_off[n_rec + 1], buf[cap]; with
+ * cap == 0 only str_off is filled (size query).  (ModifiedPeptide.cpp:199-253 at scale) */
+int pya_format_peptides(const pya_handle *h, const pya_batch *batch, uint64_t n_rec, const int64_t *rec_psm,
+                        const uint64_t *sig_bits, const int32_t *rec_valid, int64_t *str_off, char *buf,
+                        uint64_t cap);
 int pya_count_sites(const pya_handle *h, const uint8_t *pep, uint64_t pep_len, int32_t *n_sites,
                     uint8_t *site_pos /* >= PYA_MAX_PEPTIDE_LEN, 0-based residue of each site */);
 

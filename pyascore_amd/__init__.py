@@ -1,12 +1,19 @@
 """pyascore_amd -- MI355X-native implementation of pyAscore's ``PyAscore.score`` hot path.
 
-Public surface mirrors ``pyascore`` for this path (pyascore/__init__.py:17): ``PyAscore``.
+Public surface mirrors ``pyascore`` for this path (pyascore/__init__.py:17): ``PyAscore`` plus
+the auxiliary scripting classes ``PyBinnedSpectra``, ``PyModifiedPeptide``, ``PyFragmentGraph``,
+``PyLogMath``, ``PyBinomialDist``, ``PyPowerSetSum``.
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+_AUX = ("PyBinnedSpectra", "PyModifiedPeptide", "PyFragmentGraph", "PyLogMath", "PyBinomialDist", "PyPowerSetSum")
 
 
 def __getattr__(name):
     if name == "PyAscore":
         from .ascore import PyAscore
         return PyAscore
+    if name in _AUX:
+        from . import aux
+        return getattr(aux, name)
     raise AttributeError(name)

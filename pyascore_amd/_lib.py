@@ -56,9 +56,49 @@ SYMBOLS = {
                                           _vp, C.c_float, C.POINTER(C.c_float)]),
     "pya_format_peptide": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int32, _vp, _vp, C.c_uint64,
                                      C.c_uint64, C.c_int32, C.c_char_p, C.c_uint64]),
+    "pya_format_peptides": (C.c_int, [_vp, C.POINTER(Batch), C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_uint64]),
     "pya_count_sites": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_int32), _vp]),
     "pya_debug_sort": (C.c_int, [_vp, _vp, C.c_uint32, _vp]),
     "pya_version": (C.c_char_p, []),
+    # include/pyascore_aux.h
+    "pya_spectra_create": (_vp, [C.c_float, C.c_uint64]),
+    "pya_spectra_destroy": (None, [_vp]),
+    "pya_spectra_consume": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "pya_spectra_info": (None, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "pya_spectra_window_size": (C.c_int64, [_vp, C.c_uint64]),
+    "pya_spectra_peak": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pya_modpep_create": (_vp, [C.c_char_p, C.c_float, C.c_float, C.c_char_p]),
+    "pya_modpep_destroy": (None, [_vp]),
+    "pya_modpep_last_error": (C.c_char_p, [_vp]),
+    "pya_modpep_add_neutral_loss": (C.c_int, [_vp, C.c_char_p, C.c_float]),
+    "pya_modpep_consume_peptide": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint64]),
+    "pya_modpep_n_modifiable": (C.c_int64, [_vp]),
+    "pya_modpep_consume_peak": (C.c_int, [_vp, C.c_float, C.c_uint64]),
+    "pya_modpep_get_match": (C.c_int, [_vp, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
+    "pya_modpep_get_peptide": (C.c_int64, [_vp, _vp, C.c_uint64, C.c_char_p, C.c_uint64]),
+    "pya_modpep_site_ions": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_char, C.c_uint64, _vp, C.c_uint64,
+                                       C.POINTER(C.c_uint64), _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "pya_fgraph_create": (_vp, [_vp, C.c_char, C.c_uint64]),
+    "pya_fgraph_destroy": (None, [_vp]),
+    "pya_fgraph_type": (C.c_char, [_vp]),
+    "pya_fgraph_charge": (C.c_uint64, [_vp]),
+    "pya_fgraph_reset_iterator": (C.c_int, [_vp]),
+    "pya_fgraph_incr_signature": (C.c_int, [_vp]),
+    "pya_fgraph_is_signature_end": (C.c_int, [_vp]),
+    "pya_fgraph_reset_fragment": (C.c_int, [_vp]),
+    "pya_fgraph_incr_fragment": (C.c_int, [_vp]),
+    "pya_fgraph_is_fragment_end": (C.c_int, [_vp]),
+    "pya_fgraph_is_loss": (C.c_int, [_vp]),
+    "pya_fgraph_set_signature": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "pya_fgraph_get_signature": (C.c_int64, [_vp, _vp, C.c_uint64]),
+    "pya_fgraph_fragment_mz": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "pya_fgraph_fragment_size": (C.c_uint64, [_vp]),
+    "pya_fgraph_fragment_seq": (C.c_int64, [_vp, C.c_char_p, C.c_uint64]),
+    "pya_log_sum": (C.c_float, [C.c_float, C.c_float]),
+    "pya_log_bin_coef": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_float)]),
+    "pya_binomial": (C.c_int, [C.c_float, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_float)]),
+    "pya_power_set_sums": (C.c_int64, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64]),
 }
 
 _lib = None

@@ -226,6 +226,37 @@ class PyAscore:
                                      if out["status"].any() else "")
         return out
 
+    def format_batch(self, batch, sig_bits, valid=None, rec_psm=None):
+        """Modified-sequence strings (``best_sequence`` / the ``sequence`` of ``pep_scores`` records) for
+        many localisations in ONE library call: record r is the localisation ``sig_bits[r]`` of PSM
+        ``rec_psm[r]`` of ``batch`` (default: record r belongs to PSM r).  Records with ``valid[r] <= 0``
+        (pass ``n_sig``) come back as ''.  Returns a list of str."""
+        sig_bits = np.ascontiguousarray(sig_bits, np.uint64)
+        n_rec = sig_bits.size
+        rp = None if rec_psm is None else np.ascontiguousarray(rec_psm, np.int64)
+        va = None if valid is None else np.ascontiguousarray(valid, np.int32)
+        if (rp is not None and rp.size != n_rec) or (va is not None and va.size != n_rec):
+            raise ValueError("rec_psm / valid must have one entry per record")
+        arrs = [np.ascontiguousarray(batch["peak_off"], np.int64), np.ascontiguousarray(batch["pep"], np.uint8),
+                np.ascontiguousarray(batch["pep_off"], np.int64), np.ascontiguousarray(batch["n_of_mod"], np.int32),
+                np.ascontiguousarray(batch["max_charge"], np.int32), np.ascontiguousarray(batch["aux_pos"], np.uint32),
+                np.ascontiguousarray(batch["aux_mass"], np.float32), np.ascontiguousarray(batch["aux_off"], np.int64)]
+        if rp is None and n_rec != int(batch["n_psm"]):
+            raise ValueError("one localisation per PSM expected")
+        b = _lib.Batch(int(batch["n_psm"]), *[_as_ptr(a) for a in arrs])
+        off = np.zeros(n_rec + 1, np.int64)
+        rc = self._lib.pya_format_peptides(self._h, C.byref(b), n_rec, _as_ptr(rp), _as_ptr(sig_bits), _as_ptr(va),
+                                           _as_ptr(off), None, 0)
+        if rc:
+            raise ValueError("record refers to a PSM outside the batch")
+        buf = np.zeros(max(int(off[-1]), 1), np.uint8)
+        rc = self._lib.pya_format_peptides(self._h, C.byref(b), n_rec, _as_ptr(rp), _as_ptr(sig_bits), _as_ptr(va),
+                                           _as_ptr(off), _as_ptr(buf), buf.size)
+        if rc:
+            self._raise(rc)
+        text = buf.tobytes().decode("utf8")
+        return [text[off[r]:off[r + 1]] for r in range(n_rec)]
+
     # ------------------------------------------------------------------------------------------
     def _format(self, last, bits, sig_len):
         buf = C.create_string_buffer(1024)
@@ -278,12 +309,13 @@ class PyAscore:
                             sequence=self._format(last, b, ns)))
         return out
 
-    def batch_pep_scores(self, begin=0, end=None):
+    def batch_pep_scores(self, begin=0, end=None, batch=None):
         """All localisations of PSMs [begin, end) of the last ``score_batch(..., keep=True)``, in the
         reference's sorted order, as CSR arrays (bulk form of ``pep_scores``, Ascore.pyx:241-252):
         dict(rec_off i64[n+1], sig_bits u64[R] (bit j = j-th modifiable residue), counts i32[R, 10],
         scores f32[R, 10], weighted_score f32[R], total_fragments i32[R]); records of PSM i are
-        rows rec_off[i - begin] : rec_off[i - begin + 1]."""
+        rows rec_off[i - begin] : rec_off[i - begin + 1].  With ``batch`` (the scored batch) the
+        records' ``sequence`` strings are added, all formatted in one library call."""
         if self._batch_n is None:
             raise RuntimeError("no batch retained: call score_batch(batch, keep=True) first")
         end = self._batch_n if end is None else int(end)
@@ -305,6 +337,9 @@ class PyAscore:
                                                     _as_ptr(out["total_fragments"]))
             if rc:
                 self._raise(rc)
+        if batch is not None:
+            rec_psm = np.repeat(np.arange(begin, end, dtype=np.int64), np.diff(off))
+            out["sequence"] = self.format_batch(batch, out["sig_bits"], rec_psm=rec_psm)
         return out
 
     @property

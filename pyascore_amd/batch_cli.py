@@ -12,12 +12,11 @@ parsers produce (dicts); file parsing itself (pyteomics) stays out of scope.
 Output rows/columns follow docs/source/cli.rst:135-180: Scan, LocalizedSequence, PepScore,
 Ascores (';' separated), AltSites (',' within ';').
 """
-import ctypes as C
 from itertools import groupby
 
 import numpy as np
 
-from .ascore import PyAscore, _as_ptr
+from .ascore import PyAscore
 from .synth import pack_batch
 
 COLUMNS = ("Scan", "LocalizedSequence", "PepScore", "Ascores", "AltSites")
@@ -101,28 +100,18 @@ def localize(ascore, psms, spectra_map, residues, mod_mass, hit_depth=1, max_fra
         import warnings
         warnings.warn("%d of %d PSMs were not scored (first: %s); their rows carry no localisation"
                       % (bad.size, len(picked), res["status_message"]), RuntimeWarning)
+    ok = (res["status"] == 0) & (res["n_sig"] > 0)
+    seqs = ascore.format_batch(batch, res["best_sig"], valid=ok.astype(np.int32))   # every string in one call
     rows = []
-    buf = C.create_string_buffer(1024)
     for i, psm in enumerate(picked):
         if res["status"][i]:
             rows.append([scans[i], "", float("nan"), "", ""])
             continue
         k = psm["n_of_mod"]
-        pep = np.frombuffer(psm["peptide"].encode("utf8"), dtype=np.uint8)
-        ns = C.c_int32()
-        ascore._lib.pya_count_sites(ascore._h, _as_ptr(pep), pep.size, C.byref(ns), None)
-        seq = ""
-        if res["n_sig"][i] > 0:
-            n = ascore._lib.pya_format_peptide(ascore._h, _as_ptr(pep), pep.size, k, _as_ptr(psm["aux_pos"]),
-                                               _as_ptr(psm["aux_mass"]), psm["aux_pos"].size,
-                                               int(res["best_sig"][i]), ns.value, buf, 1024)
-            if n < 0:
-                ascore._raise(n)
-            seq = buf.value.decode("utf8")
         ascores = ";".join(str(s) for s in res["ascores"][i, :k])
         alts = ";".join(",".join(str(p + 1) for p in range(64) if (int(m) >> p) & 1)
                         for m in res["alt_mask"][i, :k])
-        rows.append([scans[i], seq, float(res["best_score"][i]), ascores, alts])
+        rows.append([scans[i], seqs[i], float(res["best_score"][i]), ascores, alts])
     return rows
 
 

@@ -619,24 +619,23 @@ int pya_count_sites(const pya_handle *h, const uint8_t *pep, uint64_t L, int32_t
 }
 
 /* ModifiedPeptide::getPeptide, cpp/ModifiedPeptide.cpp:199-253 */
-int pya_format_peptide(const pya_handle *h, const uint8_t *pep, uint64_t L, int32_t n_of_mod,
-                       const uint32_t *aux_pos, const float *aux_mass, uint64_t n_aux, uint64_t sig_bits,
-                       int32_t sig_len, char *buf, uint64_t cap) {
-    if (!h || !pep || !buf || cap == 0) return PYA_ERR_ARG;
-    std::vector<size_t> sites;
+static void format_one(const pya_handle *h, const uint8_t *pep, uint64_t L, int32_t n_of_mod, const uint32_t *aux_pos,
+                       const float *aux_mass, uint64_t n_aux, uint64_t sig_bits, int32_t sig_len, std::string &out) {
+    size_t sites[PYA_MAX_PEPTIDE_LEN];
+    size_t n = 0;
     for (uint64_t i = 0; i < L; i++)
-        if (h->letter_modifiable((char)pep[i], i, L)) sites.push_back(i);
-    const size_t n = sites.size();
+        if (h->letter_modifiable((char)pep[i], i, L) && n < PYA_MAX_PEPTIDE_LEN) sites[n++] = i;
     std::vector<float> mm(L + 2, 0.f);
     if ((size_t)n_of_mod > n) {
-        if (h->mod_group.find('n') != std::string::npos) mm.front() += h->mod_mass;
+        if (h->allow_n) mm.front() += h->mod_mass;
         else mm.back() += h->mod_mass;
     }
-    for (int32_t j = 0; j < sig_len; j++) {
+    if (sig_len < 0) sig_len = (int32_t)n;
+    for (int32_t j = 0; j < sig_len && j < 64; j++) {
         if (!(sig_bits >> j & 1)) continue;
         size_t pos = (size_t)j < n ? sites[j] : L;
-        char aa = pos < L ? (char)pep[pos] : 0;
-        if (h->mod_group.find(aa) != std::string::npos) mm[pos + 1] += h->mod_mass;
+        unsigned char aa = pos < L ? pep[pos] : 0;
+        if (aa && h->in_group[aa]) mm[pos + 1] += h->mod_mass;
         else if (pos == 0) mm.front() += h->mod_mass;
         else if (pos + 1 == L) mm.back() += h->mod_mass;
     }
@@ -645,19 +644,73 @@ int pya_format_peptide(const pya_handle *h, const uint8_t *pep, uint64_t L, int3
     size_t s = 0, e = mm.size();
     if (mm.front() == 0.f) s++;
     if (mm.back() == 0.f) e--;
-    std::string full = "n" + std::string((const char *)pep, L) + "c", out;
+    out.clear();
     for (size_t i = s; i < e; i++) {
-        out += full[i];
+        out += i == 0 ? 'n' : (i == L + 1 ? 'c' : (char)pep[i - 1]);
         if (mm[i] > 0.f) {
             char t[16];
             std::snprintf(t, sizeof t, "[%d]", (int)std::round(mm[i]));
             out += t;
         }
     }
+}
+
+int pya_format_peptide(const pya_handle *h, const uint8_t *pep, uint64_t L, int32_t n_of_mod,
+                       const uint32_t *aux_pos, const float *aux_mass, uint64_t n_aux, uint64_t sig_bits,
+                       int32_t sig_len, char *buf, uint64_t cap) {
+    if (!h || !pep || !buf || cap == 0) return PYA_ERR_ARG;
+    if (L > PYA_MAX_PEPTIDE_LEN) return PYA_ERR_LIMIT;
+    std::string out;
+    format_one(h, pep, L, n_of_mod, aux_pos, aux_mass, n_aux, sig_bits, sig_len, out);
     size_t ncopy = std::min<size_t>(out.size(), cap - 1);
     std::memcpy(buf, out.data(), ncopy);
     buf[ncopy] = 0;
     return (int)out.size();
+}
+
+/* the same for many records in one call (threaded above 20 000 records) */
+int pya_format_peptides(const pya_handle *h, const pya_batch *b, uint64_t n_rec, const int64_t *rec_psm,
+                        const uint64_t *sig_bits, const int32_t *rec_valid, int64_t *str_off, char *buf,
+                        uint64_t cap) {
+    if (!h || !b || !sig_bits || !str_off) return PYA_ERR_ARG;
+    if (b->n_psm && (!b->pep || !b->pep_off || !b->n_of_mod)) return PYA_ERR_ARG;
+    const bool has_aux = b->aux_off && b->aux_pos && b->aux_mass;
+    std::vector<std::string> strs(n_rec);
+    int bad = 0;
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; r++) {
+            if (rec_valid && rec_valid[r] <= 0) continue;           /* no localisation: empty string */
+            const uint64_t i = rec_psm ? (uint64_t)rec_psm[r] : r;
+            if (i >= b->n_psm) {
+                bad = 1;
+                continue;
+            }
+            const int64_t p0 = b->pep_off[i], L = b->pep_off[i + 1] - p0;
+            if (L < 1 || L > PYA_MAX_PEPTIDE_LEN) continue;         /* set-aside PSM */
+            const int64_t a0 = has_aux ? b->aux_off[i] : 0, a1 = has_aux ? b->aux_off[i + 1] : 0;
+            format_one(h, b->pep + p0, (uint64_t)L, b->n_of_mod[i], has_aux ? b->aux_pos + a0 : nullptr,
+                       has_aux ? b->aux_mass + a0 : nullptr, (uint64_t)(a1 - a0), sig_bits[r], -1, strs[r]);
+        }
+    };
+    unsigned nt = n_rec >= 20000 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (nt == 1) {
+        work(0, n_rec);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n_rec * t / nt, n_rec * (t + 1) / nt);
+        for (auto &x : th) x.join();
+    }
+    if (bad) return PYA_ERR_ARG;
+    int64_t total = 0;
+    for (uint64_t r = 0; r < n_rec; r++) {
+        str_off[r] = total;
+        total += (int64_t)strs[r].size();
+    }
+    str_off[n_rec] = total;
+    if (cap == 0 || !buf) return PYA_OK;                            /* size query */
+    if ((uint64_t)total > cap) return PYA_ERR_ARG;
+    for (uint64_t r = 0; r < n_rec; r++) std::memcpy(buf + str_off[r], strs[r].data(), strs[r].size());
+    return PYA_OK;
 }
 
 namespace {

@@ -14,17 +14,9 @@
 #include <cstdint>
 #include <vector>
 
-namespace {
+#include "binom_chain.h"
 
-float log_sum(float a, float b) {                                    /* Util.cpp:16-26 */
-    if (std::isinf(a)) return b;
-    if (std::isinf(b)) return a;
-    float m = a < b ? b : a;                                         /* std::max(a, b) */
-    float s = std::exp(a - m) + std::exp(b - m);
-    return m + std::log(s);
-}
-
-}  // namespace
+using pya_chain::log_sum;
 
 /* Appends rows n = off.size() .. n_to (inclusive) for the n_top depths.  Row layout:
  * lut[off[n] + d*(n+1) + k].  off gets one entry per n. */

@@ -1,5 +1,5 @@
 """The C-ABI library loads without a GPU and exports every symbol include/pyascore_hip.h
-declares; without a device the product fails loudly (no CPU fallback)."""
+and include/pyascore_aux.h declare; without a device the product fails loudly (no CPU fallback)."""
 import ctypes as C
 import os
 import re
@@ -9,7 +9,7 @@ import pytest
 
 from conftest import ROOT
 
-HEADER = os.path.join(ROOT, "include", "pyascore_hip.h")
+HEADERS = [os.path.join(ROOT, "include", "pyascore_hip.h"), os.path.join(ROOT, "include", "pyascore_aux.h")]
 
 
 @pytest.fixture(scope="module")
@@ -21,14 +21,14 @@ def lib():
 
 
 def declared_symbols():
-    text = open(HEADER).read()
+    text = "".join(open(h).read() for h in HEADERS)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pya_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_header_symbols_are_exported(lib):
     names = declared_symbols()
-    assert len(names) >= 18
+    assert len(names) >= 55
     from pyascore_amd import _lib
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)

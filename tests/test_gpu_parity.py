@@ -550,3 +550,22 @@ def test_drop_in_import_name():
     mz = np.array([150.0, 300.5, 420.25]); it = np.array([1.0, 2.0, 3.0])
     s.score(mz, it, "PEPTIDE", 1)
     assert s.best_sequence == "PEPT[80]IDE"
+
+
+@pytest.mark.parametrize("case", ["velos_zprec", "edge_nKc", "edge_default", "synth_cfg3"])
+def test_bulk_sequence_strings(case):
+    """pya_format_peptides: every best_sequence of a batch, and the sequence of every pep_scores record,
+    in one library call each -- equal to the reference's strings (ModifiedPeptide.cpp:199-253)."""
+    settings, batch, expected = harness.load_case(os.path.join(GOLDEN, case + ".npz"))
+    gpu = _gpu(settings)
+    res = gpu.score_batch(batch, keep=True)
+    assert gpu.format_batch(batch, res["best_sig"], valid=res["n_sig"]) == expected["best_sequence"].tolist()
+    bulk = gpu.batch_pep_scores(batch=batch)
+    assert len(bulk["sequence"]) == int(bulk["rec_off"][-1])
+    for i in range(0, batch["n_psm"], max(1, batch["n_psm"] // 6)):
+        gpu.score(**synth.unpack_psm(batch, i))
+        want = [p["sequence"] for p in gpu.pep_scores]
+        gpu.score_batch(batch, keep=True)
+        assert bulk["sequence"][int(bulk["rec_off"][i]):int(bulk["rec_off"][i + 1])] == want
+    with pytest.raises(ValueError):
+        gpu.format_batch(batch, res["best_sig"], rec_psm=np.full(batch["n_psm"], batch["n_psm"], np.int64))
