@@ -118,9 +118,16 @@ int pya_add_neutral_loss(pya_handle *h, const char *group, float mass);
 const char *pya_last_error(const pya_handle *h);
 int64_t pya_error_index(const pya_handle *h);
 
-/* host buffers in, host buffers out: H2D copy + kernels + D2H copy, synchronous */
+/* host buffers in, host buffers out: H2D copy + kernels + D2H copy, synchronous (big batches are
+ * chunked and pipelined, see pya_set_workspace_budget; a PYA_FLAG_KEEP batch is always one plan) */
 int pya_score_batch(pya_handle *h, const pya_batch *batch, const double *mz,
                     const double *intensity, uint32_t flags, const pya_results *out);
+
+/* Device memory one pya_score_batch call may hold at a time (upload ring + workspace; default 6 GiB,
+ * or PYA_WORKSPACE_MB).  Calls that need more -- and every call with more than 32 MB of spectra -- are
+ * cut into chunks of consecutive PSMs and pipelined: the upload of chunk c + 1 runs under the kernels
+ * and the result copy of chunk c.  Results do not depend on the cut. */
+int pya_set_workspace_budget(pya_handle *h, uint64_t bytes);
 
 /* per-PSM status codes (PYA_PSM_*) of the last pya_score_batch call on this handle; n must equal
  * that batch's n_psm.  All zeros unless PYA_FLAG_SKIP_INVALID let PSMs be set aside. */

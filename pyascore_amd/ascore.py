@@ -112,6 +112,14 @@ class PyAscore:
         if rc:
             self._raise(rc)
 
+    def set_workspace_budget(self, n_bytes):
+        """Device memory one ``score_batch`` call may hold at a time (default 6 GiB; 0 restores it).
+        Bigger calls are cut into chunks of consecutive PSMs and pipelined (upload of the next chunk
+        under the kernels of the current one); results do not depend on the cut."""
+        rc = self._lib.pya_set_workspace_budget(self._h, int(n_bytes))
+        if rc:
+            self._raise(rc)
+
     def score(self, mz_arr, int_arr, peptide, n_of_mod, max_fragment_charge=1, aux_mod_pos=None,
               aux_mod_mass=None):
         """Consume spectra and associated peptide information and score PTM localization

@@ -19,8 +19,10 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <condition_variable>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -174,6 +176,9 @@ struct pya_handle {
      * hundred MB cost milliseconds) */
     DevBuf<unsigned char> spare_arena;
     DevBuf<double> io_buf;                     /* spectra of big pya_score_batch calls (uploaded by a helper thread) */
+    DevBuf<double> io_ring[2];                 /* chunked calls: spectra of chunk c in slot c % 2 */
+    hipStream_t copy_stream = nullptr, run_stream = nullptr;   /* chunked calls: uploads / kernels + results */
+    size_t ws_budget = 0;                      /* device bytes one pya_score_batch call may hold (0 = default) */
     std::vector<unsigned char> stage;          /* host staging of small batches: one copy each way */
 
     std::string err;
@@ -313,6 +318,7 @@ struct pya_plan {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t last_stream = nullptr;
     bool ran = false;
+    bool quiesced = false;               /* the owner has waited for everything that used the buffers */
 
     ~pya_plan() {
         for (auto &e : ev)
@@ -587,6 +593,8 @@ void pya_destroy(pya_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->kept) pya_plan_destroy(h->kept);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->run_stream) (void)hipStreamDestroy(h->run_stream);
     delete h;
 }
 
@@ -718,6 +726,7 @@ struct IoReq {                       /* pya_score_batch: spectra and results liv
     const double *mz, *inten;
     uint32_t max_k;
     double *d_mz_ext, *d_inten_ext;  /* ... unless the caller uploads the spectra itself (big batches) */
+    hipStream_t stream;              /* metadata upload: on this stream, waited for alone (nullptr: device-wide) */
 };
 }
 
@@ -1113,8 +1122,10 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             for (const Up &u : ups) std::memcpy(h->stage.data() + u.off, u.src, u.bytes);
             HIPCHK(h, hipMemcpy(base, h->stage.data(), h2d_bytes, hipMemcpyHostToDevice));
         } else {
-            for (const Up &u : ups) HIPCHK(h, hipMemcpyAsync(base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
-            HIPCHK(h, hipDeviceSynchronize());
+            hipStream_t ust = io ? io->stream : nullptr;
+            for (const Up &u : ups) HIPCHK(h, hipMemcpyAsync(base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, ust));
+            if (ust) HIPCHK(h, hipStreamSynchronize(ust));
+            else HIPCHK(h, hipDeviceSynchronize());
         }
     }
     if (n_skipped)      /* bin_spectra never touches these entries, so they keep their code for every run */
@@ -1287,9 +1298,190 @@ void pya_plan_destroy(pya_plan *p) {
             if (v[i]) std::fprintf(stderr, "[pya stamps] phase %2d: %12llu  %5.1f%%\n", i, v[i], 100.0 * v[i] / tot);
     }
     if (p->h->kept == p) p->h->kept = nullptr;
-    (void)hipDeviceSynchronize();                       /* nothing may still be using the buffers */
+    if (!p->quiesced) (void)hipDeviceSynchronize();     /* nothing may still be using the buffers */
     p->arena.give_to(p->h->spare_arena);
     delete p;
+}
+
+namespace {
+
+const size_t kChunkMin = 32u << 20;          /* spectra bytes below which a call is not worth pipelining */
+const size_t kChunkTarget = 96u << 20;       /* spectra bytes per chunk when the budget allows more       */
+const size_t kDefaultBudget = (size_t)6 << 30;
+
+size_t workspace_budget(const pya_handle *h) {
+    if (h->ws_budget) return h->ws_budget;
+    if (const char *e = std::getenv("PYA_WORKSPACE_MB")) return (size_t)std::max(16ll, std::atoll(e)) << 20;
+    return kDefaultBudget;
+}
+
+/* Device bytes a chunk [lo, hi) holds while it is scored: its spectra in the upload ring (two
+ * slots, so twice) and its arena (retained table, grid, per-signature scores and records, results
+ * and metadata).  C(n,k) comes from the peptide letters, as in the plan's pre-pass. */
+struct ChunkCost {
+    std::vector<double> arena, io;             /* per PSM */
+};
+ChunkCost chunk_costs(pya_handle *h, const pya_batch *b, uint32_t max_k) {
+    const uint64_t n = b->n_psm;
+    ChunkCost c;
+    c.arena.resize(n);
+    c.io.resize(n);
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            const int64_t P = std::max<int64_t>(0, b->peak_off[i + 1] - b->peak_off[i]);
+            const int64_t L = b->pep_off[i + 1] - b->pep_off[i];
+            double sigs = 0;
+            if (L >= 1 && L <= PYA_MAX_PEPTIDE_LEN && b->n_of_mod[i] >= 0) {
+                uint32_t ns = 0;
+                const uint8_t *s = b->pep + b->pep_off[i];
+                for (int64_t j = 0; j < L; j++) ns += h->letter_modifiable((char)s[j], (size_t)j, (size_t)L) ? 1u : 0u;
+                const uint64_t N = ns <= PYA_MAX_SITES ? binom(ns, (uint32_t)b->n_of_mod[i]) : 0;
+                sigs = N > PYA_MAX_SIGNATURES ? 0. : (double)N;
+            }
+            c.io[i] = 16.0 * (double)P;
+            c.arena[i] = 5.0 * (double)P + 28.0 * sigs + (double)L + 2.0 * PYA_GRID_CELLS + 96.0 + 12.0 * max_k;
+        }
+    };
+    unsigned nt = n >= 20000 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (nt == 1) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        for (auto &x : th) x.join();
+    }
+    return c;
+}
+
+/* "PSM 12: ..." of a chunk that starts at PSM `lo` of the caller's batch -> "PSM <12 + lo>: ..." */
+void rebase_error(pya_handle *h, uint64_t lo) {
+    if (h->err_index >= 0) h->err_index += (int64_t)lo;
+    unsigned long long local = 0;
+    int used = 0;
+    if (lo && std::sscanf(h->err.c_str(), "PSM %llu%n", &local, &used) == 1)
+        h->err = "PSM " + std::to_string(local + lo) + h->err.substr((size_t)used);
+}
+
+}  // namespace
+
+/* Big pya_score_batch calls: the batch is cut into chunks of consecutive PSMs that fit the device
+ * budget and the chunks are pipelined -- a helper thread streams the spectra of chunk c + 1 over
+ * PCIe (the bound of this entry point: 16 bytes per peak) into the other slot of a two-slot ring
+ * while this thread plans chunk c, runs its kernels and brings its results back on a second
+ * stream.  A call of any size completes; it never fails for lack of workspace. */
+static int score_batch_chunked(pya_handle *h, const pya_batch *b, const double *mz, const double *inten,
+                               uint32_t flags, const pya_results *out, const std::vector<uint64_t> &cuts) {
+    const size_t nchunk = cuts.size() - 1;
+    const uint32_t mk = out->max_k;
+    const bool skip = (flags & PYA_FLAG_SKIP_INVALID) != 0;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->run_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->run_stream, hipStreamNonBlocking));
+    size_t slot_peaks = 0;
+    for (size_t c = 0; c < nchunk; c++)
+        slot_peaks = std::max<size_t>(slot_peaks, (size_t)(b->peak_off[cuts[c + 1]] - b->peak_off[cuts[c]]));
+    for (auto &slot : h->io_ring)
+        if (slot.n < slot_peaks * 2) HIPCHK(h, slot.alloc(slot_peaks * 2));
+    if (skip) h->last_status.assign(b->n_psm, 0);
+
+    /* uploader: chunk c may be written once chunk c - 2 has been consumed */
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t uploaded = 0, consumed = 0;
+    bool stop = false;
+    hipError_t up_err = hipSuccess;
+    const int device = h->device;
+    std::thread uploader([&]() {
+        hipError_t e = hipSetDevice(device);
+        for (size_t c = 0; c < nchunk && e == hipSuccess; c++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || c < consumed + 2; });
+                if (stop) break;
+            }
+            const int64_t p0 = b->peak_off[cuts[c]], np = b->peak_off[cuts[c + 1]] - p0;
+            double *dst = h->io_ring[c & 1].p;
+            if (np > 0) {
+                e = hipMemcpyAsync(dst, mz + p0, (size_t)np * 8, hipMemcpyHostToDevice, h->copy_stream);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(dst + np, inten + p0, (size_t)np * 8, hipMemcpyHostToDevice, h->copy_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->copy_stream);
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            up_err = e;
+            uploaded = c + 1;
+            cv.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        if (e != hipSuccess) up_err = e;
+        uploaded = nchunk;                                   /* nobody waits for chunks that will not come */
+        cv.notify_all();
+    });
+    auto finish = [&](int rc) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        uploader.join();
+        return rc;
+    };
+
+    for (size_t c = 0; c < nchunk; c++) {
+        const uint64_t lo = cuts[c], hi = cuts[c + 1], n = hi - lo;
+        const int64_t np = b->peak_off[hi] - b->peak_off[lo];
+        pya_batch sub = *b;
+        sub.n_psm = n;
+        sub.peak_off = b->peak_off + lo;
+        sub.pep_off = b->pep_off + lo;
+        sub.n_of_mod = b->n_of_mod + lo;
+        sub.max_charge = b->max_charge + lo;
+        if (b->aux_off) sub.aux_off = b->aux_off + lo;
+        IoReq io = {mz, inten, mk, h->io_ring[c & 1].p, h->io_ring[c & 1].p + np, h->run_stream};
+        pya_plan *p = nullptr;
+        int rc = plan_create_impl(h, &sub, flags & ~(PYA_FLAG_TIMING | PYA_FLAG_KEEP), &io, &p);   /* host pre-pass: under the upload */
+        if (rc) {
+            rebase_error(h, lo);
+            return finish(rc);
+        }
+        std::unique_ptr<pya_plan, void (*)(pya_plan *)> guard(p, pya_plan_destroy);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return uploaded > c; });
+            if (up_err != hipSuccess) {
+                lk.unlock();
+                return finish(h->hip_fail(up_err, "spectrum upload"));
+            }
+        }
+        pya_results d_out = {mk, p->d_best_score.p, p->d_best_sig.p, p->d_n_sig_out.p, p->d_ascores.p, p->d_alt.p};
+        rc = pya_plan_run(p, p->d_mz.p, p->d_inten.p, h->run_stream, &d_out);
+        if (rc) return finish(rc);
+        /* status + results are adjacent in the arena: one copy back, then scattered into the caller's rows */
+        h->stage.resize(std::max(h->stage.size(), p->d2h_bytes));
+        unsigned char *sg = h->stage.data();
+        hipError_t e = hipMemcpyAsync(sg, p->arena.p + p->o_status, p->d2h_bytes, hipMemcpyDeviceToHost, h->run_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->run_stream);
+        p->quiesced = e == hipSuccess;
+        {
+            std::lock_guard<std::mutex> lk(mu);             /* the chunk's ring slot may be overwritten now */
+            consumed = c + 1;
+            cv.notify_all();
+        }
+        if (e != hipSuccess) return finish(h->hip_fail(e, "results copy"));
+        if (skip) std::memcpy(h->last_status.data() + lo, sg, n * sizeof(int32_t));
+        rc = check_status(h, (const int32_t *)sg, n, skip);
+        if (rc) {
+            rebase_error(h, lo);
+            return finish(rc);
+        }
+        const size_t o = p->o_status;
+        std::memcpy(out->best_score + lo, sg + (p->o_best_score - o), n * sizeof(float));
+        std::memcpy(out->best_sig + lo, sg + (p->o_best_sig - o), n * sizeof(uint64_t));
+        std::memcpy(out->n_sig + lo, sg + (p->o_n_sig_out - o), n * sizeof(int32_t));
+        std::memcpy(out->ascores + lo * mk, sg + (p->o_ascores - o), n * mk * sizeof(float));
+        std::memcpy(out->alt_mask + lo * mk, sg + (p->o_alt - o), n * mk * sizeof(uint64_t));
+    }
+    return finish(PYA_OK);
 }
 
 int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const double *inten, uint32_t flags,
@@ -1303,6 +1495,33 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
     if (!out->best_score || !out->best_sig || !out->n_sig || !out->ascores || !out->alt_mask)
         return h->fail(PYA_ERR_ARG, -1, "NULL array in results");
     if (b->peak_off[b->n_psm] < b->peak_off[0]) return h->fail(PYA_ERR_ARG, -1, "peak_off is not monotone");
+    {
+        /* Chunking: needed when the call does not fit the device budget, worthwhile (pipelining)
+         * when there is enough PCIe traffic to hide the kernels under.  A retained batch
+         * (PYA_FLAG_KEEP) stays one plan: its records are queried by PSM afterwards. */
+        const size_t io_total = (size_t)(b->peak_off[b->n_psm] - b->peak_off[0]) * 16;
+        if (!(flags & PYA_FLAG_KEEP) && io_total >= kChunkMin && !std::getenv("PYA_NO_CHUNKS")) {
+            const size_t budget = workspace_budget(h);
+            const ChunkCost cost = chunk_costs(h, b, out->max_k);
+            double io_target = (double)kChunkTarget;
+            if (const char *e = std::getenv("PYA_CHUNK_MB")) io_target = std::max(1.0, std::atof(e)) * 1048576.0;
+            std::vector<uint64_t> cuts{0};
+            double io = 0, arena = 0;
+            for (uint64_t i = 0; i < b->n_psm; i++) {
+                const double io2 = io + cost.io[i], ar2 = arena + cost.arena[i];
+                if (i > cuts.back() && (io2 > io_target || 2.0 * io2 + ar2 > (double)budget)) {
+                    cuts.push_back(i);
+                    io = cost.io[i];
+                    arena = cost.arena[i];
+                } else {
+                    io = io2;
+                    arena = ar2;
+                }
+            }
+            cuts.push_back(b->n_psm);
+            if (cuts.size() > 2) return score_batch_chunked(h, b, mz, inten, flags, out, cuts);
+        }
+    }
     const bool host_timing = std::getenv("PYA_HOST_TIMING") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -1313,7 +1532,7 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
         t0 = t1;
     };
     pya_plan *p = nullptr;
-    IoReq io = {mz, inten, out->max_k, nullptr, nullptr};
+    IoReq io = {mz, inten, out->max_k, nullptr, nullptr, nullptr};
     /* Big batches: the spectra (16 bytes per peak, PCIe-bound) go up on a helper thread while this
      * one runs the host pre-pass of the plan; small ones ride in the plan's single staged copy. */
     const int64_t peaks_lo = b->peak_off[0], n_peaks = b->peak_off[b->n_psm] - peaks_lo;
@@ -1378,6 +1597,13 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
         if (h->kept) pya_plan_destroy(h->kept);
         h->kept = guard.release();
     }
+    return PYA_OK;
+}
+
+int pya_set_workspace_budget(pya_handle *h, uint64_t bytes) {
+    if (!h) return PYA_ERR_ARG;
+    if (bytes && bytes < ((uint64_t)16 << 20)) return h->fail(PYA_ERR_ARG, -1, "workspace budget below 16 MiB");
+    h->ws_budget = (size_t)bytes;
     return PYA_OK;
 }
 

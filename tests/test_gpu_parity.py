@@ -569,3 +569,53 @@ def test_bulk_sequence_strings(case):
         assert bulk["sequence"][int(bulk["rec_off"][i]):int(bulk["rec_off"][i + 1])] == want
     with pytest.raises(ValueError):
         gpu.format_batch(batch, res["best_sig"], rec_psm=np.full(batch["n_psm"], batch["n_psm"], np.int64))
+
+
+def test_chunked_calls_equal_one_plan(monkeypatch):
+    """pya_score_batch cuts big calls into chunks that fit the device budget and pipelines them
+    (upload of chunk c + 1 under the kernels of chunk c): same results as one plan for the whole
+    batch, whatever the cut; errors and set-aside PSMs keep their index in the caller's batch."""
+    batch, settings = synth.make_slice(synth.describe("cfg3", 60_000, seed=17)), None
+    settings = synth.describe("cfg3", 1, seed=17)["settings"]
+    gpu = _gpu(settings)
+    monkeypatch.setenv("PYA_NO_CHUNKS", "1")
+    one = gpu.score_batch(batch)
+    monkeypatch.delenv("PYA_NO_CHUNKS")
+    _same(gpu.score_batch(batch), one)                 # default: ~96 MB of spectra per chunk
+    gpu.set_workspace_budget(48 << 20)                 # tight budget: dozens of chunks
+    _same(gpu.score_batch(batch), one)
+    monkeypatch.setenv("PYA_CHUNK_MB", "3")            # ... and ~100 chunks of 3 MB
+    _same(gpu.score_batch(batch), one)
+    monkeypatch.delenv("PYA_CHUNK_MB")
+    gpu.set_workspace_budget(0)
+    with pytest.raises(ValueError):
+        gpu.set_workspace_budget(1000)
+    # an invalid PSM deep inside the batch: reported with its index in the caller's batch
+    bad = dict(batch, pep=batch["pep"].copy())
+    where = 51_234
+    bad["pep"][batch["pep_off"][where] + 1] = ord("X")
+    with pytest.raises(ValueError, match="PSM %d: unknown residue" % where):
+        gpu.score_batch(bad)
+    got = gpu.score_batch(bad, skip_invalid=True)
+    assert np.flatnonzero(got["status"]).tolist() == [where] and got["best_score"][where] == -1.0
+    keep = np.arange(batch["n_psm"]) != where
+    for key in ("n_sig", "best_sig", "best_score", "ascores", "alt_mask"):
+        assert np.array_equal(got[key][keep], one[key][keep]), key
+
+
+def test_one_call_of_a_million_heavy_psms():
+    """1M PSMs of the cfg5 shape (3003 site assignments each: 86 GB of workspace as one plan) in ONE
+    score_batch call under the default 6 GiB budget; a random sample agrees with the reference."""
+    desc = synth.describe("cfg5", 1_000_000, seed=99)
+    batch = synth.make_slice(desc)
+    gpu = _gpu(desc["settings"])
+    full = gpu.score_batch(batch)
+    assert np.all(full["n_sig"] == 3003)
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(batch["n_psm"], 100, replace=False))
+    sub = synth.pack_batch([dict(mz=kw["mz_arr"], intensity=kw["int_arr"], peptide=kw["peptide"],
+                                 n_of_mod=kw["n_of_mod"], max_charge=kw["max_fragment_charge"])
+                            for kw in (synth.unpack_psm(batch, int(i)) for i in pick)])
+    want = _checker(desc["settings"]).score_batch(sub, 5)
+    for key in ("n_sig", "best_sig", "best_score", "ascores", "alt_mask"):
+        assert np.array_equal(full[key][pick], want[key]), key
