@@ -174,7 +174,9 @@ struct pya_handle {
 
     /* device allocations recycled between pya_score_batch calls (hipMalloc/hipFree of a few
      * hundred MB cost milliseconds) */
-    DevBuf<unsigned char> spare_arena;
+    DevBuf<unsigned char> spare_arena, spare_arena2;   /* two: chunked calls keep two plans alive */
+    void *pinned_stage[2] = {nullptr, nullptr};        /* chunked calls: results of chunk c land in slot c % 2 */
+    size_t pinned_bytes[2] = {0, 0};
     DevBuf<double> io_buf;                     /* spectra of big pya_score_batch calls (uploaded by a helper thread) */
     DevBuf<double> io_ring[2];                 /* chunked calls: spectra of chunk c in slot c % 2 */
     hipStream_t copy_stream = nullptr, run_stream = nullptr;   /* chunked calls: uploads / kernels + results */
@@ -203,12 +205,27 @@ struct pya_handle {
     uint32_t shape_cache[64][64];             /* offset of the shape's order table, ~0 = unknown */
     uint8_t in_group[256] = {0};              /* letter is in mod_group */
     uint8_t is_residue[256] = {0};            /* letter has a mass in Types.h */
+    uint8_t letter_cls[256] = {0};            /* bit 0: residue of Types.h, bit 1: in mod_group */
     bool allow_n = false, allow_c = false;
+    /* validity of the letters and the number of modifiable residues of one peptide (L >= 1) */
+    bool scan_peptide(const uint8_t *s, int64_t L, uint32_t *n_sites) const {
+        uint32_t all = 1, ns = 0;
+        for (int64_t j = 0; j < L; j++) {
+            const uint32_t c = letter_cls[s[j]];
+            all &= c;
+            ns += c >> 1;
+        }
+        if (allow_n && !(letter_cls[s[0]] >> 1)) ns++;
+        if (allow_c && !(letter_cls[s[L - 1]] >> 1) && !(L == 1 && allow_n)) ns++;
+        *n_sites = ns;
+        return all & 1u;
+    }
     void build_letter_tables() {
         std::memset(in_group, 0, sizeof in_group);
         std::memset(is_residue, 0, sizeof is_residue);
         for (unsigned char c : mod_group) in_group[c] = 1;
         for (int c = 'A'; c <= 'Z'; c++) is_residue[c] = std_residue_mass((char)c) != 0.f;
+        for (int c = 0; c < 256; c++) letter_cls[c] = (uint8_t)((is_residue[c] ? 1 : 0) | (in_group[c] ? 2 : 0));
         allow_n = mod_group.find('n') != std::string::npos;
         allow_c = mod_group.find('c') != std::string::npos;
     }
@@ -593,6 +610,8 @@ void pya_destroy(pya_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->kept) pya_plan_destroy(h->kept);
+    for (void *ps : h->pinned_stage)
+        if (ps) (void)hipHostFree(ps);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->run_stream) (void)hipStreamDestroy(h->run_stream);
     delete h;
@@ -727,6 +746,7 @@ struct IoReq {                       /* pya_score_batch: spectra and results liv
     uint32_t max_k;
     double *d_mz_ext, *d_inten_ext;  /* ... unless the caller uploads the spectra itself (big batches) */
     hipStream_t stream;              /* metadata upload: on this stream, waited for alone (nullptr: device-wide) */
+    const uint8_t *pre_sites;        /* letter scan already done by the caller: sites per PSM, 255 = invalid letters */
 };
 }
 
@@ -802,10 +822,11 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                           p->aux_off[i + 1] >= p->aux_off[i];
                 uint32_t ns = 0;
                 if (ok) {
-                    const uint8_t *s = p->pep.data() + p->pep_off[i];
-                    for (int64_t j = 0; j < L; j++) {
-                        ok = ok && h->is_residue[s[j]];
-                        ns += h->letter_modifiable((char)s[j], (size_t)j, (size_t)L) ? 1u : 0u;
+                    if (io && io->pre_sites) {
+                        ns = io->pre_sites[i];
+                        ok = ns != 255u;
+                    } else {
+                        ok = h->scan_peptide(p->pep.data() + p->pep_off[i], L, &ns);
                     }
                     for (int64_t a = p->aux_off[i]; has_aux && a < p->aux_off[i + 1]; a++)
                         ok = ok && b->aux_pos[aux_base + a] <= (uint32_t)L;
@@ -824,6 +845,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             for (auto &x : th) x.join();
         }
     }
+    lap("letter scan");
     /* an invalid PSM ends the call with its message -- or, with PYA_FLAG_SKIP_INVALID, is set aside
      * (status PYA_ST_INVALID / PYA_ST_OVER_LIMIT, best_score -1, n_sig -1) while the rest is scored */
     p->pre_status.assign(n, 0);
@@ -1010,6 +1032,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             p->score_ids[sl.off + sl.n++] = (uint32_t)i;
         }
     }
+    lap("id lists");
     rc = ensure_lut(h, lut_need);
     if (rc) return rc;
     if (h->order_uploaded != h->order_tab.size() || !h->d_order.p) {
@@ -1074,7 +1097,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((n + 64) * 4),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
-        if (!p->arena.take_if_fits(h->spare_arena, total)) HIPCHK(h, p->arena.alloc(total));
+        if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
+            HIPCHK(h, p->arena.alloc(total));
         unsigned char *base = p->arena.p;
         p->d_peak_off.adopt(base + o_peak_off, n + 1);
         p->d_pep_off.adopt(base + o_pep_off, n + 1);
@@ -1299,7 +1323,10 @@ void pya_plan_destroy(pya_plan *p) {
     }
     if (p->h->kept == p) p->h->kept = nullptr;
     if (!p->quiesced) (void)hipDeviceSynchronize();     /* nothing may still be using the buffers */
-    p->arena.give_to(p->h->spare_arena);
+    if (!p->h->spare_arena.p) p->arena.give_to(p->h->spare_arena);
+    else if (!p->h->spare_arena2.p) p->arena.give_to(p->h->spare_arena2);
+    else if (p->h->spare_arena.n <= p->h->spare_arena2.n) p->arena.give_to(p->h->spare_arena);
+    else p->arena.give_to(p->h->spare_arena2);
     delete p;
 }
 
@@ -1320,22 +1347,29 @@ size_t workspace_budget(const pya_handle *h) {
  * and metadata).  C(n,k) comes from the peptide letters, as in the plan's pre-pass. */
 struct ChunkCost {
     std::vector<double> arena, io;             /* per PSM */
+    std::vector<uint8_t> sites;                /* modifiable residues per PSM, 255 = invalid letters / length */
 };
 ChunkCost chunk_costs(pya_handle *h, const pya_batch *b, uint32_t max_k) {
     const uint64_t n = b->n_psm;
     ChunkCost c;
     c.arena.resize(n);
     c.io.resize(n);
+    c.sites.assign(n, 255);
     auto work = [&](uint64_t lo, uint64_t hi) {
         for (uint64_t i = lo; i < hi; i++) {
             const int64_t P = std::max<int64_t>(0, b->peak_off[i + 1] - b->peak_off[i]);
             const int64_t L = b->pep_off[i + 1] - b->pep_off[i];
             double sigs = 0;
-            if (L >= 1 && L <= PYA_MAX_PEPTIDE_LEN && b->n_of_mod[i] >= 0) {
+            if (L >= 1 && L <= PYA_MAX_PEPTIDE_LEN) {
                 uint32_t ns = 0;
-                const uint8_t *s = b->pep + b->pep_off[i];
-                for (int64_t j = 0; j < L; j++) ns += h->letter_modifiable((char)s[j], (size_t)j, (size_t)L) ? 1u : 0u;
-                const uint64_t N = ns <= PYA_MAX_SITES ? binom(ns, (uint32_t)b->n_of_mod[i]) : 0;
+                const bool ok = h->scan_peptide(b->pep + b->pep_off[i], L, &ns);
+                if (ok && ns < 255u) c.sites[i] = (uint8_t)ns;
+                uint64_t N = 0;
+                if (ok && ns <= PYA_MAX_SITES && b->n_of_mod[i] >= 0 && (uint32_t)b->n_of_mod[i] <= ns) {
+                    uint64_t &cached = h->binom_cache[ns][b->n_of_mod[i]];      /* benign race: same value */
+                    if (cached == 0) cached = binom(ns, (uint32_t)b->n_of_mod[i]);
+                    N = cached;
+                }
                 sigs = N > PYA_MAX_SIGNATURES ? 0. : (double)N;
             }
             c.io[i] = 16.0 * (double)P;
@@ -1370,7 +1404,8 @@ void rebase_error(pya_handle *h, uint64_t lo) {
  * while this thread plans chunk c, runs its kernels and brings its results back on a second
  * stream.  A call of any size completes; it never fails for lack of workspace. */
 static int score_batch_chunked(pya_handle *h, const pya_batch *b, const double *mz, const double *inten,
-                               uint32_t flags, const pya_results *out, const std::vector<uint64_t> &cuts) {
+                               uint32_t flags, const pya_results *out, const std::vector<uint64_t> &cuts,
+                               const uint8_t *pre_sites) {
     const size_t nchunk = cuts.size() - 1;
     const uint32_t mk = out->max_k;
     const bool skip = (flags & PYA_FLAG_SKIP_INVALID) != 0;
@@ -1427,24 +1462,32 @@ static int score_batch_chunked(pya_handle *h, const pya_batch *b, const double *
         return rc;
     };
 
-    for (size_t c = 0; c < nchunk; c++) {
-        const uint64_t lo = cuts[c], hi = cuts[c + 1], n = hi - lo;
+    /* this thread: plan chunk c + 1 (host pre-pass) while the GPU runs the kernels and the result copy of
+     * chunk c; two plans alive at a time */
+    auto make_plan = [&](size_t c, pya_plan **pp) -> int {
+        const uint64_t lo = cuts[c], hi = cuts[c + 1];
         const int64_t np = b->peak_off[hi] - b->peak_off[lo];
         pya_batch sub = *b;
-        sub.n_psm = n;
+        sub.n_psm = hi - lo;
         sub.peak_off = b->peak_off + lo;
         sub.pep_off = b->pep_off + lo;
         sub.n_of_mod = b->n_of_mod + lo;
         sub.max_charge = b->max_charge + lo;
         if (b->aux_off) sub.aux_off = b->aux_off + lo;
-        IoReq io = {mz, inten, mk, h->io_ring[c & 1].p, h->io_ring[c & 1].p + np, h->run_stream};
-        pya_plan *p = nullptr;
-        int rc = plan_create_impl(h, &sub, flags & ~(PYA_FLAG_TIMING | PYA_FLAG_KEEP), &io, &p);   /* host pre-pass: under the upload */
-        if (rc) {
-            rebase_error(h, lo);
-            return finish(rc);
-        }
-        std::unique_ptr<pya_plan, void (*)(pya_plan *)> guard(p, pya_plan_destroy);
+        IoReq io = {mz, inten, mk, h->io_ring[c & 1].p, h->io_ring[c & 1].p + np, h->run_stream,
+                    pre_sites ? pre_sites + lo : nullptr};
+        int rc = plan_create_impl(h, &sub, flags & ~(PYA_FLAG_TIMING | PYA_FLAG_KEEP), &io, pp);
+        if (rc) rebase_error(h, lo);
+        return rc;
+    };
+    typedef std::unique_ptr<pya_plan, void (*)(pya_plan *)> PlanPtr;
+    pya_plan *raw = nullptr;
+    int rc = make_plan(0, &raw);
+    if (rc) return finish(rc);
+    PlanPtr cur(raw, pya_plan_destroy), next(nullptr, pya_plan_destroy);
+    for (size_t c = 0; c < nchunk; c++) {
+        const uint64_t lo = cuts[c], n = cuts[c + 1] - lo;
+        pya_plan *p = cur.get();
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return uploaded > c; });
@@ -1456,23 +1499,50 @@ static int score_batch_chunked(pya_handle *h, const pya_batch *b, const double *
         pya_results d_out = {mk, p->d_best_score.p, p->d_best_sig.p, p->d_n_sig_out.p, p->d_ascores.p, p->d_alt.p};
         rc = pya_plan_run(p, p->d_mz.p, p->d_inten.p, h->run_stream, &d_out);
         if (rc) return finish(rc);
-        /* status + results are adjacent in the arena: one copy back, then scattered into the caller's rows */
-        h->stage.resize(std::max(h->stage.size(), p->d2h_bytes));
-        unsigned char *sg = h->stage.data();
+        /* status + results are adjacent in the arena: one asynchronous copy into pinned memory */
+        void *&pin = h->pinned_stage[c & 1];
+        if (h->pinned_bytes[c & 1] < p->d2h_bytes) {
+            if (pin) (void)hipHostFree(pin);
+            pin = nullptr;
+            h->pinned_bytes[c & 1] = 0;
+            hipError_t e0 = hipHostMalloc(&pin, p->d2h_bytes + p->d2h_bytes / 4, hipHostMallocDefault);
+            if (e0 != hipSuccess) return finish(h->hip_fail(e0, "pinned result buffer"));
+            h->pinned_bytes[c & 1] = p->d2h_bytes + p->d2h_bytes / 4;
+        }
+        unsigned char *sg = (unsigned char *)pin;
         hipError_t e = hipMemcpyAsync(sg, p->arena.p + p->o_status, p->d2h_bytes, hipMemcpyDeviceToHost, h->run_stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->run_stream);
+        if (e != hipSuccess) return finish(h->hip_fail(e, "results copy"));
+        hipEvent_t done = nullptr;                                /* chunk c finished (kernels + copy) */
+        e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(done, h->run_stream);
+        if (e != hipSuccess) return finish(h->hip_fail(e, "event"));
+        int rc_next = PYA_OK;
+        if (c + 1 < nchunk) {                                     /* CPU pre-pass of the next chunk meanwhile */
+            raw = nullptr;
+            rc_next = make_plan(c + 1, &raw);
+            next.reset(raw);
+        }
+        e = hipEventSynchronize(done);
+        (void)hipEventDestroy(done);
         p->quiesced = e == hipSuccess;
         {
-            std::lock_guard<std::mutex> lk(mu);             /* the chunk's ring slot may be overwritten now */
+            std::lock_guard<std::mutex> lk(mu);                   /* the chunk's ring slot may be overwritten now */
             consumed = c + 1;
             cv.notify_all();
         }
         if (e != hipSuccess) return finish(h->hip_fail(e, "results copy"));
         if (skip) std::memcpy(h->last_status.data() + lo, sg, n * sizeof(int32_t));
+        const std::string keep_err = h->err;                      /* make_plan(c + 1) may have set a message */
+        const int64_t keep_idx = h->err_index;
         rc = check_status(h, (const int32_t *)sg, n, skip);
         if (rc) {
             rebase_error(h, lo);
             return finish(rc);
+        }
+        if (rc_next) {
+            h->err = keep_err;
+            h->err_index = keep_idx;
+            return finish(rc_next);
         }
         const size_t o = p->o_status;
         std::memcpy(out->best_score + lo, sg + (p->o_best_score - o), n * sizeof(float));
@@ -1480,6 +1550,7 @@ static int score_batch_chunked(pya_handle *h, const pya_batch *b, const double *
         std::memcpy(out->n_sig + lo, sg + (p->o_n_sig_out - o), n * sizeof(int32_t));
         std::memcpy(out->ascores + lo * mk, sg + (p->o_ascores - o), n * mk * sizeof(float));
         std::memcpy(out->alt_mask + lo * mk, sg + (p->o_alt - o), n * mk * sizeof(uint64_t));
+        cur = std::move(next);
     }
     return finish(PYA_OK);
 }
@@ -1519,7 +1590,7 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
                 }
             }
             cuts.push_back(b->n_psm);
-            if (cuts.size() > 2) return score_batch_chunked(h, b, mz, inten, flags, out, cuts);
+            if (cuts.size() > 2) return score_batch_chunked(h, b, mz, inten, flags, out, cuts, cost.sites.data());
         }
     }
     const bool host_timing = std::getenv("PYA_HOST_TIMING") != nullptr;
@@ -1532,7 +1603,7 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
         t0 = t1;
     };
     pya_plan *p = nullptr;
-    IoReq io = {mz, inten, out->max_k, nullptr, nullptr, nullptr};
+    IoReq io = {mz, inten, out->max_k, nullptr, nullptr, nullptr, nullptr};
     /* Big batches: the spectra (16 bytes per peak, PCIe-bound) go up on a helper thread while this
      * one runs the host pre-pass of the plan; small ones ride in the plan's single staged copy. */
     const int64_t peaks_lo = b->peak_off[0], n_peaks = b->peak_off[b->n_psm] - peaks_lo;
