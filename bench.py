@@ -244,7 +244,7 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    kern_ms = np.zeros(3)
+    kern_ms = np.zeros(4)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -263,7 +263,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        names = ["pya_bin_spectra_kernel", "pya_score_signatures_kernel", "pya_localize_kernel"]
+        names = ["pya_bin_spectra_kernel", "pya_score_signatures_kernel", "pya_score_localize_kernel", "pya_localize_kernel"]
         dom = int(np.argmax(kern_ms))
         alg = algorithmic_bytes(batch, plan.max_k)
         achieved = alg / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0

@@ -137,9 +137,10 @@ int pya_last_batch_status(pya_handle *h, int32_t *status, uint64_t n);
 int pya_plan_create(pya_handle *h, const pya_batch *batch, uint32_t flags, pya_plan **out);
 int pya_plan_run(pya_plan *plan, const double *d_mz, const double *d_intensity,
                  void *hip_stream, const pya_results *d_out);
-/* ms per kernel family of the last pya_plan_run (PYA_FLAG_TIMING): bin_spectra,
- * score_signatures, localize; synchronises */
-int pya_plan_timings(pya_plan *plan, float ms[3]);
+/* ms per kernel family of the last pya_plan_run (PYA_FLAG_TIMING): bin_spectra, score_signatures,
+ * score_localize (the fused kernel, with the localize launch for what it hands over), localize;
+ * synchronises */
+int pya_plan_timings(pya_plan *plan, float ms[4]);
 /* waits for the stream of the last run and reports the first PSM the kernels rejected */
 int pya_plan_check(pya_plan *plan);
 uint64_t pya_plan_workspace_bytes(const pya_plan *plan);

@@ -80,6 +80,8 @@ struct BatchDev {
     uint32_t *redo_ids;             /* [n_psm] m/z order, or equal intensities inside a window)     */
     uint32_t *redo3_count;          /* PSMs the lean localize instantiation hands to the general one */
     uint32_t *redo3_ids;            /* [n_psm]                                                       */
+    uint32_t *redo4_count;          /* PSMs the fused score + localize kernel hands to the general   */
+    uint32_t *redo4_ids;            /* [n_psm] localize instantiation                                */
     float *ws;                      /* weighted score per signature, pre-sort order         */
     uint32_t *rec;                  /* optional per-signature records: 6 words each         */
     uint32_t *sorted_idx;           /* optional sorted permutation, at sig_off              */

@@ -53,6 +53,13 @@ int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uin
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
 int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream);
+size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t push_cap);
+int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
+                     uint32_t stride, uint32_t pos_cap, uint32_t push_cap, uint32_t both, uint32_t *d_redo_count,
+                     uint32_t *d_redo_ids, hipStream_t stream);
+int pya_launch_localize_redo(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max,
+                             uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
+                             uint32_t gtp, hipStream_t stream);
 }
 
 namespace {
@@ -314,8 +321,15 @@ struct pya_plan {
     struct IdList {
         uint32_t off, n, cap, ncls;
     };
-    std::vector<uint32_t> bin_ids, score_ids;
-    std::vector<IdList> bin_lists, score_lists;
+    std::vector<uint32_t> bin_ids, score_ids, fused_ids;
+    std::vector<IdList> bin_lists, score_lists, fused_lists;
+    /* PSMs scored AND localised by the fused kernel (score_localize.hip): few site assignments, plain
+     * settings.  `fusedb` carries the caps the general localize instantiation needs for the ones the
+     * fused kernel hands over. */
+    Bucket fusedb;
+    std::vector<uint8_t> fused;         /* [n_psm] */
+    uint32_t fused_both = 0, fused_n_cap = 0, fused_stride = 0;
+    DevBuf<uint32_t> d_fused_ids, d_redo4;
     std::vector<uint8_t> ncls;          /* [n_psm] C(n,k) class of the PSM */
     std::vector<int32_t> pre_status;    /* [n_psm] PSMs the host pre-pass set aside (PYA_FLAG_SKIP_INVALID) */
     uint64_t n_skipped = 0;
@@ -332,7 +346,7 @@ struct pya_plan {
     size_t o_status = 0, d2h_bytes = 0, o_best_score = 0, o_best_sig = 0, o_n_sig_out = 0, o_ascores = 0, o_alt = 0;
     uint32_t io_max_k = 0;
     BatchDev dev;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t last_stream = nullptr;
     bool ran = false;
     bool quiesced = false;               /* the owner has waited for everything that used the buffers */
@@ -544,6 +558,8 @@ void fill_dev(pya_plan *p) {
     d.redo_ids = p->d_redo.p + 64;
     d.redo3_count = p->d_redo3.p;
     d.redo3_ids = p->d_redo3.p + 64;
+    d.redo4_count = p->d_redo4.p;
+    d.redo4_ids = p->d_redo4.p + 64;
     d.ws = p->d_ws.p;
     d.rec = p->d_rec.p;
     d.sorted_idx = p->d_sorted.p;
@@ -810,6 +826,12 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     /* Pass A (threaded for big batches): the per-letter work -- validate every PSM and count its
      * modifiable residues.  It only finds the first offending PSM; the detailed message comes from
      * the serial checks below, run for that PSM alone. */
+    /* fused score + localize kernel: plain settings with one ion type per direction; C(n,k) <= 32 when
+     * both directions are scored (one (signature, direction) walker per lane), <= 64 with one */
+    const bool both_dirs = h->cfg.n_fwd > 0 && h->cfg.n_fwd < h->cfg.n_types;
+    const bool fused_on = plain_on && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 && !std::getenv("PYA_NO_FUSED");
+    const uint32_t fused_max_n = both_dirs ? 32u : 64u;
+    p->fused.assign(n, 0);
     const bool skip_invalid = (flags & PYA_FLAG_SKIP_INVALID) != 0;
     std::vector<uint8_t> bad(n, 0);
     {
@@ -950,7 +972,9 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             int bi = 0;
             while (N > kBucketLimits[bi]) bi++;
             cls_of_i = bi;
-            Bucket &bk = p->buckets[bi];
+            const bool to_fused = fused_on && z == 1 && N <= fused_max_n;
+            Bucket &bk = to_fused ? p->fusedb : p->buckets[bi];
+            if (to_fused) p->fused[i] = 1;
             /* lean localize instantiation: no neutral losses, charge 1, summary mode (it checks the
              * residue masses itself and hands back what it cannot do) */
             if (plain_on && z == 1) bk.ids.push_back((uint32_t)i);
@@ -974,6 +998,33 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         bk.ids.insert(bk.ids.end(), bk.general_ids.begin(), bk.general_ids.end());
         bk.general_ids.clear();
         bk.general_ids.shrink_to_fit();
+    }
+    {
+        Bucket &fb = p->fusedb;
+        fb.n_plain = (uint32_t)fb.ids.size();
+        bool keep_fused = !fb.ids.empty();
+        if (keep_fused) {
+            p->fused_both = both_dirs ? 1u : 0u;
+            p->fused_n_cap = (fb.n_cap + 3u) & ~3u;
+            p->fused_stride = (both_dirs ? 2u : 1u) * p->fused_n_cap;
+            const uint32_t cap_all = (max_P + 31u) & ~31u;
+            keep_fused = pya_fused_lds_bytes(cap_all, p->fused_n_cap, p->fused_stride, fb.pos_cap, fb.push_cap()) <= 64 * 1024 &&
+                         pya_localize_lds_bytes(fb.push_cap(), fb.n_cap, fb.pos_cap, fb.pool_cap(), fb.sb()) <= kMaxLds;
+        }
+        if (!keep_fused && !fb.ids.empty()) {               /* (huge spectra) back to the two-kernel route */
+            Bucket &b0 = p->buckets[0];
+            b0.ids.insert(b0.ids.begin(), fb.ids.begin(), fb.ids.end());
+            b0.n_cap = std::max(b0.n_cap, fb.n_cap);
+            b0.list_cap = std::max(b0.list_cap, fb.list_cap);
+            b0.pos_cap = std::max(b0.pos_cap, fb.pos_cap);
+            b0.n_types = std::max(b0.n_types, fb.n_types);
+            b0.k_max = std::max(b0.k_max, fb.k_max);
+            b0.push_max = std::max(b0.push_max, fb.push_max);
+            b0.z_max = std::max(b0.z_max, fb.z_max);
+            fb.ids.clear();
+            fb.n_plain = 0;
+            std::fill(p->fused.begin(), p->fused.end(), 0);
+        }
     }
     lap("psm loop");
     p->n_skipped = n_skipped;
@@ -1001,7 +1052,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         std::sort(caps.begin(), caps.end());
         caps.erase(std::unique(caps.begin(), caps.end()), caps.end());
         const size_t nc = caps.size();
-        std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0);
+        std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0), cnt_fused(nc, 0);
         std::vector<uint8_t> pcls(n);
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;                  /* set aside: neither binned nor scored */
@@ -1010,7 +1061,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             while (caps[c] < P) c++;
             pcls[i] = (uint8_t)c;
             cnt_bin[c]++;
-            cnt_score[p->ncls[i] * nc + c]++;
+            if (p->fused[i]) cnt_fused[c]++;
+            else cnt_score[p->ncls[i] * nc + c]++;
         }
         uint32_t off = 0;
         for (size_t c = 0; c < nc; c++) {
@@ -1022,14 +1074,26 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             p->score_lists.push_back({off, 0u, caps[g % nc], (uint32_t)(g / nc)});
             off += cnt_score[g];
         }
+        uint32_t n_score = off;
+        off = 0;
+        for (size_t c = 0; c < nc; c++) {
+            p->fused_lists.push_back({off, 0u, caps[c], 0u});
+            off += cnt_fused[c];
+        }
         p->bin_ids.resize(n - n_skipped);
-        p->score_ids.resize(n - n_skipped);
+        p->score_ids.resize(n_score);
+        p->fused_ids.resize(off);
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;
             pya_plan::IdList &bl = p->bin_lists[pcls[i]];
             p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
-            pya_plan::IdList &sl = p->score_lists[p->ncls[i] * nc + pcls[i]];
-            p->score_ids[sl.off + sl.n++] = (uint32_t)i;
+            if (p->fused[i]) {
+                pya_plan::IdList &fl = p->fused_lists[pcls[i]];
+                p->fused_ids[fl.off + fl.n++] = (uint32_t)i;
+            } else {
+                pya_plan::IdList &sl = p->score_lists[p->ncls[i] * nc + pcls[i]];
+                p->score_ids[sl.off + sl.n++] = (uint32_t)i;
+            }
         }
     }
     lap("id lists");
@@ -1073,7 +1137,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_aux_pos = meta(has_aux ? b->aux_pos + aux_base : nullptr, (size_t)total_aux * 4),
                      o_aux_mass = meta(has_aux ? b->aux_mass + aux_base : nullptr, (size_t)total_aux * 4),
                      o_bin_ids = meta(p->bin_ids.data(), p->bin_ids.size() * 4),
-                     o_score_ids = meta(p->score_ids.data(), p->score_ids.size() * 4);
+                     o_score_ids = meta(p->score_ids.data(), p->score_ids.size() * 4),
+                     o_fused_ids = meta(p->fused_ids.data(), p->fused_ids.size() * 4);
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
             o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
@@ -1094,7 +1159,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
                      o_ret_mz = reserve((size_t)p->total_peaks * 4), o_ret_rank = reserve((size_t)p->total_peaks),
-                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((n + 64) * 4),
+                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((n + 64) * 4), o_redo4 = reserve((p->fused_ids.size() + 64) * 4),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
@@ -1114,6 +1179,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_aux_mass.adopt(base + o_aux_mass, (size_t)total_aux);
         p->d_bin_ids.adopt(base + o_bin_ids, p->bin_ids.size());
         p->d_score_ids.adopt(base + o_score_ids, p->score_ids.size());
+        p->d_fused_ids.adopt(base + o_fused_ids, p->fused_ids.size());
         for (int i = 0; i < kNumBuckets; i++)
             p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
         if (io) {
@@ -1137,6 +1203,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_grid.adopt(base + o_grid, n * PYA_GRID_CELLS);
         p->d_redo.adopt(base + o_redo, n + 64);
         p->d_redo3.adopt(base + o_redo3, n + 64);
+        p->d_redo4.adopt(base + o_redo4, p->fused_ids.size() + 64);
         p->d_ws.adopt(base + o_ws, (size_t)sig_total);
         p->d_rec.adopt(base + o_rec, (size_t)sig_total * PYA_REC_WORDS);
         if (flags & PYA_FLAG_KEEP) p->d_sorted.adopt(base + o_sorted, (size_t)sig_total);
@@ -1243,6 +1310,21 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
+    if (!p->fused_ids.empty()) {
+        /* few site assignments, plain settings: scored and localised in one pass (score_localize.hip);
+         * what that kernel hands over goes through the general localize instantiation */
+        HIPCHK(h, hipMemsetAsync(d.redo4_count, 0, sizeof(uint32_t), st));
+        const Bucket &fb = p->fusedb;
+        for (const pya_plan::IdList &l : p->fused_lists) {
+            e = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, p->fused_n_cap, p->fused_stride, fb.pos_cap,
+                                 fb.push_cap(), p->fused_both, d.redo4_count, d.redo4_ids, st);
+            if (e) return h->hip_fail((hipError_t)e, "score_localize launch");
+        }
+        e = pya_launch_localize_redo(&d, d.redo4_count, d.redo4_ids, (uint32_t)p->fused_ids.size(), fb.push_cap(), fb.n_cap,
+                                     fb.pos_cap, fb.pool_cap(), fb.sb(), fb.gtp(), st);
+        if (e) return h->hip_fail((hipError_t)e, "localize (hand-over) launch");
+    }
+    if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
     for (Bucket &bk : p->buckets) {
         e = pya_launch_localize(&d, bk.d_ids.p, bk.n_plain, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(),
                                 bk.gtp(), 1u, st);
@@ -1251,19 +1333,19 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
                                 bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }
-    if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
+    if (timing) HIPCHK(h, hipEventRecord(p->ev[4], st));
     p->last_stream = st;
     p->ran = true;
     p->dev = d;
     return PYA_OK;
 }
 
-int pya_plan_timings(pya_plan *p, float ms[3]) {
+int pya_plan_timings(pya_plan *p, float ms[4]) {
     if (!p || !ms) return PYA_ERR_ARG;
     pya_handle *h = p->h;
     if (!(p->flags & PYA_FLAG_TIMING) || !p->ran) return h->fail(PYA_ERR_STATE, -1, "plan has no timing events");
-    HIPCHK(h, hipEventSynchronize(p->ev[3]));
-    for (int i = 0; i < 3; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
+    HIPCHK(h, hipEventSynchronize(p->ev[4]));
+    for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
     return PYA_OK;
 }
 

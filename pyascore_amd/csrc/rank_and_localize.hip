@@ -36,14 +36,16 @@ __global__ __launch_bounds__(64, PLAIN ? LOC_WAVES_PLAIN : LOC_WAVES) void pya_l
     if (PLAIN && declined && lane_id() == 0) b.redo3_ids[atomicAdd(b.redo3_count, 1u)] = psm;
 }
 
-/* the PSMs the lean instantiation declined, on the general one: a small grid strides over the list */
-__global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_redo_kernel(BatchDev b, uint32_t push_cap,
+/* the PSMs a lean kernel declined (the lean localize instantiation, or the fused score + localize
+ * kernel), on the general one: a small grid strides over the list */
+__global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_redo_kernel(BatchDev b, const uint32_t *count,
+                                                                        const uint32_t *ids, uint32_t push_cap,
                                                                         uint32_t pos_cap, uint32_t pool_cap,
                                                                         uint32_t sb, uint32_t gtp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const uint32_t n = *b.redo3_count;
+    const uint32_t n = *count;
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        localize_body<false>(b, b.redo3_ids[k], lds_raw, push_cap, pos_cap, pool_cap, sb, gtp);
+        localize_body<false>(b, ids[k], lds_raw, push_cap, pos_cap, pool_cap, sb, gtp);
         wave_lds_sync();
     }
 }
@@ -126,8 +128,22 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     e = PYA_ENSURE_MAX_LDS(pya_localize_redo_kernel);
     if (e != hipSuccess) return (int)e;
     const uint32_t grid = n_ids < 8192u ? n_ids : 8192u;
-    hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, push_cap, pos_cap, pool_cap,
-                       sb, gtp);
+    hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, b->redo3_count, b->redo3_ids,
+                       push_cap, pos_cap, pool_cap, sb, gtp);
+    return (int)hipGetLastError();
+}
+
+/* the hand-over list of the fused kernel (score_localize.hip) on the general instantiation */
+extern "C" int pya_launch_localize_redo(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids,
+                                        uint32_t n_max, uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap,
+                                        uint32_t pool_cap, uint32_t sb, uint32_t gtp, hipStream_t stream) {
+    if (n_max == 0) return 0;
+    const size_t lds = pya_localize_lds_bytes(push_cap, n_cap, pos_cap, pool_cap, sb);
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_localize_redo_kernel);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t grid = n_max < 8192u ? n_max : 8192u;
+    hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, d_count, d_ids, push_cap,
+                       pos_cap, pool_cap, sb, gtp);
     return (int)hipGetLastError();
 }
 

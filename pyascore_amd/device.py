@@ -92,8 +92,9 @@ class DevicePlan:
         return self
 
     def timings_ms(self):
-        """(bin, score, localize) kernel durations of the last run; synchronises."""
-        ms = (C.c_float * 3)()
+        """(bin_spectra, score_signatures, score_localize, localize) kernel-family durations of the
+        last run; synchronises."""
+        ms = (C.c_float * 4)()
         rc = self._lib.pya_plan_timings(self._plan, C.byref(ms))
         if rc:
             self.scorer._raise(rc)

@@ -23,13 +23,15 @@ _LO, _HI = (int(x) for x in os.environ.get("PYA_FUZZ_SEEDS", "0:40").split(":"))
 @pytest.mark.parametrize("seed", range(_LO, _HI))
 def test_random_settings_and_batches(seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
-    # the routes a batch can take: fused single launch (small batches, default), or the three-kernel
-    # path with the lean localize instantiation / with it declining everything / general only /
-    # with the sort emulation forced
-    route = seed % 5
+    # the routes a batch can take: single launch (small batches, default), or the kernel-per-stage
+    # path with the fused score + localize kernel and the lean localize instantiation / with them
+    # declining everything / general only / with the sort emulation forced / without the fused kernel
+    route = seed % 6
     monkeypatch.setenv("PYA_PLAIN_MIN", "0")
     if route != 0:
         monkeypatch.setenv("PYA_NO_TINY", "1")
+    if route == 5:
+        monkeypatch.setenv("PYA_NO_FUSED", "1")
     if route == 2:
         monkeypatch.setenv("PYA_DEBUG", "512")
     elif route == 3:

@@ -14,17 +14,24 @@ from pyascore_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["lean_localize", "general_localize", "lean_declines", "always_sort"])
+@pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort"])
 def path(request, monkeypatch):
-    """Batches run four times: plain PSMs (no neutral losses, fragment charge 1) on the lean
-    instantiation of the localize kernel (default); every PSM on the general instantiation
-    (PYA_NO_PLAIN=1); with the lean instantiation declining every PSM (PYA_DEBUG=512), which
-    sends them through its hand-over list to the general one; and with the std::sort emulation
-    run even where a unique best PepScore makes it unnecessary (PYA_DEBUG=1024)."""
+    """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
+    assignments on the fused score + localize kernel and the other plain ones on the lean
+    instantiation of the localize kernel (default); without the fused kernel (PYA_NO_FUSED=1); every
+    PSM on the general instantiation (PYA_NO_PLAIN=1); with the fused kernel and the lean
+    instantiation declining every PSM (PYA_DEBUG=512), which sends them through their hand-over lists
+    to the general one; and with the std::sort emulation run even where a unique best PepScore makes it
+    unnecessary (PYA_DEBUG=1024), without and with the fused kernel."""
     monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
+    monkeypatch.delenv("PYA_NO_FUSED", raising=False)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
-    monkeypatch.setenv("PYA_PLAIN_MIN", "0")       # batches under 512 PSMs skip the lean kernel by default
+    monkeypatch.setenv("PYA_PLAIN_MIN", "0")       # batches under 512 PSMs skip the lean kernels by default
     monkeypatch.setenv("PYA_NO_TINY", "1")         # ... and those of up to 64 the three kernels altogether
+    if request.param in ("lean_localize", "always_sort"):
+        monkeypatch.setenv("PYA_NO_FUSED", "1")
+    if request.param == "fused_always_sort":
+        monkeypatch.setenv("PYA_DEBUG", "1024")
     if request.param == "general_localize":
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
     elif request.param == "lean_declines":
