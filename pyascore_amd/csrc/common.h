@@ -67,6 +67,9 @@ struct BatchDev {
     const uint32_t *order_off;      /* [n_psm] offset of the PSM's shape in order_tab       */
     const int64_t *sig_off;         /* [n_psm+1] offsets into ws / rec                      */
     const uint64_t *order_tab;      /* pre-sort signature order per shape (sig bits)        */
+    const uint64_t *desc;           /* [n_psm][PYA_DESC_WORDS] the offsets and counts above, packed (one  */
+                                    /* cache line per PSM): peak_off, pep_off, sig_off, aux_off,          */
+                                    /* L | n_aux << 16 | n_of_mod << 32 | n_sites << 48, n_sig | order_off << 32 */
     const DevConfig *cfg;
     const float *lut;               /* score table                                          */
     const uint32_t *lut_off;        /* [lut_n_max+1] row offsets                            */
@@ -120,5 +123,8 @@ static inline unsigned long pya_loc_lds_bytes(unsigned pos_cap, unsigned pool_ca
 
 /* per-signature record: 10 cumulative counts as u16 + total fragments */
 #define PYA_REC_WORDS 6
+
+/* packed per-PSM descriptor (BatchDev.desc) */
+#define PYA_DESC_WORDS 6
 
 #endif

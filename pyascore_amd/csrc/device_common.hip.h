@@ -125,12 +125,15 @@ DEV uint32_t xcd_slot(uint32_t b, uint32_t n) {
 #endif
 }
 
-/* LDS traffic of one wave is in order, but the compiler must not move accesses across the
- * points where lanes exchange data through LDS. */
+/* LDS traffic of one wave is in order, but the compiler must not move LDS accesses across the
+ * points where lanes exchange data through LDS.  The fences name the LDS address space only: a
+ * fence over all address spaces makes the compiler drain the vector-memory counter as well
+ * (s_waitcnt vmcnt(0)), i.e. every hand-over point would wait for every global load and store in
+ * flight -- a full round trip to memory per sync point, and the end of any fetch-ahead. */
 DEV void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 /* ---------------------------------------------------------------------------------------

@@ -4,15 +4,22 @@
  *
  * Replaces, for those PSMs, score_signatures + rank_and_localize (cpp/Ascore.cpp:53-254,
  * cpp/ModifiedPeptide.cpp:126-150, :259-320, :326-609).  The two-kernel route makes every walker
- * throw away what localisation needs again -- each fragment's m/z and the rank of the peak it
- * matched -- and then re-derives it: per-signature prefix tables walked by a handful of lanes,
- * fragment lists rebuilt from them, every surviving ion looked up in the peak table in global
- * memory, the per-signature scores, counts and the m/z grid written to HBM by one kernel and read
- * back by the next.  Here every (signature, direction) walker records its L-1 fragment m/z and
- * matched ranks in LDS while it scores (two stores per step), so that once the winner and its
- * single-move competitors are known the site-determining ions are a comparison of recorded lists
- * and a count over recorded ranks: no second walk, no lookup, nothing through HBM but the inputs
- * and the 64-byte result.
+ * throw away what localisation needs again -- the rank of the peak each fragment matched -- and
+ * then re-derives it: per-signature prefix tables, fragment lists rebuilt from them, every
+ * surviving ion looked up in the peak table in global memory, the per-signature scores, counts and
+ * the m/z grid written to HBM by one kernel and read back by the next.  Here every (signature,
+ * direction) walker records the rank each of its L-1 fragments matched (one byte per step, in
+ * LDS) while it scores; once the winner and its single-move competitors are known, only THEIR
+ * fragment m/z are re-derived (a walk without lookups: the float32 running sums) and the
+ * site-determining ions become a comparison of those few lists and a count over recorded ranks:
+ * no lookup, nothing through HBM but the inputs and the 64-byte result.
+ *
+ * This kernel's speed follows its occupancy (measured: its time is inversely proportional to the
+ * wavefronts resident per CU up to the VALU issue limit -- every wavefront is a chain of dependent
+ * LDS and memory round trips; fetching the next PSM's inputs ahead in a persistent wavefront was
+ * measured too and lost to the registers and LDS it costs), so its LDS footprint is kept small:
+ * ranks instead of m/z lists, competitors localised three at a time, and everything that is dead
+ * after the walk (rank histogram, peak table) reused for the bookkeeping that follows.
  *
  * Exactness is that of the two kernels (same walker, same window test, same std::sort emulation,
  * same neighbour-probe pairing): a PSM that needs a route this body does not have -- a residue mass
@@ -25,97 +32,118 @@
 #include "score_core.hip.h"
 #include "localize_core.hip.h"
 
-/* LDS of one wavefront:
- *   walk region  grid u16[256] | cnt u32[5][64] | resd float2[64] | peaks PeakEntry[cap + 4]
- *   lists        mzl f32[pos_cap][stride] | rkl u8[pos_cap][stride]      stride = walkers, rounded up to 4
- *   records      rec6 u32[n_cap][6] | wsl f32[n_cap]
- *   post region  (aliases cnt | resd | peaks after the walk) sort arrays, pushed competitors, per-site
- *                maxima / ties / alternative sites, per-competitor depth scores and counters            */
+#define FUSED_ROUND 3                /* competitors localised together (plus the winner) */
+
+/* LDS of one wavefront (byte offsets are computed as integers and added to the LDS base: casting
+ * pointers through integers to align them hides the address space from the compiler, which then
+ * emits FLAT accesses -- slower, and waited for together with every global load in flight):
+ *   grid u16[256]
+ *   walk region   cnt u32[5][64] | peaks PeakEntry[cap + 4]                     (dead after the walk)
+ *   post region   (same bytes) sort arrays, pushed competitors, per-site maxima / ties / alternative
+ *                 sites, depth scores and counters of a round
+ *   kept          resd float2[pos_cap + 1] | rkl u8[pos_cap][stride] | rec u32[n_cap][3] | wsl f32[n_cap]
+ *                 | mass f32[32] | flags u32[32] | selm f32[(1 + FUSED_ROUND) * ndir][pos_cap]            */
 struct FusedLds {
     uint16_t *grid;
     uint32_t *cnt;
-    float2 *resd;
     PeakEntry *peaks;
-    float *mzl;
+    float2 *resd;
     uint8_t *rkl;
-    uint32_t *rec6;
+    uint32_t *rec;           /* per signature: ten cumulative counts as bytes (<= 126 fragments) */
     float *wsl;
+    float *mass_l;
+    uint32_t *flag_l;
+    float *selm;
     /* post region */
     float *sort_key;
     uint16_t *sort_idx, *sort_l, *sort_r;
     PushedEntry *pushed;
     unsigned long long *site_alt;
     uint32_t *site_max, *site_tie, *n_pushed;
-    float *sc;               /* [(1 + push_cap)][10] depth scores: winner, then competitors */
-    uint32_t *c_tr, *c_cnt;  /* [push_cap][2] */
-    int32_t *c_depth;        /* [push_cap] */
-    uint32_t *c_site;        /* [push_cap] */
+    float *sc;               /* [1 + FUSED_ROUND][10] depth scores: winner, then the round's competitors */
+    uint32_t *c_tr, *c_cnt;  /* [FUSED_ROUND][2] */
+    int32_t *c_depth;        /* [FUSED_ROUND] */
+    uint32_t *c_site;        /* [FUSED_ROUND] */
 };
 
+__host__ __device__ static inline size_t fused_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 __host__ __device__ static inline size_t fused_post_bytes(uint32_t n_cap, uint32_t push_cap) {
-    return (size_t)n_cap * 10 + 16 + (size_t)push_cap * 16 + 64 * 8 + 64 * 4 * 2 + 16 +
-           (size_t)(1 + push_cap) * 40 + (size_t)push_cap * (8 + 8 + 4 + 4) + 64;
+    return fused_align16((size_t)n_cap * 10) + (size_t)push_cap * 16 + 64 * 8 + 64 * 4 * 2 + 16 +
+           (size_t)(1 + FUSED_ROUND) * 40 + (size_t)FUSED_ROUND * (8 + 8 + 4 + 4);
 }
 __host__ __device__ static inline size_t fused_walk_bytes(uint32_t cap) {
-    return PYA_GRID_CELLS * 2 + PYA_NTOP / 2 * 64 * 4 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8;
+    return PYA_NTOP / 2 * 64 * 4 + ((size_t)cap + PYA_TABLE_PAD) * 8;
 }
-static inline size_t fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t push_cap) {
-    const size_t walk = fused_walk_bytes(cap), post = PYA_GRID_CELLS * 2 + fused_post_bytes(n_cap, push_cap);
-    return (walk > post ? walk : post) + (size_t)pos_cap * stride * 5 + 16 + (size_t)n_cap * 28 + 64;
+__host__ __device__ static inline size_t fused_kept_bytes(uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ndir) {
+    return fused_align16(((size_t)pos_cap + 1) * 8) + fused_align16((size_t)pos_cap * stride) + (size_t)n_cap * 16 + 256 +
+           (size_t)(1 + FUSED_ROUND) * ndir * pos_cap * 4;
+}
+__host__ __device__ static inline size_t fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap,
+                                                         uint32_t push_cap, uint32_t ndir) {
+    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap);
+    return PYA_GRID_CELLS * 2 + fused_align16(walk > post ? walk : post) + fused_kept_bytes(n_cap, stride, pos_cap, ndir) + 16;
 }
 
 DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap,
-                         uint32_t push_cap) {
+                         uint32_t push_cap, uint32_t ndir) {
     FusedLds f;
     f.grid = (uint16_t *)raw;
-    f.cnt = (uint32_t *)(f.grid + PYA_GRID_CELLS);
-    f.resd = (float2 *)(f.cnt + PYA_NTOP / 2 * 64);
-    f.peaks = (PeakEntry *)(f.resd + 64);
-    /* post region: after the grid (which a handed-over PSM still has to write out) */
-    unsigned char *p = (unsigned char *)f.cnt;
-    f.sort_key = (float *)p;
-    f.sort_idx = (uint16_t *)(f.sort_key + n_cap);
-    f.sort_l = f.sort_idx + n_cap;
-    f.sort_r = f.sort_l + n_cap;
-    p = (unsigned char *)(((uintptr_t)(f.sort_r + n_cap) + 15) & ~(uintptr_t)15);
-    f.pushed = (PushedEntry *)p;
-    f.site_alt = (unsigned long long *)(f.pushed + push_cap);
-    f.site_max = (uint32_t *)(f.site_alt + 64);
-    f.site_tie = f.site_max + 64;
-    f.n_pushed = f.site_tie + 64;
-    f.sc = (float *)(f.n_pushed + 4);
-    f.c_tr = (uint32_t *)(f.sc + (size_t)(1 + push_cap) * 10);
-    f.c_cnt = f.c_tr + 2 * push_cap;
-    f.c_depth = (int32_t *)(f.c_cnt + 2 * push_cap);
-    f.c_site = (uint32_t *)(f.c_depth + push_cap);
-    const size_t walk = fused_walk_bytes(cap), post = PYA_GRID_CELLS * 2 + fused_post_bytes(n_cap, push_cap);
-    unsigned char *tail = raw + (((walk > post ? walk : post) + 15) & ~(size_t)15);
-    f.mzl = (float *)tail;
-    f.rkl = (uint8_t *)(f.mzl + (size_t)pos_cap * stride);
-    f.rec6 = (uint32_t *)(((uintptr_t)(f.rkl + (size_t)pos_cap * stride) + 15) & ~(uintptr_t)15);
-    f.wsl = (float *)(f.rec6 + (size_t)n_cap * PYA_REC_WORDS);
+    size_t o = PYA_GRID_CELLS * 2;
+    f.cnt = (uint32_t *)(raw + o);
+    f.peaks = (PeakEntry *)(raw + o + PYA_NTOP / 2 * 64 * 4);
+    /* post region over the walk region */
+    f.sort_key = (float *)(raw + o);
+    f.sort_idx = (uint16_t *)(raw + o + (size_t)n_cap * 4);
+    f.sort_l = (uint16_t *)(raw + o + (size_t)n_cap * 6);
+    f.sort_r = (uint16_t *)(raw + o + (size_t)n_cap * 8);
+    size_t q = o + fused_align16((size_t)n_cap * 10);
+    f.pushed = (PushedEntry *)(raw + q);
+    q += (size_t)push_cap * sizeof(PushedEntry);
+    f.site_alt = (unsigned long long *)(raw + q);
+    q += 64 * 8;
+    f.site_max = (uint32_t *)(raw + q);
+    q += 64 * 4;
+    f.site_tie = (uint32_t *)(raw + q);
+    q += 64 * 4;
+    f.n_pushed = (uint32_t *)(raw + q);
+    q += 16;
+    f.sc = (float *)(raw + q);
+    q += (size_t)(1 + FUSED_ROUND) * 40;
+    f.c_tr = (uint32_t *)(raw + q);
+    q += FUSED_ROUND * 8;
+    f.c_cnt = (uint32_t *)(raw + q);
+    q += FUSED_ROUND * 8;
+    f.c_depth = (int32_t *)(raw + q);
+    q += FUSED_ROUND * 4;
+    f.c_site = (uint32_t *)(raw + q);
+    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap);
+    o += fused_align16(walk > post ? walk : post);
+    f.resd = (float2 *)(raw + o);
+    o += fused_align16(((size_t)pos_cap + 1) * 8);
+    f.rkl = (uint8_t *)(raw + o);
+    o += fused_align16((size_t)pos_cap * stride);
+    f.rec = (uint32_t *)(raw + o);
+    o += (size_t)n_cap * 12;
+    f.wsl = (float *)(raw + o);
+    o += (size_t)n_cap * 4;
+    f.mass_l = (float *)(raw + o);
+    f.flag_l = (uint32_t *)(raw + o + 128);
+    f.selm = (float *)(raw + o + 256);
     return f;
 }
 
-/* the straight-line walker of walk_core.hip.h that also records every fragment's m/z and matched
- * rank in column `w` of the lists */
-DEV void walk_record(const WalkEnv &e, const PeakTable &tab, uint64_t resmask, int dir, bool active, float *mzl,
-                     uint8_t *rkl, int stride, int w) {
-    const DevConfig *cfg = e.cfg;
-    const int L = e.L;
-    double Af = 0., Bf = 0., Ab = 0., Bb = 0.;
-    if (cfg->n_fwd > 0) type_constants(cfg->types[0], &Af, &Bf);
-    if (cfg->n_fwd < cfg->n_types) type_constants(cfg->types[cfg->n_fwd], &Ab, &Bb);
-    const double A = dir ? Ab : Af, B = dir ? Bb : Bf;
+/* the straight-line walker of walk_core.hip.h that also records the rank every fragment matched in
+ * column `w` of rkl; A, B: the ion-type offsets of the lane's direction (type_constants) */
+DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, int L, uint64_t resmask, int dir, double A,
+                     double B, bool active, uint8_t *rkl, int stride, int w) {
     const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
     const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
-    const float2 *rp = e.resd + (dir ? L - 1 : 0);
+    const float2 *rp = resd + (dir ? L - 1 : 0);
     const int rstride = dir ? -1 : 1;
-    uint32_t *col = e.cnt + lane_id();
-    float *mo = mzl + w;
+    uint32_t *col = cnt + lane_id();
     uint8_t *ro = rkl + w;
     float running = 0.f;
-    for (int step = 0; step + 1 < L; step++, rp += rstride, mo += stride, ro += stride) {
+    for (int step = 0; step + 1 < L; step++, rp += rstride, ro += stride) {
         const float2 mm = *rp;
         const uint32_t word = step < 32 ? tlo : thi;
         const bool mod = (word >> (step & 31)) & 1u;
@@ -125,10 +153,25 @@ DEV void walk_record(const WalkEnv &e, const PeakTable &tab, uint64_t resmask, i
         const float f = (float)(m + 1.007825);
         const int rk = match_rank_lds(tab, f);
         hist_bump(col, active, rk);
-        if (active) {
-            *mo = f;
-            *ro = (uint8_t)rk;
-        }
+        if (active) *ro = (uint8_t)rk;
+    }
+}
+
+/* the same walk without lookups: the fragment m/z of one (signature, direction) into out[0 .. L-2] */
+DEV void walk_mz_only(const float2 *resd, int L, uint64_t resmask, int dir, double A, double B, float *out) {
+    const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
+    const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
+    const float2 *rp = resd + (dir ? L - 1 : 0);
+    const int rstride = dir ? -1 : 1;
+    float running = 0.f;
+    for (int step = 0; step + 1 < L; step++, rp += rstride) {
+        const float2 mm = *rp;
+        const uint32_t word = step < 32 ? tlo : thi;
+        const bool mod = (word >> (step & 31)) & 1u;
+        const float r = mod ? mm.y : mm.x;
+        running = r + running;
+        const double m = ((double)running + A) - B;
+        out[step] = (float)(m + 1.007825);
     }
 }
 
@@ -140,6 +183,23 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
                     uint32_t pos_cap, uint32_t push_cap) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
+    const int ndir = BOTH ? 2 : 1;
+    const FusedLds f = fused_carve(lds_raw, cap, n_cap, stride, pos_cap, push_cap, (uint32_t)ndir);
+    /* the residue table does not depend on the PSM: on its way before anything else */
+    if (lane < 32) {
+        f.mass_l[lane] = cfg->res_mass[lane];
+        f.flag_l[lane] = cfg->res_modifiable[lane];
+    }
+    /* everything the PSM's other loads depend on sits in one cache line (common.h: PYA_DESC_WORDS) */
+    const uint64_t *dw = b.desc + (size_t)psm * PYA_DESC_WORDS;
+    const int64_t p0 = (int64_t)dw[0], pep0 = (int64_t)dw[1], s0 = (int64_t)dw[2], a0 = (int64_t)dw[3];
+    const uint64_t w4 = dw[4], w5 = dw[5];
+    const int L = (int)(w4 & 0xffffu), n_aux = (int)((w4 >> 16) & 0xffffu), k = (int)((w4 >> 32) & 0xffffu);
+    const int N = (int)(uint32_t)w5;
+    const uint64_t *order = b.order_tab + (uint32_t)(w5 >> 32);
+    const int status = b.status[psm];
+    const int R = (int)b.ret_n[psm];
+
     const uint32_t max_k = b.max_k;
     float *out_asc = b.ascores + (size_t)psm * max_k;
     uint64_t *out_alt = b.alt_mask + (size_t)psm * max_k;
@@ -147,7 +207,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         out_asc[a] = 0.f;
         out_alt[a] = 0ull;
     }
-    if (b.status[psm] != PYA_ST_OK) {
+    if (status != PYA_ST_OK) {
         if (lane == 0) {
             b.best_score[psm] = -1.f;
             b.best_sig[psm] = 0ull;
@@ -155,44 +215,90 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         }
         return false;
     }
-    const FusedLds f = fused_carve(lds_raw, cap, n_cap, stride, pos_cap, push_cap);
-    const int N = (int)b.n_sig[psm];
-    const int k = b.n_of_mod[psm];
-    const uint64_t *order = b.order_tab + b.order_off[psm];
-    const int64_t s0 = b.sig_off[psm];
-
-    /* ---- score: score_core.hip.h's small-C(n,k) route with recording walkers ---- */
-    const Residues res = load_residues(b, cfg, psm);
-    PeakTable tab;
-    stage_peak_table(b, psm, f.peaks, &tab);
-    WalkEnv env;
-    env.cfg = cfg;
-    env.n_nl = 0;
-    env.nl_present = nullptr;
-    env.nl_uniq = nullptr;
-    env.resd = f.resd;
-    env.resn = nullptr;
-    env.cnt = f.cnt;
-    env.L = res.L;
-    env.zmax = 1;
-    stage_residues(res, f.resd, nullptr);
-    wave_lds_sync();
-    grid_build(&tab, f.grid);
-    hist_clear(env);
-    const int Lm1 = res.L - 1;
+    STAMP_BEGIN();
+    /* ---- inputs: letters, retained peaks, the lane's signature, fixed modifications ---- */
     const int s = BOTH ? (lane & 31) : lane;
     const int dir = BOTH ? (lane >> 5) : (cfg->n_fwd > 0 ? 0 : 1);
     const bool active = s < N;
+    const uint32_t letter = lane < L ? (uint32_t)b.pep[pep0 + lane] : (uint32_t)'A';
     const uint64_t bits = active ? order[s] : 0ull;
-    const uint64_t resmask = deposit_sites(bits, res.site_mask);
-    const int w = BOTH ? (lane >> 5) * N + s : s;          /* this lane's column of the lists */
+    uint32_t aux_pos = 0;
+    float aux_mass = 0.f;
+    if (lane < n_aux) {
+        aux_pos = b.aux_pos[a0 + lane];
+        aux_mass = b.aux_mass[a0 + lane];
+    }
+    for (int i = lane; i < R; i += 64) {
+        PeakEntry e;
+        e.mz = b.ret_mz[p0 + i];
+        e.rank = b.ret_rank[p0 + i];
+        f.peaks[i] = e;
+    }
+    if (lane < PYA_TABLE_PAD) {
+        PeakEntry e;
+        e.mz = __builtin_huge_valf();
+        e.rank = PYA_NO_MATCH;
+        f.peaks[R + lane] = e;
+    }
+    PeakTable tab;
+    tab.e = f.peaks;
+    tab.g_cell = nullptr;
+    tab.g_mz = b.ret_mz + p0;
+    tab.g_rank = b.ret_rank + p0;
+    tab.n = R;
+    tab.err = cfg->mz_error;
+    tab.half_check = cfg->mz_error > 0.49f;
+    double Af = 0., Bf = 0., Ab = 0., Bb = 0.;              /* ion-type offsets per direction of travel */
+    if (cfg->n_fwd > 0) type_constants(cfg->types[0], &Af, &Bf);
+    if (cfg->n_fwd < cfg->n_types) type_constants(cfg->types[cfg->n_fwd], &Ab, &Bb);
+    wave_lds_sync();
+    /* ---- residues (ModifiedPeptide.cpp:24-79) from the letter and the LDS table ---- */
+    float m0, m1;
+    uint64_t site_mask;
+    {
+        const bool in = lane < L;
+        const uint32_t li = (letter - 'A') & 31u;
+        m0 = f.mass_l[li];
+        const bool modifiable = in && ((f.flag_l[li] & 1u) || (cfg->allow_n && lane == 0) || (cfg->allow_c && lane == L - 1));
+        m1 = m0 + cfg->mod_mass;
+        for (int base = 0; base < n_aux; base += 64) {
+            const int n = n_aux - base < 64 ? n_aux - base : 64;
+            if (base > 0) {                                  /* (more than 64 fixed modifications) */
+                aux_pos = 0;
+                aux_mass = 0.f;
+                if (lane < n) {
+                    aux_pos = b.aux_pos[a0 + base + lane];
+                    aux_mass = b.aux_mass[a0 + base + lane];
+                }
+            }
+            for (int j = 0; j < n; j++) {
+                const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)aux_pos, j);
+                const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(aux_mass), j));
+                const int idx = pos > 0 ? (int)pos - 1 : 0;
+                if (idx == lane) {
+                    m0 += am;
+                    m1 += am;
+                }
+            }
+        }
+        site_mask = __ballot(modifiable);
+        if (in) f.resd[lane] = make_float2(m0, m1);
+    }
+    grid_build(&tab, f.grid);
+#pragma unroll
+    for (int d = 0; d < PYA_NTOP / 2; d++) f.cnt[d * 64 + lane] = 0u;
+    const int Lm1 = L - 1;
+    const uint64_t resmask = deposit_sites(bits, site_mask);
+    const int w = BOTH ? (lane >> 5) * N + s : s;          /* this lane's column of the rank lists */
     /* positive residue masses make every list ascending (what the neighbour-probe pairing needs) */
-    const bool presorted = !__any(lane < res.L && !(res.m0 > 0.f && res.m1 > 0.f));
+    const bool presorted = !__any(lane < L && !(m0 > 0.f && m1 > 0.f));
     wave_lds_sync();
-    walk_record(env, tab, resmask, dir, active, f.mzl, f.rkl, (int)stride, w);
+    STAMP(b, 40);
+    walk_record(f.resd, f.cnt, tab, L, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, active, f.rkl, (int)stride, w);
     wave_lds_sync();
+    STAMP(b, 41);
 
-    const uint32_t nfrag = (BOTH ? 2u : 1u) * (uint32_t)Lm1;
+    const uint32_t nfrag = (uint32_t)ndir * (uint32_t)Lm1;
     int fail = 0;
     float ws = 0.f;
     if (active && (!BOTH || lane < 32)) {
@@ -217,10 +323,10 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         } else {
             fail = 1;
         }
-        uint32_t *r6 = f.rec6 + (size_t)s * PYA_REC_WORDS;
-#pragma unroll
-        for (int d = 0; d < PYA_NTOP; d += 2) r6[d >> 1] = cum[d] | (cum[d + 1] << 16);
-        r6[5] = nfrag;
+        uint32_t *r3 = f.rec + (size_t)s * 3;              /* counts <= 126: a byte each */
+        r3[0] = cum[0] | cum[1] << 8 | cum[2] << 16 | cum[3] << 24;
+        r3[1] = cum[4] | cum[5] << 8 | cum[6] << 16 | cum[7] << 24;
+        r3[2] = cum[8] | cum[9] << 8;
         f.wsl[s] = ws;
     }
     if (__any(fail)) {                                      /* trial count outside the score table */
@@ -232,7 +338,8 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         }
         return false;
     }
-    wave_lds_sync();                                        /* cnt / resd / peaks are free from here on */
+    wave_lds_sync();                                        /* cnt / peaks are free from here on */
+    STAMP(b, 42);
 
     bool declined = !presorted || (b.debug & 512);
     const bool sig_lane = lane < N;                         /* lane i <-> signature i from here on */
@@ -270,6 +377,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         best_bits = __shfl(my_bits, (int)best_i, 64);
         wave_lds_sync();
     }
+    STAMP(b, 43);
     if (!declined) {
         /* ---- single-move competitors (cpp/Ascore.cpp:212-254) ---- */
         const uint64_t gone = best_bits & ~my_bits, came = my_bits & ~best_bits;
@@ -282,7 +390,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             if ((double)__builtin_fabsf(best_ws - my_ws) < 1e-6) {
                 /* ties the winner: Ascore 0 (Ascore.cpp:159-161), no ion work needed */
                 f.site_tie[a] = 1u;
-                atomicOr(&f.site_alt[a], 1ull << nth_set_bit(res.site_mask, __builtin_ctzll(came)));
+                atomicOr(&f.site_alt[a], 1ull << nth_set_bit(site_mask, __builtin_ctzll(came)));
             } else {
                 const uint32_t slot = atomicAdd(f.n_pushed, 1u);
                 if (slot < push_cap) {
@@ -299,23 +407,38 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         if (np > push_cap) np = push_cap;                   /* cannot happen: push_cap >= k * (n_sites - k) */
         if (b.debug & 16) np = 0;
     }
+    STAMP(b, 44);
     float my_asc = __builtin_huge_valf();                   /* lane a keeps site a */
-    if (!declined && np > 0) {
-        /* ---- depth scores of the winner and the competitors, read off the score table ---- */
-        const int S = 1 + (int)np;
-        for (int i = lane; i < S * 10; i += 64) {
+    const float err = cfg->mz_error;
+    const FastDiv divL = fastdiv_make((uint32_t)(Lm1 > 0 ? Lm1 : 1));
+    int p2 = 1;
+    while (p2 <= Lm1) p2 <<= 1;                              /* the partner search covers indices 0 .. Lm1 */
+    /* ---- Ascores, FUSED_ROUND competitors at a time ---- */
+    for (uint32_t e0 = 0; !declined && e0 < np; e0 += FUSED_ROUND) {
+        const int nc = (int)(np - e0) < FUSED_ROUND ? (int)(np - e0) : FUSED_ROUND;
+        const int S = 1 + nc;
+        /* fragment m/z of the winner (first round only) and of the round's competitors: one lane per
+         * (signature, direction), the walk of walk_record without its lookups */
+        if (lane < S * ndir && (e0 == 0 || lane >= ndir)) {
+            const int sg = lane / ndir, d = lane - sg * ndir;
+            const uint64_t sb = sg == 0 ? best_bits : f.pushed[e0 + sg - 1].bits;
+            const int dd = BOTH ? d : (cfg->n_fwd > 0 ? 0 : 1);
+            walk_mz_only(f.resd, L, deposit_sites(sb, site_mask), dd, dd ? Ab : Af, dd ? Bb : Bf,
+                         f.selm + (size_t)lane * pos_cap);
+        }
+        /* depth scores of the winner and the competitors, read off the score table */
+        for (int i = (e0 == 0 ? 0 : 10) + lane; i < S * 10; i += 64) {
             const int sg = i / 10, d = i - sg * 10;
-            const uint32_t who = sg == 0 ? best_i : f.pushed[sg - 1].idx;
-            const uint32_t *r6 = f.rec6 + (size_t)who * PYA_REC_WORDS;
-            const uint32_t cum = (r6[d >> 1] >> ((d & 1) * 16)) & 0xffffu;
+            const uint32_t who = sg == 0 ? best_i : f.pushed[e0 + sg - 1].idx;
+            const uint32_t cum = (f.rec[(size_t)who * 3 + (d >> 2)] >> ((d & 3) * 8)) & 0xffu;
             f.sc[i] = b.lut[lut_row(nfrag) + (uint32_t)d * (nfrag + 1) + cum];
         }
         wave_lds_sync();
-        if (lane < (int)np) {
-            const PushedEntry pe = f.pushed[lane];
+        if (lane < nc) {
+            const PushedEntry pe = f.pushed[e0 + lane];
             const uint64_t gone = best_bits & ~pe.bits, came = pe.bits & ~best_bits;
             const int a = __popcll(best_bits & (gone - 1));
-            atomicOr(&f.site_alt[a], 1ull << nth_set_bit(res.site_mask, __builtin_ctzll(came)));
+            atomicOr(&f.site_alt[a], 1ull << nth_set_bit(site_mask, __builtin_ctzll(came)));
             f.c_site[lane] = (uint32_t)a;
             float best = 0.f;                               /* depth of the largest score gap (Ascore.cpp:164-172) */
             int depth = 0;
@@ -328,22 +451,19 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             }
             f.c_depth[lane] = depth;
         }
-        for (int i = lane; i < (int)np * 2; i += 64) {
-            f.c_tr[i] = 0;
-            f.c_cnt[i] = 0;
+        if (lane < nc * 2) {
+            f.c_tr[lane] = 0;
+            f.c_cnt[lane] = 0;
         }
         wave_lds_sync();
-        /* ---- site-determining ions from the recorded lists (cpp/ModifiedPeptide.cpp:259-320): an
-         * ion survives when the other signature's list has no ion within mz_error of it.  The lists
-         * are ascending and position-indexed, so the candidates sit at the ion's own index and its
-         * neighbours; with at most one partner per ion the reference's greedy walk cancels exactly
-         * the partnered pairs (localize_core.hip.h), an ion with two partners hands the PSM over. ---- */
-        const float err = cfg->mz_error;
-        const int ndir = BOTH ? 2 : 1;
-        const int items = (int)np * ndir * 2 * Lm1;
-        const FastDiv divL = fastdiv_make((uint32_t)(Lm1 > 0 ? Lm1 : 1));
-        int p2 = 1;
-        while (p2 <= Lm1) p2 <<= 1;                          /* the search covers indices 0 .. Lm1 */
+        STAMP(b, 45);
+        /* ---- site-determining ions (cpp/ModifiedPeptide.cpp:259-320): an ion survives when the other
+         * signature's list has no ion within mz_error of it.  The lists are ascending and
+         * position-indexed, so the candidates sit at the ion's own index and its neighbours (a
+         * binary search otherwise); with at most one partner per ion the reference's greedy walk
+         * cancels exactly the partnered pairs (localize_core.hip.h), an ion with two partners
+         * hands the PSM over. ---- */
+        const int items = nc * ndir * 2 * Lm1;
         bool odd = false;
         if (!(b.debug & 1))
         for (int base = 0; base < items; base += 64) {
@@ -354,17 +474,17 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
                 const int side = (int)ts & 1;
                 const int d = BOTH ? ((int)ts >> 1) & 1 : 0;
                 const int c = BOTH ? (int)ts >> 2 : (int)ts >> 1;
-                const int col_best = d * N + (int)best_i, col_comp = d * N + (int)f.pushed[c].idx;
-                const float *mine = f.mzl + (side ? col_comp : col_best);
-                const float *other = f.mzl + (side ? col_best : col_comp);
-                const float me = mine[(size_t)i * stride];
+                const float *la = f.selm + (size_t)d * pos_cap;                            /* winner     */
+                const float *lb = f.selm + (size_t)((1 + c) * ndir + d) * pos_cap;         /* competitor */
+                const float *mine = side ? lb : la, *other = side ? la : lb;
+                const float me = mine[i];
                 float df[4];
                 bool ok[4], sk[4];
 #pragma unroll
                 for (int uu = 0; uu < 4; uu++) {
                     const int q = i - 1 + uu;
                     ok[uu] = q >= 0 && q < Lm1;
-                    const float o = ok[uu] ? other[(size_t)q * stride] : (q < 0 ? -__builtin_huge_valf() : __builtin_huge_valf());
+                    const float o = ok[uu] ? other[q] : (q < 0 ? -__builtin_huge_valf() : __builtin_huge_valf());
                     df[uu] = side ? (o - me) : (me - o);   /* always (winner's ion) - (competitor's ion) */
                     sk[uu] = side ? (df[uu] <= -err) : (df[uu] >= err);
                 }
@@ -375,37 +495,37 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
                 if (sk[0] && !sk[1]) cnt = w1 + w2;          /* first candidate = index i     */
                 else if (sk[1] && !sk[2]) cnt = w2 + w3;     /* first candidate = index i + 1 */
                 if (cnt < 0) {
-                    /* the first candidate is further away (ions between the two moved sites): binary
-                     * search for the first ion of the other list that is not skipped */
+                    /* the first candidate is further away (ions between the two moved sites) */
                     int j = 0;
                     for (int step = p2 >> 1; step > 0; step >>= 1) {
                         const int probe = j + step;
-                        const float o = probe - 1 < Lm1 ? other[(size_t)(probe - 1) * stride] : __builtin_huge_valf();
+                        const float o = probe - 1 < Lm1 ? other[probe - 1] : __builtin_huge_valf();
                         const float dd = side ? (o - me) : (me - o);
                         if (side ? (dd <= -err) : (dd >= err)) j = probe;
                     }
                     cnt = 0;
                     for (int q = j; q < j + 2 && q < Lm1; q++) {
-                        const float o = other[(size_t)q * stride];
-                        const float dd = side ? (o - me) : (me - o);
+                        const float dd = side ? (other[q] - me) : (me - other[q]);
                         cnt += (__builtin_fabsf(dd) < err) ? 1 : 0;
                     }
                 }
                 if (cnt > 1) {
                     odd = true;                             /* two partners: the serial walk decides */
                 } else if (cnt == 0) {
+                    const uint32_t who = side ? f.pushed[e0 + c].idx : best_i;
                     atomicAdd(&f.c_tr[c * 2 + side], 1u);
-                    if ((int)f.rkl[(size_t)i * stride + (side ? col_comp : col_best)] <= f.c_depth[c])
+                    if ((int)f.rkl[(size_t)i * stride + (d * N + (int)who)] <= f.c_depth[c])
                         atomicAdd(&f.c_cnt[c * 2 + side], 1u);
                 }
             }
         }
         if (__any(odd)) declined = true;
         wave_lds_sync();
+        STAMP(b, 46);
         if (!declined) {
             /* ---- Ascores (cpp/Ascore.cpp:200-209, :239-251, :305-313) ---- */
             float asc_l = 0.f;
-            if (lane < (int)np) {
+            if (lane < nc) {
                 const uint32_t tr0 = f.c_tr[lane * 2], tr1 = f.c_tr[lane * 2 + 1];
                 const uint32_t n0 = f.c_cnt[lane * 2], n1 = f.c_cnt[lane * 2 + 1];
                 const uint32_t depth = (uint32_t)f.c_depth[lane];
@@ -417,26 +537,32 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
                     asc_l = sc0 - sc1;
                 }
             }
-            for (int c = 0; c < (int)np; c++) {
+            for (int c = 0; c < nc; c++) {
                 const float asc = __shfl(asc_l, c, 64);
                 if (lane == (int)f.c_site[c]) my_asc = asc < my_asc ? asc : my_asc;
             }
         }
+        wave_lds_sync();
     }
     if (declined) {
         /* ---- hand-over: leave what score_signatures would have left ---- */
         if (sig_lane) {
             b.ws[s0 + lane] = my_ws;
             if (b.rec) {
-                const uint32_t *r6 = f.rec6 + (size_t)lane * PYA_REC_WORDS;
+                const uint32_t *r3 = f.rec + (size_t)lane * 3;
                 uint32_t *dst = b.rec + (s0 + lane) * PYA_REC_WORDS;
+                uint32_t cum[PYA_NTOP];
 #pragma unroll
-                for (int d = 0; d < PYA_REC_WORDS; d++) dst[d] = r6[d];
+                for (int d = 0; d < PYA_NTOP; d++) cum[d] = (r3[d >> 2] >> ((d & 3) * 8)) & 0xffu;
+#pragma unroll
+                for (int d = 0; d < PYA_NTOP; d += 2) dst[d >> 1] = cum[d] | (cum[d + 1] << 16);
+                dst[5] = nfrag;
             }
         }
         ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)f.grid)[lane];
         return true;
     }
+    STAMP(b, 47);
     if (lane < k && f.site_tie[lane]) my_asc = 0.f < my_asc ? 0.f : my_asc;
     if (lane < k && lane < (int)max_k) {
         out_asc[lane] = my_asc;

@@ -53,7 +53,7 @@ int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uin
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
 int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream);
-size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t push_cap);
+size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t push_cap, uint32_t both);
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
                      uint32_t stride, uint32_t pos_cap, uint32_t push_cap, uint32_t both, uint32_t *d_redo_count,
                      uint32_t *d_redo_ids, hipStream_t stream);
@@ -328,6 +328,8 @@ struct pya_plan {
      * fused kernel hands over. */
     Bucket fusedb;
     std::vector<uint8_t> fused;         /* [n_psm] */
+    std::vector<uint64_t> desc;         /* [n_psm][PYA_DESC_WORDS] packed descriptors (common.h) */
+    DevBuf<uint64_t> d_desc;
     uint32_t fused_both = 0, fused_n_cap = 0, fused_stride = 0;
     DevBuf<uint32_t> d_fused_ids, d_redo4;
     std::vector<uint8_t> ncls;          /* [n_psm] C(n,k) class of the PSM */
@@ -545,6 +547,7 @@ void fill_dev(pya_plan *p) {
     d.n_sig = p->d_n_sig.p;
     d.order_off = p->d_order_off.p;
     d.sig_off = p->d_sig_off.p;
+    d.desc = p->d_desc.p;
     d.order_tab = h->d_order.p;
     d.cfg = h->d_cfg.p;
     d.lut = h->d_lut.p;
@@ -1008,7 +1011,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             p->fused_n_cap = (fb.n_cap + 3u) & ~3u;
             p->fused_stride = (both_dirs ? 2u : 1u) * p->fused_n_cap;
             const uint32_t cap_all = (max_P + 31u) & ~31u;
-            keep_fused = pya_fused_lds_bytes(cap_all, p->fused_n_cap, p->fused_stride, fb.pos_cap, fb.push_cap()) <= 64 * 1024 &&
+            keep_fused = pya_fused_lds_bytes(cap_all, p->fused_n_cap, p->fused_stride, fb.pos_cap, fb.push_cap(), p->fused_both) <= 64 * 1024 &&
                          pya_localize_lds_bytes(fb.push_cap(), fb.n_cap, fb.pos_cap, fb.pool_cap(), fb.sb()) <= kMaxLds;
         }
         if (!keep_fused && !fb.ids.empty()) {               /* (huge spectra) back to the two-kernel route */
@@ -1096,6 +1099,25 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             }
         }
     }
+    /* packed descriptors: what a kernel needs to know about a PSM before it can fetch anything else,
+     * in one cache line (fetched ahead by the fused kernel) */
+    p->desc.resize((size_t)n * PYA_DESC_WORDS);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t *w = &p->desc[(size_t)i * PYA_DESC_WORDS];
+        const uint64_t L = (uint64_t)std::max<int64_t>(0, std::min<int64_t>(p->pep_off[i + 1] - p->pep_off[i], 0xffff));
+        const uint64_t na = (uint64_t)std::max<int64_t>(0, std::min<int64_t>(p->aux_off[i + 1] - p->aux_off[i], 0xffff));
+        w[0] = (uint64_t)p->peak_off[i];
+        w[1] = (uint64_t)p->pep_off[i];
+        w[2] = (uint64_t)p->sig_off[i];
+        w[3] = (uint64_t)p->aux_off[i];
+        w[4] = L | na << 16 | (uint64_t)((uint32_t)p->n_of_mod[i] & 0xffffu) << 32 | (uint64_t)p->n_sites[i] << 48;
+        w[5] = (uint64_t)p->n_sig[i] | (uint64_t)p->order_off[i] << 32;
+    }
+    /* the fused kernel keeps one row of the score table in LDS: PSMs of equal length back to back */
+    for (pya_plan::IdList &fl : p->fused_lists)
+        std::stable_sort(p->fused_ids.begin() + fl.off, p->fused_ids.begin() + fl.off + fl.n, [&](uint32_t a, uint32_t b2) {
+            return p->pep_off[a + 1] - p->pep_off[a] < p->pep_off[b2 + 1] - p->pep_off[b2];
+        });
     lap("id lists");
     rc = ensure_lut(h, lut_need);
     if (rc) return rc;
@@ -1138,7 +1160,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_aux_mass = meta(has_aux ? b->aux_mass + aux_base : nullptr, (size_t)total_aux * 4),
                      o_bin_ids = meta(p->bin_ids.data(), p->bin_ids.size() * 4),
                      o_score_ids = meta(p->score_ids.data(), p->score_ids.size() * 4),
-                     o_fused_ids = meta(p->fused_ids.data(), p->fused_ids.size() * 4);
+                     o_fused_ids = meta(p->fused_ids.data(), p->fused_ids.size() * 4),
+                     o_desc = meta(p->desc.data(), p->desc.size() * 8);
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
             o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
@@ -1180,6 +1203,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_bin_ids.adopt(base + o_bin_ids, p->bin_ids.size());
         p->d_score_ids.adopt(base + o_score_ids, p->score_ids.size());
         p->d_fused_ids.adopt(base + o_fused_ids, p->fused_ids.size());
+        p->d_desc.adopt(base + o_desc, p->desc.size());
         for (int i = 0; i < kNumBuckets; i++)
             p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
         if (io) {

@@ -2,16 +2,16 @@
  * pass of one wavefront, for PSMs with few site assignments and the plain scorer settings (no
  * neutral losses, fragment charge 1, one ion type per direction).  See fused_core.hip.h.
  *
- * HBM traffic per PSM: the retained table (5 B x R), the peptide and its signature table (L2
- * resident) in; the 64-byte result out.  No per-signature scores, count records or m/z grid go
- * through HBM (they do on the score_signatures -> rank_and_localize route: 28 B x C(n,k) + 512 B
- * written and read back per PSM).  PSMs this kernel cannot finish are appended to a hand-over list
- * and redone by the general localize instantiation (pya_launch_localize_redo).
+ * HBM traffic per PSM: the retained table (5 B x R), the peptide, its descriptor and its signature
+ * table (L2 resident) in; the 64-byte result out.  No per-signature scores, count records or m/z
+ * grid go through HBM (they do on the score_signatures -> rank_and_localize route: 28 B x C(n,k) +
+ * 512 B written and read back per PSM).  PSMs this kernel cannot finish are appended to a
+ * hand-over list and redone by the general localize instantiation (pya_launch_localize_redo).
  */
 #include "fused_core.hip.h"
 
 #ifndef FUSED_WAVES
-#define FUSED_WAVES 5
+#define FUSED_WAVES 6
 #endif
 
 template <bool BOTH>
@@ -25,15 +25,16 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void pya_score_localize_kernel(
     if (declined && lane_id() == 0) redo_ids[atomicAdd(redo_count, 1u)] = psm;
 }
 
-extern "C" size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t push_cap) {
-    return fused_lds_bytes(cap, n_cap, stride, pos_cap, push_cap);
+extern "C" size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t push_cap,
+                                      uint32_t both) {
+    return fused_lds_bytes(cap, n_cap, stride, pos_cap, push_cap, both ? 2u : 1u);
 }
 
 extern "C" int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
                                 uint32_t stride, uint32_t pos_cap, uint32_t push_cap, uint32_t both,
                                 uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream) {
     if (n_ids == 0) return 0;
-    const size_t lds = fused_lds_bytes(cap, n_cap, stride, pos_cap, push_cap);
+    const size_t lds = fused_lds_bytes(cap, n_cap, stride, pos_cap, push_cap, both ? 2u : 1u);
     hipError_t e = both ? PYA_ENSURE_MAX_LDS(pya_score_localize_kernel<true>)
                         : PYA_ENSURE_MAX_LDS(pya_score_localize_kernel<false>);
     if (e != hipSuccess) return (int)e;
