@@ -162,6 +162,8 @@ def main():
                     help="weak: every GPU gets --psms PSMs' worth of work; strong: the job (--total) is fixed")
     ap.add_argument("--total", type=int, default=None, help="PSMs of the whole job with --scaling strong "
                     "(default: the config's size, e.g. 1M for cfg3)")
+    ap.add_argument("--max-charge", type=int, default=None,
+                    help="override the config's max fragment charge (real 3+/4+ precursors are scored at 2/3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -198,7 +200,8 @@ def main():
         total = args.total or (world * args.psms if args.psms else synth.CONFIGS[args.config]["n_psm"])
     else:
         total = world * n_per_gpu
-    desc = synth.describe(args.config, n_psm=total, seed=1000)
+    over = {} if args.max_charge is None else {"max_charge": args.max_charge}
+    desc = synth.describe(args.config, n_psm=total, seed=1000, **over)
     settings = desc["settings"]
     weights = shard.work_estimate_shapes(desc["n_sites"], desc["n_mod"], desc["L"], desc["max_charge"],
                                          n_types=len(settings["fragment_types"]))
@@ -290,7 +293,7 @@ def main():
             del a, b2, back
         pcie_bytes = batch["mz"].nbytes + batch["intensity"].nbytes + sum(v.nbytes for v in res.values())
         copy_gbs = achievable_hbm_gbs(torch, dev)
-        default_size = args.psms is None and args.config != "cfg3"
+        default_size = args.psms is None and args.config != "cfg3" and args.max_charge is None
         traffic, traffic_src, valu_share = profiled_traffic(args.config, names[dom], default_size)
         line = {
             "metric": METRIC, "value": total * args.steps / elapsed, "unit": "PSMs/s",

@@ -69,7 +69,7 @@ struct BatchDev {
     const uint64_t *order_tab;      /* pre-sort signature order per shape (sig bits)        */
     const uint64_t *desc;           /* [n_psm][PYA_DESC_WORDS] the offsets and counts above, packed (one  */
                                     /* cache line per PSM): peak_off, pep_off, sig_off, aux_off,          */
-                                    /* L | n_aux << 16 | n_of_mod << 32 | n_sites << 48, n_sig | order_off << 32 */
+                                    /* L | n_aux << 16 | n_of_mod << 32 | n_sites << 48 | max_charge << 56, n_sig | order_off << 32 */
     const DevConfig *cfg;
     const float *lut;               /* score table                                          */
     const uint32_t *lut_off;        /* [lut_n_max+1] row offsets                            */
@@ -101,7 +101,8 @@ struct BatchDev {
      * tables, 8 no sort emulation, 16 no competitors, 32 no window ranking, 64 no compaction.
      * Route selection, results stay exact (used by the tests): 128 every spectrum through
      * pya_bin_exact_kernel, 512 the lean localize instantiation declines every PSM, 1024 the
-     * std::sort emulation runs even for a unique best PepScore. */
+     * std::sort emulation runs even for a unique best PepScore, 2048 the fused kernel replays every
+     * (competitor, direction) task with the serial walk. */
     uint32_t debug;
     unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */
 };

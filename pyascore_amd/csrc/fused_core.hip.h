@@ -1,6 +1,7 @@
 /* fused_core.hip.h -- scoring AND localisation of one PSM by one wavefront, in one pass, for the
  * PSMs that make up most real batches: few site assignments (C(n,k) <= 32, or <= 64 with ion types
- * of one direction only), no neutral losses, fragment charge 1, one ion type per direction.
+ * of one direction only), no neutral losses, one ion type per direction, at most 255 fragments per
+ * site assignment (any fragment charge).
  *
  * Replaces, for those PSMs, score_signatures + rank_and_localize (cpp/Ascore.cpp:53-254,
  * cpp/ModifiedPeptide.cpp:126-150, :259-320, :326-609).  The two-kernel route makes every walker
@@ -21,11 +22,17 @@
  * ranks instead of m/z lists, competitors localised three at a time, and everything that is dead
  * after the walk (rank histogram, peak table) reused for the bookkeeping that follows.
  *
+ * Fragment charges above 1 are in: a list is then one ascending run per charge; an ion looks for
+ * partners among its neighbours in the run of its own charge and by binary search in the others.
+ * A (competitor, direction) task in which some ion has two partners within mz_error -- common once
+ * charge states interleave -- is replayed right here with the reference's serial walk over the two
+ * lists, merged by rank computation; only those tasks, one lane each.
+ *
  * Exactness is that of the two kernels (same walker, same window test, same std::sort emulation,
- * same neighbour-probe pairing): a PSM that needs a route this body does not have -- a residue mass
- * that is not positive (lists not ascending), an ion with two partners within mz_error, introsort
- * running out of depth -- is handed over: its scores, count records and grid are written where
- * score_signatures would have left them and the general localize instantiation redoes it.
+ * same pairing rule): a PSM that needs a route this body does not have -- a residue mass that is
+ * not positive (lists not ascending), introsort running out of depth -- is handed over: its scores,
+ * count records and grid are written where score_signatures would have left them and the general
+ * localize instantiation redoes it.
  */
 #ifndef PYA_FUSED_CORE_H
 #define PYA_FUSED_CORE_H
@@ -41,8 +48,9 @@
  *   walk region   cnt u32[5][64] | peaks PeakEntry[cap + 4]                     (dead after the walk)
  *   post region   (same bytes) sort arrays, pushed competitors, per-site maxima / ties / alternative
  *                 sites, depth scores and counters of a round
- *   kept          resd float2[pos_cap + 1] | rkl u8[pos_cap][stride] | rec u32[n_cap][3] | wsl f32[n_cap]
- *                 | mass f32[32] | flags u32[32] | selm f32[(1 + FUSED_ROUND) * ndir][pos_cap]            */
+ *   kept          resd float2[pos_cap + 1] | rkl u8[ent_cap][stride] | rec u32[n_cap][3] | wsl f32[n_cap]
+ *                 | mass f32[32] | flags u32[32] | selm f32[(1 + FUSED_ROUND) * ndir][ent_cap]
+ *                 (pos_cap = L - 1, ent_cap = (L - 1) x charges: list entries per (signature, direction)) */
 struct FusedLds {
     uint16_t *grid;
     uint32_t *cnt;
@@ -61,31 +69,39 @@ struct FusedLds {
     unsigned long long *site_alt;
     uint32_t *site_max, *site_tie, *n_pushed;
     float *sc;               /* [1 + FUSED_ROUND][10] depth scores: winner, then the round's competitors */
-    uint32_t *c_tr, *c_cnt;  /* [FUSED_ROUND][2] */
+    uint32_t *c_tr, *c_cnt;  /* [FUSED_ROUND * ndir][2] per task (competitor, direction) and side */
+    uint32_t *bad_tasks;     /* bit t: task t has an ion with two partners -> replayed serially */
+    float *srt_v;            /* [FUSED_ROUND * ndir][2][ent_cap] a task's two lists, sorted (only filled for replays) */
+    uint8_t *srt_h;          /* same shape: the ion matched a peak of rank <= depth */
     int32_t *c_depth;        /* [FUSED_ROUND] */
     uint32_t *c_site;        /* [FUSED_ROUND] */
 };
 
 __host__ __device__ static inline size_t fused_align16(size_t v) { return (v + 15) & ~(size_t)15; }
-__host__ __device__ static inline size_t fused_post_bytes(uint32_t n_cap, uint32_t push_cap) {
+__host__ __device__ static inline size_t fused_post_bytes(uint32_t n_cap, uint32_t push_cap, uint32_t ent_cap, uint32_t ndir) {
     return fused_align16((size_t)n_cap * 10) + (size_t)push_cap * 16 + 64 * 8 + 64 * 4 * 2 + 16 +
-           (size_t)(1 + FUSED_ROUND) * 40 + (size_t)FUSED_ROUND * (8 + 8 + 4 + 4);
+           (size_t)(1 + FUSED_ROUND) * 40 + (size_t)FUSED_ROUND * (16 * ndir + 4 + 4) + 16 +
+           fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap * 4) + fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap);
 }
 __host__ __device__ static inline size_t fused_walk_bytes(uint32_t cap) {
     return PYA_NTOP / 2 * 64 * 4 + ((size_t)cap + PYA_TABLE_PAD) * 8;
 }
-__host__ __device__ static inline size_t fused_kept_bytes(uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ndir) {
-    return fused_align16(((size_t)pos_cap + 1) * 8) + fused_align16((size_t)pos_cap * stride) + (size_t)n_cap * 16 + 256 +
-           (size_t)(1 + FUSED_ROUND) * ndir * pos_cap * 4;
+/* pos_cap = largest L - 1 of the launch, ent_cap = largest (L - 1) x charges: list entries per
+ * (signature, direction) */
+__host__ __device__ static inline size_t fused_kept_bytes(uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap,
+                                                          uint32_t ndir) {
+    return fused_align16(((size_t)pos_cap + 1) * 8) + fused_align16((size_t)ent_cap * stride) + (size_t)n_cap * 16 + 256 +
+           (size_t)(1 + FUSED_ROUND) * ndir * ent_cap * 4;
 }
 __host__ __device__ static inline size_t fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap,
-                                                         uint32_t push_cap, uint32_t ndir) {
-    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap);
-    return PYA_GRID_CELLS * 2 + fused_align16(walk > post ? walk : post) + fused_kept_bytes(n_cap, stride, pos_cap, ndir) + 16;
+                                                         uint32_t ent_cap, uint32_t push_cap, uint32_t ndir) {
+    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap, ent_cap, ndir);
+    return PYA_GRID_CELLS * 2 + fused_align16(walk > post ? walk : post) +
+           fused_kept_bytes(n_cap, stride, pos_cap, ent_cap, ndir) + 16;
 }
 
 DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap,
-                         uint32_t push_cap, uint32_t ndir) {
+                         uint32_t ent_cap, uint32_t push_cap, uint32_t ndir) {
     FusedLds f;
     f.grid = (uint16_t *)raw;
     size_t o = PYA_GRID_CELLS * 2;
@@ -110,18 +126,24 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
     f.sc = (float *)(raw + q);
     q += (size_t)(1 + FUSED_ROUND) * 40;
     f.c_tr = (uint32_t *)(raw + q);
-    q += FUSED_ROUND * 8;
+    q += (size_t)FUSED_ROUND * ndir * 8;
     f.c_cnt = (uint32_t *)(raw + q);
-    q += FUSED_ROUND * 8;
+    q += (size_t)FUSED_ROUND * ndir * 8;
     f.c_depth = (int32_t *)(raw + q);
     q += FUSED_ROUND * 4;
     f.c_site = (uint32_t *)(raw + q);
-    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap);
+    q += FUSED_ROUND * 4;
+    f.bad_tasks = (uint32_t *)(raw + q);
+    q += 16;
+    f.srt_v = (float *)(raw + q);
+    q += fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap * 4);
+    f.srt_h = (uint8_t *)(raw + q);
+    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap, ent_cap, ndir);
     o += fused_align16(walk > post ? walk : post);
     f.resd = (float2 *)(raw + o);
     o += fused_align16(((size_t)pos_cap + 1) * 8);
     f.rkl = (uint8_t *)(raw + o);
-    o += fused_align16((size_t)pos_cap * stride);
+    o += fused_align16((size_t)ent_cap * stride);
     f.rec = (uint32_t *)(raw + o);
     o += (size_t)n_cap * 12;
     f.wsl = (float *)(raw + o);
@@ -133,9 +155,9 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
 }
 
 /* the straight-line walker of walk_core.hip.h that also records the rank every fragment matched in
- * column `w` of rkl; A, B: the ion-type offsets of the lane's direction (type_constants) */
-DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, int L, uint64_t resmask, int dir, double A,
-                     double B, bool active, uint8_t *rkl, int stride, int w) {
+ * column `w` of rkl (entry step * zmax + z - 1); A, B: the ion-type offsets of the lane's direction */
+DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, int L, int zmax, uint64_t resmask, int dir,
+                     double A, double B, bool active, uint8_t *rkl, int stride, int w) {
     const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
     const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
     const float2 *rp = resd + (dir ? L - 1 : 0);
@@ -143,26 +165,33 @@ DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, in
     uint32_t *col = cnt + lane_id();
     uint8_t *ro = rkl + w;
     float running = 0.f;
-    for (int step = 0; step + 1 < L; step++, rp += rstride, ro += stride) {
+    for (int step = 0; step + 1 < L; step++, rp += rstride) {
         const float2 mm = *rp;
         const uint32_t word = step < 32 ? tlo : thi;
         const bool mod = (word >> (step & 31)) & 1u;
         const float r = mod ? mm.y : mm.x;
         running = r + running;                             /* ModifiedPeptide.cpp:385-389 */
         const double m = ((double)running + A) - B;
-        const float f = (float)(m + 1.007825);
-        const int rk = match_rank_lds(tab, f);
+        const int rk = match_rank_lds(tab, (float)(m + 1.007825));
         hist_bump(col, active, rk);
         if (active) *ro = (uint8_t)rk;
+        ro += stride;
+        for (int z = 2; z <= zmax; z++, ro += stride) {
+            const int rz = match_rank_lds(tab, charge_mz(m, z));
+            hist_bump(col, active, rz);
+            if (active) *ro = (uint8_t)rz;
+        }
     }
 }
 
-/* the same walk without lookups: the fragment m/z of one (signature, direction) into out[0 .. L-2] */
-DEV void walk_mz_only(const float2 *resd, int L, uint64_t resmask, int dir, double A, double B, float *out) {
+/* the same walk without lookups: the fragment m/z of one (signature, direction), charge-major:
+ * out[(z - 1) * (L - 1) + step] -- one ascending, position-indexed run per charge */
+DEV void walk_mz_only(const float2 *resd, int L, int zmax, uint64_t resmask, int dir, double A, double B, float *out) {
     const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
     const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
     const float2 *rp = resd + (dir ? L - 1 : 0);
     const int rstride = dir ? -1 : 1;
+    const int Lm1 = L - 1;
     float running = 0.f;
     for (int step = 0; step + 1 < L; step++, rp += rstride) {
         const float2 mm = *rp;
@@ -172,7 +201,26 @@ DEV void walk_mz_only(const float2 *resd, int L, uint64_t resmask, int dir, doub
         running = r + running;
         const double m = ((double)running + A) - B;
         out[step] = (float)(m + 1.007825);
+        for (int z = 2; z <= zmax; z++) out[(z - 1) * Lm1 + step] = charge_mz(m, z);
     }
+}
+
+/* ions of one ascending run within mz_error of `me` (0, 1, or 2 = "more than one"): binary search
+ * for the first ion that is not skipped, then the two candidates from there (localize_core.hip.h) */
+DEV int partners_in_run(const float *run, int n, int p2, float me, int side, float err) {
+    int j = 0;
+    for (int step = p2 >> 1; step > 0; step >>= 1) {
+        const int probe = j + step;
+        const float o = probe - 1 < n ? run[probe - 1] : __builtin_huge_valf();
+        const float dd = side ? (o - me) : (me - o);
+        if (side ? (dd <= -err) : (dd >= err)) j = probe;
+    }
+    int cnt = 0;
+    for (int q = j; q < j + 2 && q < n; q++) {
+        const float dd = side ? (run[q] - me) : (me - run[q]);
+        cnt += (__builtin_fabsf(dd) < err) ? 1 : 0;
+    }
+    return cnt;
 }
 
 /* BOTH: ion types of both directions -- lanes 0..31 walk from the N-terminus, lanes 32..63 from the
@@ -180,11 +228,11 @@ DEV void walk_mz_only(const float2 *resd, int L, uint64_t resmask, int dir, doub
  * Returns true when the PSM was handed over to the general localize instantiation. */
 template <bool BOTH>
 DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t n_cap, uint32_t stride,
-                    uint32_t pos_cap, uint32_t push_cap) {
+                    uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int ndir = BOTH ? 2 : 1;
-    const FusedLds f = fused_carve(lds_raw, cap, n_cap, stride, pos_cap, push_cap, (uint32_t)ndir);
+    const FusedLds f = fused_carve(lds_raw, cap, n_cap, stride, pos_cap, ent_cap, push_cap, (uint32_t)ndir);
     /* the residue table does not depend on the PSM: on its way before anything else */
     if (lane < 32) {
         f.mass_l[lane] = cfg->res_mass[lane];
@@ -195,6 +243,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const int64_t p0 = (int64_t)dw[0], pep0 = (int64_t)dw[1], s0 = (int64_t)dw[2], a0 = (int64_t)dw[3];
     const uint64_t w4 = dw[4], w5 = dw[5];
     const int L = (int)(w4 & 0xffffu), n_aux = (int)((w4 >> 16) & 0xffffu), k = (int)((w4 >> 32) & 0xffffu);
+    const int zmax = (int)(w4 >> 56);
     const int N = (int)(uint32_t)w5;
     const uint64_t *order = b.order_tab + (uint32_t)(w5 >> 32);
     const int status = b.status[psm];
@@ -294,11 +343,11 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const bool presorted = !__any(lane < L && !(m0 > 0.f && m1 > 0.f));
     wave_lds_sync();
     STAMP(b, 40);
-    walk_record(f.resd, f.cnt, tab, L, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, active, f.rkl, (int)stride, w);
+    walk_record(f.resd, f.cnt, tab, L, zmax, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, active, f.rkl, (int)stride, w);
     wave_lds_sync();
     STAMP(b, 41);
 
-    const uint32_t nfrag = (uint32_t)ndir * (uint32_t)Lm1;
+    const uint32_t nfrag = (uint32_t)ndir * (uint32_t)Lm1 * (uint32_t)zmax;     /* <= 255 (host) */
     int fail = 0;
     float ws = 0.f;
     if (active && (!BOTH || lane < 32)) {
@@ -423,8 +472,8 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             const int sg = lane / ndir, d = lane - sg * ndir;
             const uint64_t sb = sg == 0 ? best_bits : f.pushed[e0 + sg - 1].bits;
             const int dd = BOTH ? d : (cfg->n_fwd > 0 ? 0 : 1);
-            walk_mz_only(f.resd, L, deposit_sites(sb, site_mask), dd, dd ? Ab : Af, dd ? Bb : Bf,
-                         f.selm + (size_t)lane * pos_cap);
+            walk_mz_only(f.resd, L, zmax, deposit_sites(sb, site_mask), dd, dd ? Ab : Af, dd ? Bb : Bf,
+                         f.selm + (size_t)lane * ent_cap);
         }
         /* depth scores of the winner and the competitors, read off the score table */
         for (int i = (e0 == 0 ? 0 : 10) + lane; i < S * 10; i += 64) {
@@ -451,83 +500,157 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             }
             f.c_depth[lane] = depth;
         }
-        if (lane < nc * 2) {
+        if (lane < nc * ndir * 2) {
             f.c_tr[lane] = 0;
             f.c_cnt[lane] = 0;
         }
+        if (lane == 0) *f.bad_tasks = 0u;
         wave_lds_sync();
         STAMP(b, 45);
         /* ---- site-determining ions (cpp/ModifiedPeptide.cpp:259-320): an ion survives when the other
          * signature's list has no ion within mz_error of it.  The lists are ascending and
          * position-indexed, so the candidates sit at the ion's own index and its neighbours (a
          * binary search otherwise); with at most one partner per ion the reference's greedy walk
-         * cancels exactly the partnered pairs (localize_core.hip.h), an ion with two partners
-         * hands the PSM over. ---- */
-        const int items = nc * ndir * 2 * Lm1;
-        bool odd = false;
+         * cancels exactly the partnered pairs (localize_core.hip.h); a task with a doubly partnered
+         * ion is replayed below. ---- */
+        const int ents = Lm1 * zmax;                        /* ions of one list: one ascending run per charge */
+        const int items = nc * ndir * 2 * ents;
+        const FastDiv divE = fastdiv_make((uint32_t)(ents > 0 ? ents : 1));
         if (!(b.debug & 1))
         for (int base = 0; base < items; base += 64) {
             const int e = base + lane;
             if (e < items) {
-                const uint32_t ts = fastdiv((uint32_t)e, divL);
-                const int i = e - (int)ts * Lm1;
+                const uint32_t ts = fastdiv((uint32_t)e, divE);
+                const int en = e - (int)ts * ents;
+                const int z0 = zmax == 1 ? 0 : (int)fastdiv((uint32_t)en, divL), i = en - z0 * Lm1;
                 const int side = (int)ts & 1;
                 const int d = BOTH ? ((int)ts >> 1) & 1 : 0;
                 const int c = BOTH ? (int)ts >> 2 : (int)ts >> 1;
-                const float *la = f.selm + (size_t)d * pos_cap;                            /* winner     */
-                const float *lb = f.selm + (size_t)((1 + c) * ndir + d) * pos_cap;         /* competitor */
-                const float *mine = side ? lb : la, *other = side ? la : lb;
-                const float me = mine[i];
-                float df[4];
-                bool ok[4], sk[4];
+                const float *la = f.selm + (size_t)d * ent_cap;                            /* winner     */
+                const float *lb = f.selm + (size_t)((1 + c) * ndir + d) * ent_cap;         /* competitor */
+                const float *mine = side ? lb : la, *others = side ? la : lb;
+                const float me = mine[en];
+                int total = 0;                              /* ions of the other list within mz_error of this one */
+                {
+                    /* the run of the same charge: position-indexed like mine */
+                    const float *other = others + z0 * Lm1;
+                    float df[4];
+                    bool ok[4], sk[4];
 #pragma unroll
-                for (int uu = 0; uu < 4; uu++) {
-                    const int q = i - 1 + uu;
-                    ok[uu] = q >= 0 && q < Lm1;
-                    const float o = ok[uu] ? other[q] : (q < 0 ? -__builtin_huge_valf() : __builtin_huge_valf());
-                    df[uu] = side ? (o - me) : (me - o);   /* always (winner's ion) - (competitor's ion) */
-                    sk[uu] = side ? (df[uu] <= -err) : (df[uu] >= err);
-                }
-                const int w1 = (ok[1] && __builtin_fabsf(df[1]) < err) ? 1 : 0;
-                const int w2 = (ok[2] && __builtin_fabsf(df[2]) < err) ? 1 : 0;
-                const int w3 = (ok[3] && __builtin_fabsf(df[3]) < err) ? 1 : 0;
-                int cnt = -1;
-                if (sk[0] && !sk[1]) cnt = w1 + w2;          /* first candidate = index i     */
-                else if (sk[1] && !sk[2]) cnt = w2 + w3;     /* first candidate = index i + 1 */
-                if (cnt < 0) {
-                    /* the first candidate is further away (ions between the two moved sites) */
-                    int j = 0;
-                    for (int step = p2 >> 1; step > 0; step >>= 1) {
-                        const int probe = j + step;
-                        const float o = probe - 1 < Lm1 ? other[probe - 1] : __builtin_huge_valf();
-                        const float dd = side ? (o - me) : (me - o);
-                        if (side ? (dd <= -err) : (dd >= err)) j = probe;
+                    for (int uu = 0; uu < 4; uu++) {
+                        const int q = i - 1 + uu;
+                        ok[uu] = q >= 0 && q < Lm1;
+                        const float o = ok[uu] ? other[q] : (q < 0 ? -__builtin_huge_valf() : __builtin_huge_valf());
+                        df[uu] = side ? (o - me) : (me - o);   /* always (winner's ion) - (competitor's ion) */
+                        sk[uu] = side ? (df[uu] <= -err) : (df[uu] >= err);
                     }
-                    cnt = 0;
-                    for (int q = j; q < j + 2 && q < Lm1; q++) {
-                        const float dd = side ? (other[q] - me) : (me - other[q]);
-                        cnt += (__builtin_fabsf(dd) < err) ? 1 : 0;
-                    }
+                    const int w1 = (ok[1] && __builtin_fabsf(df[1]) < err) ? 1 : 0;
+                    const int w2 = (ok[2] && __builtin_fabsf(df[2]) < err) ? 1 : 0;
+                    const int w3 = (ok[3] && __builtin_fabsf(df[3]) < err) ? 1 : 0;
+                    int cnt = -1;
+                    if (sk[0] && !sk[1]) cnt = w1 + w2;      /* first candidate = index i     */
+                    else if (sk[1] && !sk[2]) cnt = w2 + w3; /* first candidate = index i + 1 */
+                    if (cnt < 0) cnt = partners_in_run(other, Lm1, p2, me, side, err);
+                    total = cnt;
                 }
-                if (cnt > 1) {
-                    odd = true;                             /* two partners: the serial walk decides */
-                } else if (cnt == 0) {
+                for (int zz = 0; zz < zmax; zz++)           /* the runs of the other charges: anywhere */
+                    if (zz != z0) total += partners_in_run(others + zz * Lm1, Lm1, p2, me, side, err);
+                const int task = c * ndir + d;
+                if (total > 1 || (b.debug & 2048)) {
+                    atomicOr(f.bad_tasks, 1u << task);      /* two partners: the serial walk decides */
+                } else if (total == 0) {
                     const uint32_t who = side ? f.pushed[e0 + c].idx : best_i;
-                    atomicAdd(&f.c_tr[c * 2 + side], 1u);
-                    if ((int)f.rkl[(size_t)i * stride + (d * N + (int)who)] <= f.c_depth[c])
-                        atomicAdd(&f.c_cnt[c * 2 + side], 1u);
+                    atomicAdd(&f.c_tr[task * 2 + side], 1u);
+                    if ((int)f.rkl[(size_t)(i * zmax + z0) * stride + (d * N + (int)who)] <= f.c_depth[c])
+                        atomicAdd(&f.c_cnt[task * 2 + side], 1u);
                 }
             }
         }
-        if (__any(odd)) declined = true;
         wave_lds_sync();
+        const uint32_t bad = *f.bad_tasks;
+        if (bad) {
+            /* ---- a task with a doubly partnered ion is replayed with the reference's serial walk over its
+             * two sorted lists (ModifiedPeptide.cpp:291-316).  Sorting = merging the per-charge runs:
+             * an ion's place is its index in its own run plus, for every other run, the number of ions
+             * that sort before it (equal values: the lower charge first). ---- */
+            for (int base = 0; base < items; base += 64) {
+                const int e = base + lane;
+                if (e < items) {
+                    const uint32_t ts = fastdiv((uint32_t)e, divE);
+                    const int en = e - (int)ts * ents;
+                    const int z0 = zmax == 1 ? 0 : (int)fastdiv((uint32_t)en, divL), i = en - z0 * Lm1;
+                    const int side = (int)ts & 1;
+                    const int d = BOTH ? ((int)ts >> 1) & 1 : 0;
+                    const int c = BOTH ? (int)ts >> 2 : (int)ts >> 1;
+                    const int task = c * ndir + d;
+                    if ((bad >> task) & 1u) {
+                        const float *mine = f.selm + (size_t)((side ? (1 + c) * ndir : 0) + d) * ent_cap;
+                        const float me = mine[en];
+                        int pos = i;
+                        for (int zz = 0; zz < zmax; zz++) {
+                            if (zz == z0) continue;
+                            const float *run = mine + zz * Lm1;
+                            int j = 0;                          /* ions of run zz that sort before this one */
+                            for (int step = p2 >> 1; step > 0; step >>= 1) {
+                                const int probe = j + step;
+                                if (probe - 1 < Lm1 && (zz < z0 ? run[probe - 1] <= me : run[probe - 1] < me)) j = probe;
+                            }
+                            pos += j;
+                        }
+                        const uint32_t who = side ? f.pushed[e0 + c].idx : best_i;
+                        const size_t at = (size_t)(task * 2 + side) * ent_cap + pos;
+                        f.srt_v[at] = me;
+                        f.srt_h[at] = (int)f.rkl[(size_t)(i * zmax + z0) * stride + (d * N + (int)who)] <= f.c_depth[c] ? 1 : 0;
+                    }
+                }
+            }
+            wave_lds_sync();
+            if (lane < nc * ndir && ((bad >> lane) & 1u)) {
+                const float *va = f.srt_v + (size_t)(lane * 2) * ent_cap, *vb = va + ent_cap;
+                const uint8_t *ha = f.srt_h + (size_t)(lane * 2) * ent_cap, *hb = ha + ent_cap;
+                uint32_t tr0 = 0, tr1 = 0, n0 = 0, n1 = 0;
+                int ia = 0, ib = 0;
+                while (ia < ents || ib < ents) {
+                    if (ib == ents) {
+                        tr0++;
+                        n0 += ha[ia++];
+                    } else if (ia == ents) {
+                        tr1++;
+                        n1 += hb[ib++];
+                    } else {
+                        const float xa = va[ia], xb = vb[ib];
+                        if (__builtin_fabsf(xa - xb) < err) {
+                            ia++;
+                            ib++;
+                        } else if (xa < xb) {
+                            tr0++;
+                            n0 += ha[ia++];
+                        } else {
+                            tr1++;
+                            n1 += hb[ib++];
+                        }
+                    }
+                }
+                f.c_tr[lane * 2] = tr0;
+                f.c_tr[lane * 2 + 1] = tr1;
+                f.c_cnt[lane * 2] = n0;
+                f.c_cnt[lane * 2 + 1] = n1;
+            }
+            wave_lds_sync();
+        }
         STAMP(b, 46);
         if (!declined) {
             /* ---- Ascores (cpp/Ascore.cpp:200-209, :239-251, :305-313) ---- */
             float asc_l = 0.f;
             if (lane < nc) {
-                const uint32_t tr0 = f.c_tr[lane * 2], tr1 = f.c_tr[lane * 2 + 1];
-                const uint32_t n0 = f.c_cnt[lane * 2], n1 = f.c_cnt[lane * 2 + 1];
+                uint32_t tr0 = 0, tr1 = 0, n0 = 0, n1 = 0;
+                for (int d = 0; d < ndir; d++) {            /* a competitor's tasks: one per direction */
+                    const int t = lane * ndir + d;
+                    tr0 += f.c_tr[t * 2];
+                    tr1 += f.c_tr[t * 2 + 1];
+                    n0 += f.c_cnt[t * 2];
+                    n1 += f.c_cnt[t * 2 + 1];
+                }
                 const uint32_t depth = (uint32_t)f.c_depth[lane];
                 if (tr0 > b.lut_n_max || tr1 > b.lut_n_max) {
                     fail = 1;

@@ -53,10 +53,11 @@ int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uin
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
 int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream);
-size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t push_cap, uint32_t both);
+size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap,
+                           uint32_t both);
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
-                     uint32_t stride, uint32_t pos_cap, uint32_t push_cap, uint32_t both, uint32_t *d_redo_count,
-                     uint32_t *d_redo_ids, hipStream_t stream);
+                     uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
+                     uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
 int pya_launch_localize_redo(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max,
                              uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
                              uint32_t gtp, hipStream_t stream);
@@ -330,7 +331,7 @@ struct pya_plan {
     std::vector<uint8_t> fused;         /* [n_psm] */
     std::vector<uint64_t> desc;         /* [n_psm][PYA_DESC_WORDS] packed descriptors (common.h) */
     DevBuf<uint64_t> d_desc;
-    uint32_t fused_both = 0, fused_n_cap = 0, fused_stride = 0;
+    uint32_t fused_both = 0, fused_n_cap = 0, fused_stride = 0, fused_ent_cap = 1;
     DevBuf<uint32_t> d_fused_ids, d_redo4;
     std::vector<uint8_t> ncls;          /* [n_psm] C(n,k) class of the PSM */
     std::vector<int32_t> pre_status;    /* [n_psm] PSMs the host pre-pass set aside (PYA_FLAG_SKIP_INVALID) */
@@ -975,12 +976,17 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             int bi = 0;
             while (N > kBucketLimits[bi]) bi++;
             cls_of_i = bi;
-            const bool to_fused = fused_on && z == 1 && N <= fused_max_n;
+            /* (its count records hold the cumulative counts as bytes: at most 255 fragments) */
+            const uint32_t frags = (both_dirs ? 2u : 1u) * (uint32_t)(L - 1) * (uint32_t)z;
+            const bool to_fused = fused_on && N <= fused_max_n && frags <= 255u;
             Bucket &bk = to_fused ? p->fusedb : p->buckets[bi];
-            if (to_fused) p->fused[i] = 1;
+            if (to_fused) {
+                p->fused[i] = 1;
+                p->fused_ent_cap = std::max(p->fused_ent_cap, (uint32_t)(L - 1) * (uint32_t)z);
+            }
             /* lean localize instantiation: no neutral losses, charge 1, summary mode (it checks the
              * residue masses itself and hands back what it cannot do) */
-            if (plain_on && z == 1) bk.ids.push_back((uint32_t)i);
+            if (to_fused || (plain_on && z == 1)) bk.ids.push_back((uint32_t)i);
             else bk.general_ids.push_back((uint32_t)i);
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
             bk.list_cap = std::max<uint32_t>(bk.list_cap, next_pow2(std::max<uint32_t>(per_type, 1)));
@@ -1011,12 +1017,16 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             p->fused_n_cap = (fb.n_cap + 3u) & ~3u;
             p->fused_stride = (both_dirs ? 2u : 1u) * p->fused_n_cap;
             const uint32_t cap_all = (max_P + 31u) & ~31u;
-            keep_fused = pya_fused_lds_bytes(cap_all, p->fused_n_cap, p->fused_stride, fb.pos_cap, fb.push_cap(), p->fused_both) <= 64 * 1024 &&
+            keep_fused = pya_fused_lds_bytes(cap_all, p->fused_n_cap, p->fused_stride, fb.pos_cap, p->fused_ent_cap, fb.push_cap(), p->fused_both) <= 64 * 1024 &&
                          pya_localize_lds_bytes(fb.push_cap(), fb.n_cap, fb.pos_cap, fb.pool_cap(), fb.sb()) <= kMaxLds;
         }
         if (!keep_fused && !fb.ids.empty()) {               /* (huge spectra) back to the two-kernel route */
             Bucket &b0 = p->buckets[0];
-            b0.ids.insert(b0.ids.begin(), fb.ids.begin(), fb.ids.end());
+            std::vector<uint32_t> lean, general;                /* charge 1 -> lean localize instantiation */
+            for (uint32_t id : fb.ids) (p->max_charge[id] == 1 ? lean : general).push_back(id);
+            b0.ids.insert(b0.ids.begin(), lean.begin(), lean.end());
+            b0.n_plain += (uint32_t)lean.size();
+            b0.ids.insert(b0.ids.end(), general.begin(), general.end());
             b0.n_cap = std::max(b0.n_cap, fb.n_cap);
             b0.list_cap = std::max(b0.list_cap, fb.list_cap);
             b0.pos_cap = std::max(b0.pos_cap, fb.pos_cap);
@@ -1110,7 +1120,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         w[1] = (uint64_t)p->pep_off[i];
         w[2] = (uint64_t)p->sig_off[i];
         w[3] = (uint64_t)p->aux_off[i];
-        w[4] = L | na << 16 | (uint64_t)((uint32_t)p->n_of_mod[i] & 0xffffu) << 32 | (uint64_t)p->n_sites[i] << 48;
+        w[4] = L | na << 16 | (uint64_t)((uint32_t)p->n_of_mod[i] & 0xffffu) << 32 | (uint64_t)p->n_sites[i] << 48 |
+               (uint64_t)((uint32_t)p->max_charge[i] & 0xffu) << 56;
         w[5] = (uint64_t)p->n_sig[i] | (uint64_t)p->order_off[i] << 32;
     }
     /* the fused kernel keeps one row of the score table in LDS: PSMs of equal length back to back */
@@ -1341,7 +1352,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         const Bucket &fb = p->fusedb;
         for (const pya_plan::IdList &l : p->fused_lists) {
             e = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, p->fused_n_cap, p->fused_stride, fb.pos_cap,
-                                 fb.push_cap(), p->fused_both, d.redo4_count, d.redo4_ids, st);
+                                 p->fused_ent_cap, fb.push_cap(), p->fused_both, d.redo4_count, d.redo4_ids, st);
             if (e) return h->hip_fail((hipError_t)e, "score_localize launch");
         }
         e = pya_launch_localize_redo(&d, d.redo4_count, d.redo4_ids, (uint32_t)p->fused_ids.size(), fb.push_cap(), fb.n_cap,
@@ -1406,6 +1417,13 @@ int pya_plan_check(pya_plan *p) {
     HIPCHK(h, hipStreamSynchronize(p->last_stream));
     std::vector<int32_t> st(p->n_psm);
     HIPCHK(h, hipMemcpy(st.data(), p->d_status.p, p->n_psm * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (std::getenv("PYA_HOST_TIMING")) {                  /* diagnostics: how many PSMs the lean kernels handed over */
+        uint32_t r3 = 0, r4 = 0;
+        (void)hipMemcpy(&r3, p->d_redo3.p, 4, hipMemcpyDeviceToHost);
+        if (p->d_redo4.p) (void)hipMemcpy(&r4, p->d_redo4.p, 4, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[pya plan] handed over: %u by the lean localize instantiation (last bucket), %u of %zu by the fused kernel\n",
+                     r3, r4, p->fused_ids.size());
+    }
     const bool skip = (p->flags & PYA_FLAG_SKIP_INVALID) != 0;
     if (skip) h->last_status = st;
     return check_status(h, st.data(), p->n_psm, skip);

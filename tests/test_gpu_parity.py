@@ -14,7 +14,8 @@ from pyascore_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort"])
+@pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
+                        "fused_replay"])
 def path(request, monkeypatch):
     """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
     assignments on the fused score + localize kernel and the other plain ones on the lean
@@ -22,7 +23,8 @@ def path(request, monkeypatch):
     PSM on the general instantiation (PYA_NO_PLAIN=1); with the fused kernel and the lean
     instantiation declining every PSM (PYA_DEBUG=512), which sends them through their hand-over lists
     to the general one; and with the std::sort emulation run even where a unique best PepScore makes it
-    unnecessary (PYA_DEBUG=1024), without and with the fused kernel."""
+    unnecessary (PYA_DEBUG=1024), without and with the fused kernel; and with the fused kernel replaying
+    every (competitor, direction) task serially (PYA_DEBUG=2048)."""
     monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
     monkeypatch.delenv("PYA_NO_FUSED", raising=False)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
@@ -32,6 +34,8 @@ def path(request, monkeypatch):
         monkeypatch.setenv("PYA_NO_FUSED", "1")
     if request.param == "fused_always_sort":
         monkeypatch.setenv("PYA_DEBUG", "1024")
+    if request.param == "fused_replay":            # every task of the fused kernel through its serial replay
+        monkeypatch.setenv("PYA_DEBUG", "2048")
     if request.param == "general_localize":
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
     elif request.param == "lean_declines":
