@@ -67,6 +67,8 @@ struct BatchDev {
     const uint32_t *order_off;      /* [n_psm] offset of the PSM's shape in order_tab       */
     const int64_t *sig_off;         /* [n_psm+1] offsets into ws / rec                      */
     const uint64_t *order_tab;      /* pre-sort signature order per shape (sig bits)        */
+    const uint32_t *inv_tab;        /* same offsets: combination rank of a signature -> its index in order_tab */
+    const uint32_t *binom;          /* [64][64] C(p, t), saturated: the combination rank is sum C(p_t, t)       */
     const uint64_t *desc;           /* [n_psm][PYA_DESC_WORDS] the offsets and counts above, packed (one  */
                                     /* cache line per PSM): peak_off, pep_off, sig_off, aux_off,          */
                                     /* L | n_aux << 16 | n_of_mod << 32 | n_sites << 48 | max_charge << 56, n_sig | order_off << 32 */
@@ -86,6 +88,8 @@ struct BatchDev {
     uint32_t *redo4_count;          /* PSMs the fused score + localize kernel hands to the general   */
     uint32_t *redo4_ids;            /* [n_psm] localize instantiation                                */
     float *ws;                      /* weighted score per signature, pre-sort order         */
+    uint32_t *ws_top;               /* [n_psm][4] score_signatures' summary of ws: largest value (bits), how many */
+                                    /* signatures have it (0 = not known), the first of them; localize starts here */
     uint32_t *rec;                  /* optional per-signature records: 6 words each         */
     uint32_t *sorted_idx;           /* optional sorted permutation, at sig_off              */
     int32_t *status;                /* [n_psm]                                              */

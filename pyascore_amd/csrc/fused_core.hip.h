@@ -683,6 +683,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             }
         }
         ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)f.grid)[lane];
+        if (lane == 0) b.ws_top[(size_t)psm * 4 + 1] = 0u;  /* no summary of the scores: localize scans them */
         return true;
     }
     STAMP(b, 47);

@@ -177,8 +177,10 @@ struct pya_handle {
 
     std::map<uint32_t, uint32_t> shape_off;   /* (n << 8 | k) -> offset into order_tab */
     std::vector<uint64_t> order_tab;
+    std::vector<uint32_t> inv_tab;            /* same offsets: combination rank -> index in order_tab */
     size_t order_uploaded = 0;
     DevBuf<uint64_t> d_order;
+    DevBuf<uint32_t> d_inv, d_binom;
 
     /* device allocations recycled between pya_score_batch calls (hipMalloc/hipFree of a few
      * hundred MB cost milliseconds) */
@@ -332,7 +334,7 @@ struct pya_plan {
     std::vector<uint64_t> desc;         /* [n_psm][PYA_DESC_WORDS] packed descriptors (common.h) */
     DevBuf<uint64_t> d_desc;
     uint32_t fused_both = 0, fused_n_cap = 0, fused_stride = 0, fused_ent_cap = 1;
-    DevBuf<uint32_t> d_fused_ids, d_redo4;
+    DevBuf<uint32_t> d_fused_ids, d_redo4, d_ws_top;
     std::vector<uint8_t> ncls;          /* [n_psm] C(n,k) class of the PSM */
     std::vector<int32_t> pre_status;    /* [n_psm] PSMs the host pre-pass set aside (PYA_FLAG_SKIP_INVALID) */
     uint64_t n_skipped = 0;
@@ -511,6 +513,19 @@ uint32_t shape_offset(pya_handle *h, uint32_t n, uint32_t k) {
         }
     }
     for (auto &kv : order) h->order_tab.push_back(kv.second);
+    /* inverse: colexicographic rank of a signature (sum over its set bits of C(position, ordinal)) ->
+     * where the signature sits in the pre-sort order; localize enumerates single-move competitors with it */
+    h->inv_tab.resize(h->order_tab.size(), 0u);
+    for (size_t i = off; i < h->order_tab.size(); i++) {
+        uint64_t m = h->order_tab[i];
+        uint64_t rank = 0;
+        for (uint32_t t = 1; m; t++) {
+            const uint32_t pos = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            rank += binom(pos, t);
+        }
+        h->inv_tab[off + rank] = (uint32_t)(i - off);
+    }
     h->shape_off[key] = off;
     return off;
 }
@@ -526,6 +541,8 @@ void refresh_shared(pya_plan *p) {
     pya_handle *h = p->h;
     BatchDev &d = p->dev;
     d.order_tab = h->d_order.p;
+    d.inv_tab = h->d_inv.p;
+    d.binom = h->d_binom.p;
     d.cfg = h->d_cfg.p;
     d.lut = h->d_lut.p;
     d.lut_off = h->d_lut_off.p;
@@ -550,6 +567,8 @@ void fill_dev(pya_plan *p) {
     d.sig_off = p->d_sig_off.p;
     d.desc = p->d_desc.p;
     d.order_tab = h->d_order.p;
+    d.inv_tab = h->d_inv.p;
+    d.binom = h->d_binom.p;
     d.cfg = h->d_cfg.p;
     d.lut = h->d_lut.p;
     d.lut_off = h->d_lut_off.p;
@@ -565,6 +584,7 @@ void fill_dev(pya_plan *p) {
     d.redo4_count = p->d_redo4.p;
     d.redo4_ids = p->d_redo4.p + 64;
     d.ws = p->d_ws.p;
+    d.ws_top = p->d_ws_top.p;
     d.rec = p->d_rec.p;
     d.sorted_idx = p->d_sorted.p;
     d.status = p->d_status.p;
@@ -1134,6 +1154,13 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     if (rc) return rc;
     if (h->order_uploaded != h->order_tab.size() || !h->d_order.p) {
         HIPCHK(h, h->d_order.upload(h->order_tab.data(), h->order_tab.size()));
+        HIPCHK(h, h->d_inv.upload(h->inv_tab.data(), h->inv_tab.size()));
+        if (!h->d_binom.p) {
+            std::vector<uint32_t> bt(64 * 64);
+            for (uint32_t pp = 0; pp < 64; pp++)
+                for (uint32_t t = 0; t < 64; t++) bt[pp * 64 + t] = (uint32_t)std::min<uint64_t>(binom(pp, t), 0xffffffffull);
+            HIPCHK(h, h->d_binom.upload(bt.data(), bt.size()));
+        }
         h->order_uploaded = h->order_tab.size();
     }
     if (io && io->max_k < max_k)
@@ -1193,7 +1220,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
                      o_ret_mz = reserve((size_t)p->total_peaks * 4), o_ret_rank = reserve((size_t)p->total_peaks),
-                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((n + 64) * 4), o_redo4 = reserve((p->fused_ids.size() + 64) * 4),
+                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((n + 64) * 4), o_redo4 = reserve((p->fused_ids.size() + 64) * 4), o_ws_top = reserve(n * 16),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
@@ -1239,6 +1266,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_redo.adopt(base + o_redo, n + 64);
         p->d_redo3.adopt(base + o_redo3, n + 64);
         p->d_redo4.adopt(base + o_redo4, p->fused_ids.size() + 64);
+        p->d_ws_top.adopt(base + o_ws_top, n * 4);
         p->d_ws.adopt(base + o_ws, (size_t)sig_total);
         p->d_rec.adopt(base + o_rec, (size_t)sig_total * PYA_REC_WORDS);
         if (flags & PYA_FLAG_KEEP) p->d_sorted.adopt(base + o_sorted, (size_t)sig_total);

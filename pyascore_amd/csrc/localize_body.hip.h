@@ -98,22 +98,31 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
      * whichever std::sort leaves first.  When the maximum is unique (4 PSMs in 5) no emulation is
      * needed to name it. */
     const float ws_lane = lane < N ? ws[lane] : 0.f;       /* the first 64 scores stay in a register */
-    uint32_t kmax = 0;
-    for (int i = lane; i < N; i += 64) {
-        const uint32_t u = __float_as_uint(i < 64 ? ws_lane : ws[i]);   /* scores are >= 0: bit order = value order */
-        kmax = u > kmax ? u : kmax;
-    }
-    kmax = wave_max_u32(kmax);
+    uint32_t kmax = 0, first_max = 0xffffffffu;
     int n_max = 0;
-    uint32_t first_max = 0xffffffffu;
-    for (int i = lane; i < N; i += 64) {
-        if (__float_as_uint(i < 64 ? ws_lane : ws[i]) == kmax) {
-            n_max++;
-            first_max = first_max < (uint32_t)i ? first_max : (uint32_t)i;
-        }
+    {
+        const uint32_t *top = b.ws_top + (size_t)psm * 4;  /* score_signatures' summary (0 signatures = none) */
+        kmax = top[0];
+        n_max = (int)top[1];
+        first_max = top[2];
     }
-    n_max = wave_sum_i32(n_max);
-    first_max = wave_min_u32(first_max);
+    if (n_max == 0) {
+        kmax = 0;
+        first_max = 0xffffffffu;
+        for (int i = lane; i < N; i += 64) {
+            const uint32_t u = __float_as_uint(i < 64 ? ws_lane : ws[i]);   /* scores are >= 0: bit order = value order */
+            kmax = u > kmax ? u : kmax;
+        }
+        kmax = wave_max_u32(kmax);
+        for (int i = lane; i < N; i += 64) {
+            if (__float_as_uint(i < 64 ? ws_lane : ws[i]) == kmax) {
+                n_max++;
+                first_max = first_max < (uint32_t)i ? first_max : (uint32_t)i;
+            }
+        }
+        n_max = wave_sum_i32(n_max);
+        first_max = wave_min_u32(first_max);
+    }
     uint32_t best_i = first_max;
     STAMP(b, 21);
     if (n_max != 1 || b.keep || (b.debug & 1024)) {
@@ -148,33 +157,63 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     wave_lds_sync();
 
     STAMP(b, 23);
-    /* ---- single-move competitors (cpp/Ascore.cpp:212-254) ---- */
-    for (int pass = 0; pass < 2; pass++) {
-        for (int base = 0; base < N; base += 64) {
-            const int i = base + lane;
-            if (i < N) {
-                const uint64_t c = order[i];
-                const uint64_t gone = best_bits & ~c, came = c & ~best_bits;
-                if (__popcll(gone) == 1 && __popcll(came) == 1) {
-                    const int a = __popcll(best_bits & (gone - 1));
-                    const uint32_t u = __float_as_uint(ws[i]);
-                    if (pass == 0) {
-                        atomicMax(&lds.site_max[a], u);
-                    } else if (u == lds.site_max[a]) {
-                        if ((double)__builtin_fabsf(best_ws - __uint_as_float(u)) < 1e-6) {
-                            /* ties the winner: Ascore 0 (Ascore.cpp:159-161), no ion work needed */
-                            lds.site_tie[a] = 1u;
-                            atomicOr(&lds.site_alt[a], 1ull << nth_set_bit(site_mask_u, __builtin_ctzll(came)));
-                            continue;
-                        }
-                        const uint32_t slot = atomicAdd(lds.n_pushed, 1u);
-                        if (slot < push_cap) {
-                            PushedEntry pe;
-                            pe.bits = c;
-                            pe.ws = __uint_as_float(u);
-                            pe.idx = (uint32_t)i;
-                            lds.pushed[slot] = pe;
-                        }
+    /* ---- single-move competitors (cpp/Ascore.cpp:212-254).  The reference finds them by scanning the
+     * sorted list; they are exactly the k * (n - k) signatures that differ from the winner by one moved
+     * modification, so they are enumerated directly: signature -> combination rank (sum of C(p_t, t)
+     * over its set bits) -> its index in the pre-sort order (inv_tab) -> its PepScore.  One item per
+     * (modified site, free site) pair instead of two passes over all C(n,k) signatures. ---- */
+    {
+        const uint64_t all_sites = n_sites >= 64 ? ~0ull : ((1ull << n_sites) - 1ull);
+        const uint64_t free_bits = all_sites & ~best_bits;
+        const int n_free = n_sites - k, items = k * n_free;
+        const uint32_t *inv = b.inv_tab + b.order_off[psm];
+        const FastDiv divF = fastdiv_make((uint32_t)(n_free > 0 ? n_free : 1));
+        /* items <= 126 (PYA_MAX_PUSHED): two per lane at most, both kept in registers between the passes */
+        uint64_t c_r[2] = {0ull, 0ull};
+        int a_r[2] = {0, 0};
+        uint32_t u_r[2] = {0u, 0u}, idx_r[2] = {0u, 0u};
+        bool on_r[2] = {false, false};
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int e = r * 64 + lane;
+            on_r[r] = e < items;
+            if (on_r[r]) {
+                const int a = (int)fastdiv((uint32_t)e, divF);
+                const int fb = e - a * n_free;
+                const int pos_a = nth_set_bit(best_bits, a), pos_b = nth_set_bit(free_bits, fb);
+                const uint64_t c = (best_bits & ~(1ull << pos_a)) | (1ull << pos_b);
+                uint32_t rank = 0;
+                uint64_t m = c;
+                for (int t = 1; m; t++) {                      /* colexicographic rank of the combination */
+                    const int pos = __builtin_ctzll(m);
+                    m &= m - 1;
+                    rank += b.binom[pos * 64 + t];
+                }
+                const uint32_t idx = inv[rank];
+                const uint32_t u = __float_as_uint(ws[idx]);
+                atomicMax(&lds.site_max[a], u);
+                c_r[r] = c;
+                a_r[r] = a;
+                u_r[r] = u;
+                idx_r[r] = idx;
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            if (on_r[r] && u_r[r] == lds.site_max[a_r[r]]) {
+                if ((double)__builtin_fabsf(best_ws - __uint_as_float(u_r[r])) < 1e-6) {
+                    /* ties the winner: Ascore 0 (Ascore.cpp:159-161), no ion work needed */
+                    lds.site_tie[a_r[r]] = 1u;
+                    atomicOr(&lds.site_alt[a_r[r]], 1ull << nth_set_bit(site_mask_u, __builtin_ctzll(c_r[r] & ~best_bits)));
+                } else {
+                    const uint32_t slot = atomicAdd(lds.n_pushed, 1u);
+                    if (slot < push_cap) {
+                        PushedEntry pe;
+                        pe.bits = c_r[r];
+                        pe.ws = __uint_as_float(u_r[r]);
+                        pe.idx = idx_r[r];
+                        lds.pushed[slot] = pe;
                     }
                 }
             }

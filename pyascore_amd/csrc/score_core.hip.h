@@ -98,6 +98,7 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)grid)[lane];
 
     int lut_fail = 0;
+    uint32_t top_u = 0, top_n = 0, top_i = 0xffffffffu;     /* this lane's share of the summary of ws */
     const bool split = N <= 32 && both_dirs;     /* lanes 0..31 forward, 32..63 backward */
     const bool simple = walk_is_simple(env);
     const uint32_t simple_nfrag = (uint32_t)((has_f ? 1 : 0) + (has_b ? 1 : 0)) * (uint32_t)(res.L - 1) * (uint32_t)zmax;
@@ -220,6 +221,14 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
                 lut_fail = 1;
             }
             b.ws[s0 + s] = ws;
+            const uint32_t u = __float_as_uint(ws);              /* scores are >= 0: bit order = value order */
+            if (ws >= 0.f && (top_n == 0 || u > top_u)) {
+                top_u = u;
+                top_n = 1;
+                top_i = s;
+            } else if (ws >= 0.f && u == top_u) {
+                top_n++;
+            }
             if (b.rec) {
                 uint32_t *rec = b.rec + (s0 + s) * PYA_REC_WORDS;
 #pragma unroll
@@ -230,6 +239,20 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         wave_lds_sync();                                    /* columns are cleared again next round */
     }
     if (__any(lut_fail) && lane == 0) b.status[psm] = PYA_ST_LUT_RANGE;
+    {
+        /* largest PepScore, how many signatures share it and the first of them: localize needs no pass
+         * over the scores to find its winner */
+        const uint32_t kmax = wave_max_u32(top_n ? top_u : 0u);
+        const bool mine = top_n && top_u == kmax;
+        const int n_max = wave_sum_i32(mine ? (int)top_n : 0);
+        const uint32_t first = wave_min_u32(mine ? top_i : 0xffffffffu);
+        if (lane == 0) {
+            uint32_t *t = b.ws_top + (size_t)psm * 4;
+            t[0] = kmax;
+            t[1] = (uint32_t)n_max;
+            t[2] = first;
+        }
+    }
 }
 
 static inline size_t score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact) {
