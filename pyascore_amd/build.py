@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libpyascore_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-DEVICE_SRC = ["bin_spectra.hip", "score_signatures.hip", "rank_and_localize.hip", "score_localize.hip", "tiny_batch.hip"]
+DEVICE_SRC = ["bin_spectra.hip", "score_signatures.hip", "score_big.hip", "rank_and_localize.hip", "score_localize.hip", "tiny_batch.hip"]
 HOST_SRC = ["host.cpp", "score_table.cpp", "aux_api.cpp"]
 HEADERS = ["common.h", "device_common.hip.h", "bin_core.hip.h", "walk_core.hip.h", "score_core.hip.h",
            "localize_core.hip.h", "localize_body.hip.h", "fused_core.hip.h", "binom_chain.h", os.path.join("..", "..", "include", "pyascore_hip.h"),

@@ -366,6 +366,39 @@ DEV int match_rank_lds(const PeakTable &t, float f) {
     return best;
 }
 
+/* The same lookup in two parts, so that a caller can have several lookups in flight: look4 is
+ * straight-line (grid cell, four entries, select-reduce) and says whether the window extends past
+ * the fourth entry; look_rest finishes those (rare).  Only for mz_error <= 0.49 (no half_check). */
+struct Look {
+    int best, idx;
+    float lo, hi;
+    bool more;
+};
+DEV Look look4(const PeakTable &t, float f) {
+    Look k;
+    k.lo = f - t.err;
+    k.hi = f + t.err;
+    k.idx = (int)t.cell[grid_cell(t, k.lo)];
+    const PeakEntry e0 = t.e[k.idx], e1 = t.e[k.idx + 1], e2 = t.e[k.idx + 2], e3 = t.e[k.idx + 3];
+    int best = PYA_NO_MATCH, r;
+    r = e0.mz > k.lo ? (int)e0.rank : PYA_NO_MATCH; r = e0.mz < k.hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
+    r = e1.mz > k.lo ? (int)e1.rank : PYA_NO_MATCH; r = e1.mz < k.hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
+    r = e2.mz > k.lo ? (int)e2.rank : PYA_NO_MATCH; r = e2.mz < k.hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
+    r = e3.mz > k.lo ? (int)e3.rank : PYA_NO_MATCH; r = e3.mz < k.hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
+    k.best = best;
+    k.more = e3.mz < k.hi;
+    return k;
+}
+DEV int look_rest(const PeakTable &t, const Look &k) {
+    int best = k.best;
+    for (int idx = k.idx + 4;; idx++) {
+        const PeakEntry x = t.e[idx];
+        if (!(x.mz < k.hi)) break;
+        if (x.mz > k.lo) best = (int)x.rank < best ? (int)x.rank : best;
+    }
+    return best;
+}
+
 DEV int match_rank(const PeakTable &t, float f) {
     return t.e ? match_rank_lds(t, f) : match_rank_global(t, f);
 }

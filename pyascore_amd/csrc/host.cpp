@@ -53,6 +53,9 @@ int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uin
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
 int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream);
+size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap);
+int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap,
+                         hipStream_t stream);
 size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap,
                            uint32_t both);
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
@@ -324,8 +327,11 @@ struct pya_plan {
     struct IdList {
         uint32_t off, n, cap, ncls;
     };
-    std::vector<uint32_t> bin_ids, score_ids, fused_ids;
-    std::vector<IdList> bin_lists, score_lists, fused_lists;
+    std::vector<uint32_t> bin_ids, score_ids, fused_ids, big_ids;
+    std::vector<IdList> bin_lists, score_lists, fused_lists, big_lists;
+    std::vector<uint8_t> big;           /* [n_psm] scored by score_big.hip (thousands of site assignments, plain settings) */
+    DevBuf<uint32_t> d_big_ids;
+    uint32_t big_pos_cap = 1;
     /* PSMs scored AND localised by the fused kernel (score_localize.hip): few site assignments, plain
      * settings.  `fusedb` carries the caps the general localize instantiation needs for the ones the
      * fused kernel hands over. */
@@ -856,6 +862,10 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     const bool fused_on = plain_on && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 && !std::getenv("PYA_NO_FUSED");
     const uint32_t fused_max_n = both_dirs ? 32u : 64u;
     p->fused.assign(n, 0);
+    /* score_big.hip: one PSM per 8-wave workgroup, fragment tree shared two levels deep */
+    const bool big_on = h->cfg.n_nl == 0 && both_dirs && h->cfg.n_fwd == 1 && h->cfg.n_types == 2 && h->mz_error <= 0.49f &&
+                        !std::getenv("PYA_NO_BIG");
+    p->big.assign(n, 0);
     const bool skip_invalid = (flags & PYA_FLAG_SKIP_INVALID) != 0;
     std::vector<uint8_t> bad(n, 0);
     {
@@ -999,6 +1009,10 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             /* (its count records hold the cumulative counts as bytes: at most 255 fragments) */
             const uint32_t frags = (both_dirs ? 2u : 1u) * (uint32_t)(L - 1) * (uint32_t)z;
             const bool to_fused = fused_on && N <= fused_max_n && frags <= 255u;
+            if (big_on && z == 1 && N > 1024) {                 /* (C(n,k) > 1024 implies n >= 13 sites) */
+                p->big[i] = 1;
+                p->big_pos_cap = std::max(p->big_pos_cap, (uint32_t)(L - 1));
+            }
             Bucket &bk = to_fused ? p->fusedb : p->buckets[bi];
             if (to_fused) {
                 p->fused[i] = 1;
@@ -1085,7 +1099,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         std::sort(caps.begin(), caps.end());
         caps.erase(std::unique(caps.begin(), caps.end()), caps.end());
         const size_t nc = caps.size();
-        std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0), cnt_fused(nc, 0);
+        std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0), cnt_fused(nc, 0), cnt_big(nc, 0);
         std::vector<uint8_t> pcls(n);
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;                  /* set aside: neither binned nor scored */
@@ -1095,6 +1109,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             pcls[i] = (uint8_t)c;
             cnt_bin[c]++;
             if (p->fused[i]) cnt_fused[c]++;
+            else if (p->big[i]) cnt_big[c]++;
             else cnt_score[p->ncls[i] * nc + c]++;
         }
         uint32_t off = 0;
@@ -1113,9 +1128,15 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             p->fused_lists.push_back({off, 0u, caps[c], 0u});
             off += cnt_fused[c];
         }
+        p->fused_ids.resize(off);
+        off = 0;
+        for (size_t c = 0; c < nc; c++) {
+            p->big_lists.push_back({off, 0u, caps[c], 0u});
+            off += cnt_big[c];
+        }
+        p->big_ids.resize(off);
         p->bin_ids.resize(n - n_skipped);
         p->score_ids.resize(n_score);
-        p->fused_ids.resize(off);
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;
             pya_plan::IdList &bl = p->bin_lists[pcls[i]];
@@ -1123,6 +1144,9 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             if (p->fused[i]) {
                 pya_plan::IdList &fl = p->fused_lists[pcls[i]];
                 p->fused_ids[fl.off + fl.n++] = (uint32_t)i;
+            } else if (p->big[i]) {
+                pya_plan::IdList &gl = p->big_lists[pcls[i]];
+                p->big_ids[gl.off + gl.n++] = (uint32_t)i;
             } else {
                 pya_plan::IdList &sl = p->score_lists[p->ncls[i] * nc + pcls[i]];
                 p->score_ids[sl.off + sl.n++] = (uint32_t)i;
@@ -1199,7 +1223,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_bin_ids = meta(p->bin_ids.data(), p->bin_ids.size() * 4),
                      o_score_ids = meta(p->score_ids.data(), p->score_ids.size() * 4),
                      o_fused_ids = meta(p->fused_ids.data(), p->fused_ids.size() * 4),
-                     o_desc = meta(p->desc.data(), p->desc.size() * 8);
+                     o_desc = meta(p->desc.data(), p->desc.size() * 8),
+                     o_big_ids = meta(p->big_ids.data(), p->big_ids.size() * 4);
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
             o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
@@ -1242,6 +1267,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_score_ids.adopt(base + o_score_ids, p->score_ids.size());
         p->d_fused_ids.adopt(base + o_fused_ids, p->fused_ids.size());
         p->d_desc.adopt(base + o_desc, p->desc.size());
+        p->d_big_ids.adopt(base + o_big_ids, p->big_ids.size());
         for (int i = 0; i < kNumBuckets; i++)
             p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
         if (io) {
@@ -1371,6 +1397,10 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
                                   p->buckets[l.ncls].z_max == 1) ? 1u : 0u;
         e = pya_launch_score(&d, p->d_score_ids.p + l.off, l.n, l.cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact, st);
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
+    }
+    for (const pya_plan::IdList &l : p->big_lists) {
+        e = pya_launch_score_big(&d, p->d_big_ids.p + l.off, l.n, l.cap, p->big_pos_cap, st);
+        if (e) return h->hip_fail((hipError_t)e, "score_big launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
     if (!p->fused_ids.empty()) {

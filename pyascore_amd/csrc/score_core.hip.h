@@ -156,33 +156,44 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         uint32_t nfrag = 0;
         hist_clear(env);
         if (shared) {
+            WalkState sts[2] = {{0.f, 0u}, {0.f, 0u}};
             for (int dir = 0; dir < 2; dir++) {
                 if (dir == 0 ? !has_f : !has_b) continue;
                 const uint32_t pat = dir == 0 ? (uint32_t)(bits & 63ull)
                                               : (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 63ull);
-                WalkState st = {0.f, 0u};
                 if (compact) {
                     const PrefixCompact pc = prc[dir * 64 + pat];
-                    st.running = pc.running;
+                    sts[dir].running = pc.running;
                     p8lo += pc.lo;                           /* fields stay below 256: <= 63 per direction */
                     p8hi += pc.hi;
                 } else {
                     const PrefixState ps = pre[dir * 64 + pat];
-                    st.running = ps.running;
-                    st.nl_state = ps.nl_state;
+                    sts[dir].running = ps.running;
+                    sts[dir].nl_state = ps.nl_state;
                     ph.a += ps.ha;
                     ph.b += ps.hb;
                     ph.c += ps.hc;
                     nfrag += ps.nfrag;
                 }
-                if (simple) walk_simple_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, st);
-                else walk_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, st, nfrag);
+            }
+            if (simple && both_dirs && zmax == 1 && !tab.half_check) {
+                /* the two directions side by side: two lookups in flight per iteration */
+                walk_simple_both(env, tab, resmask, active, stop[0], res.L - 1, sts[0], stop[1], res.L - 1, sts[1]);
+            } else {
+                for (int dir = 0; dir < 2; dir++) {
+                    if (dir == 0 ? !has_f : !has_b) continue;
+                    if (simple) walk_simple_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, sts[dir]);
+                    else walk_range(env, tab, resmask, dir, active, stop[dir], res.L - 1, sts[dir], nfrag);
+                }
             }
         } else {
             WalkState st = {0.f, 0u};
             if (split) {
                 if (simple) walk_simple_range(env, tab, resmask, lane >> 5, active, 0, res.L - 1, st);
                 else walk_range(env, tab, resmask, lane >> 5, active, 0, res.L - 1, st, nfrag);
+            } else if (simple && both_dirs && zmax == 1 && !tab.half_check) {
+                WalkState st1 = {0.f, 0u};
+                walk_simple_both(env, tab, resmask, active, 0, res.L - 1, st, 0, res.L - 1, st1);
             } else {
                 for (int dir = 0; dir < 2; dir++) {
                     if (dir == 0 ? !has_f : !has_b) continue;

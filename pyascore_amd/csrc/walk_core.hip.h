@@ -138,6 +138,43 @@ DEV void walk_simple_range(const WalkEnv &e, const PeakTable &tab, uint64_t resm
     st.running = running;
 }
 
+/* Both directions of one signature in one loop (charge 1, mz_error <= 0.49): the forward and the
+ * backward walker of a lane are independent chains, so every iteration has two lookups in flight
+ * instead of one -- the walk is a chain of dependent LDS round trips otherwise.  Steps
+ * [begin_d, end_d) of direction d; the two ranges may differ in length. */
+DEV void walk_simple_both(const WalkEnv &e, const PeakTable &tab, uint64_t resmask, bool active, int begin0, int end0,
+                          WalkState &st0, int begin1, int end1, WalkState &st1) {
+    const DevConfig *cfg = e.cfg;
+    const int L = e.L;
+    double A0 = 0., B0 = 0., A1 = 0., B1 = 0.;
+    type_constants(cfg->types[0], &A0, &B0);
+    type_constants(cfg->types[cfg->n_fwd], &A1, &B1);
+    const uint64_t tm0 = resmask, tm1 = __brevll(resmask) >> (64 - L);
+    const float2 *rp0 = e.resd + begin0, *rp1 = e.resd + (L - 1 - begin1);
+    uint32_t *col = e.cnt + lane_id();
+    float run0 = st0.running, run1 = st1.running;
+    const int n0 = end0 - begin0, n1 = end1 - begin1, n = n0 > n1 ? n0 : n1;
+    for (int i = 0; i < n; i++, rp0++, rp1--) {
+        const bool on0 = i < n0, on1 = i < n1;              /* wave-uniform */
+        const int s0 = begin0 + i, s1 = begin1 + i;
+        const float2 m0 = on0 ? *rp0 : make_float2(0.f, 0.f), m1 = on1 ? *rp1 : make_float2(0.f, 0.f);
+        const float r0 = ((tm0 >> (s0 & 63)) & 1ull) ? m0.y : m0.x, r1 = ((tm1 >> (s1 & 63)) & 1ull) ? m1.y : m1.x;
+        if (on0) run0 = r0 + run0;                           /* ModifiedPeptide.cpp:385-389 */
+        if (on1) run1 = r1 + run1;
+        const float f0 = (float)((((double)run0 + A0) - B0) + 1.007825), f1 = (float)((((double)run1 + A1) - B1) + 1.007825);
+        const Look k0 = look4(tab, f0), k1 = look4(tab, f1);
+        int rk0 = k0.best, rk1 = k1.best;
+        if (__any(k0.more || k1.more)) {
+            if (k0.more) rk0 = look_rest(tab, k0);
+            if (k1.more) rk1 = look_rest(tab, k1);
+        }
+        hist_bump(col, active && on0, rk0);
+        hist_bump(col, active && on1, rk1);
+    }
+    st0.running = run0;
+    st1.running = run1;
+}
+
 DEV bool walk_is_simple(const WalkEnv &e) {
     const int n_f = e.cfg->n_fwd, n_b = e.cfg->n_types - e.cfg->n_fwd;
     return e.n_nl == 0 && n_f <= 1 && n_b <= 1;
