@@ -226,7 +226,8 @@ DEV int partners_in_run(const float *run, int n, int p2, float me, int side, flo
 /* BOTH: ion types of both directions -- lanes 0..31 walk from the N-terminus, lanes 32..63 from the
  * C-terminus (C(n,k) <= 32); otherwise one direction, one signature per lane (C(n,k) <= 64).
  * Returns true when the PSM was handed over to the general localize instantiation. */
-template <bool BOTH>
+/* ZM: fragment charges above 1 possible (otherwise the charge loops compile away). */
+template <bool BOTH, bool ZM>
 DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t n_cap, uint32_t stride,
                     uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap) {
     const int lane = lane_id();
@@ -243,7 +244,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const int64_t p0 = (int64_t)dw[0], pep0 = (int64_t)dw[1], s0 = (int64_t)dw[2], a0 = (int64_t)dw[3];
     const uint64_t w4 = dw[4], w5 = dw[5];
     const int L = (int)(w4 & 0xffffu), n_aux = (int)((w4 >> 16) & 0xffffu), k = (int)((w4 >> 32) & 0xffffu);
-    const int zmax = (int)(w4 >> 56);
+    const int zmax = ZM ? (int)(w4 >> 56) : 1;
     const int N = (int)(uint32_t)w5;
     const uint64_t *order = b.order_tab + (uint32_t)(w5 >> 32);
     const int status = b.status[psm];

@@ -60,7 +60,7 @@ size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32
                            uint32_t both);
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
                      uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
-                     uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
+                     uint32_t multi_z, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
 int pya_launch_localize_redo(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max,
                              uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
                              uint32_t gtp, hipStream_t stream);
@@ -1099,7 +1099,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         std::sort(caps.begin(), caps.end());
         caps.erase(std::unique(caps.begin(), caps.end()), caps.end());
         const size_t nc = caps.size();
-        std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0), cnt_fused(nc, 0), cnt_big(nc, 0);
+        std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0), cnt_fused(nc * 2, 0), cnt_big(nc, 0);
         std::vector<uint8_t> pcls(n);
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;                  /* set aside: neither binned nor scored */
@@ -1108,7 +1108,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             while (caps[c] < P) c++;
             pcls[i] = (uint8_t)c;
             cnt_bin[c]++;
-            if (p->fused[i]) cnt_fused[c]++;
+            if (p->fused[i]) cnt_fused[c * 2 + (p->max_charge[i] > 1 ? 1 : 0)]++;
             else if (p->big[i]) cnt_big[c]++;
             else cnt_score[p->ncls[i] * nc + c]++;
         }
@@ -1124,8 +1124,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         }
         uint32_t n_score = off;
         off = 0;
-        for (size_t c = 0; c < nc; c++) {
-            p->fused_lists.push_back({off, 0u, caps[c], 0u});
+        for (size_t c = 0; c < nc * 2; c++) {                /* per peak class: fragment charge 1, then above (ncls = 1) */
+            p->fused_lists.push_back({off, 0u, caps[c / 2], (uint32_t)(c & 1)});
             off += cnt_fused[c];
         }
         p->fused_ids.resize(off);
@@ -1142,7 +1142,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             pya_plan::IdList &bl = p->bin_lists[pcls[i]];
             p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
             if (p->fused[i]) {
-                pya_plan::IdList &fl = p->fused_lists[pcls[i]];
+                pya_plan::IdList &fl = p->fused_lists[pcls[i] * 2 + (p->max_charge[i] > 1 ? 1 : 0)];
                 p->fused_ids[fl.off + fl.n++] = (uint32_t)i;
             } else if (p->big[i]) {
                 pya_plan::IdList &gl = p->big_lists[pcls[i]];
@@ -1410,7 +1410,8 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         const Bucket &fb = p->fusedb;
         for (const pya_plan::IdList &l : p->fused_lists) {
             e = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, p->fused_n_cap, p->fused_stride, fb.pos_cap,
-                                 p->fused_ent_cap, fb.push_cap(), p->fused_both, d.redo4_count, d.redo4_ids, st);
+                                 l.ncls ? p->fused_ent_cap : fb.pos_cap, fb.push_cap(), p->fused_both, l.ncls, d.redo4_count,
+                                 d.redo4_ids, st);
             if (e) return h->hip_fail((hipError_t)e, "score_localize launch");
         }
         e = pya_launch_localize_redo(&d, d.redo4_count, d.redo4_ids, (uint32_t)p->fused_ids.size(), fb.push_cap(), fb.n_cap,
