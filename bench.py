@@ -43,34 +43,40 @@ def algorithmic_bytes(batch, max_k):
 
 
 def profiled_traffic(cfg, kernel, default_size):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary of this config
-    (profiles/*_rocprof_<cfg>/pmc_summary.csv, collected by scripts/profile.sh in separate --pmc
-    passes).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 128-byte requests as
-    64 bytes, hence the factor 2 (MI355X_MICROARCH.md, HBM section).  None when the run is not the
-    profiled workload."""
+    """HBM bytes per step of the kernel family `kernel` (all its instantiations and launches) from the
+    newest committed PMC summary of this config (profiles/*_rocprof_<cfg>/pmc_summary.csv, collected by
+    scripts/profile.sh in separate --pmc passes).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950
+    FETCH_SIZE tallies 128-byte requests as 64 bytes, hence the factor 2 (MI355X_MICROARCH.md, HBM
+    section).  Also returns the whole path's traffic (every pya_* kernel) and the share of the
+    family's SIMD cycles in which a vector instruction issues.  None when the run is not the profiled
+    workload."""
     import csv
     import glob
+    none = (None, None, None, None)
     if not default_size:
-        return None, None, None
+        return none
     dirs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_" + cfg)))
     if not dirs:
-        return None, None, None
+        return none
     path = os.path.join(dirs[-1], "pmc_summary.csv")
-    vals = {}
+    fam, path_total = {}, {}
     try:
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                if row["kernel"] == kernel:
-                    vals[row["counter"]] = float(row["mean_value"])
+                val = float(row.get("per_step") or row["mean_value"])
+                path_total[row["counter"]] = path_total.get(row["counter"], 0.0) + val
+                if row["kernel"].split("<")[0] == kernel:
+                    fam[row["counter"]] = fam.get(row["counter"], 0.0) + val
     except OSError:
-        return None, None, None
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None, None, None
+        return none
+    if "FETCH_SIZE" not in fam or "WRITE_SIZE" not in fam:
+        return none
     valu = None
-    if vals.get("SQ_BUSY_CYCLES") and "SQ_INSTS_VALU" in vals:
-        # a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; 1024 SIMDs, 32 shader engines
-        valu = vals["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (vals["SQ_BUSY_CYCLES"] / 32.0)
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT), valu
+    if fam.get("SQ_BUSY_CYCLES") and "SQ_INSTS_VALU" in fam:
+        # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles; 1024 SIMDs; SQ_BUSY_CYCLES sums 32 shader engines
+        valu = fam["SQ_INSTS_VALU"] * 2.0 / 1024.0 / (fam["SQ_BUSY_CYCLES"] / 32.0)
+    whole = (2.0 * path_total.get("FETCH_SIZE", 0.0) + path_total.get("WRITE_SIZE", 0.0)) * 1024.0
+    return (2.0 * fam["FETCH_SIZE"] + fam["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT), valu, whole
 
 
 def achievable_hbm_gbs(torch, dev, nbytes=1 << 30, reps=5):
@@ -165,6 +171,8 @@ def main():
     ap.add_argument("--max-charge", type=int, default=None,
                     help="override the config's max fragment charge (real 3+/4+ precursors are scored at 2/3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true",
+                    help="skip the host-array legs (profiling runs: only the timed device-resident steps launch kernels)")
     args = ap.parse_args()
 
     import torch
@@ -271,30 +279,38 @@ def main():
         alg = algorithmic_bytes(batch, plan.max_k)
         achieved = alg / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
         # host API rate (host arrays in -> host results out; PCIe and host pre-pass included)
-        scorer.score_batch(batch)                          # first call allocates the workspace (reused afterwards)
-        host_s = []
-        for _ in range(3):
-            t = time.perf_counter()
-            res = scorer.score_batch(batch)
-            host_s.append(time.perf_counter() - t)
-        host_rate = batch["n_psm"] / min(host_s)
-        # what PCIe alone costs this entry point: the same host arrays up (16 bytes per peak, pageable
-        # memory as a caller holds it) and the result arrays back, nothing else
-        pcie_s = []
-        d_res = {k: torch.from_numpy(v).to(dev) for k, v in res.items()}
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            a = torch.from_numpy(batch["mz"]).to(dev)
-            b2 = torch.from_numpy(batch["intensity"]).to(dev)
-            back = [v.cpu() for v in d_res.values()]
-            torch.cuda.synchronize()
-            pcie_s.append(time.perf_counter() - t)
-            del a, b2, back
-        pcie_bytes = batch["mz"].nbytes + batch["intensity"].nbytes + sum(v.nbytes for v in res.values())
+        host = None
+        if not args.no_host_api:
+            scorer.score_batch(batch)                          # first call allocates the workspace (reused afterwards)
+            host_s = []
+            for _ in range(3):
+                t = time.perf_counter()
+                res = scorer.score_batch(batch)
+                host_s.append(time.perf_counter() - t)
+            host_rate = batch["n_psm"] / min(host_s)
+            # what PCIe alone costs this entry point: the same host arrays up (16 bytes per peak, pageable
+            # memory as a caller holds it) and the result arrays back, nothing else
+            pcie_s = []
+            d_res = {k: torch.from_numpy(v).to(dev) for k, v in res.items()}
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                a = torch.from_numpy(batch["mz"]).to(dev)
+                b2 = torch.from_numpy(batch["intensity"]).to(dev)
+                back = [v.cpu() for v in d_res.values()]
+                torch.cuda.synchronize()
+                pcie_s.append(time.perf_counter() - t)
+                del a, b2, back
+            pcie_bytes = batch["mz"].nbytes + batch["intensity"].nbytes + sum(v.nbytes for v in res.values())
+            host = {"value": host_rate, "unit": "PSMs/s", "ms": 1e3 * min(host_s),
+                    "pcie_only_ms": 1e3 * min(pcie_s), "pcie_gbs": pcie_bytes / min(pcie_s) / 1e9,
+                    "frac_of_pcie": min(pcie_s) / min(host_s),
+                    "note": "PyAscore.score_batch: host arrays in, host results out (chunked, upload pipelined "
+                            "with planning, kernels and result copies); pcie_only = the same bytes copied up "
+                            "and back with nothing else"}
         copy_gbs = achievable_hbm_gbs(torch, dev)
         default_size = args.psms is None and args.config != "cfg3" and args.max_charge is None
-        traffic, traffic_src, valu_share = profiled_traffic(args.config, names[dom], default_size)
+        traffic, traffic_src, valu_share, traffic_path = profiled_traffic(args.config, names[dom], default_size)
         line = {
             "metric": METRIC, "value": total * args.steps / elapsed, "unit": "PSMs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -312,16 +328,14 @@ def main():
                          "traffic_source": traffic_src,
                          # what actually bounds the kernel: share of its cycles in which the vector ALUs issue
                          "valu_issue_share": valu_share,
+                         # HBM bytes of the whole path per step (every kernel) next to the algorithmic bytes
+                         "traffic_whole_path": traffic_path,
+                         "traffic_over_algorithmic": (traffic_path / alg) if traffic_path else None,
                          "algorithmic_bytes_per_launch": alg,
                          "achievable_peak": copy_gbs, "frac_of_achievable": achieved / copy_gbs,
                          "whole_path_gbs": alg / (float(kern_ms.sum()) * 1e-3) / 1e9 if kern_ms.sum() > 0 else 0.0,
                          "kernel_ms": {n: float(m) for n, m in zip(names, kern_ms)}},
-            "host_api": {"value": host_rate, "unit": "PSMs/s", "ms": 1e3 * min(host_s),
-                         "pcie_only_ms": 1e3 * min(pcie_s), "pcie_gbs": pcie_bytes / min(pcie_s) / 1e9,
-                         "frac_of_pcie": min(pcie_s) / min(host_s),
-                         "note": "PyAscore.score_batch: host arrays in, host results out (chunked, upload pipelined "
-                                 "with planning, kernels and result copies); pcie_only = the same bytes copied up "
-                                 "and back with nothing else"},
+            "host_api": host,
             "workspace_bytes": plan.workspace_bytes,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -33,7 +33,7 @@ static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint3
  *   PLAIN = false -- everything. */
 template <bool PLAIN>
 DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t push_cap, uint32_t pos_cap,
-                       uint32_t pool_cap, uint32_t sb, uint32_t gtp) {
+                       uint32_t pool_cap, uint32_t sb, uint32_t gtp, bool sort_room = true) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int k = b.n_of_mod[psm];
@@ -125,6 +125,11 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     }
     uint32_t best_i = first_max;
     STAMP(b, 21);
+    /* The sort emulation needs 10 bytes of LDS per signature, which for thousands of signatures is
+     * what decides this kernel's occupancy -- and most PSMs have a unique best PepScore and never
+     * sort.  Big-C(n,k) launches of the lean instantiation therefore run without that room and hand the
+     * PSMs with a tie at the top to the general instantiation. */
+    if (PLAIN && !sort_room && (n_max != 1 || (b.debug & 1024))) return true;
     if (n_max != 1 || b.keep || (b.debug & 1024)) {
         SortLds srt;
         srt.key = (float *)lds.scratch;

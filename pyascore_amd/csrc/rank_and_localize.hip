@@ -28,11 +28,11 @@ extern "C" size_t pya_localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint
 template <bool PLAIN>
 __global__ __launch_bounds__(64, PLAIN ? LOC_WAVES_PLAIN : LOC_WAVES) void pya_localize_kernel(
     BatchDev b, const uint32_t *psm_ids, uint32_t n_ids, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap,
-    uint32_t sb, uint32_t gtp) {
+    uint32_t sb, uint32_t gtp, uint32_t sort_room) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
-    const bool declined = localize_body<PLAIN>(b, psm, lds_raw, push_cap, pos_cap, pool_cap, sb, gtp);
+    const bool declined = localize_body<PLAIN>(b, psm, lds_raw, push_cap, pos_cap, pool_cap, sb, gtp, sort_room != 0);
     if (PLAIN && declined && lane_id() == 0) b.redo3_ids[atomicAdd(b.redo3_count, 1u)] = psm;
 }
 
@@ -113,7 +113,7 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
         e = PYA_ENSURE_MAX_LDS(pya_localize_kernel<false>);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(pya_localize_kernel<false>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, push_cap,
-                           pos_cap, pool_cap, sb, gtp);
+                           pos_cap, pool_cap, sb, gtp, 1u);
         return (int)hipGetLastError();
     }
     /* lean instantiation first, then whatever it declined on the general one */
@@ -121,8 +121,12 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     if (e != hipSuccess) return (int)e;
     e = PYA_ENSURE_MAX_LDS(pya_localize_kernel<true>);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, push_cap,
-                       pos_cap, pool_cap, sb, gtp);
+    /* more than 1024 signatures: the lean launch without room for the sort emulation (LDS -> occupancy);
+     * PSMs with a tie at the top go to the general instantiation through the hand-over list */
+    const uint32_t sort_room = (n_cap <= 1024 || getenv("PYA_SORT_ROOM")) ? 1u : 0u;
+    const size_t lds_lean = sort_room ? lds : pya_localize_lds_bytes(push_cap, 0, pos_cap, pool_cap, sb);
+    hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds_lean, stream, *b, d_ids, n_ids, push_cap,
+                       pos_cap, pool_cap, sb, gtp, sort_room);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     e = PYA_ENSURE_MAX_LDS(pya_localize_redo_kernel);
