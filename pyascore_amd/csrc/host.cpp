@@ -328,7 +328,14 @@ struct pya_plan {
         uint32_t off, n, cap, ncls;
     };
     std::vector<uint32_t> bin_ids, score_ids, fused_ids, big_ids;
-    std::vector<IdList> bin_lists, score_lists, fused_lists, big_lists;
+    std::vector<IdList> bin_lists, score_lists, big_lists;
+    /* launches of the fused kernel: per peak class and charge class, and -- since the kernel's speed
+     * follows its LDS footprint -- per LDS class: short peptides with a handful of signatures are not
+     * launched with the footprint of the longest peptide with 32 */
+    struct FusedLaunch {
+        uint32_t off, n, cap, multi_z, n_cap, stride, pos_cap, ent_cap, push_cap;
+    };
+    std::vector<FusedLaunch> fused_launches;
     std::vector<uint8_t> big;           /* [n_psm] scored by score_big.hip (thousands of site assignments, plain settings) */
     DevBuf<uint32_t> d_big_ids;
     uint32_t big_pos_cap = 1;
@@ -1099,7 +1106,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         std::sort(caps.begin(), caps.end());
         caps.erase(std::unique(caps.begin(), caps.end()), caps.end());
         const size_t nc = caps.size();
-        std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0), cnt_fused(nc * 2, 0), cnt_big(nc, 0);
+        std::vector<uint32_t> cnt_bin(nc, 0), cnt_score(nc * kNumBuckets, 0), cnt_big(nc, 0);
         std::vector<uint8_t> pcls(n);
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;                  /* set aside: neither binned nor scored */
@@ -1108,8 +1115,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             while (caps[c] < P) c++;
             pcls[i] = (uint8_t)c;
             cnt_bin[c]++;
-            if (p->fused[i]) cnt_fused[c * 2 + (p->max_charge[i] > 1 ? 1 : 0)]++;
-            else if (p->big[i]) cnt_big[c]++;
+            if (p->fused[i]) continue;
+            if (p->big[i]) cnt_big[c]++;
             else cnt_score[p->ncls[i] * nc + c]++;
         }
         uint32_t off = 0;
@@ -1124,12 +1131,6 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         }
         uint32_t n_score = off;
         off = 0;
-        for (size_t c = 0; c < nc * 2; c++) {                /* per peak class: fragment charge 1, then above (ncls = 1) */
-            p->fused_lists.push_back({off, 0u, caps[c / 2], (uint32_t)(c & 1)});
-            off += cnt_fused[c];
-        }
-        p->fused_ids.resize(off);
-        off = 0;
         for (size_t c = 0; c < nc; c++) {
             p->big_lists.push_back({off, 0u, caps[c], 0u});
             off += cnt_big[c];
@@ -1142,14 +1143,70 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             pya_plan::IdList &bl = p->bin_lists[pcls[i]];
             p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
             if (p->fused[i]) {
-                pya_plan::IdList &fl = p->fused_lists[pcls[i] * 2 + (p->max_charge[i] > 1 ? 1 : 0)];
-                p->fused_ids[fl.off + fl.n++] = (uint32_t)i;
+                /* (listed below) */
             } else if (p->big[i]) {
                 pya_plan::IdList &gl = p->big_lists[pcls[i]];
                 p->big_ids[gl.off + gl.n++] = (uint32_t)i;
             } else {
                 pya_plan::IdList &sl = p->score_lists[p->ncls[i] * nc + pcls[i]];
                 p->score_ids[sl.off + sl.n++] = (uint32_t)i;
+            }
+        }
+            {
+            /* ---- launches of the fused kernel ---- */
+            struct Item { uint32_t id, group; size_t need; uint32_t n_cap, pos, ent, push; };
+            std::vector<Item> items;
+            const uint32_t ndir = both_dirs ? 2u : 1u;
+            for (uint64_t i = 0; i < n; i++) {
+                if (!p->fused[i] || p->pre_status[i]) continue;
+                Item it;
+                it.id = (uint32_t)i;
+                const uint32_t z = (uint32_t)p->max_charge[i], Lm1 = (uint32_t)(p->pep_off[i + 1] - p->pep_off[i] - 1);
+                const uint32_t kk = (uint32_t)p->n_of_mod[i], ns = p->n_sites[i];
+                it.group = (uint32_t)pcls[i] * 2 + (z > 1 ? 1u : 0u);
+                it.n_cap = (p->n_sig[i] + 3u) & ~3u;
+                it.pos = std::max(Lm1, 1u);
+                it.ent = std::max(Lm1 * z, 1u);
+                it.push = std::min<uint32_t>(PYA_MAX_PUSHED, (kk * (ns - kk) + 7u) & ~7u);
+                if (it.push < 8) it.push = 8;
+                it.need = pya_fused_lds_bytes(caps[pcls[i]], it.n_cap, ndir * it.n_cap, it.pos, it.ent, it.push, p->fused_both);
+                items.push_back(it);
+            }
+            std::sort(items.begin(), items.end(), [](const Item &a, const Item &b2) {
+                return a.group != b2.group ? a.group < b2.group : (a.need != b2.need ? a.need < b2.need : a.id < b2.id);
+            });
+            p->fused_ids.resize(items.size());
+            size_t g0 = 0;
+            while (g0 < items.size()) {
+                size_t g1 = g0;
+                while (g1 < items.size() && items[g1].group == items[g0].group) g1++;
+                /* LDS classes inside the group: cut at the median and the 85th percentile of the footprint when
+                 * that buys at least a fifth of the largest footprint (every launch has its own ramp-up and tail) */
+                std::vector<size_t> cuts{g0};
+                if (g1 - g0 >= 8192 && !std::getenv("PYA_ONE_LDS_CLASS")) {
+                    const size_t need_max = items[g1 - 1].need;
+                    for (double q : {0.5, 0.85}) {
+                        const size_t at = g0 + (size_t)(q * (double)(g1 - g0));
+                        size_t cut = at;
+                        while (cut < g1 && items[cut].need == items[at].need) cut++;    /* equal footprints stay together */
+                        if (cut < g1 && cut > cuts.back() && items[at].need * 5 <= need_max * 4) cuts.push_back(cut);
+                    }
+                }
+                cuts.push_back(g1);
+                for (size_t c = 0; c + 1 < cuts.size(); c++) {
+                    pya_plan::FusedLaunch fl = {(uint32_t)cuts[c], (uint32_t)(cuts[c + 1] - cuts[c]), caps[items[g0].group / 2],
+                                                items[g0].group & 1u, 4, 4, 1, 1, 8};
+                    for (size_t t = cuts[c]; t < cuts[c + 1]; t++) {
+                        fl.n_cap = std::max(fl.n_cap, items[t].n_cap);
+                        fl.pos_cap = std::max(fl.pos_cap, items[t].pos);
+                        fl.ent_cap = std::max(fl.ent_cap, items[t].ent);
+                        fl.push_cap = std::max(fl.push_cap, items[t].push);
+                        p->fused_ids[t] = items[t].id;
+                    }
+                    fl.stride = ndir * fl.n_cap;
+                    p->fused_launches.push_back(fl);
+                }
+                g0 = g1;
             }
         }
     }
@@ -1168,11 +1225,6 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                (uint64_t)((uint32_t)p->max_charge[i] & 0xffu) << 56;
         w[5] = (uint64_t)p->n_sig[i] | (uint64_t)p->order_off[i] << 32;
     }
-    /* the fused kernel keeps one row of the score table in LDS: PSMs of equal length back to back */
-    for (pya_plan::IdList &fl : p->fused_lists)
-        std::stable_sort(p->fused_ids.begin() + fl.off, p->fused_ids.begin() + fl.off + fl.n, [&](uint32_t a, uint32_t b2) {
-            return p->pep_off[a + 1] - p->pep_off[a] < p->pep_off[b2 + 1] - p->pep_off[b2];
-        });
     lap("id lists");
     rc = ensure_lut(h, lut_need);
     if (rc) return rc;
@@ -1408,10 +1460,9 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
          * what that kernel hands over goes through the general localize instantiation */
         HIPCHK(h, hipMemsetAsync(d.redo4_count, 0, sizeof(uint32_t), st));
         const Bucket &fb = p->fusedb;
-        for (const pya_plan::IdList &l : p->fused_lists) {
-            e = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, p->fused_n_cap, p->fused_stride, fb.pos_cap,
-                                 l.ncls ? p->fused_ent_cap : fb.pos_cap, fb.push_cap(), p->fused_both, l.ncls, d.redo4_count,
-                                 d.redo4_ids, st);
+        for (const pya_plan::FusedLaunch &l : p->fused_launches) {
+            e = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, l.n_cap, l.stride, l.pos_cap, l.ent_cap, l.push_cap,
+                                 p->fused_both, l.multi_z, d.redo4_count, d.redo4_ids, st);
             if (e) return h->hip_fail((hipError_t)e, "score_localize launch");
         }
         e = pya_launch_localize_redo(&d, d.redo4_count, d.redo4_ids, (uint32_t)p->fused_ids.size(), fb.push_cap(), fb.n_cap,
