@@ -4,6 +4,7 @@ There is no fallback: if the library is missing or no HIP device is usable, impo
 scorer fails loudly.
 """
 import ctypes as C
+import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -105,6 +106,26 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm ships its own copy (torch/lib/libamdhip64.so,
+    soname libamdhip64.so.7) and asks for it by FILE name; this library asks for the soname.  Loaded
+    torch-first, the loader hands us torch's copy; loaded the other way round it would bring in a second
+    runtime next to /opt/rocm's, torch would then find "No HIP GPUs", and device.DevicePlan could not
+    take torch's device pointers.  So when a ROCm torch is installed, its copy goes in first (without
+    importing torch)."""
+    if any("libamdhip64" in line for line in open("/proc/self/maps")):
+        return                                    # a runtime is already in the process: the loader reuses it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Loads the HIP library (no device needed for loading; pya_create needs one)."""
     global _lib
@@ -114,6 +135,7 @@ def load():
         raise ImportError(
             "pyascore_amd: %s is missing. Build it with `python -m pyascore_amd.build` "
             "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError = header/library mismatch: fail loudly

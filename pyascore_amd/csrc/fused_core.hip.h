@@ -163,23 +163,40 @@ DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, in
     const float2 *rp = resd + (dir ? L - 1 : 0);
     const int rstride = dir ? -1 : 1;
     uint32_t *col = cnt + lane_id();
+    /* Straight-line steps: this kernel issues about as many scalar as vector instructions and a CU has
+     * ONE scalar unit, so every per-lane branch (exec-mask save / restore / skip) costs as much as the
+     * vector work it guards.  Lanes without a walker therefore run the same code: they bump their own
+     * histogram column by zero and record into a spare column (`w` = stride - 1 for them). */
     uint8_t *ro = rkl + w;
     float running = 0.f;
+    if (tab.half_check) {                                    /* mz_error > 0.49: the lookup with the extra test */
+        for (int step = 0; step + 1 < L; step++, rp += rstride) {
+            const float2 mm = *rp;
+            const uint32_t word = step < 32 ? tlo : thi;
+            const bool mod = (word >> (step & 31)) & 1u;
+            running = (mod ? mm.y : mm.x) + running;
+            const double m = ((double)running + A) - B;
+            for (int z = 1; z <= zmax; z++, ro += stride) {
+                const int rk = match_rank_lds(tab, charge_mz(m, z));
+                hist_bump(col, active, rk);
+                *ro = (uint8_t)rk;
+            }
+        }
+        return;
+    }
     for (int step = 0; step + 1 < L; step++, rp += rstride) {
         const float2 mm = *rp;
         const uint32_t word = step < 32 ? tlo : thi;
         const bool mod = (word >> (step & 31)) & 1u;
-        const float r = mod ? mm.y : mm.x;
-        running = r + running;                             /* ModifiedPeptide.cpp:385-389 */
+        running = (mod ? mm.y : mm.x) + running;             /* ModifiedPeptide.cpp:385-389 */
         const double m = ((double)running + A) - B;
-        const int rk = match_rank_lds(tab, (float)(m + 1.007825));
-        hist_bump(col, active, rk);
-        if (active) *ro = (uint8_t)rk;
-        ro += stride;
-        for (int z = 2; z <= zmax; z++, ro += stride) {
-            const int rz = match_rank_lds(tab, charge_mz(m, z));
-            hist_bump(col, active, rz);
-            if (active) *ro = (uint8_t)rz;
+        for (int z = 1; z <= zmax; z++, ro += stride) {
+            const Look k = look4(tab, charge_mz(m, z));
+            int rk = k.best;
+            if (__any(k.more) && k.more) rk = look_rest(tab, k);
+            const bool hit = active && rk < PYA_NTOP;
+            atomicAdd(col + ((hit ? rk : 0) >> 1) * 64, hit ? 1u << ((rk & 1) * 16) : 0u);
+            *ro = (uint8_t)rk;
         }
     }
 }
@@ -339,7 +356,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     for (int d = 0; d < PYA_NTOP / 2; d++) f.cnt[d * 64 + lane] = 0u;
     const int Lm1 = L - 1;
     const uint64_t resmask = deposit_sites(bits, site_mask);
-    const int w = BOTH ? (lane >> 5) * N + s : s;          /* this lane's column of the rank lists */
+    const int w = !active ? (int)stride - 1 : (BOTH ? (lane >> 5) * N + s : s);   /* this lane's column of the rank lists (last: spare) */
     /* positive residue masses make every list ascending (what the neighbour-probe pairing needs) */
     const bool presorted = !__any(lane < L && !(m0 > 0.f && m1 > 0.f));
     wave_lds_sync();

@@ -1056,7 +1056,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         if (keep_fused) {
             p->fused_both = both_dirs ? 1u : 0u;
             p->fused_n_cap = (fb.n_cap + 3u) & ~3u;
-            p->fused_stride = (both_dirs ? 2u : 1u) * p->fused_n_cap;
+            p->fused_stride = (both_dirs ? 2u : 1u) * p->fused_n_cap + 4u;
             const uint32_t cap_all = (max_P + 31u) & ~31u;
             keep_fused = pya_fused_lds_bytes(cap_all, p->fused_n_cap, p->fused_stride, fb.pos_cap, p->fused_ent_cap, fb.push_cap(), p->fused_both) <= 64 * 1024 &&
                          pya_localize_lds_bytes(fb.push_cap(), fb.n_cap, fb.pos_cap, fb.pool_cap(), fb.sb()) <= kMaxLds;
@@ -1169,7 +1169,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                 it.ent = std::max(Lm1 * z, 1u);
                 it.push = std::min<uint32_t>(PYA_MAX_PUSHED, (kk * (ns - kk) + 7u) & ~7u);
                 if (it.push < 8) it.push = 8;
-                it.need = pya_fused_lds_bytes(caps[pcls[i]], it.n_cap, ndir * it.n_cap, it.pos, it.ent, it.push, p->fused_both);
+                it.need = pya_fused_lds_bytes(caps[pcls[i]], it.n_cap, ndir * it.n_cap + 4, it.pos, it.ent, it.push, p->fused_both);
                 items.push_back(it);
             }
             std::sort(items.begin(), items.end(), [](const Item &a, const Item &b2) {
@@ -1203,7 +1203,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                         fl.push_cap = std::max(fl.push_cap, items[t].push);
                         p->fused_ids[t] = items[t].id;
                     }
-                    fl.stride = ndir * fl.n_cap;
+                    fl.stride = ndir * fl.n_cap + 4;            /* + a spare column for lanes without a walker */
                     p->fused_launches.push_back(fl);
                 }
                 g0 = g1;

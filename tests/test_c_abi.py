@@ -62,3 +62,15 @@ def test_product_does_not_import_the_oracle():
                 assert "libascore_oracle" not in text and "libascore_ref" not in text, f
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "oracle_abi.h" not in text, f
+
+
+def test_one_hip_runtime_whichever_is_imported_first():
+    """The library loaded BEFORE torch must not leave the process with two HIP runtimes (torch would
+    then report "No HIP GPUs" and could not share device pointers with device.DevicePlan)."""
+    import subprocess
+    import sys
+    code = ("import pyascore_amd._lib as L; L.load(); import torch; "
+            "print(len({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "1"

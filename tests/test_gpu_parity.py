@@ -630,3 +630,31 @@ def test_one_call_of_a_million_heavy_psms():
     want = _checker(desc["settings"]).score_batch(sub, 5)
     for key in ("n_sig", "best_sig", "best_score", "ascores", "alt_mask"):
         assert np.array_equal(full[key][pick], want[key]), key
+
+
+def test_scorer_first_then_torch_in_one_process():
+    """Import order must not matter: score through the library, THEN bring up torch's HIP runtime and run
+    a device-resident plan on torch tensors in the same process."""
+    import subprocess
+    import sys
+    code = """
+import numpy as np
+from pyascore_amd import PyAscore, synth
+from pyascore_amd.device import DevicePlan, unpack_summary
+batch, st = synth.make_batch("cfg3", n_psm=400, seed=5)
+s = PyAscore(st["bin_size"], st["n_top"], st["mod_group"], st["mod_mass"], mz_error=st["mz_error"],
+             fragment_types=st["fragment_types"])
+want = s.score_batch(batch)
+import torch
+dev = torch.device("cuda", s.device)
+plan = DevicePlan(s, batch)
+plan.run(torch.from_numpy(batch["mz"]).to(dev), torch.from_numpy(batch["intensity"]).to(dev))
+plan.check()
+got = unpack_summary(plan.packed_summary().cpu().numpy(), int(batch["n_of_mod"].max()))
+assert np.array_equal(got["best_score"].view(np.uint32), want["best_score"].view(np.uint32))
+assert np.array_equal(got["best_sig"], want["best_sig"])
+print("same")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("same"), out.stderr[-2000:]
