@@ -171,6 +171,9 @@ DEV void run_exact_ranks(const R &r, int len, uint8_t *rank_out) {
  * peak order, ties resolved as std::nth_element + std::sort do).  Two instantiations in two
  * kernels, because the rare paths would otherwise double the registers of the common one. */
 #define PYA_BIN_REDO (-2)
+#ifndef BIN_BLOCK
+#define BIN_BLOCK 6
+#endif
 template <bool EXACT>
 DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
                  const uint8_t **out_rank, int *status) {
@@ -180,6 +183,8 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     uint16_t *s_bin = (uint16_t *)(s_mzf + cap);
     uint8_t *s_rank = (uint8_t *)(s_bin + cap);
 
+    STAMP_BEGIN();
+    STAMP_T(b, 1, -1);
     const int64_t p0 = b.peak_off[psm];
     const int P = (int)(b.peak_off[psm + 1] - p0);
     const double *mz = b.mz + p0;
@@ -200,56 +205,98 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     uint32_t n_bins = 0;
     int unsorted = 0;
     *status = PYA_ST_OK;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    /* window bounds from the extremes (Spectra.cpp:46-48); false = no usable number of windows */
+    auto bounds = [&](float *nb_out) -> bool {
         min_mz = (float)(__builtin_floor(mn / 100.) * 100.);
         const float max_mz = (float)(__builtin_ceil(mx / 100.) * 100.);
         const float nb_f = __builtin_ceilf((max_mz - min_mz) / bin_size);   /* float arithmetic, :48 */
+        *nb_out = nb_f;
         const bool ok = nb_f >= 1.f && nb_f <= 65535.f;
-        if (!ok && attempt == 1) {
-            *status = nb_f > 65535.f ? PYA_ST_TOO_MANY_BINS : PYA_ST_NO_BINS;
-            return -1;
-        }
         n_bins = ok ? (uint32_t)nb_f : 1u;
-        /* window id per peak (double arithmetic, Spectra.cpp:55-58) */
+        return ok;
+    };
+    /* window id of one peak (double arithmetic, Spectra.cpp:55-58): floor((v - min) / bin_size) as the
+     * reference's double division gives it, without the division: every multiple k * bin_size
+     * (k < 2^16, bin_size a float) is exact in double, so the rounded quotient reaches k exactly when
+     * the true one does and the floor equals the mathematical one -- which a reciprocal estimate plus
+     * an exact remainder (fma) pins down. */
+    auto window_of = [&](double v) -> uint16_t {
+        const double x = v - (double)min_mz;
+        double q = __builtin_floor(x * inv_bs);
+        const double r = __builtin_fma(-q, bsd, x);
+        q = r < 0. ? q - 1. : (r >= bsd ? q + 1. : q);
+        const uint32_t w = q >= (double)(n_bins - 1) ? n_bins - 1 : (uint32_t)q;
+        return (uint16_t)w;
+    };
+    bool ok = true;
+    {
+        /* The sweep that bins the peaks, checks the order and tracks the true extremes.  The spectrum
+         * comes in blocks of 64 * BIN_BLOCK peaks whose loads are ALL issued before the first of them is used: a
+         * wavefront's time here is HBM round trips, and a load-use-load-use loop makes one (two with
+         * the look at the next peak) per 64 peaks instead of one per block.  The next peak comes from
+         * the neighbouring lane, the one after a chunk's last from the next chunk or one extra load. */
+        constexpr int U = BIN_BLOCK;
         double tmn = __builtin_huge_val(), tmx = -__builtin_huge_val();
         int uns = 0;
-        for (int i = lane; i < P; i += 64) {
-            const double v = mz[i];
-            if (attempt == 0) {
-                const double nx = (i + 1 < P) ? mz[i + 1] : v;
-                tmn = v < tmn ? v : tmn;
-                tmx = v > tmx ? v : tmx;
-                uns |= (v > nx) ? 1 : 0;
-                s_inten[i] = inten[i];
-                s_mzf[i] = (float)v;
+        for (int base = 0; base < P; base += 64 * U) {
+            double v[U], it[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = base + u * 64 + lane;          /* (past the end: the last peak again) */
+                const int ic = i < P ? i : P - 1;
+                v[u] = mz[ic];
+                it[u] = inten[ic];
             }
-            /* floor((v - min) / bin_size) as the reference's double division gives it, without
-             * the division: every multiple k * bin_size (k < 2^16, bin_size a float) is exact in
-             * double, so the rounded quotient reaches k exactly when the true one does and the
-             * floor equals the mathematical one -- which a reciprocal estimate plus an exact
-             * remainder (fma) pins down. */
-            const double x = v - (double)min_mz;
-            double q = __builtin_floor(x * inv_bs);
-            const double r = __builtin_fma(-q, bsd, x);
-            q = r < 0. ? q - 1. : (r >= bsd ? q + 1. : q);
-            const uint32_t w = q >= (double)(n_bins - 1) ? n_bins - 1 : (uint32_t)q;
-            s_bin[i] = (uint16_t)w;
+            const int ie = base + 64 * U;
+            const double edge = mz[ie < P ? ie : P - 1];
+            if (base == 0) {
+                float nb_f;
+                ok = bounds(&nb_f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                /* (one chunk at a time: interleaving the eight costs 140 registers and the occupancy) */
+                __builtin_amdgcn_sched_barrier(0);
+                if (base + u * 64 < P) {
+                    const int i = base + u * 64 + lane;
+                    const bool next_chunk = base + (u + 1) * 64 < P;
+                    double nx = __shfl_down(v[u], 1, 64);
+                    const double after = !next_chunk ? v[u] : (u + 1 < U ? wave_bcast(v[u + 1 < U ? u + 1 : u], 0) : edge);
+                    if (lane == 63) nx = after;
+                    if (i < P) {
+                        const double x = v[u];
+                        tmn = x < tmn ? x : tmn;
+                        tmx = x > tmx ? x : tmx;
+                        uns |= (x > nx) ? 1 : 0;
+                        s_inten[i] = it[u];
+                        s_mzf[i] = (float)x;
+                        s_bin[i] = window_of(x);
+                    }
+                }
+            }
         }
-        if (attempt == 0) {
-            unsorted = __any(uns);
-            bool redo = !ok;
-            if (unsorted) {
-                tmn = wave_min_f64(tmn);
-                tmx = wave_max_f64(tmx);
-                redo = redo || tmn != mn || tmx != mx;
-                mn = tmn;
-                mx = tmx;
+        unsorted = __any(uns);
+        bool redo = !ok;
+        if (unsorted) {
+            tmn = wave_min_f64(tmn);
+            tmx = wave_max_f64(tmx);
+            redo = redo || tmn != mn || tmx != mx;
+            mn = tmn;
+            mx = tmx;
+        }
+        if (redo) {
+            /* the ends were not the extremes (or gave no windows): bin again from the true ones */
+            float nb_f;
+            if (!bounds(&nb_f)) {
+                *status = nb_f > 65535.f ? PYA_ST_TOO_MANY_BINS : PYA_ST_NO_BINS;
+                return -1;
             }
-            if (!redo) break;
+            for (int i = lane; i < P; i += 64) s_bin[i] = window_of(mz[i]);
         }
     }
     if (!EXACT && (unsorted || (b.debug & 128))) return PYA_BIN_REDO;
     wave_lds_sync();
+    STAMP_T(b, 2, -1);
 
     /* pass 3: intensity rank inside the window = number of window mates that are more intense
      * (ties: the earlier peak ranks first; the reference leaves ties unspecified).
@@ -439,6 +486,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
         }
     }
     wave_lds_sync();
+    STAMP_T(b, 3, -1);
 
     /* pass 4: retained peaks in ascending float m/z, written over the (no longer needed)
      * intensity array */
@@ -478,6 +526,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
         }
     }
     wave_lds_sync();
+    STAMP_T(b, 4, -1);
     *out_mz = o_mz;
     *out_rank = o_rank;
     return total;

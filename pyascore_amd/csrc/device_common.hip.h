@@ -42,9 +42,17 @@ static inline hipError_t pya_set_max_lds(const void *fn, std::atomic<uint32_t> &
         if ((b).stamps && (threadIdx.x & 63) == 0) atomicAdd(&(b).stamps[k], now_ - stamp_t_); \
         stamp_t_ = __builtin_amdgcn_s_memtime();                                     \
     } while (0)
+/* truncation profile: with PYA_DEBUG=k<<16 every wave stops at stamp k (results are garbage; the kernel's
+ * duration as a function of k is a cumulative time profile that does not depend on where s_memtime lands) */
+#define STAMP_T(b, k, ret)                                                           \
+    do {                                                                             \
+        STAMP(b, k);                                                                 \
+        if (((b).debug >> 16) == (uint32_t)(k)) return ret;                          \
+    } while (0)
 #else
 #define STAMP_BEGIN() do {} while (0)
 #define STAMP(b, k) do {} while (0)
+#define STAMP_T(b, k, ret) do {} while (0)
 #endif
 
 DEV int lane_id() { return (int)(threadIdx.x & 63); }
@@ -238,9 +246,13 @@ DEV void stage_peak_table(const BatchDev &b, uint32_t psm, PeakEntry *dst, PeakT
 
 /* monotone non-decreasing in x: float subtract, multiply by a positive constant, truncate */
 DEV int grid_cell(const PeakTable &t, float x) {
-    float rel = (x - t.base) * t.inv_w;
-    int c = (int)__builtin_fmaxf(rel, 0.f);
-    return c > t.last_cell ? t.last_cell : c;
+    const float rel = (x - t.base) * t.inv_w;
+    /* v_cvt_u32_f32 saturates: below zero (and NaN) to 0, above the range to 2^32 - 1 -- the clamp at
+     * zero without an instruction of its own */
+    uint32_t c;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(c) : "v"(rel));
+    const uint32_t last = (uint32_t)t.last_cell;
+    return (int)(c > last ? last : c);
 }
 
 /* cell geometry from the first and last retained m/z (same arithmetic wherever it is needed) */
@@ -270,7 +282,7 @@ DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
     for (int i = lane; i < t->n; i += 64) {
         const int c = grid_cell(*t, t->e[i].mz);
         const int cp = i > 0 ? grid_cell(*t, t->e[i - 1].mz) : -1;
-        for (int k = cp + 1; k <= c; k++) cell_lds[k] = (uint16_t)i;
+        for (int k = cp + 1; k <= c; k++) cell_lds[k] = (uint16_t)(i & ~1);   /* even: entries4 reads 16-byte pairs */
     }
 }
 
@@ -334,11 +346,29 @@ DEV int match_rank_global(const PeakTable &t, float f) {
     return best;
 }
 
+/* Four entries from the even index at or below `idx`, as two 16-byte reads: the LDS serves a
+ * ds_read_b128 in 4 cycles and a ds_read2_b64 (what four 8-byte entries from an odd index become) in
+ * 8, and the lookups of a walk are what fills the LDS pipe.  An entry below idx sits in an earlier
+ * grid cell than the window's lower bound, so it fails the window test by itself.  (t.e is 16-byte
+ * aligned in every kernel's LDS layout.)  Returns the index after the four. */
+DEV int entries4(const PeakTable &t, uint32_t idx, PeakEntry *e) {
+    const uint32_t base = idx;                               /* (grid_build stores even indices) */
+    const uint4 *p = (const uint4 *)__builtin_assume_aligned((const unsigned char *)t.e + base * 8u, 16);
+    const uint4 a = p[0], c = p[1];
+    e[0].mz = __uint_as_float(a.x); e[0].rank = a.y;
+    e[1].mz = __uint_as_float(a.z); e[1].rank = a.w;
+    e[2].mz = __uint_as_float(c.x); e[2].rank = c.y;
+    e[3].mz = __uint_as_float(c.z); e[3].rank = c.w;
+    return (int)base + 4;
+}
+
 DEV int match_rank_lds(const PeakTable &t, float f) {
     const float lo = f - t.err;
     const float hi = f + t.err;
     int idx = (int)t.cell[grid_cell(t, lo)];              /* every peak > lo has index >= idx  */
-    const PeakEntry e0 = t.e[idx], e1 = t.e[idx + 1], e2 = t.e[idx + 2], e3 = t.e[idx + 3];
+    PeakEntry e4[4];
+    const int next = entries4(t, (uint32_t)idx, e4);
+    const PeakEntry e0 = e4[0], e1 = e4[1], e2 = e4[2], e3 = e4[3];
     int best = PYA_NO_MATCH;
     if (!t.half_check) {
         int r;
@@ -347,7 +377,7 @@ DEV int match_rank_lds(const PeakTable &t, float f) {
         r = e2.mz > lo ? (int)e2.rank : PYA_NO_MATCH; r = e2.mz < hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
         r = e3.mz > lo ? (int)e3.rank : PYA_NO_MATCH; r = e3.mz < hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
         if (e3.mz < hi) {                                  /* rare: more than four entries to look at */
-            idx += 4;
+            idx = next;
             for (;;) {
                 const PeakEntry x = t.e[idx];
                 if (!(x.mz < hi)) break;
@@ -371,27 +401,32 @@ DEV int match_rank_lds(const PeakTable &t, float f) {
  * the fourth entry; look_rest finishes those (rare).  Only for mz_error <= 0.49 (no half_check). */
 struct Look {
     int best, idx;
-    float lo, hi;
-    bool more;
+    float lo, hi, last;       /* last: m/z of the fourth entry */
+    /* the window extends past the fourth entry (rare).  Callers branch on it per lane -- the compiler
+     * skips the block when no lane needs it, and a wave-wide "any" would cost two vector instructions */
+    DEV bool more() const { return last < hi; }
 };
 DEV Look look4(const PeakTable &t, float f) {
     Look k;
     k.lo = f - t.err;
     k.hi = f + t.err;
-    k.idx = (int)t.cell[grid_cell(t, k.lo)];
-    const PeakEntry e0 = t.e[k.idx], e1 = t.e[k.idx + 1], e2 = t.e[k.idx + 2], e3 = t.e[k.idx + 3];
-    int best = PYA_NO_MATCH, r;
-    r = e0.mz > k.lo ? (int)e0.rank : PYA_NO_MATCH; r = e0.mz < k.hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
-    r = e1.mz > k.lo ? (int)e1.rank : PYA_NO_MATCH; r = e1.mz < k.hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
-    r = e2.mz > k.lo ? (int)e2.rank : PYA_NO_MATCH; r = e2.mz < k.hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
-    r = e3.mz > k.lo ? (int)e3.rank : PYA_NO_MATCH; r = e3.mz < k.hi ? r : PYA_NO_MATCH; best = r < best ? r : best;
+    PeakEntry e4[4];
+    k.idx = entries4(t, (uint32_t)t.cell[grid_cell(t, k.lo)], e4); /* (where look_rest resumes) */
+    const PeakEntry e0 = e4[0], e1 = e4[1], e2 = e4[2], e3 = e4[3];
+    /* one select per entry, then min3 + min (ranks are at most PYA_NO_MATCH = 15) */
+    const int r0 = (e0.mz > k.lo && e0.mz < k.hi) ? (int)e0.rank : PYA_NO_MATCH;
+    const int r1 = (e1.mz > k.lo && e1.mz < k.hi) ? (int)e1.rank : PYA_NO_MATCH;
+    const int r2 = (e2.mz > k.lo && e2.mz < k.hi) ? (int)e2.rank : PYA_NO_MATCH;
+    const int r3 = (e3.mz > k.lo && e3.mz < k.hi) ? (int)e3.rank : PYA_NO_MATCH;
+    const int m01 = r0 < r1 ? r0 : r1, m23 = r2 < r3 ? r2 : r3;
+    const int best = m01 < m23 ? m01 : m23;
     k.best = best;
-    k.more = e3.mz < k.hi;
+    k.last = e3.mz;
     return k;
 }
 DEV int look_rest(const PeakTable &t, const Look &k) {
     int best = k.best;
-    for (int idx = k.idx + 4;; idx++) {
+    for (int idx = k.idx;; idx++) {
         const PeakEntry x = t.e[idx];
         if (!(x.mz < k.hi)) break;
         if (x.mz > k.lo) best = (int)x.rank < best ? (int)x.rank : best;

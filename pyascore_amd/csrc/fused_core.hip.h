@@ -155,21 +155,36 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
 }
 
 /* the straight-line walker of walk_core.hip.h that also records the rank every fragment matched in
- * column `w` of rkl (entry step * zmax + z - 1); A, B: the ion-type offsets of the lane's direction */
+ * column `w` of rkl (entry step * zmax + z - 1); A, B: the ion-type offsets of the lane's direction.
+ * Lanes without a walker run the same code: they bump their own histogram column by zero and
+ * record into a spare column (`w` = stride - 1 for them) -- no per-lane branches in the loop.
+ * BZ: no direction subtracts an offset (every ion type but z / Z), so that instruction is left out. */
+template <bool BZ>
+DEV void walk_record_steps(const float2 *&rp, int rstride, StepBits &bits, float &running, uint32_t *col, const PeakTable &tab,
+                           int zmax, double A, double B, bool active, uint8_t *&ro, int stride, int count) {
+    for (int i = 0; i < count; i++, rp += rstride) {
+        const float2 mm = *rp;
+        running = (bits.next() ? mm.y : mm.x) + running;     /* ModifiedPeptide.cpp:385-389 */
+        const double m = BZ ? (double)running + A : ((double)running + A) - B;
+        for (int z = 1; z <= zmax; z++, ro += stride) {
+            const Look k = look4(tab, charge_mz(m, z));
+            int rk = k.best;
+            if (k.more()) rk = look_rest(tab, k);
+            hist_bump(col, active, rk);
+            *ro = (uint8_t)rk;
+        }
+    }
+}
 DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, int L, int zmax, uint64_t resmask, int dir,
-                     double A, double B, bool active, uint8_t *rkl, int stride, int w) {
+                     double A, double B, bool all_b_zero, bool active, uint8_t *rkl, int stride, int w) {
     const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
-    const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
     const float2 *rp = resd + (dir ? L - 1 : 0);
     const int rstride = dir ? -1 : 1;
     uint32_t *col = cnt + lane_id();
-    /* Straight-line steps: this kernel issues about as many scalar as vector instructions and a CU has
-     * ONE scalar unit, so every per-lane branch (exec-mask save / restore / skip) costs as much as the
-     * vector work it guards.  Lanes without a walker therefore run the same code: they bump their own
-     * histogram column by zero and record into a spare column (`w` = stride - 1 for them). */
     uint8_t *ro = rkl + w;
     float running = 0.f;
     if (tab.half_check) {                                    /* mz_error > 0.49: the lookup with the extra test */
+        const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
         for (int step = 0; step + 1 < L; step++, rp += rstride) {
             const float2 mm = *rp;
             const uint32_t word = step < 32 ? tlo : thi;
@@ -184,41 +199,36 @@ DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, in
         }
         return;
     }
-    for (int step = 0; step + 1 < L; step++, rp += rstride) {
-        const float2 mm = *rp;
-        const uint32_t word = step < 32 ? tlo : thi;
-        const bool mod = (word >> (step & 31)) & 1u;
-        running = (mod ? mm.y : mm.x) + running;             /* ModifiedPeptide.cpp:385-389 */
-        const double m = ((double)running + A) - B;
-        for (int z = 1; z <= zmax; z++, ro += stride) {
-            const Look k = look4(tab, charge_mz(m, z));
-            int rk = k.best;
-            if (__any(k.more) && k.more) rk = look_rest(tab, k);
-            const bool hit = active && rk < PYA_NTOP;
-            atomicAdd(col + ((hit ? rk : 0) >> 1) * 64, hit ? 1u << ((rk & 1) * 16) : 0u);
-            *ro = (uint8_t)rk;
-        }
+    const uint64_t M = msb_first_from(tmask, 0);
+    const int n = L - 1;
+    for (int seg = 0; seg < 2; seg++) {                      /* the mask words change after 32 steps */
+        StepBits bits = {seg ? (uint32_t)M : (uint32_t)(M >> 32)};
+        int c = (n < seg * 32 + 32 ? n : seg * 32 + 32) - seg * 32;
+        if (c < 0) c = 0;
+        if (all_b_zero) walk_record_steps<true>(rp, rstride, bits, running, col, tab, zmax, A, B, active, ro, stride, c);
+        else walk_record_steps<false>(rp, rstride, bits, running, col, tab, zmax, A, B, active, ro, stride, c);
     }
 }
 
-/* the same walk without lookups: the fragment m/z of one (signature, direction), charge-major:
- * out[(z - 1) * (L - 1) + step] -- one ascending, position-indexed run per charge */
+/* the same walk without lookups: fragment m/z of one signature and direction to out[z-1][step] */
 DEV void walk_mz_only(const float2 *resd, int L, int zmax, uint64_t resmask, int dir, double A, double B, float *out) {
     const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
-    const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
+    const uint64_t M = msb_first_from(tmask, 0);
     const float2 *rp = resd + (dir ? L - 1 : 0);
     const int rstride = dir ? -1 : 1;
     const int Lm1 = L - 1;
     float running = 0.f;
-    for (int step = 0; step + 1 < L; step++, rp += rstride) {
-        const float2 mm = *rp;
-        const uint32_t word = step < 32 ? tlo : thi;
-        const bool mod = (word >> (step & 31)) & 1u;
-        const float r = mod ? mm.y : mm.x;
-        running = r + running;
-        const double m = ((double)running + A) - B;
-        out[step] = (float)(m + 1.007825);
-        for (int z = 2; z <= zmax; z++) out[(z - 1) * Lm1 + step] = charge_mz(m, z);
+    int step = 0;
+    for (int seg = 0; seg < 2; seg++) {
+        StepBits bits = {seg ? (uint32_t)M : (uint32_t)(M >> 32)};
+        const int end = Lm1 < seg * 32 + 32 ? Lm1 : seg * 32 + 32;
+        for (; step < end; step++, rp += rstride) {
+            const float2 mm = *rp;
+            running = (bits.next() ? mm.y : mm.x) + running;
+            const double m = ((double)running + A) - B;
+            out[step] = (float)(m + 1.007825);
+            for (int z = 2; z <= zmax; z++) out[(z - 1) * Lm1 + step] = charge_mz(m, z);
+        }
     }
 }
 
@@ -251,6 +261,8 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const DevConfig *cfg = b.cfg;
     const int ndir = BOTH ? 2 : 1;
     const FusedLds f = fused_carve(lds_raw, cap, n_cap, stride, pos_cap, ent_cap, push_cap, (uint32_t)ndir);
+    STAMP_BEGIN();
+    STAMP_T(b, 38, false);
     /* the residue table does not depend on the PSM: on its way before anything else */
     if (lane < 32) {
         f.mass_l[lane] = cfg->res_mass[lane];
@@ -282,7 +294,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         }
         return false;
     }
-    STAMP_BEGIN();
+    STAMP_T(b, 39, false);
     /* ---- inputs: letters, retained peaks, the lane's signature, fixed modifications ---- */
     const int s = BOTH ? (lane & 31) : lane;
     const int dir = BOTH ? (lane >> 5) : (cfg->n_fwd > 0 ? 0 : 1);
@@ -319,6 +331,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     if (cfg->n_fwd > 0) type_constants(cfg->types[0], &Af, &Bf);
     if (cfg->n_fwd < cfg->n_types) type_constants(cfg->types[cfg->n_fwd], &Ab, &Bb);
     wave_lds_sync();
+    STAMP_T(b, 48, false);
     /* ---- residues (ModifiedPeptide.cpp:24-79) from the letter and the LDS table ---- */
     float m0, m1;
     uint64_t site_mask;
@@ -351,7 +364,9 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         site_mask = __ballot(modifiable);
         if (in) f.resd[lane] = make_float2(m0, m1);
     }
+    STAMP_T(b, 49, false);
     grid_build(&tab, f.grid);
+    STAMP_T(b, 50, false);
 #pragma unroll
     for (int d = 0; d < PYA_NTOP / 2; d++) f.cnt[d * 64 + lane] = 0u;
     const int Lm1 = L - 1;
@@ -360,10 +375,11 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     /* positive residue masses make every list ascending (what the neighbour-probe pairing needs) */
     const bool presorted = !__any(lane < L && !(m0 > 0.f && m1 > 0.f));
     wave_lds_sync();
-    STAMP(b, 40);
-    walk_record(f.resd, f.cnt, tab, L, zmax, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, active, f.rkl, (int)stride, w);
+    STAMP_T(b, 40, false);
+    walk_record(f.resd, f.cnt, tab, L, zmax, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, Bf == 0. && Bb == 0., active, f.rkl,
+                (int)stride, w);
     wave_lds_sync();
-    STAMP(b, 41);
+    STAMP_T(b, 41, false);
 
     const uint32_t nfrag = (uint32_t)ndir * (uint32_t)Lm1 * (uint32_t)zmax;     /* <= 255 (host) */
     int fail = 0;
@@ -406,7 +422,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         return false;
     }
     wave_lds_sync();                                        /* cnt / peaks are free from here on */
-    STAMP(b, 42);
+    STAMP_T(b, 42, false);
 
     bool declined = !presorted || (b.debug & 512);
     const bool sig_lane = lane < N;                         /* lane i <-> signature i from here on */
@@ -444,7 +460,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         best_bits = __shfl(my_bits, (int)best_i, 64);
         wave_lds_sync();
     }
-    STAMP(b, 43);
+    STAMP_T(b, 43, false);
     if (!declined) {
         /* ---- single-move competitors (cpp/Ascore.cpp:212-254) ---- */
         const uint64_t gone = best_bits & ~my_bits, came = my_bits & ~best_bits;
@@ -474,7 +490,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         if (np > push_cap) np = push_cap;                   /* cannot happen: push_cap >= k * (n_sites - k) */
         if (b.debug & 16) np = 0;
     }
-    STAMP(b, 44);
+    STAMP_T(b, 44, false);
     float my_asc = __builtin_huge_valf();                   /* lane a keeps site a */
     const float err = cfg->mz_error;
     const FastDiv divL = fastdiv_make((uint32_t)(Lm1 > 0 ? Lm1 : 1));
@@ -524,7 +540,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         }
         if (lane == 0) *f.bad_tasks = 0u;
         wave_lds_sync();
-        STAMP(b, 45);
+        STAMP_T(b, 45, false);
         /* ---- site-determining ions (cpp/ModifiedPeptide.cpp:259-320): an ion survives when the other
          * signature's list has no ion within mz_error of it.  The lists are ascending and
          * position-indexed, so the candidates sit at the ion's own index and its neighbours (a
@@ -656,7 +672,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             }
             wave_lds_sync();
         }
-        STAMP(b, 46);
+        STAMP_T(b, 46, false);
         if (!declined) {
             /* ---- Ascores (cpp/Ascore.cpp:200-209, :239-251, :305-313) ---- */
             float asc_l = 0.f;
@@ -704,7 +720,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         if (lane == 0) b.ws_top[(size_t)psm * 4 + 1] = 0u;  /* no summary of the scores: localize scans them */
         return true;
     }
-    STAMP(b, 47);
+    STAMP_T(b, 47, false);
     if (lane < k && f.site_tie[lane]) my_asc = 0.f < my_asc ? 0.f : my_asc;
     if (lane < k && lane < (int)max_k) {
         out_asc[lane] = my_asc;

@@ -28,9 +28,15 @@ DEV void hist_clear(const WalkEnv &e) {
 #pragma unroll
     for (int d = 0; d < PYA_NTOP / 2; d++) e.cnt[d * 64 + lane] = 0u;
 }
+/* (branch-free: a lane without a hit adds zero, wherever its row index points -- rows 5..7 of a miss
+ * lie in whatever follows the histogram inside the workgroup's LDS, and adding zero changes nothing) */
 DEV void hist_bump(uint32_t *col, bool active, int rank) {
-    if (active && rank < PYA_NTOP) atomicAdd(col + (rank >> 1) * 64, 1u << ((rank & 1) * 16));
+    const bool hit = active && rank < PYA_NTOP;
+    uint32_t row = (uint32_t)rank >> 1;
+    asm("" : "+v"(row));                                   /* (keeps shift + shift-add: 2 instructions, not 3) */
+    atomicAdd(col + row * 64u, hit ? 1u << (((uint32_t)rank << 4) & 31u) : 0u);
 }
+
 /* count of rank d in column `lane` */
 DEV uint32_t hist_count(const uint32_t *cnt, int lane, int d) {
     return (cnt[(d >> 1) * 64 + lane] >> ((d & 1) * 16)) & 0xffffu;
@@ -138,10 +144,68 @@ DEV void walk_simple_range(const WalkEnv &e, const PeakTable &tab, uint64_t resm
     st.running = running;
 }
 
+/* "Is the residue of this step modified" for a run of steps, one VALU instruction per step: the
+ * travel-order mask is kept MSB-first, and doubling the word shifts it by one step with the bit
+ * that falls out as the carry. */
+struct StepBits {
+    uint32_t w;
+    DEV bool next() {
+        uint32_t nw;
+        const bool c = __builtin_add_overflow(w, w, &nw);
+        w = nw;
+        return c;
+    }
+};
+/* MSB-first mask of the steps from `begin` on: bit 63 = step `begin` (tmask bit s = step s) */
+DEV uint64_t msb_first_from(uint64_t tmask, int begin) { return __brevll(tmask) << begin; }
+
+/* These kernels are bound by the VALU issue rate, so the walkers below count
+ * vector instructions: the ion-type offsets that are zero (b: both, y and c: the second) are not
+ * added -- x + 0.0 and x - 0.0 are x -- which the two instantiations of the loop know at compile time. */
+template <bool BY>
+DEV void walk_both_steps(const PeakTable &tab, uint32_t *col, bool active, const float2 *&rp0, const float2 *&rp1,
+                         StepBits &b0, StepBits &b1, float &run0, float &run1, double A0, double B0, double A1, double B1,
+                         int count) {
+    for (int i = 0; i < count; i++, rp0++, rp1--) {
+        const float2 m0 = *rp0, m1 = *rp1;
+        const float r0 = b0.next() ? m0.y : m0.x, r1 = b1.next() ? m1.y : m1.x;
+        run0 = r0 + run0;                                    /* ModifiedPeptide.cpp:385-389 */
+        run1 = r1 + run1;
+        float f0, f1;
+        if (BY) {
+            f0 = (float)((double)run0 + 1.007825);
+            f1 = (float)(((double)run1 + A1) + 1.007825);
+        } else {
+            f0 = (float)((((double)run0 + A0) - B0) + 1.007825);
+            f1 = (float)((((double)run1 + A1) - B1) + 1.007825);
+        }
+        const Look k0 = look4(tab, f0), k1 = look4(tab, f1);
+        int rk0 = k0.best, rk1 = k1.best;
+        if (k0.more()) rk0 = look_rest(tab, k0);
+        if (k1.more()) rk1 = look_rest(tab, k1);
+        hist_bump(col, active, rk0);
+        hist_bump(col, active, rk1);
+    }
+}
+template <bool BY>
+DEV void walk_one_steps(const PeakTable &tab, uint32_t *col, bool active, const float2 *&rp, int stride, StepBits &bits,
+                        float &run, double A, double B, int count) {
+    for (int i = 0; i < count; i++, rp += stride) {
+        const float2 mm = *rp;
+        const float r = bits.next() ? mm.y : mm.x;
+        run = r + run;
+        const float f = BY ? (float)(((double)run + A) + 1.007825) : (float)((((double)run + A) - B) + 1.007825);
+        const Look k = look4(tab, f);
+        int rk = k.best;
+        if (k.more()) rk = look_rest(tab, k);
+        hist_bump(col, active, rk);
+    }
+}
+
 /* Both directions of one signature in one loop (charge 1, mz_error <= 0.49): the forward and the
- * backward walker of a lane are independent chains, so every iteration has two lookups in flight
- * instead of one -- the walk is a chain of dependent LDS round trips otherwise.  Steps
- * [begin_d, end_d) of direction d; the two ranges may differ in length. */
+ * backward walker of a lane are independent chains, so every iteration has two lookups in flight.
+ * Steps [begin_d, end_d) of direction d; the steps the two ranges have in common run in the paired
+ * loop, the rest of the longer one on its own; the mask words change after 32 steps. */
 DEV void walk_simple_both(const WalkEnv &e, const PeakTable &tab, uint64_t resmask, bool active, int begin0, int end0,
                           WalkState &st0, int begin1, int end1, WalkState &st1) {
     const DevConfig *cfg = e.cfg;
@@ -149,27 +213,29 @@ DEV void walk_simple_both(const WalkEnv &e, const PeakTable &tab, uint64_t resma
     double A0 = 0., B0 = 0., A1 = 0., B1 = 0.;
     type_constants(cfg->types[0], &A0, &B0);
     type_constants(cfg->types[cfg->n_fwd], &A1, &B1);
-    const uint64_t tm0 = resmask, tm1 = __brevll(resmask) >> (64 - L);
+    const bool by = A0 == 0. && B0 == 0. && B1 == 0.;      /* b with y (or c: A1 is whatever it is) */
+    const uint64_t M0 = msb_first_from(resmask, begin0), M1 = msb_first_from(__brevll(resmask) >> (64 - L), begin1);
     const float2 *rp0 = e.resd + begin0, *rp1 = e.resd + (L - 1 - begin1);
     uint32_t *col = e.cnt + lane_id();
     float run0 = st0.running, run1 = st1.running;
-    const int n0 = end0 - begin0, n1 = end1 - begin1, n = n0 > n1 ? n0 : n1;
-    for (int i = 0; i < n; i++, rp0++, rp1--) {
-        const bool on0 = i < n0, on1 = i < n1;              /* wave-uniform */
-        const int s0 = begin0 + i, s1 = begin1 + i;
-        const float2 m0 = on0 ? *rp0 : make_float2(0.f, 0.f), m1 = on1 ? *rp1 : make_float2(0.f, 0.f);
-        const float r0 = ((tm0 >> (s0 & 63)) & 1ull) ? m0.y : m0.x, r1 = ((tm1 >> (s1 & 63)) & 1ull) ? m1.y : m1.x;
-        if (on0) run0 = r0 + run0;                           /* ModifiedPeptide.cpp:385-389 */
-        if (on1) run1 = r1 + run1;
-        const float f0 = (float)((((double)run0 + A0) - B0) + 1.007825), f1 = (float)((((double)run1 + A1) - B1) + 1.007825);
-        const Look k0 = look4(tab, f0), k1 = look4(tab, f1);
-        int rk0 = k0.best, rk1 = k1.best;
-        if (__any(k0.more || k1.more)) {
-            if (k0.more) rk0 = look_rest(tab, k0);
-            if (k1.more) rk1 = look_rest(tab, k1);
+    const int n0 = end0 - begin0, n1 = end1 - begin1, both = n0 < n1 ? n0 : n1;
+    for (int seg = 0; seg < 2; seg++) {                      /* steps 0..31, 32..63 from `begin` */
+        StepBits b0 = {seg ? (uint32_t)M0 : (uint32_t)(M0 >> 32)}, b1 = {seg ? (uint32_t)M1 : (uint32_t)(M1 >> 32)};
+        const int lo = seg * 32, hi = lo + 32;
+        int c = (both < hi ? both : hi) - lo;               /* paired steps of this segment */
+        if (c < 0) c = 0;
+        if (by) walk_both_steps<true>(tab, col, active, rp0, rp1, b0, b1, run0, run1, A0, B0, A1, B1, c);
+        else walk_both_steps<false>(tab, col, active, rp0, rp1, b0, b1, run0, run1, A0, B0, A1, B1, c);
+        const int from = lo + c;                            /* first unpaired step of this segment */
+        int t0 = (n0 < hi ? n0 : hi) - from, t1 = (n1 < hi ? n1 : hi) - from;
+        if (t0 > 0) {
+            if (by) walk_one_steps<true>(tab, col, active, rp0, 1, b0, run0, A0, B0, t0);
+            else walk_one_steps<false>(tab, col, active, rp0, 1, b0, run0, A0, B0, t0);
         }
-        hist_bump(col, active && on0, rk0);
-        hist_bump(col, active && on1, rk1);
+        if (t1 > 0) {
+            if (by) walk_one_steps<true>(tab, col, active, rp1, -1, b1, run1, A1, B1, t1);
+            else walk_one_steps<false>(tab, col, active, rp1, -1, b1, run1, A1, B1, t1);
+        }
     }
     st0.running = run0;
     st1.running = run1;
