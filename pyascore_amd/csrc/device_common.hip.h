@@ -211,6 +211,7 @@ struct PeakTable {
     float err;
     float base;             /* m/z of the first retained peak                                    */
     float inv_w;            /* cells per m/z                                                     */
+    float nb;               /* -(base * inv_w): cell(x) = fma(x, inv_w, nb), one instruction      */
     int last_cell;
     bool half_check;        /* mz_error > 0.49: the reference's lower_bound(mz - .5) can bite    */
 };
@@ -246,7 +247,9 @@ DEV void stage_peak_table(const BatchDev &b, uint32_t psm, PeakEntry *dst, PeakT
 
 /* monotone non-decreasing in x: float subtract, multiply by a positive constant, truncate */
 DEV int grid_cell(const PeakTable &t, float x) {
-    const float rel = (x - t.base) * t.inv_w;
+    /* any function that does not decrease with x serves (a peak above the window's lower bound must not
+     * land in an earlier cell than the bound), as long as peaks and bounds go through the same one */
+    const float rel = __builtin_fmaf(x, t.inv_w, t.nb);
     /* v_cvt_u32_f32 saturates: below zero (and NaN) to 0, above the range to 2^32 - 1 -- the clamp at
      * zero without an instruction of its own */
     uint32_t c;
@@ -262,28 +265,57 @@ DEV void grid_params(PeakTable *t, float first, float last) {
     float inv_w = 0.125f;                                 /* 8 m/z per cell ...                */
     if (range * inv_w > (float)(PYA_GRID_CELLS - 2)) inv_w = (float)(PYA_GRID_CELLS - 2) / range;
     t->inv_w = inv_w;                                     /* ... or wider to fit the grid      */
-    int lc = (int)(range * inv_w);
-    if (lc > PYA_GRID_CELLS - 1) lc = PYA_GRID_CELLS - 1;
-    t->last_cell = lc;
+    t->nb = -(first * inv_w);
+    t->last_cell = PYA_GRID_CELLS - 1;
+    t->last_cell = grid_cell(*t, last);                   /* the last peak's own cell: every cell up to it gets filled */
 }
 
-/* builds the grid for the n staged peaks (wave-cooperative; caller syncs LDS before and after) */
+/* builds the grid for the n staged peaks (wave-cooperative; caller syncs LDS before and after):
+ * cell k = the (even) index at or before the first peak whose cell is >= k.  The first peak of every
+ * occupied cell writes its index; the empty cells then take the value of the next occupied one --
+ * four cells per lane, the lane's own suffix first, the rest from the nearest lane to the right that
+ * has an occupied cell (one ballot, one shuffle).  (A loop that lets every peak fill the cells back to
+ * its predecessor's runs as long as the widest gap: 200 vector instructions where this takes 50.) */
 DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
+    static_assert(PYA_GRID_CELLS == 256, "four cells per lane");
     const int lane = lane_id();
     t->cell = cell_lds;
     if (t->n <= 0) {
         t->base = 0.f;
         t->inv_w = 0.f;
+        t->nb = 0.f;
         t->last_cell = 0;
         if (lane == 0) cell_lds[0] = 0;
         return;
     }
     grid_params(t, t->e[0].mz, t->e[t->n - 1].mz);
-    for (int i = lane; i < t->n; i += 64) {
-        const int c = grid_cell(*t, t->e[i].mz);
-        const int cp = i > 0 ? grid_cell(*t, t->e[i - 1].mz) : -1;
-        for (int k = cp + 1; k <= c; k++) cell_lds[k] = (uint16_t)(i & ~1);   /* even: entries4 reads 16-byte pairs */
+    uint64_t *cells4 = (uint64_t *)cell_lds;
+    cells4[lane] = ~0ull;
+    wave_lds_sync();
+    int before = -1;                                      /* cell of the peak before this chunk */
+    for (int base = 0; base < t->n; base += 64) {
+        const int i = base + lane;
+        const bool in = i < t->n;
+        const int c = in ? grid_cell(*t, t->e[i].mz) : 0x7fffffff;
+        int cp = __shfl_up(c, 1, 64);
+        if (lane == 0) cp = before;
+        if (in && cp < c) cell_lds[c] = (uint16_t)(i & ~1);   /* even: entries4 reads 16-byte pairs */
+        before = __builtin_amdgcn_readlane(c, 63);
     }
+    wave_lds_sync();
+    const uint64_t w = cells4[lane];
+    const uint32_t E = 0xffffu;
+    uint32_t v0 = (uint32_t)w & E, v1 = (uint32_t)(w >> 16) & E, v2 = (uint32_t)(w >> 32) & E, v3 = (uint32_t)(w >> 48);
+    const uint32_t mine = v0 != E ? v0 : (v1 != E ? v1 : (v2 != E ? v2 : v3));   /* first occupied cell of the lane */
+    const uint64_t occupied = __ballot(mine != E);
+    const uint64_t right = lane == 63 ? 0ull : occupied & (~0ull << (lane + 1));
+    const int src = right ? __builtin_ctzll(right) : lane;
+    const uint32_t next = (uint32_t)__shfl((int)mine, src, 64);   /* (none: only past the last peak's cell, never read) */
+    v3 = v3 != E ? v3 : next;
+    v2 = v2 != E ? v2 : v3;
+    v1 = v1 != E ? v1 : v2;
+    v0 = v0 != E ? v0 : v1;
+    cells4[lane] = (uint64_t)(v0 | (v1 << 16)) | ((uint64_t)(v2 | (v3 << 16)) << 32);
 }
 
 /* Branch-light lookup: the grid gives an index at or before the first peak > lo; four entries
@@ -302,6 +334,7 @@ DEV void global_peak_table(const BatchDev &b, uint32_t psm, PeakTable *t) {
     t->half_check = b.cfg->mz_error > 0.49f;
     t->base = 0.f;
     t->inv_w = 0.f;
+    t->nb = 0.f;
     t->last_cell = 0;
     if (t->n > 0) grid_params(t, t->g_mz[0], t->g_mz[t->n - 1]);
 }

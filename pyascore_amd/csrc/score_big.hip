@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchD
     } else {
         tab.cell = grid;
         if (tab.n > 0) grid_params(&tab, t_e[0].mz, t_e[tab.n - 1].mz);
-        else { tab.base = 0.f; tab.inv_w = 0.f; tab.last_cell = 0; }
+        else { tab.base = 0.f; tab.inv_w = 0.f; tab.nb = 0.f; tab.last_cell = 0; }
     }
     __syncthreads();
     if (wave == 0) ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)grid)[lane];
