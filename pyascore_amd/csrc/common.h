@@ -85,6 +85,8 @@ struct BatchDev {
     uint32_t *redo_ids;             /* [n_psm] m/z order, or equal intensities inside a window)     */
     uint32_t *redo3_count;          /* PSMs the lean localize instantiation hands to the general one */
     uint32_t *redo3_ids;            /* [n_psm]                                                       */
+    uint32_t *redo3b_count;         /* ... and what the lean instantiation's second (sorting) pass declines */
+    uint32_t *redo3b_ids;           /* [n_psm]                                                       */
     uint32_t *redo4_count;          /* PSMs the fused score + localize kernel hands to the general   */
     uint32_t *redo4_ids;            /* [n_psm] localize instantiation                                */
     float *ws;                      /* weighted score per signature, pre-sort order         */

@@ -594,6 +594,8 @@ void fill_dev(pya_plan *p) {
     d.redo_ids = p->d_redo.p + 64;
     d.redo3_count = p->d_redo3.p;
     d.redo3_ids = p->d_redo3.p + 64;
+    d.redo3b_count = p->d_redo3.p + 1;
+    d.redo3b_ids = p->d_redo3.p + 64 + p->n_psm;
     d.redo4_count = p->d_redo4.p;
     d.redo4_ids = p->d_redo4.p + 64;
     d.ws = p->d_ws.p;
@@ -1297,7 +1299,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
                      o_ret_mz = reserve((size_t)p->total_peaks * 4), o_ret_rank = reserve((size_t)p->total_peaks),
-                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((n + 64) * 4), o_redo4 = reserve((p->fused_ids.size() + 64) * 4), o_ws_top = reserve(n * 16),
+                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve((p->fused_ids.size() + 64) * 4), o_ws_top = reserve(n * 16),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
@@ -1342,7 +1344,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_ret_rank.adopt(base + o_ret_rank, (size_t)p->total_peaks);
         p->d_grid.adopt(base + o_grid, n * PYA_GRID_CELLS);
         p->d_redo.adopt(base + o_redo, n + 64);
-        p->d_redo3.adopt(base + o_redo3, n + 64);
+        p->d_redo3.adopt(base + o_redo3, 2 * n + 64);
         p->d_redo4.adopt(base + o_redo4, p->fused_ids.size() + 64);
         p->d_ws_top.adopt(base + o_ws_top, n * 4);
         p->d_ws.adopt(base + o_ws, (size_t)sig_total);

@@ -87,7 +87,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     const bool presorted = zmax == 1 && cfg->n_nl == 0 &&
                            !__any(lane < res.L && !(res.m0 > 0.f && res.m1 > 0.f));
     if (PLAIN && (!presorted || b.keep || (b.debug & 512))) return true;   /* not this kernel's PSM */
-    STAMP(b, 20);
+    STAMP_T(b, 20, false);
 
     /* ---- sort (cpp/Ascore.cpp:141-146) ---- */
     if (lane == 0) *lds.n_pushed = 0;
@@ -124,7 +124,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
         first_max = wave_min_u32(first_max);
     }
     uint32_t best_i = first_max;
-    STAMP(b, 21);
+    STAMP_T(b, 21, false);
     /* The sort emulation needs 10 bytes of LDS per signature, which for thousands of signatures is
      * what decides this kernel's occupancy -- and most PSMs have a unique best PepScore and never
      * sort.  Big-C(n,k) launches of the lean instantiation therefore run without that room and hand the
@@ -136,19 +136,35 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
         srt.idx = (uint16_t *)(srt.key + N);
         srt.lpos = srt.idx + N;
         srt.rpos = srt.lpos + N;
-        for (int i = lane; i < N; i += 64) {
-            srt.key[i] = i < 64 ? ws_lane : ws[i];
-            srt.idx[i] = (uint16_t)i;
+        /* (eight loads on their way before the first is stored: thousands of scores, and a wavefront
+         * that makes one memory round trip per 64 of them spends its time waiting) */
+        for (int base = 0; base < N; base += 512) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = base + u * 64 + lane;
+                v[u] = ws[i < N ? i : N - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = base + u * 64 + lane;
+                if (i < N) {
+                    srt.key[i] = v[u];
+                    srt.idx[i] = (uint16_t)i;
+                }
+            }
         }
         wave_lds_sync();
         /* only the left spine of the partition tree decides the front element; the full sort is
          * needed when the caller wants the whole ordering */
+        int front_len = N;
         if (!(b.debug & 8)) {
-            if (sort_introsort_loop<PLAIN>(srt, N, b.keep == 0)) return true;
+            if (sort_introsort_loop<PLAIN>(srt, N, b.keep == 0, &front_len)) return true;
         }
-        /* front of the sorted list = left-most maximum of the partitioned array */
+        /* front of the sorted list = left-most maximum of the partitioned array (which the spine's last,
+         * left-most run holds: every element of it is at least as large as anything to its right) */
         uint32_t first_pos = 0xffffffffu;
-        for (int i = lane; i < N; i += 64)
+        for (int i = lane; i < front_len; i += 64)
             if (__float_as_uint(srt.key[i]) == kmax) first_pos = first_pos < (uint32_t)i ? first_pos : (uint32_t)i;
         first_pos = wave_min_u32(first_pos);
         best_i = srt.idx[first_pos];
@@ -156,12 +172,12 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
             for (int i = lane; i < N; i += 64) b.sorted_idx[s0 + sort_final_pos(srt, i, N)] = srt.idx[i];
         }
     }
-    STAMP(b, 22);
+    STAMP_T(b, 22, false);
     const float best_ws = __uint_as_float(kmax);
     const uint64_t best_bits = order[best_i];
     wave_lds_sync();
 
-    STAMP(b, 23);
+    STAMP_T(b, 23, false);
     /* ---- single-move competitors (cpp/Ascore.cpp:212-254).  The reference finds them by scanning the
      * sorted list; they are exactly the k * (n - k) signatures that differ from the winner by one moved
      * modification, so they are enumerated directly: signature -> combination rank (sum of C(p_t, t)
@@ -231,7 +247,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     uint32_t np = n_pushed < push_cap ? n_pushed : push_cap;
     if (b.debug & 16) np = 0;
 
-    STAMP(b, 24);
+    STAMP_T(b, 24, false);
     /* ---- Ascores, sb-1 competitors at a time ---- */
     ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap, sb);
     ctx.sb = (int)sb;
@@ -248,14 +264,14 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     if (lane == 0) w.sig_mask[0] = deposit_sites(best_bits, res.site_mask);
     wave_lds_sync();
 
-    STAMP(b, 25);
+    STAMP_T(b, 25, false);
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
     const bool declined = loc_ascore_all<PLAIN>(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
                    best_bits, best_ws, best_i, res.site_mask,
                    &my_asc, &my_alt, &fail);
     if (PLAIN && declined) return true;
-    STAMP(b, 36);
+    STAMP_T(b, 36, false);
     if (lane < k && lds.site_tie[lane]) my_asc = 0.f < my_asc ? 0.f : my_asc;
     if (lane < k) my_alt |= lds.site_alt[lane];
     if (lane < k && lane < (int)max_k) {

@@ -73,7 +73,12 @@ DEV void heap_sort_serial(const SortLds &s, int first, int last) {
     }
 }
 
-/* __unguarded_partition_pivot(first=f, last=l); returns the cut.  Wave-cooperative. */
+/* __unguarded_partition_pivot(first=f, last=l); returns the cut.  Wave-cooperative.
+ * LEFT_ONLY: the caller follows the left part only (the front of the sorted list is all it wants), so
+ * the elements a swap would move into the right part are not written.
+ * A wavefront here has little company on its CU (the sort room decides the occupancy), so the sweeps
+ * read four chunks before they use the first: one LDS round trip per 256 elements, not per 64. */
+template <bool LEFT_ONLY>
 DEV int sort_partition(const SortLds &s, int f, int l) {
     const int lane = lane_id();
     const int mid = f + (l - f) / 2;
@@ -95,37 +100,79 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
     const float pv = s.key[f];
     /* stops of the left cursor: positions in [f+1, l) ascending whose key is NOT > pivot */
     int nL = 0;
-    for (int base = f + 1; base < l; base += 64) {
-        const int i = base + lane;
-        const bool stop = i < l && !(s.key[i] > pv);
-        const uint64_t m = __ballot(stop);
-        if (stop) s.lpos[nL + __popcll(m & lanemask_lt())] = (uint16_t)i;
-        nL += __popcll(m);
+    for (int base = f + 1; base < l; base += 256) {
+        float k[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * 64 + lane;
+            k[u] = s.key[i < l ? i : l - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * 64 + lane;
+            const bool stop = i < l && !(k[u] > pv);
+            const uint64_t m = __ballot(stop);
+            if (stop) s.lpos[nL + __popcll(m & lanemask_lt())] = (uint16_t)i;
+            nL += __popcll(m);
+        }
     }
     /* stops of the right cursor: positions in [f, l) descending for which pivot is NOT > key */
     int nR = 0;
-    for (int base = l - 1; base >= f; base -= 64) {
-        const int i = base - lane;
-        const bool stop = i >= f && !(pv > s.key[i]);
-        const uint64_t m = __ballot(stop);
-        if (stop) s.rpos[nR + __popcll(m & lanemask_lt())] = (uint16_t)i;
-        nR += __popcll(m);
+    for (int base = l - 1; base >= f; base -= 256) {
+        float k[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base - u * 64 - lane;
+            k[u] = s.key[i >= f ? i : f];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base - u * 64 - lane;
+            const bool stop = i >= f && !(pv > k[u]);
+            const uint64_t m = __ballot(stop);
+            if (stop) s.rpos[nR + __popcll(m & lanemask_lt())] = (uint16_t)i;
+            nR += __popcll(m);
+        }
     }
     wave_lds_sync();
-    /* pair the r-th stops; they are exchanged while the cursors have not met */
+    /* pair the r-th stops; they are exchanged while the cursors have not met (all positions distinct) */
     const int np = nL < nR ? nL : nR;
     int m_sw = 0;
-    for (int base = 0; base < np; base += 64) {
-        const int r = base + lane;
-        bool sw = false;
-        int a = 0, b = 0;
-        if (r < np) {
-            a = s.lpos[r];
-            b = s.rpos[r];
-            sw = a < b;
+    for (int base = 0; base < np; base += 128) {
+        int a[2], b[2];
+        bool sw[2];
+        float ka[2], kb[2];
+        uint16_t ia[2], ib[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int r = base + u * 64 + lane;
+            a[u] = 0;
+            b[u] = 0;
+            if (r < np) {
+                a[u] = s.lpos[r];
+                b[u] = s.rpos[r];
+            }
+            sw[u] = r < np && a[u] < b[u];
         }
-        if (sw) sort_swap(s, a, b);
-        m_sw += __popcll(__ballot(sw));
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            ka[u] = s.key[a[u]];
+            kb[u] = s.key[b[u]];
+            ia[u] = s.idx[a[u]];
+            ib[u] = s.idx[b[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (sw[u]) {
+                s.key[a[u]] = kb[u];
+                s.idx[a[u]] = ib[u];
+                if (!LEFT_ONLY) {
+                    s.key[b[u]] = ka[u];
+                    s.idx[b[u]] = ia[u];
+                }
+            }
+            m_sw += __popcll(__ballot(sw[u]));
+        }
     }
     const int cand_l = m_sw < nL ? (int)s.lpos[m_sw] : 0x7fffffff;
     const int cand_r = m_sw >= 1 ? (int)s.rpos[m_sw - 1] : l;
@@ -138,12 +185,32 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
 /* PLAIN (the lean instantiation of the localize kernel, see rank_and_localize.hip) gives up --
  * returns true -- where the depth limit would call for the serial heap sort. */
 template <bool PLAIN>
-DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only) {
+DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only, int *front_len = nullptr) {
+    if (front_len) *front_len = N;
     if (N <= 16) return false;
     const int lane = lane_id();
     int depth0 = 0;
     for (int t = N; t > 1; t >>= 1) depth0++;
     depth0 *= 2;
+    if (spine_only) {
+        /* the front of the sorted list comes out of the left-most run: follow the left parts only.
+         * (The discarded right parts keep stale copies of what was swapped out of them.) */
+        int l = N, d = depth0;
+        while (l > 16) {
+            if (d == 0) {
+                if (PLAIN) return true;
+                wave_lds_sync();
+                if (lane == 0) heap_sort_serial(s, 0, l);   /* (stale right parts do not reach in here) */
+                wave_lds_sync();
+                break;
+            }
+            d--;
+            l = sort_partition<true>(s, 0, l);
+        }
+        if (front_len) *front_len = l;
+        wave_lds_sync();
+        return false;
+    }
     /* explicit stack, one entry per lane */
     int st_f = 0, st_l = 0, st_d = 0;
     int sp = 0;
@@ -161,11 +228,9 @@ DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only) {
                 break;
             }
             d--;
-            const int cut = sort_partition(s, f, l);
-            if (!spine_only) {
-                if (lane == sp) { st_f = cut; st_l = l; st_d = d; }
-                sp++;
-            }
+            const int cut = sort_partition<false>(s, f, l);
+            if (lane == sp) { st_f = cut; st_l = l; st_d = d; }
+            sp++;
             l = cut;
         }
     }
@@ -670,7 +735,7 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
             }
         }
         wave_lds_sync();
-        STAMP(*c.b, 30);
+        STAMP_T(*c.b, 30, false);
         if (!PLAIN) {
         /* ---- out of order anywhere?  then pad to the stride and run the bitonic network ---- */
         const int nlists = nsl << gt;
@@ -686,7 +751,7 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
             const float *base = w.pool + ((size_t)lid << g2);
             if (i + 1 < M && base[i] > base[i + 1]) unsorted = 1;
         }
-        STAMP(*c.b, 31);
+        STAMP_T(*c.b, 31, false);
         if (__any(unsorted)) {
             for (int e = lane; e < (nlists << g2); e += 64) {
                 const int lid = e >> g2, i = e & (P2 - 1);
@@ -716,7 +781,7 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
             }
         }
         }
-        STAMP(*c.b, 32);
+        STAMP_T(*c.b, 32, false);
         /* ---- cancel.  Site-determining ions = what the reference's greedy two-pointer walk
          * over the two sorted lists leaves (ModifiedPeptide.cpp:291-316).  When every ion has at
          * most one partner within mz_error in the other list, the walk cancels exactly those
@@ -816,7 +881,7 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
         if (!bad_tasks) {
             while (staged > 0) loc_stage_flush(c, staged);
             wave_lds_sync();
-            STAMP(*c.b, 33);
+            STAMP_T(*c.b, 33, false);
             continue;
         }
         if (PLAIN) continue;                               /* (unreachable: bad_tasks is empty) */
@@ -827,7 +892,7 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
             w.c_cnt[lane] = snap_cnt;
         }
         wave_lds_sync();
-        STAMP(*c.b, 33);
+        STAMP_T(*c.b, 33, false);
         {
             const int task = lane;                               /* ntask <= 64 */
             if (task < ntask && ((bad_tasks >> task) & 1ull)) {
@@ -860,7 +925,7 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
             }
             wave_lds_sync();
         }
-        STAMP(*c.b, 37);
+        STAMP_T(*c.b, 37, false);
         /* ---- match the surviving ions from the keep flags ---- */
         staged = 0;
         for (int base = 0; base < pair_items; base += 64) {
@@ -887,7 +952,7 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
         }
         while (staged > 0) loc_stage_flush(c, staged);
         wave_lds_sync();
-        STAMP(*c.b, 34);
+        STAMP_T(*c.b, 34, false);
     }
     return false;
 }
@@ -926,13 +991,13 @@ DEV bool loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, uns
             w.c_pre[lane] = pe.idx;
         }
         e += (uint32_t)take;
-        STAMP(b, 26);
+        STAMP_T(b, 26, false);
         if (S == 1) continue;
         if (lane == 0) w.c_pre[0] = best_i;
         wave_lds_sync();
         if (!(b.debug & 4)) loc_prefix_tables<PLAIN>(ctx, S);
         wave_lds_sync();
-        STAMP(b, 27);
+        STAMP_T(b, 27, false);
         {
             /* depth scores of signatures [have_best, S) from the recorded cumulative counts */
             for (int i = (have_best ? 10 : 0) + lane; i < S * 10; i += 64) {
@@ -946,13 +1011,13 @@ DEV bool loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, uns
                 w.scores[i] = sc;
             }
             wave_lds_sync();
-            STAMP(b, 28);
+            STAMP_T(b, 28, false);
         }
         have_best = true;
         if (!(b.debug & 1)) {
             if (loc_site_ions<PLAIN>(ctx, S)) return true;
         }
-        STAMP(b, 35);
+        STAMP_T(b, 35, false);
         /* one competitor per lane: the table reads of all of them are in flight together */
         float asc_l = 0.f;
         if (lane >= 1 && lane < S) {

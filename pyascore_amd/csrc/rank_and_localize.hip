@@ -50,6 +50,22 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_redo_kernel(BatchD
     }
 }
 
+/* Second pass of the lean instantiation, for launches whose first pass ran without room for the sort
+ * emulation: the PSMs that pass set aside (a tie for the best PepScore), now with that room; what this
+ * pass declines as well goes to the general instantiation through the second list. */
+__global__ __launch_bounds__(64, LOC_WAVES_PLAIN) void pya_localize_ties_kernel(BatchDev b, uint32_t push_cap,
+                                                                              uint32_t pos_cap, uint32_t pool_cap,
+                                                                              uint32_t sb, uint32_t gtp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t n = *b.redo3_count;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const uint32_t psm = b.redo3_ids[k];
+        const bool declined = localize_body<true>(b, psm, lds_raw, push_cap, pos_cap, pool_cap, sb, gtp, true);
+        if (declined && lane_id() == 0) b.redo3b_ids[atomicAdd(b.redo3b_count, 1u)] = psm;
+        wave_lds_sync();
+    }
+}
+
 /* PyAscore.calculate_ambiguity for PSM `psm` with caller-supplied score containers */
 __global__ __launch_bounds__(64) void pya_ambiguity_kernel(BatchDev b, uint32_t psm, uint32_t peak_cap,
                                                            uint32_t list_cap, uint64_t ref_bits,
@@ -117,23 +133,34 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
         return (int)hipGetLastError();
     }
     /* lean instantiation first, then whatever it declined on the general one */
-    e = hipMemsetAsync(b->redo3_count, 0, sizeof(uint32_t), stream);
+    e = hipMemsetAsync(b->redo3_count, 0, 2 * sizeof(uint32_t), stream);      /* both lists' counts */
     if (e != hipSuccess) return (int)e;
     e = PYA_ENSURE_MAX_LDS(pya_localize_kernel<true>);
     if (e != hipSuccess) return (int)e;
     /* more than 1024 signatures: the lean launch without room for the sort emulation (LDS -> occupancy);
-     * PSMs with a tie at the top go to the general instantiation through the hand-over list */
+     * PSMs with a tie at the top go through the hand-over list to a second lean pass that has the room */
     const uint32_t sort_room = (n_cap <= 1024 || getenv("PYA_SORT_ROOM")) ? 1u : 0u;
     const size_t lds_lean = sort_room ? lds : pya_localize_lds_bytes(push_cap, 0, pos_cap, pool_cap, sb);
     hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds_lean, stream, *b, d_ids, n_ids, push_cap,
                        pos_cap, pool_cap, sb, gtp, sort_room);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    const uint32_t grid = n_ids < 8192u ? n_ids : 8192u;
+    const uint32_t *count = b->redo3_count, *ids = b->redo3_ids;
+    if (!sort_room) {
+        e = PYA_ENSURE_MAX_LDS(pya_localize_ties_kernel);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(pya_localize_ties_kernel, dim3(grid), dim3(64), lds, stream, *b, push_cap, pos_cap, pool_cap, sb,
+                           gtp);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        count = b->redo3b_count;
+        ids = b->redo3b_ids;
+    }
     e = PYA_ENSURE_MAX_LDS(pya_localize_redo_kernel);
     if (e != hipSuccess) return (int)e;
-    const uint32_t grid = n_ids < 8192u ? n_ids : 8192u;
-    hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, b->redo3_count, b->redo3_ids,
-                       push_cap, pos_cap, pool_cap, sb, gtp);
+    hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, count, ids, push_cap, pos_cap,
+                       pool_cap, sb, gtp);
     return (int)hipGetLastError();
 }
 

@@ -22,4 +22,6 @@ plan = DevicePlan(s, batch)
 for _ in range(2):
     plan.run(mz, it)
 torch.cuda.synchronize()
+if os.environ["PYA_DEBUG"] == "0":
+    plan.check()                      # (PYA_HOST_TIMING=1: prints how many PSMs the lean kernels handed over)
 plan.close()
