@@ -48,7 +48,7 @@ def profiled_traffic(cfg, kernel, default_size):
     scripts/profile.sh in separate --pmc passes).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950
     FETCH_SIZE tallies 128-byte requests as 64 bytes, hence the factor 2 (MI355X_MICROARCH.md, HBM
     section).  Also returns the whole path's traffic (every pya_* kernel) and the share of the
-    family's SIMD cycles in which a vector instruction issues.  None when the run is not the profiled
+    family's SIMD cycles in which the vector ALU is occupied.  None when the run is not the profiled
     workload."""
     import csv
     import glob
@@ -72,9 +72,13 @@ def profiled_traffic(cfg, kernel, default_size):
     if "FETCH_SIZE" not in fam or "WRITE_SIZE" not in fam:
         return none
     valu = None
-    if fam.get("SQ_BUSY_CYCLES") and "SQ_INSTS_VALU" in fam:
-        # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles; 1024 SIMDs; SQ_BUSY_CYCLES sums 32 shader engines
-        valu = fam["SQ_INSTS_VALU"] * 2.0 / 1024.0 / (fam["SQ_BUSY_CYCLES"] / 32.0)
+    if fam.get("SQ_BUSY_CYCLES") and ("SQ_ACTIVE_INST_VALU" in fam or "SQ_INSTS_VALU" in fam):
+        # The bound these kernels actually run into: the vector ALUs.  SQ_ACTIVE_INST_VALU counts, in
+        # quad-cycles, the time waves spend executing vector instructions (it equals SQ_INSTS_VALU here:
+        # four cycles per wave64 instruction of this integer / compare / f64 mix); 1024 SIMDs;
+        # SQ_BUSY_CYCLES sums 32 shader engines.  1.0 = every SIMD's VALU occupied all the time.
+        quads = fam.get("SQ_ACTIVE_INST_VALU", fam.get("SQ_INSTS_VALU"))
+        valu = quads * 4.0 / 1024.0 / (fam["SQ_BUSY_CYCLES"] / 32.0)
     whole = (2.0 * path_total.get("FETCH_SIZE", 0.0) + path_total.get("WRITE_SIZE", 0.0)) * 1024.0
     return (2.0 * fam["FETCH_SIZE"] + fam["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT), valu, whole
 
@@ -326,8 +330,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         # what actually bounds the kernel: share of its cycles in which the vector ALUs issue
-                         "valu_issue_share": valu_share,
+                         # what actually bounds the kernel: share of its cycles in which the SIMDs' vector ALUs are
+                         # occupied (SQ_ACTIVE_INST_VALU x 4 / SIMDs / busy cycles of the committed counter pass)
+                         "valu_busy": valu_share,
                          # HBM bytes of the whole path per step (every kernel) next to the algorithmic bytes
                          "traffic_whole_path": traffic_path,
                          "traffic_over_algorithmic": (traffic_path / alg) if traffic_path else None,

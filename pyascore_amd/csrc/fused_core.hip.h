@@ -71,6 +71,7 @@ struct FusedLds {
     float *sc;               /* [1 + FUSED_ROUND][10] depth scores: winner, then the round's competitors */
     uint32_t *c_tr, *c_cnt;  /* [FUSED_ROUND * ndir][2] per task (competitor, direction) and side */
     uint32_t *bad_tasks;     /* bit t: task t has an ion with two partners -> replayed serially */
+    uint32_t *t_lo, *t_off;  /* [8] per task: first step of its span, items before it (see the pairing) */
     float *srt_v;            /* [FUSED_ROUND * ndir][2][ent_cap] a task's two lists, sorted (only filled for replays) */
     uint8_t *srt_h;          /* same shape: the ion matched a peak of rank <= depth */
     int32_t *c_depth;        /* [FUSED_ROUND] */
@@ -80,7 +81,7 @@ struct FusedLds {
 __host__ __device__ static inline size_t fused_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 __host__ __device__ static inline size_t fused_post_bytes(uint32_t n_cap, uint32_t push_cap, uint32_t ent_cap, uint32_t ndir) {
     return fused_align16((size_t)n_cap * 10) + (size_t)push_cap * 16 + 64 * 8 + 64 * 4 * 2 + 16 +
-           (size_t)(1 + FUSED_ROUND) * 40 + (size_t)FUSED_ROUND * (16 * ndir + 4 + 4) + 16 +
+           (size_t)(1 + FUSED_ROUND) * 40 + (size_t)FUSED_ROUND * (16 * ndir + 4 + 4) + 16 + 64 +
            fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap * 4) + fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap);
 }
 __host__ __device__ static inline size_t fused_walk_bytes(uint32_t cap) {
@@ -135,6 +136,9 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
     q += FUSED_ROUND * 4;
     f.bad_tasks = (uint32_t *)(raw + q);
     q += 16;
+    f.t_lo = (uint32_t *)(raw + q);
+    f.t_off = f.t_lo + 8;
+    q += 64;
     f.srt_v = (float *)(raw + q);
     q += fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap * 4);
     f.srt_h = (uint8_t *)(raw + q);
@@ -374,6 +378,9 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const int w = !active ? (int)stride - 1 : (BOTH ? (lane >> 5) * N + s : s);   /* this lane's column of the rank lists (last: spare) */
     /* positive residue masses make every list ascending (what the neighbour-probe pairing needs) */
     const bool presorted = !__any(lane < L && !(m0 > 0.f && m1 > 0.f));
+    /* every residue heavier than 1: neighbouring ions of a list are more than two tolerances apart
+     * (mz_error <= 0.49 here), so an ion has at most one partner in the other list */
+    const bool wide = !__any(lane < L && !(m0 > 1.f && m1 > 1.f));
     wave_lds_sync();
     STAMP_T(b, 40, false);
     walk_record(f.resd, f.cnt, tab, L, zmax, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, Bf == 0. && Bb == 0., active, f.rkl,
@@ -548,18 +555,61 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
          * cancels exactly the partnered pairs (localize_core.hip.h); a task with a doubly partnered
          * ion is replayed below. ---- */
         const int ents = Lm1 * zmax;                        /* ions of one list: one ascending run per charge */
-        const int items = nc * ndir * 2 * ents;
+        const int items_all = nc * ndir * 2 * ents;
         const FastDiv divE = fastdiv_make((uint32_t)(ents > 0 ? ents : 1));
+        /* Charge 1 and `wide`: the winner and a competitor differ in the modification state of some
+         * residues; the fragments that contain none of them, or all of them, have the same residues in
+         * both signatures -- their ions differ by rounding at most, pair with each other and (wide) with
+         * nothing else, so they are not site-determining.  Only the steps in between are examined: from the
+         * step that takes in the first differing residue to the one before the last (in travel order). */
+        const bool spans = !ZM && wide && !(b.debug & 2048);
+        int items = items_all;
+        if (spans) {
+            const int ntask = nc * ndir;
+            if (lane < ntask) {
+                const int c = lane / ndir, d = lane - c * ndir;
+                const int dd = BOTH ? d : (cfg->n_fwd > 0 ? 0 : 1);
+                const uint64_t diff = best_bits ^ f.pushed[e0 + c].bits;            /* site indices */
+                const int r_lo = nth_set_bit(site_mask, __builtin_ctzll(diff));
+                const int r_hi = nth_set_bit(site_mask, 63 - __builtin_clzll(diff));
+                const int lo = dd ? L - 1 - r_hi : r_lo, hi = dd ? L - 1 - r_lo : r_hi;
+                f.t_lo[lane] = (uint32_t)lo;
+                f.t_off[lane] = (uint32_t)(2 * (hi - lo));       /* both sides */
+            }
+            wave_lds_sync();
+            uint32_t acc = 0;
+            for (int t = 0; t < ntask; t++) {                 /* (at most FUSED_ROUND x 2 tasks: all lanes, same values) */
+                const uint32_t n = f.t_off[t];
+                wave_lds_sync();
+                if (lane == 0) f.t_off[t] = acc;
+                acc += n;
+            }
+            if (lane == 0) f.t_off[ntask] = acc;
+            items = (int)acc;
+            wave_lds_sync();
+        }
         if (!(b.debug & 1))
         for (int base = 0; base < items; base += 64) {
             const int e = base + lane;
             if (e < items) {
-                const uint32_t ts = fastdiv((uint32_t)e, divE);
-                const int en = e - (int)ts * ents;
+                int task, side, en;
+                if (spans) {
+                    const int ntask = nc * ndir;
+                    task = 0;
+                    for (int t = 1; t < ntask; t++) task += (uint32_t)e >= f.t_off[t] ? 1 : 0;
+                    const int rem = e - (int)f.t_off[task];
+                    const int len = (int)(f.t_off[task + 1] - f.t_off[task]) >> 1;
+                    side = rem >= len ? 1 : 0;
+                    en = (int)f.t_lo[task] + rem - side * len;
+                } else {
+                    const uint32_t ts = fastdiv((uint32_t)e, divE);
+                    en = e - (int)ts * ents;
+                    side = (int)ts & 1;
+                    task = (int)ts >> 1;
+                }
                 const int z0 = zmax == 1 ? 0 : (int)fastdiv((uint32_t)en, divL), i = en - z0 * Lm1;
-                const int side = (int)ts & 1;
-                const int d = BOTH ? ((int)ts >> 1) & 1 : 0;
-                const int c = BOTH ? (int)ts >> 2 : (int)ts >> 1;
+                const int d = BOTH ? task & 1 : 0;
+                const int c = BOTH ? task >> 1 : task;
                 const float *la = f.selm + (size_t)d * ent_cap;                            /* winner     */
                 const float *lb = f.selm + (size_t)((1 + c) * ndir + d) * ent_cap;         /* competitor */
                 const float *mine = side ? lb : la, *others = side ? la : lb;
@@ -589,7 +639,6 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
                 }
                 for (int zz = 0; zz < zmax; zz++)           /* the runs of the other charges: anywhere */
                     if (zz != z0) total += partners_in_run(others + zz * Lm1, Lm1, p2, me, side, err);
-                const int task = c * ndir + d;
                 if (total > 1 || (b.debug & 2048)) {
                     atomicOr(f.bad_tasks, 1u << task);      /* two partners: the serial walk decides */
                 } else if (total == 0) {
@@ -607,9 +656,9 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
              * two sorted lists (ModifiedPeptide.cpp:291-316).  Sorting = merging the per-charge runs:
              * an ion's place is its index in its own run plus, for every other run, the number of ions
              * that sort before it (equal values: the lower charge first). ---- */
-            for (int base = 0; base < items; base += 64) {
+            for (int base = 0; base < items_all; base += 64) {
                 const int e = base + lane;
-                if (e < items) {
+                if (e < items_all) {
                     const uint32_t ts = fastdiv((uint32_t)e, divE);
                     const int en = e - (int)ts * ents;
                     const int z0 = zmax == 1 ? 0 : (int)fastdiv((uint32_t)en, divL), i = en - z0 * Lm1;
