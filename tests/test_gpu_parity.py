@@ -658,3 +658,52 @@ print("same")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("same"), out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mod_mass,mz_error", [(57.02146, 0.05), (57.02146, 0.45), (114.04293, 0.3), (0.984016, 0.02),
+                                                (79.966331, 0.49)])
+def test_modification_mass_that_mimics_residues(mod_mass, mz_error, path):
+    """Site-determining ions when moving the modification reproduces other fragments' m/z: a modification as
+    heavy as glycine (or two of them, next to GG), and one lighter than a dalton (deamidation) with a
+    tolerance that makes neighbouring lists overlap.  The fused kernel pairs ions only between the first and
+    the last differing residue and relies on "at most one partner per ion" there; these are the inputs that
+    stress both assumptions, on every route of the scorer."""
+    rng = np.random.default_rng(int(mod_mass * 1000) + int(mz_error * 100))
+    settings = dict(bin_size=100.0, n_top=10, mod_group="STYN", mod_mass=mod_mass, mz_error=mz_error,
+                    fragment_types="by", neutral_losses=[])
+    peps = ["SGSGTGYGK", "GSGGSGGTK", "NGSGNGTGYR", "AGSTGGYGSGK", "SGGGSAGTGNK", "GGSGGSGGTGGYK", "TGSGNR", "SGTK"]
+    psms = []
+    for rep in range(40):
+        pep = peps[rep % len(peps)]
+        n_sites = sum(ch in "STYN" for ch in pep)
+        k = 1 + rep % min(3, n_sites - 1)
+        # peaks: every b/y fragment of a random assignment, jittered inside and just outside the tolerance,
+        # plus noise
+        masses = dict(G=57.02146, S=87.03203, T=101.04768, Y=163.06333, N=114.04293, A=71.03711, K=128.09496, R=156.10111)
+        sites = [i for i, ch in enumerate(pep) if ch in "STYN"]
+        chosen = set(rng.choice(sites, size=k, replace=False).tolist())
+        res = [masses[ch] + (mod_mass if i in chosen else 0.0) for i, ch in enumerate(pep)]
+        frag = []
+        run = 0.0
+        for m in res[:-1]:
+            run += m
+            frag.append(run + 1.007825)
+        run = 18.010565
+        for m in res[::-1][:-1]:
+            run += m
+            frag.append(run + 1.007825)
+        mz = np.array(frag)
+        mz = np.concatenate([mz + rng.uniform(-1.2, 1.2, mz.size) * mz_error, rng.uniform(60.0, 1400.0, 30)])
+        mz = np.sort(mz)
+        psm = dict(mz=mz, intensity=rng.lognormal(5, 1, mz.size), peptide=pep, n_of_mod=k, max_charge=1)
+        if rep % 5 == 4:
+            # a fixed modification that leaves a glycine lighter than a dalton: neighbouring ions of one list
+            # closer than two tolerances, the case the span shortcut must not be taken for
+            psm["aux_pos"] = np.array([pep.index("G") + 1], np.uint32)
+            psm["aux_mass"] = np.array([-56.42], np.float32)
+        psms.append(psm)
+    batch = synth.pack_batch(psms)
+    got = _gpu(settings).score_batch(batch)
+    want = _checker(settings).score_batch(batch, got["ascores"].shape[1])
+    _same(got, want)
