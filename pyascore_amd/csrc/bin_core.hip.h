@@ -222,11 +222,13 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
      * an exact remainder (fma) pins down. */
     auto window_of = [&](double v) -> uint16_t {
         const double x = v - (double)min_mz;
-        double q = __builtin_floor(x * inv_bs);
+        const double q = __builtin_floor(x * inv_bs);
         const double r = __builtin_fma(-q, bsd, x);
-        q = r < 0. ? q - 1. : (r >= bsd ? q + 1. : q);
-        const uint32_t w = q >= (double)(n_bins - 1) ? n_bins - 1 : (uint32_t)q;
-        return (uint16_t)w;
+        int qi = (int)q;                                    /* (the +-1 and the clamp as integers: five instructions for ten) */
+        qi += r >= bsd ? 1 : 0;
+        qi -= r < 0. ? 1 : 0;
+        const int last = (int)n_bins - 1;
+        return (uint16_t)(qi > last ? last : qi);
     };
     bool ok = true;
     {
@@ -265,8 +267,10 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                     if (lane == 63) nx = after;
                     if (i < P) {
                         const double x = v[u];
-                        tmn = x < tmn ? x : tmn;
-                        tmx = x > tmx ? x : tmx;
+                        if (EXACT) {                         /* (the common-case kernel hands unsorted spectra over) */
+                            tmn = x < tmn ? x : tmn;
+                            tmx = x > tmx ? x : tmx;
+                        }
                         uns |= (x > nx) ? 1 : 0;
                         s_inten[i] = it[u];
                         s_mzf[i] = (float)x;
@@ -276,6 +280,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             }
         }
         unsorted = __any(uns);
+        if (!EXACT && unsorted) return PYA_BIN_REDO;
         bool redo = !ok;
         if (unsorted) {
             tmn = wave_min_f64(tmn);
@@ -340,7 +345,23 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                 const int lo = le ? base + 63 - __builtin_clzll(le) : carry_lo;
                 const int hi = gt ? base + __builtin_ctzll(gt) - 1 : run_end;
                 const int len = in ? hi - lo + 1 : 0;
-                const int t_max = (int)wave_max_u32((uint32_t)len);
+                /* longest run that reaches into this chunk, from the ballot of the run starts: scalar work */
+                int t_max = 0;
+                {
+                    uint64_t m = starts;
+                    int prev = carry_lo;
+                    if (m & 1ull) {
+                        prev = base;
+                        m &= ~1ull;
+                    }
+                    while (m) {
+                        const int p = base + __builtin_ctzll(m);
+                        t_max = p - prev > t_max ? p - prev : t_max;
+                        prev = p;
+                        m &= m - 1;
+                    }
+                    t_max = run_end - prev + 1 > t_max ? run_end - prev + 1 : t_max;
+                }
                 carry_lo = __builtin_amdgcn_readlane(lo, 63);
                 /* mates are read at lo + t straight through the end of the lane's run (whatever
                  * follows in LDS is masked by t < len), so the address is one running pointer */
