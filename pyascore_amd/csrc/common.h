@@ -108,7 +108,10 @@ struct BatchDev {
      * Route selection, results stay exact (used by the tests): 128 every spectrum through
      * pya_bin_exact_kernel, 512 the lean localize instantiation declines every PSM, 1024 the
      * std::sort emulation runs even for a unique best PepScore, 2048 the fused kernel replays every
-     * (competitor, direction) task with the serial walk. */
+     * (competitor, direction) task with the serial walk (and pairs ions over whole lists, not spans),
+     * 4096 the general localize instantiation replays a task with a doubly partnered ion serially
+     * instead of walking its clusters in parallel.  Bits 16..31: truncation point of the diagnostic
+     * build (device_common.hip.h, STAMP_T). */
     uint32_t debug;
     unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */
 };

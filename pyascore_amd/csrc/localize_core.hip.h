@@ -792,6 +792,71 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
         const int ntask = ncomp << gt;
         const int pair_items = ntask * 2 * (int)mmax;
         uint64_t bad_tasks = 0;
+        /* Lists that are not position-indexed (several charges / neutral-loss variants merged by the
+         * sort): most tasks have an ion with two partners, and replaying a whole task serially costs
+         * 300 steps on one lane.  The greedy walk forgets everything at a gap: an ion that lies
+         * mz_error or more above every ion before it (of both lists, in merged order, list A first
+         * on ties) is reached with both cursors exactly past those ions, whatever happened before.
+         * So every such ion starts its own walk -- one lane per cluster of ions chained by gaps below
+         * mz_error, typically one to four steps -- and walks until the next ion would be such a start.
+         * One binary search per ion (its predecessor in the other list) finds the starts. */
+        const bool clusters = !PLAIN && !c.presorted && !(c.b->debug & 4096);
+        if (clusters) {
+            for (int base = 0; base < pair_items; base += 64) {
+                const int e = base + lane;
+                if (e >= pair_items) continue;
+                const uint32_t ts = fastdiv((uint32_t)e, divM);     /* task*2 + side */
+                const int i = e - (int)ts * (int)mmax;
+                const int side = (int)ts & 1, task = (int)ts >> 1;
+                const int t = task & ((1 << gt) - 1), cj = task >> gt;
+                if (tb + t >= T) continue;
+                const int cc = c0 + cj;
+                const int d = tb + t < cfg->n_fwd ? 0 : 1;
+                const int na = (int)w.tot[0 * 2 + d] * c.zmax, nb = (int)w.tot[cc * 2 + d] * c.zmax;
+                if (i >= (side ? nb : na)) continue;
+                const float *la = w.pool + ((size_t)t << g2);
+                const float *lb = w.pool + ((size_t)(((cj + 1) << gt) + t) << g2);
+                const float *mine = side ? lb : la, *other = side ? la : lb;
+                const int Mo = side ? na : nb;
+                const float me = mine[i];
+                /* ions of the other list that come before this one in merged order */
+                int j = 0;                                   /* in 0 .. Mo (a list can fill its stride: start at P2) */
+                for (int step = P2; step > 0; step >>= 1) {
+                    const int probe = j + step;
+                    const float o = probe - 1 < Mo ? other[probe - 1] : __builtin_huge_valf();
+                    if (side ? (o <= me) : (o < me)) j = probe;
+                }
+                const float before_own = i > 0 ? mine[i - 1] : -__builtin_huge_valf();
+                const float before_other = j > 0 ? other[j - 1] : -__builtin_huge_valf();
+                if (!(me - before_own >= err && me - before_other >= err)) continue;
+                uint8_t *ka = w.keep + ((size_t)(task * 2) << g2);
+                uint8_t *kb = ka + P2;
+                int ia = side ? j : i, ib = side ? i : j;
+                float reached = -__builtin_huge_valf();      /* largest ion this walk has consumed */
+                for (bool first = true;; first = false) {
+                    const float x = ia < na ? la[ia] : __builtin_huge_valf();
+                    const float y = ib < nb ? lb[ib] : __builtin_huge_valf();
+                    const float next = x <= y ? x : y;
+                    if (next == __builtin_huge_valf()) break;                 /* both lists done */
+                    if (!first && next - reached >= err) break;              /* the next walk's start */
+                    if (__builtin_fabsf(x - y) < err) {          /* ModifiedPeptide.cpp:291-316 */
+                        ka[ia++] = 0;
+                        kb[ib++] = 0;
+                        reached = __builtin_fmaxf(reached, x > y ? x : y);
+                    } else if (x < y) {
+                        ka[ia++] = 1;
+                        reached = __builtin_fmaxf(reached, x);
+                    } else {
+                        kb[ib++] = 1;
+                        reached = __builtin_fmaxf(reached, y);
+                    }
+                }
+            }
+            wave_lds_sync();
+            STAMP_T(*c.b, 33, false);
+            STAMP_T(*c.b, 37, false);
+        } else {
+
         /* Optimistic: an ion without a partner is staged for its lookup right here.  Should a task
          * turn out to need the serial replay (rare), the counts are put back and the round is
          * redone from the keep flags. */
@@ -926,8 +991,9 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
             wave_lds_sync();
         }
         STAMP_T(*c.b, 37, false);
+        }
         /* ---- match the surviving ions from the keep flags ---- */
-        staged = 0;
+        int staged = 0;
         for (int base = 0; base < pair_items; base += 64) {
             const int e = base + lane;
             bool kept = false;

@@ -139,7 +139,8 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     if (e != hipSuccess) return (int)e;
     /* more than 1024 signatures: the lean launch without room for the sort emulation (LDS -> occupancy);
      * PSMs with a tie at the top go through the hand-over list to a second lean pass that has the room */
-    const uint32_t sort_room = (n_cap <= 1024 || getenv("PYA_SORT_ROOM")) ? 1u : 0u;
+    static const uint32_t room_max = getenv("PYA_SORT_ROOM_MAX") ? (uint32_t)atoi(getenv("PYA_SORT_ROOM_MAX")) : 1024u;
+    const uint32_t sort_room = (n_cap <= room_max || getenv("PYA_SORT_ROOM")) ? 1u : 0u;
     const size_t lds_lean = sort_room ? lds : pya_localize_lds_bytes(push_cap, 0, pos_cap, pool_cap, sb);
     hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds_lean, stream, *b, d_ids, n_ids, push_cap,
                        pos_cap, pool_cap, sb, gtp, sort_room);

@@ -9,7 +9,8 @@ from pyascore_amd import PyAscore, synth
 from pyascore_amd.device import DevicePlan
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-desc = synth.describe(cfg, 125000 if cfg == "cfg3" else None, seed=1000)
+over = dict(max_charge=int(os.environ["PYA_MAX_CHARGE"])) if os.environ.get("PYA_MAX_CHARGE") else {}
+desc = synth.describe(cfg, 125000 if cfg == "cfg3" else None, seed=1000, **over)
 batch = synth.make_slice(desc)
 st = desc["settings"]
 s = PyAscore(st["bin_size"], st["n_top"], st["mod_group"], st["mod_mass"], mz_error=st["mz_error"],

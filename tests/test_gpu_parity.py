@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
-                        "fused_replay"])
+                        "fused_replay", "general_serial_replay"])
 def path(request, monkeypatch):
     """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
     assignments on the fused score + localize kernel and the other plain ones on the lean
@@ -24,7 +24,8 @@ def path(request, monkeypatch):
     instantiation declining every PSM (PYA_DEBUG=512), which sends them through their hand-over lists
     to the general one; and with the std::sort emulation run even where a unique best PepScore makes it
     unnecessary (PYA_DEBUG=1024), without and with the fused kernel; and with the fused kernel replaying
-    every (competitor, direction) task serially (PYA_DEBUG=2048)."""
+    every (competitor, direction) task serially (PYA_DEBUG=2048); and the general instantiation with whole-task
+    serial replays instead of cluster walks (PYA_NO_PLAIN=1, PYA_DEBUG=4096)."""
     monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
     monkeypatch.delenv("PYA_NO_FUSED", raising=False)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
@@ -38,6 +39,9 @@ def path(request, monkeypatch):
         monkeypatch.setenv("PYA_DEBUG", "2048")
     if request.param == "general_localize":
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
+    elif request.param == "general_serial_replay":
+        monkeypatch.setenv("PYA_NO_PLAIN", "1")
+        monkeypatch.setenv("PYA_DEBUG", "4096")
     elif request.param == "lean_declines":
         monkeypatch.setenv("PYA_DEBUG", "512")
     elif request.param == "always_sort":
