@@ -764,16 +764,16 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
             const int gh = g2 - 1;                               /* pairs per list = 1 << gh */
             for (int k = 2; k <= P2; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
+                    /* the lists sit back to back at the stride P2 = 2 * (pairs per list), so a pair's index
+                     * across all lists with a zero bit inserted at j is its lower element's pool index */
                     for (int e = lane; e < (nlists << gh); e += 64) {
-                        const int lid = e >> gh, tt = e & ((1 << gh) - 1);
-                        const int lo = ((tt & ~(j - 1)) << 1) | (tt & (j - 1));
-                        const int hi = lo | j;
-                        const bool up = (lo & k) == 0;
-                        float *base = w.pool + ((size_t)lid << g2);
-                        const float a = base[lo], bb = base[hi];
+                        const int lo = ((e & ~(j - 1)) << 1) | (e & (j - 1));
+                        const bool up = (lo & k & (P2 - 1)) == 0;    /* (k = P2: the last merge, ascending in every list) */
+                        float *at = w.pool + lo;
+                        const float a = at[0], bb = at[j];
                         if ((a > bb) == up) {
-                            base[lo] = bb;
-                            base[hi] = a;
+                            at[0] = bb;
+                            at[j] = a;
                         }
                     }
                     wave_lds_sync();
