@@ -42,6 +42,15 @@ def algorithmic_bytes(batch, max_k):
     return 16 * peaks + res + 8 * n + 8 * aux + 16 * n + 64 * n
 
 
+# the kernels between two of the plan's timing events = one family of the bench line
+FAMILIES = {
+    "pya_bin_spectra_kernel": ("pya_bin_spectra_kernel", "pya_bin_exact_kernel"),
+    "pya_score_signatures_kernel": ("pya_score_signatures_kernel", "pya_score_big_kernel"),
+    "pya_score_localize_kernel": ("pya_score_localize_kernel",),
+    "pya_localize_kernel": ("pya_localize_kernel", "pya_localize_ties_kernel", "pya_localize_redo_kernel"),
+}
+
+
 def profiled_traffic(cfg, kernel, default_size):
     """HBM bytes per step of the kernel family `kernel` (all its instantiations and launches) from the
     newest committed PMC summary of this config (profiles/*_rocprof_<cfg>/pmc_summary.csv, collected by
@@ -65,7 +74,7 @@ def profiled_traffic(cfg, kernel, default_size):
             for row in csv.DictReader(f):
                 val = float(row.get("per_step") or row["mean_value"])
                 path_total[row["counter"]] = path_total.get(row["counter"], 0.0) + val
-                if row["kernel"].split("<")[0] == kernel:
+                if row["kernel"].split("<")[0] in FAMILIES.get(kernel, (kernel,)):
                     fam[row["counter"]] = fam.get(row["counter"], 0.0) + val
     except OSError:
         return none
