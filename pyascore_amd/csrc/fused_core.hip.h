@@ -63,8 +63,7 @@ struct FusedLds {
     uint32_t *flag_l;
     float *selm;
     /* post region */
-    float *sort_key;
-    uint16_t *sort_idx, *sort_l, *sort_r;
+    unsigned char *sort_raw;   /* sort_carve(sort_raw, N): the std::sort emulation's work area */
     PushedEntry *pushed;
     unsigned long long *site_alt;
     uint32_t *site_max, *site_tie, *n_pushed;
@@ -79,8 +78,13 @@ struct FusedLds {
 };
 
 __host__ __device__ static inline size_t fused_align16(size_t v) { return (v + 15) & ~(size_t)15; }
+/* (sort_lds_bytes of localize_core.hip.h, restated for the host side of this header) */
+__host__ __device__ static inline size_t fused_sort_bytes(uint32_t n) {
+    if (n <= 64) return ((size_t)n * 10 + 15) & ~(size_t)15;
+    return (((size_t)n * 6 + 15) & ~(size_t)15) + ((size_t)n / 64 + 2) * 16 + 2 * 128 * 2;
+}
 __host__ __device__ static inline size_t fused_post_bytes(uint32_t n_cap, uint32_t push_cap, uint32_t ent_cap, uint32_t ndir) {
-    return fused_align16((size_t)n_cap * 10) + (size_t)push_cap * 16 + 64 * 8 + 64 * 4 * 2 + 16 +
+    return fused_align16(fused_sort_bytes(n_cap)) + (size_t)push_cap * 16 + 64 * 8 + 64 * 4 * 2 + 16 +
            (size_t)(1 + FUSED_ROUND) * 40 + (size_t)FUSED_ROUND * (16 * ndir + 4 + 4) + 16 + 64 +
            fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap * 4) + fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap);
 }
@@ -109,11 +113,8 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
     f.cnt = (uint32_t *)(raw + o);
     f.peaks = (PeakEntry *)(raw + o + PYA_NTOP / 2 * 64 * 4);
     /* post region over the walk region */
-    f.sort_key = (float *)(raw + o);
-    f.sort_idx = (uint16_t *)(raw + o + (size_t)n_cap * 4);
-    f.sort_l = (uint16_t *)(raw + o + (size_t)n_cap * 6);
-    f.sort_r = (uint16_t *)(raw + o + (size_t)n_cap * 8);
-    size_t q = o + fused_align16((size_t)n_cap * 10);
+    f.sort_raw = raw + o;
+    size_t q = o + fused_align16(fused_sort_bytes(n_cap));
     f.pushed = (PushedEntry *)(raw + q);
     q += (size_t)push_cap * sizeof(PushedEntry);
     f.site_alt = (unsigned long long *)(raw + q);
@@ -449,17 +450,13 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         f.site_tie[lane] = 0;
         f.site_alt[lane] = 0ull;
         if (__popcll(at_max) != 1 || (b.debug & 1024)) {
-            SortLds srt;
-            srt.key = f.sort_key;
-            srt.idx = f.sort_idx;
-            srt.lpos = f.sort_l;
-            srt.rpos = f.sort_r;
+            const SortLds srt = sort_carve(f.sort_raw, N);
             if (sig_lane) {
                 srt.key[lane] = my_ws;
                 srt.idx[lane] = (uint16_t)lane;
             }
             wave_lds_sync();
-            if (!(b.debug & 8) && sort_introsort_loop<true>(srt, N, true)) declined = true;
+            if (!(b.debug & 8) && sort_introsort_loop<true, true>(srt, N, true)) declined = true;
             const uint64_t m2 = __ballot(sig_lane && __float_as_uint(srt.key[lane]) == kmax);
             best_i = srt.idx[__builtin_ctzll(m2)];
         }

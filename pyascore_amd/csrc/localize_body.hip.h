@@ -9,7 +9,7 @@ static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint3
                                         uint32_t sb) {
     /* (the localize kernel looks peaks up in global memory: no peak table here) */
     size_t fixed = 512 + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + 64 * 16 + 16;
-    size_t srt = (size_t)n_cap * 10 + 64;
+    size_t srt = n_cap ? sort_lds_bytes(n_cap) + 64 : 64;
     size_t lst = pya_loc_lds_bytes(pos_cap, pool_cap, sb);
     return fixed + (srt > lst ? srt : lst) + 64;
 }
@@ -131,11 +131,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
      * PSMs with a tie at the top to the general instantiation. */
     if (PLAIN && !sort_room && (n_max != 1 || (b.debug & 1024))) return true;
     if (n_max != 1 || b.keep || (b.debug & 1024)) {
-        SortLds srt;
-        srt.key = (float *)lds.scratch;
-        srt.idx = (uint16_t *)(srt.key + N);
-        srt.lpos = srt.idx + N;
-        srt.rpos = srt.lpos + N;
+        const SortLds srt = sort_carve(lds.scratch, N);
         /* (eight loads on their way before the first is stored: thousands of scores, and a wavefront
          * that makes one memory round trip per 64 of them spends its time waiting) */
         for (int base = 0; base < N; base += 512) {

@@ -9,12 +9,42 @@
 /* ======================================================================================= */
 /* std::sort emulation                                                                      */
 /* ======================================================================================= */
+/* Work area of the sort emulation: 6 bytes per element (key, index) plus, per 64 elements, the two
+ * 64-bit masks of a partition pass's cursor stops, plus two 128-entry queues the stops are unpacked
+ * into as the pass pairs them.  (Listing every stop -- 4 more bytes per element -- made the sort room
+ * 10 bytes per signature, and that room decides how many wavefronts a CU holds while thousands of
+ * scores are sorted: 30 KB -> 19 KB for 3003.) */
 struct SortLds {
-    float *key;       /* [N] */
-    uint16_t *idx;    /* [N] */
-    uint16_t *lpos;   /* [N] */
-    uint16_t *rpos;   /* [N] */
+    float *key;          /* [N] */
+    uint16_t *idx;       /* [N] */
+    uint64_t *lmask;     /* [N / 64 + 2] stops of the left cursor, chunk by chunk from the left   */
+    uint64_t *rmask;     /* [N / 64 + 2] stops of the right cursor, chunk by chunk from the right */
+    uint16_t *lq, *rq;   /* [qmask + 1] each: positions of the stops being paired                */
+    int qmask;           /* 127; 63 when there are at most 64 elements (no stop index reaches 64) */
 };
+__host__ __device__ static inline size_t sort_lds_bytes(size_t n) {
+    if (n <= 64) return (n * 10 + 15) & ~(size_t)15;      /* two plain lists of n stops, no masks */
+    return ((n * 6 + 15) & ~(size_t)15) + (n / 64 + 2) * 16 + 2 * 128 * 2;
+}
+DEV SortLds sort_carve(unsigned char *raw, int N) {
+    SortLds s;
+    s.key = (float *)raw;
+    s.idx = (uint16_t *)(s.key + N);
+    if (N <= 64) {
+        s.qmask = 63;
+        s.lmask = s.rmask = nullptr;
+        s.lq = s.idx + N;
+        s.rq = s.lq + N;
+        return s;
+    }
+    unsigned char *m = raw + (((size_t)N * 6 + 15) & ~(size_t)15);
+    s.lmask = (uint64_t *)m;
+    s.rmask = s.lmask + (N / 64 + 2);
+    s.qmask = 127;
+    s.lq = (uint16_t *)(s.rmask + (N / 64 + 2));
+    s.rq = s.lq + 128;
+    return s;
+}
 
 DEV void sort_swap(const SortLds &s, int i, int j) {
     float k = s.key[i];
@@ -78,7 +108,9 @@ DEV void heap_sort_serial(const SortLds &s, int first, int last) {
  * the elements a swap would move into the right part are not written.
  * A wavefront here has little company on its CU (the sort room decides the occupancy), so the sweeps
  * read four chunks before they use the first: one LDS round trip per 256 elements, not per 64. */
-template <bool LEFT_ONLY>
+/* SMALL_ONLY: the caller never has more than 64 elements (the fused kernel): the general path is not
+ * compiled in -- its arrays would cost that kernel a scratch allocation. */
+template <bool LEFT_ONLY, bool SMALL_ONLY = false>
 DEV int sort_partition(const SortLds &s, int f, int l) {
     const int lane = lane_id();
     const int mid = f + (l - f) / 2;
@@ -98,8 +130,44 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
         wave_lds_sync();
     }
     const float pv = s.key[f];
-    /* stops of the left cursor: positions in [f+1, l) ascending whose key is NOT > pivot */
-    int nL = 0;
+    if (SMALL_ONLY || s.qmask == 63) {
+        /* at most 64 elements: one chunk per cursor, and every stop fits the queues, which then are
+         * plain lists */
+        const int il = f + 1 + lane, ir = l - 1 - lane;
+        const float kl = s.key[il < l ? il : l - 1], kr = s.key[ir >= f ? ir : f];
+        const bool stop_l = il < l && !(kl > pv), stop_r = ir >= f && !(pv > kr);
+        const uint64_t ml = __ballot(stop_l), mr = __ballot(stop_r);
+        if (stop_l) s.lq[__popcll(ml & lanemask_lt())] = (uint16_t)il;
+        if (stop_r) s.rq[__popcll(mr & lanemask_lt())] = (uint16_t)ir;
+        const int nL = __popcll(ml), nR = __popcll(mr);
+        wave_lds_sync();
+        const int np = nL < nR ? nL : nR;
+        int a = 0, b = 0;
+        if (lane < np) {
+            a = s.lq[lane];
+            b = s.rq[lane];
+        }
+        const bool sw = lane < np && a < b;
+        const float ka = s.key[a], kb = s.key[b];
+        const uint16_t ia = s.idx[a], ib = s.idx[b];
+        if (sw) {
+            s.key[a] = kb;
+            s.idx[a] = ib;
+            if (!LEFT_ONLY) {
+                s.key[b] = ka;
+                s.idx[b] = ia;
+            }
+        }
+        const int m_sw = __popcll(__ballot(sw));
+        const int cand_l = m_sw < nL ? (int)s.lq[m_sw] : 0x7fffffff;
+        const int cand_r = m_sw >= 1 ? (int)s.rq[m_sw - 1] : l;
+        wave_lds_sync();
+        return cand_l < cand_r ? cand_l : cand_r;
+    }
+    if (SMALL_ONLY) return l;                               /* (not reached) */
+    /* stops of the left cursor: positions in [f+1, l) ascending whose key is NOT > pivot -- one mask
+     * per chunk of 64 positions */
+    int nL = 0, nLc = 0;
     for (int base = f + 1; base < l; base += 256) {
         float k[4];
 #pragma unroll
@@ -109,15 +177,17 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int i = base + u * 64 + lane;
-            const bool stop = i < l && !(k[u] > pv);
-            const uint64_t m = __ballot(stop);
-            if (stop) s.lpos[nL + __popcll(m & lanemask_lt())] = (uint16_t)i;
-            nL += __popcll(m);
+            if (base + u * 64 < l) {                         /* (wave-uniform) */
+                const int i = base + u * 64 + lane;
+                const uint64_t m = __ballot(i < l && !(k[u] > pv));
+                if (lane == 0) s.lmask[nLc] = m;
+                nLc++;
+                nL += __popcll(m);
+            }
         }
     }
     /* stops of the right cursor: positions in [f, l) descending for which pivot is NOT > key */
-    int nR = 0;
+    int nR = 0, nRc = 0;
     for (int base = l - 1; base >= f; base -= 256) {
         float k[4];
 #pragma unroll
@@ -127,55 +197,74 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int i = base - u * 64 - lane;
-            const bool stop = i >= f && !(pv > k[u]);
-            const uint64_t m = __ballot(stop);
-            if (stop) s.rpos[nR + __popcll(m & lanemask_lt())] = (uint16_t)i;
-            nR += __popcll(m);
+            if (base - u * 64 >= f) {
+                const int i = base - u * 64 - lane;
+                const uint64_t m = __ballot(i >= f && !(pv > k[u]));
+                if (lane == 0) s.rmask[nRc] = m;
+                nRc++;
+                nR += __popcll(m);
+            }
         }
     }
     wave_lds_sync();
-    /* pair the r-th stops; they are exchanged while the cursors have not met (all positions distinct) */
+    /* Pair the r-th stops; they are exchanged while the cursors have not met (the left stops ascend, the
+     * right ones descend: once a pair has met, all later ones have).  The stops of a chunk are unpacked
+     * into the queues -- entry r at slot r mod 128 (mod 64 for at most 64 elements) -- just ahead of the block of 64 pairs that needs them. */
     const int np = nL < nR ? nL : nR;
-    int m_sw = 0;
-    for (int base = 0; base < np; base += 128) {
-        int a[2], b[2];
-        bool sw[2];
-        float ka[2], kb[2];
-        uint16_t ia[2], ib[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int r = base + u * 64 + lane;
-            a[u] = 0;
-            b[u] = 0;
-            if (r < np) {
-                a[u] = s.lpos[r];
-                b[u] = s.rpos[r];
+    int m_sw = 0, lprod = 0, rprod = 0, lc = 0, rc = 0;
+    auto unpack_left = [&](int upto) {                     /* until entry `upto` exists (or no chunk is left) */
+        while (lprod <= upto && lc < nLc) {
+            const uint64_t mv = s.lmask[lc];
+            const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mv >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mv);
+            if ((m >> lane) & 1ull) s.lq[(lprod + __popcll(m & lanemask_lt())) & s.qmask] = (uint16_t)(f + 1 + lc * 64 + lane);
+            lprod += __popcll(m);
+            lc++;
+        }
+    };
+    auto unpack_right = [&](int upto) {
+        while (rprod <= upto && rc < nRc) {
+            const uint64_t mv = s.rmask[rc];
+            const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mv >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mv);
+            if ((m >> lane) & 1ull) s.rq[(rprod + __popcll(m & lanemask_lt())) & s.qmask] = (uint16_t)(l - 1 - rc * 64 - lane);
+            rprod += __popcll(m);
+            rc++;
+        }
+    };
+    for (int r0 = 0; r0 < np; r0 += 64) {
+        unpack_left(r0 + 63);
+        unpack_right(r0 + 63);
+        wave_lds_sync();
+        const int r = r0 + lane;
+        int a = 0, b = 0;
+        if (r < np) {
+            a = s.lq[r & s.qmask];
+            b = s.rq[r & s.qmask];
+        }
+        const bool sw = r < np && a < b;
+        const float ka = s.key[a], kb = s.key[b];
+        const uint16_t ia = s.idx[a], ib = s.idx[b];
+        if (sw) {
+            s.key[a] = kb;
+            s.idx[a] = ib;
+            if (!LEFT_ONLY) {
+                s.key[b] = ka;
+                s.idx[b] = ia;
             }
-            sw[u] = r < np && a[u] < b[u];
         }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            ka[u] = s.key[a[u]];
-            kb[u] = s.key[b[u]];
-            ia[u] = s.idx[a[u]];
-            ib[u] = s.idx[b[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            if (sw[u]) {
-                s.key[a[u]] = kb[u];
-                s.idx[a[u]] = ib[u];
-                if (!LEFT_ONLY) {
-                    s.key[b[u]] = ka[u];
-                    s.idx[b[u]] = ia[u];
-                }
-            }
-            m_sw += __popcll(__ballot(sw[u]));
-        }
+        const int n_sw = __popcll(__ballot(sw));
+        m_sw += n_sw;
+        wave_lds_sync();
+        if (n_sw < 64) break;                              /* the cursors have met (or the pairs ran out) */
     }
-    const int cand_l = m_sw < nL ? (int)s.lpos[m_sw] : 0x7fffffff;
-    const int cand_r = m_sw >= 1 ? (int)s.rpos[m_sw - 1] : l;
+    int cand_l = 0x7fffffff;
+    if (m_sw < nL) {
+        unpack_left(m_sw);
+        wave_lds_sync();
+        cand_l = (int)s.lq[m_sw & s.qmask];
+    }
+    const int cand_r = m_sw >= 1 ? (int)s.rq[(m_sw - 1) & s.qmask] : l;
     wave_lds_sync();
     return cand_l < cand_r ? cand_l : cand_r;
 }
@@ -184,7 +273,7 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
  * (or heap-sorted runs) exactly as libstdc++ leaves it before __final_insertion_sort. */
 /* PLAIN (the lean instantiation of the localize kernel, see rank_and_localize.hip) gives up --
  * returns true -- where the depth limit would call for the serial heap sort. */
-template <bool PLAIN>
+template <bool PLAIN, bool SMALL_ONLY = false>
 DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only, int *front_len = nullptr) {
     if (front_len) *front_len = N;
     if (N <= 16) return false;
@@ -205,7 +294,7 @@ DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only, int *fron
                 break;
             }
             d--;
-            l = sort_partition<true>(s, 0, l);
+            l = sort_partition<true, SMALL_ONLY>(s, 0, l);
         }
         if (front_len) *front_len = l;
         wave_lds_sync();
@@ -228,7 +317,7 @@ DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only, int *fron
                 break;
             }
             d--;
-            const int cut = sort_partition<false>(s, f, l);
+            const int cut = sort_partition<false, SMALL_ONLY>(s, f, l);
             if (lane == sp) { st_f = cut; st_l = l; st_d = d; }
             sp++;
             l = cut;

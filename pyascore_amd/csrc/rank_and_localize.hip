@@ -105,11 +105,7 @@ __global__ __launch_bounds__(64) void pya_debug_sort_kernel(const float *keys, u
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     const int N = (int)n;
-    SortLds srt;
-    srt.key = (float *)lds_raw;
-    srt.idx = (uint16_t *)(srt.key + N);
-    srt.lpos = srt.idx + N;
-    srt.rpos = srt.lpos + N;
+    const SortLds srt = sort_carve(lds_raw, N);
     for (int i = lane; i < N; i += 64) {
         srt.key[i] = keys[i];
         srt.idx[i] = (uint16_t)i;
@@ -196,7 +192,7 @@ extern "C" int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t pe
 }
 
 extern "C" int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream) {
-    size_t lds = (size_t)n * 10 + 64;
+    size_t lds = sort_lds_bytes(n) + 64;
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_debug_sort_kernel);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_debug_sort_kernel, dim3(1), dim3(64), lds, stream, d_keys, n, d_perm);
