@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64, LOC_WAVES) void pya_localize_redo_kernel(BatchD
 /* Second pass of the lean instantiation, for launches whose first pass ran without room for the sort
  * emulation: the PSMs that pass set aside (a tie for the best PepScore), now with that room; what this
  * pass declines as well goes to the general instantiation through the second list. */
-__global__ __launch_bounds__(64, LOC_WAVES_PLAIN) void pya_localize_ties_kernel(BatchDev b, uint32_t push_cap,
+/* (its sort room holds it to two wavefronts per SIMD anyway: registers to match, no spills) */
+__global__ __launch_bounds__(64, 2) void pya_localize_ties_kernel(BatchDev b, uint32_t push_cap,
                                                                               uint32_t pos_cap, uint32_t pool_cap,
                                                                               uint32_t sb, uint32_t gtp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
