@@ -379,9 +379,11 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const int w = !active ? (int)stride - 1 : (BOTH ? (lane >> 5) * N + s : s);   /* this lane's column of the rank lists (last: spare) */
     /* positive residue masses make every list ascending (what the neighbour-probe pairing needs) */
     const bool presorted = !__any(lane < L && !(m0 > 0.f && m1 > 0.f));
-    /* every residue heavier than 1: neighbouring ions of a list are more than two tolerances apart
-     * (mz_error <= 0.49 here), so an ion has at most one partner in the other list */
-    const bool wide = !__any(lane < L && !(m0 > 1.f && m1 > 1.f));
+    /* every residue heavier than two tolerances (and a margin for the rounding of the running sums):
+     * neighbouring ions of a list are more than two tolerances apart, so an ion has at most one partner
+     * in the other list */
+    const float wide_min = 2.f * cfg->mz_error + 0.02f;
+    const bool wide = !__any(lane < L && !(m0 > wide_min && m1 > wide_min));
     wave_lds_sync();
     STAMP_T(b, 40, false);
     walk_record(f.resd, f.cnt, tab, L, zmax, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, Bf == 0. && Bb == 0., active, f.rkl,
@@ -554,7 +556,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         const int ents = Lm1 * zmax;                        /* ions of one list: one ascending run per charge */
         const int items_all = nc * ndir * 2 * ents;
         const FastDiv divE = fastdiv_make((uint32_t)(ents > 0 ? ents : 1));
-        /* Charge 1 and `wide`: the winner and a competitor differ in the modification state of some
+        /* Charge 1 and `wide` (above): the winner and a competitor differ in the modification state of some
          * residues; the fragments that contain none of them, or all of them, have the same residues in
          * both signatures -- their ions differ by rounding at most, pair with each other and (wide) with
          * nothing else, so they are not site-determining.  Only the steps in between are examined: from the

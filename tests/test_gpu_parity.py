@@ -666,7 +666,7 @@ print("same")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mod_mass,mz_error", [(57.02146, 0.05), (57.02146, 0.45), (114.04293, 0.3), (0.984016, 0.02),
-                                                (79.966331, 0.49)])
+                                                (79.966331, 0.49), (79.966331, 4.0), (57.02146, 4.0)])
 def test_modification_mass_that_mimics_residues(mod_mass, mz_error, path):
     """Site-determining ions when moving the modification reproduces other fragments' m/z: a modification as
     heavy as glycine (or two of them, next to GG), and one lighter than a dalton (deamidation) with a
