@@ -9,6 +9,9 @@ __version__ = "0.2.0"
 _AUX = ("PyBinnedSpectra", "PyModifiedPeptide", "PyFragmentGraph", "PyLogMath", "PyBinomialDist", "PyPowerSetSum")
 
 
+_INGEST = ("SpectraParser", "IdentificationParser", "MassCorrector", "COMMON_MODS", "STD_AA_MASS")
+
+
 def __getattr__(name):
     if name == "PyAscore":
         from .ascore import PyAscore
@@ -16,4 +19,7 @@ def __getattr__(name):
     if name in _AUX:
         from . import aux
         return getattr(aux, name)
+    if name in _INGEST:
+        from . import ingest
+        return getattr(ingest, name)
     raise AttributeError(name)
