@@ -562,6 +562,12 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
          * nothing else, so they are not site-determining.  Only the steps in between are examined: from the
          * step that takes in the first differing residue to the one before the last (in travel order). */
         const bool spans = !ZM && wide && !(b.debug & 2048);
+        /* Several fragment charges: a list is one ascending run per charge, and an ion's partners can sit in
+         * any run of the other list.  Instead of probing every run and replaying a task serially when an ion
+         * has two partners, both lists are merged by rank (below) and the reference's greedy walk runs per
+         * cluster of ions chained by gaps below the tolerance, one lane per cluster (localize_core.hip.h,
+         * same argument): one binary search per ion, no replay. */
+        const bool zm_clusters = ZM && !(b.debug & 2048);
         int items = items_all;
         if (spans) {
             const int ntask = nc * ndir;
@@ -587,7 +593,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             items = (int)acc;
             wave_lds_sync();
         }
-        if (!(b.debug & 1))
+        if (!(b.debug & 1) && !zm_clusters)
         for (int base = 0; base < items; base += 64) {
             const int e = base + lane;
             if (e < items) {
@@ -649,8 +655,8 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             }
         }
         wave_lds_sync();
-        const uint32_t bad = *f.bad_tasks;
-        if (bad) {
+        const uint32_t bad = zm_clusters ? (1u << (nc * ndir)) - 1u : *f.bad_tasks;
+        if (bad && !(b.debug & 1)) {
             /* ---- a task with a doubly partnered ion is replayed with the reference's serial walk over its
              * two sorted lists (ModifiedPeptide.cpp:291-316).  Sorting = merging the per-charge runs:
              * an ion's place is its index in its own run plus, for every other run, the number of ions
@@ -687,6 +693,59 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
                 }
             }
             wave_lds_sync();
+            if (zm_clusters) {
+                int p2e = 1;
+                while (p2e <= ents) p2e <<= 1;
+                for (int base = 0; base < items_all; base += 64) {
+                    const int e = base + lane;
+                    if (e >= items_all) continue;
+                    const uint32_t ts = fastdiv((uint32_t)e, divE);     /* task * 2 + side, as the lists are laid out */
+                    const int i = e - (int)ts * ents;
+                    const int side = (int)ts & 1;
+                    const int d = BOTH ? ((int)ts >> 1) & 1 : 0;
+                    const int c = BOTH ? (int)ts >> 2 : (int)ts >> 1;
+                    const int task = c * ndir + d;
+                    const float *va = f.srt_v + (size_t)(task * 2) * ent_cap, *vb = va + ent_cap;
+                    const uint8_t *ha = f.srt_h + (size_t)(task * 2) * ent_cap, *hb = ha + ent_cap;
+                    const float *mine = side ? vb : va, *other = side ? va : vb;
+                    const float me = mine[i];
+                    int j = 0;                              /* ions of the other list before this one (A first on ties) */
+                    for (int step = p2e >> 1; step > 0; step >>= 1) {
+                        const int probe = j + step;
+                        if (probe - 1 < ents && (side ? other[probe - 1] <= me : other[probe - 1] < me)) j = probe;
+                    }
+                    const float before_own = i > 0 ? mine[i - 1] : -__builtin_huge_valf();
+                    const float before_other = j > 0 ? other[j - 1] : -__builtin_huge_valf();
+                    if (!(me - before_own >= err && me - before_other >= err)) continue;
+                    int ia = side ? j : i, ib = side ? i : j;
+                    uint32_t tr0 = 0, tr1 = 0, n0 = 0, n1 = 0;
+                    float reached = -__builtin_huge_valf();
+                    for (bool first = true;; first = false) {
+                        const float xa = ia < ents ? va[ia] : __builtin_huge_valf();
+                        const float xb = ib < ents ? vb[ib] : __builtin_huge_valf();
+                        const float next = xa <= xb ? xa : xb;
+                        if (next == __builtin_huge_valf()) break;
+                        if (!first && next - reached >= err) break;
+                        if (__builtin_fabsf(xa - xb) < err) {       /* ModifiedPeptide.cpp:291-316 */
+                            ia++;
+                            ib++;
+                            reached = __builtin_fmaxf(reached, xa > xb ? xa : xb);
+                        } else if (xa < xb) {
+                            tr0++;
+                            n0 += ha[ia++];
+                            reached = __builtin_fmaxf(reached, xa);
+                        } else {
+                            tr1++;
+                            n1 += hb[ib++];
+                            reached = __builtin_fmaxf(reached, xb);
+                        }
+                    }
+                    if (tr0) atomicAdd(&f.c_tr[task * 2], tr0);
+                    if (tr1) atomicAdd(&f.c_tr[task * 2 + 1], tr1);
+                    if (n0) atomicAdd(&f.c_cnt[task * 2], n0);
+                    if (n1) atomicAdd(&f.c_cnt[task * 2 + 1], n1);
+                }
+            } else
             if (lane < nc * ndir && ((bad >> lane) & 1u)) {
                 const float *va = f.srt_v + (size_t)(lane * 2) * ent_cap, *vb = va + ent_cap;
                 const uint8_t *ha = f.srt_h + (size_t)(lane * 2) * ent_cap, *hb = ha + ent_cap;
