@@ -252,7 +252,7 @@ def main():
             # records overlaps the kernels of the next batch (at most one gather behind)
             buf = send[flip[0]]
             flip[0] ^= 1
-            buf[: hi - lo] = plan.packed_summary()
+            plan.packed_summary(out=buf[: hi - lo])
             in_flight.append(dist_gather(buf, 0, async_op=True))
             if len(in_flight) > 1:
                 in_flight.pop(0)[0].wait()

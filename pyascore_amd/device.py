@@ -105,14 +105,18 @@ class DevicePlan:
         if rc:
             self.scorer._raise(rc)
 
-    def packed_summary(self):
+    def packed_summary(self, out=None):
         """Results as one [n_psm, 4 + 3*max_k] int32 device tensor (fixed-size records for the
-        gather): best_score bits, n_sig, best_sig lo/hi, then per site ascore bits, alt lo/hi."""
+        gather): best_score bits, n_sig, best_sig lo/hi, then per site ascore bits, alt lo/hi.
+        ``out``: a preallocated [n_psm, width] int32 tensor (e.g. a slice of the send buffer) to pack
+        into with one kernel, instead of a new tensor that is then copied."""
         torch = self._torch
         k = self.max_k
         cols = [self.best_score.view(torch.int32).unsqueeze(1), self.n_sig.unsqueeze(1),
                 self.best_sig.view(torch.int32).view(-1, 2),
                 self.ascores.view(torch.int32), self.alt_mask.view(torch.int32).view(-1, 2 * k)]
+        if out is not None:
+            return torch.cat(cols, dim=1, out=out)
         return torch.cat(cols, dim=1).contiguous()
 
 
