@@ -128,7 +128,8 @@ struct PushedEntry {
 #define PYA_LOC_SB_MAX 8           /* signatures worked on together: the winner + 7 competitors */
 static inline unsigned long pya_loc_lds_bytes(unsigned pos_cap, unsigned pool_cap, unsigned sb) {
     return 64ul * 4 * 2 + 64 + sb * 8ul + (unsigned long)sb * 2 * pos_cap * 8 + sb * 2 * 4ul +
-           sb * 10 * 4ul + sb * 4 * 3ul + sb * 2 * 4 * 2ul + (unsigned long)pool_cap * 6 + 128 * 8 + 64;
+           sb * 10 * 4ul + sb * 4 * 3ul + sb * 2 * 4 * 2ul + (unsigned long)pool_cap * 6 + 128 * 8 + 64 +
+           (32 + 33) * 4ul;                                       /* span tables of the lean pairing */
 }
 
 /* per-signature record: 10 cumulative counts as u16 + total fragments */

@@ -86,6 +86,8 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     const int zmax = b.max_charge[psm];
     const bool presorted = zmax == 1 && cfg->n_nl == 0 &&
                            !__any(lane < res.L && !(res.m0 > 0.f && res.m1 > 0.f));
+    const float wide_min = 2.f * cfg->mz_error + 0.02f;
+    const bool wide = presorted && !__any(lane < res.L && !(res.m0 > wide_min && res.m1 > wide_min)) && !(b.debug & 2048);
     if (PLAIN && (!presorted || b.keep || (b.debug & 512))) return true;   /* not this kernel's PSM */
     STAMP_T(b, 20, false);
 
@@ -251,6 +253,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     ctx.L = res.L;
     ctx.zmax = zmax;
     ctx.presorted = presorted;
+    ctx.wide = wide;
     ctx.pos_cap = pos_cap;
     ctx.pool_cap = pool_cap;
     const LocLds &w = ctx.w;

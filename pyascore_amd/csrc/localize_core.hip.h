@@ -552,6 +552,7 @@ struct LocLds {
     uint8_t *keep;            /* [2 * pool_cap] keep flags [task][side][P2]               */
     float *stage_val;         /* [LOC_STAGE] surviving ions waiting for their lookup      */
     uint32_t *stage_tag;      /* [LOC_STAGE] competitor * 2 + side                        */
+    uint32_t *t_lo, *t_off;   /* [32], [33] per task: first step of its span, items before it (lean pairing) */
 };
 
 DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, uint32_t LOC_SB) {
@@ -564,7 +565,9 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, ui
     w.pool = w.scores + LOC_SB * 10;
     w.stage_val = w.pool + pool_cap;
     w.stage_tag = (uint32_t *)(w.stage_val + 128);
-    w.tot = w.stage_tag + 128;
+    w.t_lo = w.stage_tag + 128;
+    w.t_off = w.t_lo + 32;
+    w.tot = w.t_off + 33;
     w.c_idx = w.tot + LOC_SB * 2;
     w.c_pre = w.c_idx + LOC_SB;
     w.c_depth = (int32_t *)(w.c_pre + LOC_SB);
@@ -620,6 +623,9 @@ struct LocCtx {
     int gtp;                  /* log2 of the ion types localised per pass                  */
     bool presorted;           /* charge 1, no neutral losses, all residue masses positive:  */
                               /* every fragment list comes out ascending, no check needed   */
+    bool wide;                /* ... and every residue heavier than two tolerances: an ion has at most one
+                               * partner, and only fragments between the first and the last residue in which
+                               * two signatures differ can be site-determining (fused_core.hip.h) */
 };
 
 template <bool PLAIN>
@@ -955,14 +961,57 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
             snap_cnt = w.c_cnt[lane];
         }
         int staged = 0;
-        for (int base = 0; base < pair_items; base += 64) {      /* wave-uniform trip count */
+        /* Lean route with `wide` residues: only the steps between the first and the last residue in which
+         * the winner and the competitor differ are looked at (one ion per step here); the items of a task
+         * are the two sides of its span, tasks back to back. */
+        const bool spans = PLAIN && c.wide && ntask <= 32;
+        int n_items = pair_items;
+        if (spans) {
+            if (lane < ntask) {
+                const int t = lane & ((1 << gt) - 1), cc = c0 + (lane >> gt);
+                uint32_t lo = 0, len = 0;
+                if (tb + t < T) {
+                    const uint64_t diff = w.sig_mask[0] ^ w.sig_mask[cc];         /* residue positions */
+                    const int r_lo = __builtin_ctzll(diff), r_hi = 63 - __builtin_clzll(diff);
+                    const int d = tb + t < cfg->n_fwd ? 0 : 1;
+                    lo = (uint32_t)(d ? c.L - 1 - r_hi : r_lo);
+                    len = (uint32_t)(r_hi - r_lo);
+                }
+                w.t_lo[lane] = lo;
+                w.t_off[lane] = 2u * len;                      /* both sides */
+            }
+            wave_lds_sync();
+            uint32_t acc = 0;
+            for (int tk = 0; tk < ntask; tk++) {              /* (every lane, same values) */
+                const uint32_t n = w.t_off[tk];
+                wave_lds_sync();
+                if (lane == 0) w.t_off[tk] = acc;
+                acc += n;
+            }
+            if (lane == 0) w.t_off[ntask] = acc;
+            n_items = (int)acc;
+            wave_lds_sync();
+        }
+        for (int base = 0; base < n_items; base += 64) {         /* wave-uniform trip count */
             const int e = base + lane;
             bool multi = false, kept = false;
             float me = 0.f;
             uint32_t tag = 0;
-            if (e < pair_items) {
-                const uint32_t ts = fastdiv((uint32_t)e, divM);     /* task*2 + side */
-                const int i = e - (int)ts * (int)mmax;
+            if (e < n_items) {
+                uint32_t ts;                                     /* task*2 + side */
+                int i;
+                if (spans) {
+                    int task = 0;
+                    for (int tk = 1; tk < ntask; tk++) task += (uint32_t)e >= w.t_off[tk] ? 1 : 0;
+                    const int rem = e - (int)w.t_off[task];
+                    const int len = (int)(w.t_off[task + 1] - w.t_off[task]) >> 1;
+                    const int sd = rem >= len ? 1 : 0;
+                    ts = (uint32_t)(task * 2 + sd);
+                    i = (int)w.t_lo[task] + rem - sd * len;
+                } else {
+                    ts = fastdiv((uint32_t)e, divM);
+                    i = e - (int)ts * (int)mmax;
+                }
                 const int side = (int)ts & 1, task = (int)ts >> 1;
                 const int t = task & ((1 << gt) - 1), cj = task >> gt;   /* competitor slot - 1 */
                 if (tb + t < T) {
