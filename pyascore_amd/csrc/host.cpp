@@ -1406,7 +1406,13 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     Bucket m;                                               /* caps that cover every PSM of the batch */
     uint32_t prefix = 0, compact = 0;
     if (tiny) {
-        for (const Bucket &bk : p->buckets) {
+        /* (the PSMs the fused kernel would take are accounted in their own bucket: its caps count too --
+         * leaving them out sized this launch's work areas for the other PSMs only) */
+        std::vector<const Bucket *> all;
+        for (const Bucket &bk : p->buckets) all.push_back(&bk);
+        all.push_back(&p->fusedb);
+        for (const Bucket *pbk : all) {
+            const Bucket &bk = *pbk;
             if (bk.ids.empty()) continue;
             m.n_cap = std::max(m.n_cap, bk.n_cap);
             m.list_cap = std::max(m.list_cap, bk.list_cap);

@@ -20,7 +20,13 @@ from fuzzcase import random_case as _random_case
 _LO, _HI = (int(x) for x in os.environ.get("PYA_FUZZ_SEEDS", "0:40").split(":"))
 
 
-@pytest.mark.parametrize("seed", range(_LO, _HI))
+# seeds a soak found something with (each is a regression test now):
+#   270 -- a batch for the single-launch kernel whose longest peptide has few site assignments (its caps
+#          were accounted with the fused kernel's PSMs and left out of that launch's sizing)
+_FOUND = [270]
+
+
+@pytest.mark.parametrize("seed", list(range(_LO, _HI)) + [s for s in _FOUND if not _LO <= s < _HI])
 def test_random_settings_and_batches(seed, monkeypatch):
     rng = np.random.default_rng(9000 + seed)
     # the routes a batch can take: single launch (small batches, default), or the kernel-per-stage

@@ -711,3 +711,4 @@ def test_modification_mass_that_mimics_residues(mod_mass, mz_error, path):
     got = _gpu(settings).score_batch(batch)
     want = _checker(settings).score_batch(batch, got["ascores"].shape[1])
     _same(got, want)
+
