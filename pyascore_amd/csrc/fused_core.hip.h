@@ -83,10 +83,17 @@ __host__ __device__ static inline size_t fused_sort_bytes(uint32_t n) {
     if (n <= 64) return ((size_t)n * 10 + 15) & ~(size_t)15;
     return (((size_t)n * 6 + 15) & ~(size_t)15) + ((size_t)n / 64 + 2) * 16 + 2 * 128 * 2;
 }
-__host__ __device__ static inline size_t fused_post_bytes(uint32_t n_cap, uint32_t push_cap, uint32_t ent_cap, uint32_t ndir) {
+/* multi_z: the merged lists of the multi-charge instantiation (srt_v, srt_h).  The charge-1 instantiation
+ * has no use for them -- a task with a doubly partnered ion, which its residue-mass condition all but
+ * rules out, is handed to the general kernel instead of being replayed here -- and without them the
+ * post region is no larger than the walk region it overlays: a fifth more wavefronts per CU on cfg2. */
+__host__ __device__ static inline size_t fused_post_bytes(uint32_t n_cap, uint32_t push_cap, uint32_t ent_cap, uint32_t ndir,
+                                                          bool multi_z) {
     return fused_align16(fused_sort_bytes(n_cap)) + (size_t)push_cap * 16 + 64 * 8 + 64 * 4 * 2 + 16 +
            (size_t)(1 + FUSED_ROUND) * 40 + (size_t)FUSED_ROUND * (16 * ndir + 4 + 4) + 16 + 64 +
-           fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap * 4) + fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap);
+           (multi_z ? fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap * 4) +
+                          fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap)
+                    : 0);
 }
 __host__ __device__ static inline size_t fused_walk_bytes(uint32_t cap) {
     return PYA_NTOP / 2 * 64 * 4 + ((size_t)cap + PYA_TABLE_PAD) * 8;
@@ -99,14 +106,14 @@ __host__ __device__ static inline size_t fused_kept_bytes(uint32_t n_cap, uint32
            (size_t)(1 + FUSED_ROUND) * ndir * ent_cap * 4;
 }
 __host__ __device__ static inline size_t fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap,
-                                                         uint32_t ent_cap, uint32_t push_cap, uint32_t ndir) {
-    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap, ent_cap, ndir);
+                                                         uint32_t ent_cap, uint32_t push_cap, uint32_t ndir, bool multi_z) {
+    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap, ent_cap, ndir, multi_z);
     return PYA_GRID_CELLS * 2 + fused_align16(walk > post ? walk : post) +
            fused_kept_bytes(n_cap, stride, pos_cap, ent_cap, ndir) + 16;
 }
 
 DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap,
-                         uint32_t ent_cap, uint32_t push_cap, uint32_t ndir) {
+                         uint32_t ent_cap, uint32_t push_cap, uint32_t ndir, bool multi_z) {
     FusedLds f;
     f.grid = (uint16_t *)raw;
     size_t o = PYA_GRID_CELLS * 2;
@@ -143,7 +150,7 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
     f.srt_v = (float *)(raw + q);
     q += fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap * 4);
     f.srt_h = (uint8_t *)(raw + q);
-    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap, ent_cap, ndir);
+    const size_t walk = fused_walk_bytes(cap), post = fused_post_bytes(n_cap, push_cap, ent_cap, ndir, multi_z);
     o += fused_align16(walk > post ? walk : post);
     f.resd = (float2 *)(raw + o);
     o += fused_align16(((size_t)pos_cap + 1) * 8);
@@ -265,7 +272,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int ndir = BOTH ? 2 : 1;
-    const FusedLds f = fused_carve(lds_raw, cap, n_cap, stride, pos_cap, ent_cap, push_cap, (uint32_t)ndir);
+    const FusedLds f = fused_carve(lds_raw, cap, n_cap, stride, pos_cap, ent_cap, push_cap, (uint32_t)ndir, ZM);
     STAMP_BEGIN();
     STAMP_T(b, 38, false);
     /* the residue table does not depend on the PSM: on its way before anything else */
@@ -656,7 +663,8 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         }
         wave_lds_sync();
         const uint32_t bad = zm_clusters ? (1u << (nc * ndir)) - 1u : *f.bad_tasks;
-        if (bad && !(b.debug & 1)) {
+        if (!ZM && bad) declined = true;                     /* (no room for a replay here: the general kernel takes it) */
+        if (ZM && bad && !(b.debug & 1)) {
             /* ---- a task with a doubly partnered ion is replayed with the reference's serial walk over its
              * two sorted lists (ModifiedPeptide.cpp:291-316).  Sorting = merging the per-charge runs:
              * an ion's place is its index in its own run plus, for every other run, the number of ions

@@ -57,7 +57,7 @@ size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap);
 int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap,
                          hipStream_t stream);
 size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap,
-                           uint32_t both);
+                           uint32_t both, uint32_t multi_z);
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
                      uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
                      uint32_t multi_z, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
@@ -1060,7 +1060,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             p->fused_n_cap = (fb.n_cap + 3u) & ~3u;
             p->fused_stride = (both_dirs ? 2u : 1u) * p->fused_n_cap + 4u;
             const uint32_t cap_all = (max_P + 31u) & ~31u;
-            keep_fused = pya_fused_lds_bytes(cap_all, p->fused_n_cap, p->fused_stride, fb.pos_cap, p->fused_ent_cap, fb.push_cap(), p->fused_both) <= 64 * 1024 &&
+            keep_fused = pya_fused_lds_bytes(cap_all, p->fused_n_cap, p->fused_stride, fb.pos_cap, p->fused_ent_cap, fb.push_cap(), p->fused_both, 1u) <= 64 * 1024 &&
                          pya_localize_lds_bytes(fb.push_cap(), fb.n_cap, fb.pos_cap, fb.pool_cap(), fb.sb()) <= kMaxLds;
         }
         if (!keep_fused && !fb.ids.empty()) {               /* (huge spectra) back to the two-kernel route */
@@ -1171,7 +1171,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                 it.ent = std::max(Lm1 * z, 1u);
                 it.push = std::min<uint32_t>(PYA_MAX_PUSHED, (kk * (ns - kk) + 7u) & ~7u);
                 if (it.push < 8) it.push = 8;
-                it.need = pya_fused_lds_bytes(caps[pcls[i]], it.n_cap, ndir * it.n_cap + 4, it.pos, it.ent, it.push, p->fused_both);
+                it.need = pya_fused_lds_bytes(caps[pcls[i]], it.n_cap, ndir * it.n_cap + 4, it.pos, it.ent, it.push, p->fused_both, z > 1 ? 1u : 0u);
                 items.push_back(it);
             }
             std::sort(items.begin(), items.end(), [](const Item &a, const Item &b2) {

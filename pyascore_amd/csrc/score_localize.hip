@@ -26,15 +26,15 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void pya_score_localize_kernel(
 }
 
 extern "C" size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap,
-                                      uint32_t push_cap, uint32_t both) {
-    return fused_lds_bytes(cap, n_cap, stride, pos_cap, ent_cap, push_cap, both ? 2u : 1u);
+                                      uint32_t push_cap, uint32_t both, uint32_t multi_z) {
+    return fused_lds_bytes(cap, n_cap, stride, pos_cap, ent_cap, push_cap, both ? 2u : 1u, multi_z != 0);
 }
 
 extern "C" int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
                                 uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
                                 uint32_t multi_z, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream) {
     if (n_ids == 0) return 0;
-    const size_t lds = fused_lds_bytes(cap, n_cap, stride, pos_cap, ent_cap, push_cap, both ? 2u : 1u);
+    const size_t lds = fused_lds_bytes(cap, n_cap, stride, pos_cap, ent_cap, push_cap, both ? 2u : 1u, multi_z != 0);
 #define PYA_FUSED_LAUNCH(B, Z)                                                                                          \
     do {                                                                                                                \
         hipError_t e = PYA_ENSURE_MAX_LDS((pya_score_localize_kernel<B, Z>));                                           \
