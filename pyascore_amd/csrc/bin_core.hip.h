@@ -346,7 +346,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                 const int hi = gt ? base + __builtin_ctzll(gt) - 1 : run_end;
                 const int len = in ? hi - lo + 1 : 0;
                 /* longest run that reaches into this chunk, from the ballot of the run starts: scalar work */
-                int t_max = 0;
+                int t_max = 0, t_min = 0x7fffffff;            /* ... and the shortest: below it no lane needs the length test */
                 {
                     uint64_t m = starts;
                     int prev = carry_lo;
@@ -357,10 +357,12 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                     while (m) {
                         const int p = base + __builtin_ctzll(m);
                         t_max = p - prev > t_max ? p - prev : t_max;
+                        t_min = p - prev < t_min ? p - prev : t_min;
                         prev = p;
                         m &= m - 1;
                     }
                     t_max = run_end - prev + 1 > t_max ? run_end - prev + 1 : t_max;
+                    t_min = run_end - prev + 1 < t_min ? run_end - prev + 1 : t_min;
                 }
                 carry_lo = __builtin_amdgcn_readlane(lo, 63);
                 /* mates are read at lo + t straight through the end of the lane's run (whatever
@@ -368,9 +370,12 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                 const double *src = s_inten + (in ? lo : 0);
                 int cnt = 0;
                 const int t_end = __builtin_amdgcn_readfirstlane(t_max);
+                const int t_all = __builtin_amdgcn_readfirstlane(t_min);
                 if (sweep == 0) {
 #pragma unroll 4
-                    for (int t = 0; t < t_end; t++) {
+                    for (int t = 0; t < t_all; t++) cnt += (int)(src[t] > me);   /* every run of the chunk reaches this far */
+#pragma unroll 4
+                    for (int t = t_all; t < t_end; t++) {
                         const double o = src[t];                  /* unconditional: no branch around the read */
                         cnt += (int)((t < len) & (o > me));
                     }
