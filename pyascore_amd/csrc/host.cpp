@@ -872,6 +872,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     const uint32_t fused_max_n = both_dirs ? 32u : 64u;
     p->fused.assign(n, 0);
     /* score_big.hip: one PSM per 8-wave workgroup, fragment tree shared two levels deep */
+    static const uint64_t big_min_n = std::getenv("PYA_BIG_MIN_N") ? (uint64_t)std::atoll(std::getenv("PYA_BIG_MIN_N")) : 1024;
     const bool big_on = h->cfg.n_nl == 0 && both_dirs && h->cfg.n_fwd == 1 && h->cfg.n_types == 2 && h->mz_error <= 0.49f &&
                         !std::getenv("PYA_NO_BIG");
     p->big.assign(n, 0);
@@ -1018,7 +1019,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             /* (its count records hold the cumulative counts as bytes: at most 255 fragments) */
             const uint32_t frags = (both_dirs ? 2u : 1u) * (uint32_t)(L - 1) * (uint32_t)z;
             const bool to_fused = fused_on && N <= fused_max_n && frags <= 255u;
-            if (big_on && z == 1 && N > 1024) {                 /* (C(n,k) > 1024 implies n >= 13 sites) */
+            if (big_on && z == 1 && N > big_min_n && ns >= 11) { /* (its second level shares ten sites: at least eleven) */
                 p->big[i] = 1;
                 p->big_pos_cap = std::max(p->big_pos_cap, (uint32_t)(L - 1));
             }
