@@ -15,8 +15,9 @@ Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline     : the dominant kernel's achieved algorithmic GB/s vs the 8 TB/s HBM peak,
                  timed with HIP events on the launch stream inside the timed region;
   cpu_baseline : the reference's own C++ core (oracle/_ref, if its prebuilt library travelled;
-                 otherwise this repo's CPU restatement) timed on one host core on a bounded
-                 sample of the same workload.
+                 otherwise this repo's CPU restatement) on the host cores, one PROCESS per core
+                 (fresh children started before this program's first GPU call), on a bounded
+                 sample of the same workload; one-core rate and parallel efficiency beside it.
 """
 import argparse
 import json
@@ -51,45 +52,84 @@ FAMILIES = {
 }
 
 
-def profiled_traffic(cfg, kernel, default_size):
-    """HBM bytes per step of the kernel family `kernel` (all its instantiations and launches) from the
-    newest committed PMC summary of this config (profiles/*_rocprof_<cfg>/pmc_summary.csv, collected by
-    scripts/profile.sh in separate --pmc passes).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950
-    FETCH_SIZE tallies 128-byte requests as 64 bytes, hence the factor 2 (MI355X_MICROARCH.md, HBM
-    section).  Also returns the whole path's traffic (every pya_* kernel) and the share of the
-    family's SIMD cycles in which the vector ALU is occupied.  None when the run is not the profiled
-    workload."""
+def valu_costs():
+    """Measured cycles a SIMD spends per vector instruction of each kernel's own instruction mix
+    (profiles/r03_isa_mix.json = scripts/isa_hist.py over the kernels' inner loops, every class priced
+    from profiles/r03_valu_ceiling.csv = scripts/valu_ceiling.hip on MI355X at 6 waves per SIMD), and
+    the scalar unit's measured rate (one instruction per cycle per CU)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_isa_mix.json")) as f:
+            mix = json.load(f)
+    except OSError:
+        return {}, 3.7
+    cost = {k: v.get("inner_loops_cycles_per_valu") or v.get("all_cycles_per_valu") for k, v in mix.items()}
+    vals = [c for c in cost.values() if c]
+    return cost, (sum(vals) / len(vals) if vals else 3.7)
+
+
+def profiled_counters(cfg, kern_ms, names, default_size):
+    """Per kernel family of the bench line, from the newest committed PMC summary of this config
+    (profiles/*_rocprof_<cfg>/pmc_summary.csv, separate --pmc passes, scripts/profile.sh):
+      traffic      HBM bytes per step, 2 x FETCH_SIZE + WRITE_SIZE (KB counters; gfx950's FETCH_SIZE tallies
+                   128-byte requests as 64: MI355X_MICROARCH.md, HBM section);
+      hbm_actual   that over the family's live HIP-event duration, GB/s;
+      valu_busy    SQ_INSTS_VALU x the measured cost of a vector instruction of the kernel's own mix
+                   / (1024 SIMDs x the kernel's cycles): the share of SIMD time its vector instructions
+                   need at the measured issue rates (profiles/r03_valu_ceiling.md); <= 1 by construction
+                   of the cost (measured at saturation);
+      salu_busy    SQ_INSTS_SALU / (256 CUs x cycles): the one scalar unit of a CU issues one per cycle;
+      lanes        active lanes per vector instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 4... of 64);
+      lds_conflict LDS bank-conflict cycles per active LDS cycle.
+    Kernel cycles = SQ_BUSY_CYCLES / 32 (the counter sums the 32 shader engines).  None when the run
+    is not the profiled workload."""
     import csv
     import glob
-    none = (None, None, None, None)
     if not default_size:
-        return none
+        return None, None
     dirs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_" + cfg)))
     if not dirs:
-        return none
+        return None, None
     path = os.path.join(dirs[-1], "pmc_summary.csv")
-    fam, path_total = {}, {}
+    per_kernel = {}
     try:
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                val = float(row.get("per_step") or row["mean_value"])
-                path_total[row["counter"]] = path_total.get(row["counter"], 0.0) + val
-                if row["kernel"].split("<")[0] in FAMILIES.get(kernel, (kernel,)):
-                    fam[row["counter"]] = fam.get(row["counter"], 0.0) + val
+                per_kernel.setdefault(row["kernel"], {})[row["counter"]] = float(row.get("per_step") or row["mean_value"])
     except OSError:
-        return none
-    if "FETCH_SIZE" not in fam or "WRITE_SIZE" not in fam:
-        return none
-    valu = None
-    if fam.get("SQ_BUSY_CYCLES") and ("SQ_ACTIVE_INST_VALU" in fam or "SQ_INSTS_VALU" in fam):
-        # The bound these kernels actually run into: the vector ALUs.  SQ_ACTIVE_INST_VALU counts, in
-        # quad-cycles, the time waves spend executing vector instructions (it equals SQ_INSTS_VALU here:
-        # four cycles per wave64 instruction of this integer / compare / f64 mix); 1024 SIMDs;
-        # SQ_BUSY_CYCLES sums 32 shader engines.  1.0 = every SIMD's VALU occupied all the time.
-        quads = fam.get("SQ_ACTIVE_INST_VALU", fam.get("SQ_INSTS_VALU"))
-        valu = quads * 4.0 / 1024.0 / (fam["SQ_BUSY_CYCLES"] / 32.0)
-    whole = (2.0 * path_total.get("FETCH_SIZE", 0.0) + path_total.get("WRITE_SIZE", 0.0)) * 1024.0
-    return (2.0 * fam["FETCH_SIZE"] + fam["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT), valu, whole
+        return None, None
+    cost, cost_default = valu_costs()
+    fams = {}
+    whole = 0.0
+    for fam_name, ms in zip(names, kern_ms):
+        members = FAMILIES.get(fam_name, (fam_name,))
+        acc = {"traffic": 0.0, "valu_cyc": 0.0, "valu": 0.0, "salu": 0.0, "cycles": 0.0, "thread_cyc": 0.0,
+               "lds_conf": 0.0, "lds_act": 0.0, "kernels": []}
+        for kname, c in per_kernel.items():
+            if kname.split("<")[0] not in members or "FETCH_SIZE" not in c:
+                continue
+            acc["kernels"].append(kname)
+            acc["traffic"] += (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0
+            acc["valu"] += c.get("SQ_INSTS_VALU", 0.0)
+            acc["valu_cyc"] += c.get("SQ_INSTS_VALU", 0.0) * (cost.get(kname) or cost_default)
+            acc["salu"] += c.get("SQ_INSTS_SALU", 0.0)
+            acc["cycles"] += c.get("SQ_BUSY_CYCLES", 0.0) / 32.0
+            acc["thread_cyc"] += c.get("SQ_THREAD_CYCLES_VALU", 0.0)
+            acc["lds_conf"] += c.get("SQ_LDS_BANK_CONFLICT", 0.0)
+            acc["lds_act"] += c.get("SQ_LDS_IDX_ACTIVE", 0.0)
+        if not acc["kernels"]:
+            continue
+        whole += acc["traffic"]
+        cyc = acc["cycles"]
+        fams[fam_name] = {
+            "kernels": sorted(acc["kernels"]), "traffic": acc["traffic"],
+            "hbm_actual": acc["traffic"] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            "valu_cycles_per_inst": acc["valu_cyc"] / acc["valu"] if acc["valu"] else None,
+            "valu_busy": acc["valu_cyc"] / (1024.0 * cyc) if cyc else None,
+            "salu_busy": acc["salu"] / (256.0 * cyc) if cyc else None,
+            "lanes_per_valu": acc["thread_cyc"] / acc["valu"] / 4.0 if acc["valu"] and acc["thread_cyc"] else None,
+            "lds_conflict_share": acc["lds_conf"] / acc["lds_act"] if acc["lds_act"] else None,
+            "ms_live": float(ms)}
+    return {"source": os.path.relpath(path, ROOT), "families": fams, "whole_path_traffic": whole}, fams
 
 
 def achievable_hbm_gbs(torch, dev, nbytes=1 << 30, reps=5):
@@ -108,52 +148,88 @@ def achievable_hbm_gbs(torch, dev, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (t0.elapsed_time(t1) * 1e-3) / 1e9
 
 
+def effective_cores():
+    """CPUs this process may really use: the affinity mask, cut to the cgroup's CPU quota when there is
+    one (a container that sees 256 logical CPUs but may run 16 of them at a time gains nothing from 256
+    workers).  Returns (count, how it was determined)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    why = "affinity mask"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota = txt[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = float(f.read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    n, why = q, "cgroup quota %s/%d" % (quota, int(period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 256)), why
+
+
 def cpu_baseline(batch, settings, target_seconds=12.0):
-    """The reference's C++ core (oracle/_ref; the CPU restatement if that library did not travel)
-    on the host cores of this box: one scorer per thread (ctypes releases the GIL), every thread a
-    contiguous slice of a bounded sample of rank 0's batch.  Reports the all-core rate as `value`
-    and the single-thread rate beside it."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import harness, orc
+    """The reference's C++ core (oracle/_ref; the CPU restatement if that library did not travel) on
+    the host cores of this box, ONE PROCESS PER CORE (oracle/cpu_worker.py: fresh children that never
+    touch the GPU; this function itself runs before bench.py's first GPU call).  Every worker scores
+    a contiguous slice of a bounded sample of rank 0's batch; all start at a common wall-clock time;
+    the all-core rate is the PSMs of all workers over (last end - common start).  The one-core rate is
+    one such worker alone; `efficiency` = all_cores / (cores x one_core)."""
     import subprocess
+    import tempfile
+    from oracle import orc
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"])
     kind = "ref" if orc.available("ref") else "oracle"
+    cores, cores_why = effective_cores()
+    worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
+    n_avail = int(batch["n_psm"])
+    tmp = tempfile.mkdtemp(prefix="pya_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path = os.path.join(tmp, "sample.npz")
+    n_sample = min(n_avail, max(cores * 64, 20000))
     from pyascore_amd.synth import slice_batch
-    k = int(batch["n_of_mod"].max())
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    scorers = [harness.make_scorer(orc.OracleAscore, settings, kind=kind) for _ in range(cores)]
-    probe = min(200, batch["n_psm"])
-    t = time.perf_counter()
-    scorers[0].score_batch(slice_batch(batch, 0, probe), k)
-    rate1 = probe / max(time.perf_counter() - t, 1e-9)
-    # single thread: about a third of the budget; all cores: the rest
-    n1 = int(min(batch["n_psm"], max(probe, rate1 * target_seconds / 3)))
-    t = time.perf_counter()
-    scorers[0].score_batch(slice_batch(batch, 0, n1), k)
-    dt1 = time.perf_counter() - t
-    # all-core rate from a short probe first (64 threads rarely scale 64x: memory-bound slices)
-    probe_all = int(min(batch["n_psm"], cores * 64))
-    pc = [probe_all * i // cores for i in range(cores + 1)]
-    t = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda i: scorers[i].score_batch(slice_batch(batch, pc[i], pc[i + 1]), k) if pc[i + 1] > pc[i]
-                    else None, range(cores)))
-    rate_all = probe_all / max(time.perf_counter() - t, 1e-9)
-    want = max(rate_all, rate1) * target_seconds * 2 / 3     # PSMs for the all-core leg
-    n = int(min(batch["n_psm"], max(probe, want)))
-    reps = max(1, int(round(want / n)))                      # small batches are scored several times over
-    cuts = [n * i // cores for i in range(cores + 1)]
+    sample = slice_batch(batch, 0, n_sample)
+    np.savez(path, settings=np.asarray(json.dumps(settings)), **{k: np.asarray(v) for k, v in sample.items()})
 
-    def work(i):
-        part = slice_batch(batch, cuts[i], cuts[i + 1])
-        for _ in range(reps):
-            scorers[i].score_batch(part, k)
+    def run(slices, reps):
+        t_start = time.time() + 4.0 + 0.02 * len(slices)         # every worker is loaded and waiting by then
+        procs = [subprocess.Popen([sys.executable, worker, path, str(lo), str(hi), str(reps), repr(t_start), kind],
+                                  stdout=subprocess.PIPE, text=True) for lo, hi in slices]
+        outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+        late = max(o["t0"] for o in outs) - t_start
+        n = sum(o["n"] for o in outs)
+        return n, max(o["t1"] for o in outs) - min(o["t0"] for o in outs), late
 
-    t = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(work, range(cores)))
-    dt = time.perf_counter() - t
-    n *= reps
+    try:
+        # one core: a probe sizes the leg at about a third of the budget
+        n_probe = min(n_sample, 400)
+        n, dt, _ = run([(0, n_probe)], 1)
+        rate1 = n / max(dt, 1e-9)
+        n1 = int(min(n_sample, max(n_probe, rate1 * target_seconds / 3)))
+        reps1 = max(1, int(round(rate1 * target_seconds / 3 / n1)))
+        n_one, dt_one, _ = run([(0, n1)], reps1)
+        rate1 = n_one / dt_one
+        # all cores: every worker a slice of the sample, repeated to fill two thirds of the budget
+        cuts = [n_sample * i // cores for i in range(cores + 1)]
+        slices = [(cuts[i], cuts[i + 1]) for i in range(cores) if cuts[i + 1] > cuts[i]]
+        per_worker = max(1, n_sample // cores)
+        # (sized from a short all-core probe, not from cores x one core: shared caches, memory bandwidth and
+        # SMT siblings make the all-core rate whatever it is)
+        reps_probe = max(1, int(round(rate1 * 1.0 / per_worker)))
+        n_p, dt_p, _ = run(slices, reps_probe)
+        reps = max(1, int(round((n_p / dt_p) * target_seconds * 2 / 3 / n_sample)))
+        n_all, dt_all, late = run(slices, reps)
+    finally:
+        try:
+            os.remove(path)
+            os.rmdir(tmp)
+        except OSError:
+            pass
     cpu_model = "unknown CPU"
     try:
         with open("/proc/cpuinfo") as f:
@@ -163,11 +239,15 @@ def cpu_baseline(batch, settings, target_seconds=12.0):
                     break
     except OSError:
         pass
-    return {"value": n / dt, "unit": "PSMs/s", "cores": cores, "cpu": cpu_model,
+    rate_all = n_all / dt_all
+    return {"value": rate_all, "unit": "PSMs/s", "cores": len(slices), "cores_from": cores_why,
+            "logical_cpus": os.cpu_count(), "cpu": cpu_model,
             "kind": "reference" if kind == "ref" else "port",
-            "sample": "%d PSMs (first %d of rank 0's batch x %d) in %d slices, one thread each, %.1f s"
-                      % (n, n // reps, reps, cores, dt),
-            "one_core": {"value": n1 / dt1, "sample": "first %d PSMs, one thread, %.1f s" % (n1, dt1)}}
+            "sample": "%d PSMs = the first %d of rank 0's batch in %d slices x %d passes, one PROCESS per core "
+                      "(oracle/cpu_worker.py), common start, %.1f s (last worker started %.2f s late)"
+                      % (n_all, n_sample, len(slices), reps, dt_all, max(late, 0.0)),
+            "one_core": {"value": rate1, "sample": "first %d PSMs x %d passes, one process, %.1f s" % (n1, reps1, dt_one)},
+            "efficiency": rate_all / (len(slices) * rate1)}
 
 
 def main():
@@ -188,29 +268,15 @@ def main():
                     help="skip the host-array legs (profiling runs: only the timed device-resident steps launch kernels)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from pyascore_amd import PyAscore, shard, synth
-    from pyascore_amd.device import DevicePlan
-    from pyascore_amd.shard import dist_gather
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device; there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # PYA_BENCH_FORCE_DIST=1 runs the collective path with a world of one (the only way to exercise
-    # RCCL on a single-GPU box)
-    use_dist = world > 1 or bool(os.environ.get("PYA_BENCH_FORCE_DIST"))
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    # ---- CPU only up to the marked line: the job, this rank's shard, and the CPU baseline's worker
+    # processes all come before the first call that initialises the GPU ----
+    from pyascore_amd import shard, synth
     # ONE job description (per-PSM shapes only) that every rank derives from the same seed; the job is
     # cut into contiguous ranges balanced by C(n,k) x (L-1) x types x charges (shard.partition) and
     # every rank generates the spectra of its own range only.
@@ -231,6 +297,27 @@ def main():
     batch = synth.make_slice(desc, lo, hi)
     job_max_k = max(1, int(desc["n_mod"].max()))
     longest = max(h - l for l, h in ranges)
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(batch, settings)
+    # ---- GPU from here on ----
+    import torch
+    import torch.distributed as dist
+    from pyascore_amd import PyAscore
+    from pyascore_amd.device import DevicePlan
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # PYA_BENCH_FORCE_DIST=1 runs the collective path with a world of one (the only way to exercise
+    # RCCL on a single-GPU box)
+    use_dist = world > 1 or bool(os.environ.get("PYA_BENCH_FORCE_DIST"))
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
     scorer = PyAscore(settings["bin_size"], settings["n_top"], settings["mod_group"], settings["mod_mass"],
                       settings["mz_error"], settings["fragment_types"], device=local_rank)
     for g, m in settings["neutral_losses"]:
@@ -240,40 +327,26 @@ def main():
     d_int = torch.from_numpy(batch["intensity"]).to(dev)
     plan = DevicePlan(scorer, batch, timing=True, max_k=job_max_k)
 
-    in_flight = []
-    # two send buffers of the job-wide record shape (longest shard x width): equal on every rank
-    send = [torch.zeros((longest, shard.record_width(job_max_k)), dtype=torch.int32, device=dev) for _ in range(2)]
-    flip = [0]
-
-    def step():
-        plan.run(d_mz, d_int)
-        if use_dist:
-            # the single RCCL gather of the path, asynchronous: the gather of this batch's packed
-            # records overlaps the kernels of the next batch (at most one gather behind)
-            buf = send[flip[0]]
-            flip[0] ^= 1
-            plan.packed_summary(out=buf[: hi - lo])
-            in_flight.append(dist_gather(buf, 0, async_op=True))
-            if len(in_flight) > 1:
-                in_flight.pop(0)[0].wait()
-
-    def drain():
-        while in_flight:
-            in_flight.pop(0)[0].wait()
+    # the step loop lives in pyascore_amd.shard (the gloo test drives the same class on CPU): kernels of
+    # this rank's shard, then the step's single RCCL gather of the packed records, asynchronous, waited
+    # for one step later
+    pipe = shard.StepPipeline(lambda: plan.run(d_mz, d_int), lambda out: plan.packed_summary(out=out), hi - lo, longest,
+                              shard.record_width(job_max_k), dev, enabled=use_dist)
 
     for _ in range(args.warmup):
-        step()
-    drain()
+        pipe.step()
+    pipe.drain()
     plan.check()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
+    pipe.reset_stats()
     kern_ms = np.zeros(4)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        pipe.step()
         kern_ms += np.asarray(plan.timings_ms())           # HIP events on the launch stream
-    drain()                                                # every gather of the timed steps has landed
+    pipe.drain()                                           # every gather of the timed steps has landed
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -281,10 +354,18 @@ def main():
     plan.check()
     kern_ms /= max(args.steps, 1)
 
+    per_rank = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed_own, elapsed = elapsed, float(t.item())
+        # what every rank measured, so that the first real scaling run explains itself: per-rank kernel
+        # family times, time spent waiting for gathers, own wall time, shard size and work estimate
+        mine = torch.tensor(list(kern_ms) + [1e3 * pipe.gather_wait_s / max(args.steps, 1), 1e3 * elapsed_own / max(args.steps, 1),
+                                             float(hi - lo), float(weights[lo:hi].sum())], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x) for x in r.tolist()] for r in allr]
 
     if rank == 0:
         names = ["pya_bin_spectra_kernel", "pya_score_signatures_kernel", "pya_score_localize_kernel", "pya_localize_kernel"]
@@ -322,8 +403,10 @@ def main():
                             "with planning, kernels and result copies); pcie_only = the same bytes copied up "
                             "and back with nothing else"}
         copy_gbs = achievable_hbm_gbs(torch, dev)
-        default_size = args.psms is None and args.config != "cfg3" and args.max_charge is None
-        traffic, traffic_src, valu_share, traffic_path = profiled_traffic(args.config, names[dom], default_size)
+        default_size = args.psms is None and args.max_charge is None and args.scaling == "weak"
+        counters, fams = profiled_counters(args.config, kern_ms, names, default_size)
+        dom_c = (fams or {}).get(names[dom], {})
+        traffic_path = counters["whole_path_traffic"] if counters else None
         line = {
             "metric": METRIC, "value": total * args.steps / elapsed, "unit": "PSMs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -335,25 +418,41 @@ def main():
                        "signatures_total_per_gpu": plan.total_signatures, "mz_error": settings["mz_error"],
                        "fragment_types": settings["fragment_types"],
                        "max_fragment_charge": int(batch["max_charge"].max()),
-                       "neutral_losses": settings["neutral_losses"], "parallelism": "psm-shard x%d + 1 gather" % world},
+                       "neutral_losses": settings["neutral_losses"],
+                       "timed_region": "spectra resident in HBM, plan pre-built, kernels only%s; results stay on the device "
+                                       "(host arrays in -> host results out is `host_api`)"
+                                       % (" + the step's gather of fixed-size records to rank 0" if use_dist else ""),
+                       "parallelism": ("psm-shard x%d + 1 gather per step" % world) if use_dist else "1 GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         # what actually bounds the kernel: share of its cycles in which the SIMDs' vector ALUs are
-                         # occupied (SQ_ACTIVE_INST_VALU x 4 / SIMDs / busy cycles of the committed counter pass)
-                         "valu_busy": valu_share,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": dom_c.get("traffic"),
+                         "traffic_source": counters["source"] if counters else None,
+                         # HBM bytes the dominant kernel family really moved (counters) over its live duration
+                         "hbm_actual": dom_c.get("hbm_actual"),
+                         # what actually bounds the kernel: share of SIMD time its vector instructions need at the
+                         # issue rates measured for its own instruction mix (profiles/r03_valu_ceiling.md)
+                         "valu_busy": dom_c.get("valu_busy"), "valu_cycles_per_inst": dom_c.get("valu_cycles_per_inst"),
+                         "salu_busy": dom_c.get("salu_busy"),
                          # HBM bytes of the whole path per step (every kernel) next to the algorithmic bytes
                          "traffic_whole_path": traffic_path,
                          "traffic_over_algorithmic": (traffic_path / alg) if traffic_path else None,
                          "algorithmic_bytes_per_launch": alg,
                          "achievable_peak": copy_gbs, "frac_of_achievable": achieved / copy_gbs,
                          "whole_path_gbs": alg / (float(kern_ms.sum()) * 1e-3) / 1e9 if kern_ms.sum() > 0 else 0.0,
-                         "kernel_ms": {n: float(m) for n, m in zip(names, kern_ms)}},
+                         "kernel_ms": {n: float(m) for n, m in zip(names, kern_ms)},
+                         "per_kernel": fams},
             "host_api": host,
             "workspace_bytes": plan.workspace_bytes,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(batch, settings)
+        if per_rank is not None:
+            cols = names + ["gather_wait_ms", "wall_ms_per_step", "shard_psms", "work_estimate"]
+            line["multi_gpu"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                                 "columns": cols, "per_rank": per_rank,
+                                 "record_bytes_per_step": longest * shard.record_width(job_max_k) * 4 * world,
+                                 "note": "per rank: mean HIP-event ms of each kernel family per step, ms per step spent "
+                                         "waiting for the previous step's gather, own wall ms per step, shard size, "
+                                         "sum of the work estimate the partition balanced"}
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -122,3 +122,67 @@ def dist_gather(tensor, dst=0, async_op=False):
     parts = [torch.empty_like(tensor) for _ in range(world)] if dist.get_rank() == dst else None
     work = dist.gather(tensor, parts, dst=dst, async_op=async_op)
     return (work, parts) if async_op else parts
+
+
+class StepPipeline:
+    """The per-step loop of a rank in a multi-GPU job -- the code bench.py runs on 8 GPUs and the gloo
+    test runs on CPU: score this rank's shard, pack its fixed-size records into one of two send
+    buffers of the JOB-wide shape (longest shard x record_width(job max_k): equal on every rank), start
+    the step's single gather asynchronously, and wait for the gather of the step before -- so the
+    collective of batch i overlaps the kernels of batch i + 1 and at most one gather is in flight when
+    the next one starts.
+
+    run_fn()            enqueues / performs the scoring of the shard
+    pack_fn(out)        writes the shard's records into out ([n_local, width] int32 view of the send buffer)
+    gather_fn(t, dst, async_op=True) -> (work, parts): dist_gather by default
+
+    Collects what a first real scaling run needs to explain itself: seconds spent waiting for
+    gathers (gather_wait_s), steps, and on rank 0 the records of the last completed gather."""
+
+    def __init__(self, run_fn, pack_fn, n_local, longest, width, device, gather_fn=None, enabled=True):
+        import torch
+        self.run_fn, self.pack_fn = run_fn, pack_fn
+        self.n_local, self.longest, self.width = int(n_local), int(longest), int(width)
+        self.gather_fn = gather_fn or (lambda t, dst: dist_gather(t, dst, async_op=True))
+        self.enabled = enabled
+        self.send = [torch.zeros((self.longest, self.width), dtype=torch.int32, device=device) for _ in range(2)] if enabled else []
+        self.flip = 0
+        self.in_flight = []
+        self.gather_wait_s = 0.0
+        self.steps = 0
+        self.last_parts = None
+
+    def _wait_oldest(self):
+        import time
+        work, parts = self.in_flight.pop(0)
+        t = time.perf_counter()
+        work.wait()
+        self.gather_wait_s += time.perf_counter() - t
+        self.last_parts = parts
+
+    def step(self):
+        self.run_fn()
+        self.steps += 1
+        if not self.enabled:
+            return
+        buf = self.send[self.flip]
+        self.flip ^= 1
+        self.pack_fn(buf[: self.n_local])
+        self.in_flight.append(self.gather_fn(buf, 0))
+        if len(self.in_flight) > 1:
+            self._wait_oldest()
+
+    def drain(self):
+        while self.in_flight:
+            self._wait_oldest()
+
+    def reset_stats(self):
+        self.gather_wait_s = 0.0
+        self.steps = 0
+
+    def gathered(self, ranges):
+        """Rank 0, after drain(): the records of the last step of the whole job in input order."""
+        import torch
+        if self.last_parts is None:
+            return None
+        return torch.cat([self.last_parts[r][: h - l] for r, (l, h) in enumerate(ranges)], dim=0)

@@ -137,3 +137,72 @@ def test_work_estimate_is_vectorised_and_counts_termini():
     t = time.perf_counter()
     shard.work_estimate_shapes(desc["n_sites"], desc["n_mod"], desc["L"], desc["max_charge"])
     assert time.perf_counter() - t < 2.0
+
+
+def _pipeline_worker(rank, world, port, out_path):
+    """bench.py's N > 1 step loop (shard.StepPipeline) on CPU: three steps over gloo, asynchronous
+    gathers one step behind, the job-wide record shape on every rank."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import harness, orc
+    from pyascore_amd import shard, synth
+    desc = _skewed_job(n=90)
+    w = shard.work_estimate_shapes(desc["n_sites"], desc["n_mod"], desc["L"], desc["max_charge"])
+    ranges = shard.partition(w, world)
+    max_k = int(desc["n_mod"].max())
+    lo, hi = ranges[rank]
+    mine = synth.make_slice(desc, lo, hi, threads=1)
+    scorer = harness.make_scorer(orc.OracleAscore, desc["settings"], kind="oracle")
+    state = {"rec": None, "runs": 0, "gathers": 0}
+
+    def run():
+        state["rec"] = torch.from_numpy(_records(scorer.score_batch(mine, max_k), max_k))
+        state["runs"] += 1
+
+    def pack(out):
+        assert tuple(out.shape) == (hi - lo, shard.record_width(max_k))
+        out.copy_(state["rec"])
+
+    def gather(t, dst):
+        state["gathers"] += 1
+        assert tuple(t.shape) == (max(h - l for l, h in ranges), shard.record_width(max_k))   # job-wide shape
+        return shard.dist_gather(t, dst, async_op=True)
+
+    pipe = shard.StepPipeline(run, pack, hi - lo, max(h - l for l, h in ranges), shard.record_width(max_k), "cpu",
+                              gather_fn=gather)
+    for step in range(3):
+        pipe.step()
+        assert len(pipe.in_flight) == 1                   # at most one gather behind
+    pipe.drain()
+    assert not pipe.in_flight and state["runs"] == 3 and state["gathers"] == 3 and pipe.steps == 3
+    out = pipe.gathered(ranges)
+    if rank == 0:
+        np.save(out_path, out.numpy())
+    else:
+        assert out is None
+    # a world of one without a process group behind it: the pipeline only runs the scorer
+    solo = shard.StepPipeline(run, pack, hi - lo, hi - lo, shard.record_width(max_k), "cpu", enabled=False)
+    solo.step()
+    solo.drain()
+    assert state["runs"] == 4 and state["gathers"] == 3
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_pipeline_is_what_bench_runs(tmp_path):
+    from oracle import harness, orc
+    from pyascore_amd import synth
+    from pyascore_amd.device import unpack_summary
+    import inspect
+    import bench
+    assert "shard.StepPipeline(" in inspect.getsource(bench.main)      # the bench's loop IS this class
+    out = str(tmp_path / "rec.npy")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    desc = _skewed_job(n=90)
+    got = unpack_summary(np.load(out), 4)
+    want = harness.make_scorer(orc.OracleAscore, desc["settings"], kind="oracle").score_batch(synth.make_slice(desc, threads=1), 4)
+    for key in ("best_score", "n_sig", "best_sig", "ascores", "alt_mask"):
+        assert np.array_equal(got[key], want[key]), key
