@@ -313,9 +313,15 @@ def main():
     # PYA_BENCH_FORCE_DIST=1 runs the collective path with a world of one (the only way to exercise
     # RCCL on a single-GPU box)
     use_dist = world > 1 or bool(os.environ.get("PYA_BENCH_FORCE_DIST"))
+    real_stdout = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL prints a version banner through C stdio on rank 0; stdout carries ONE JSON line and nothing
+        # else, so the C-level stdout is pointed at stderr while the process group lives
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     scorer = PyAscore(settings["bin_size"], settings["n_top"], settings["mod_group"], settings["mod_mass"],
@@ -453,10 +459,18 @@ def main():
                                          "sum of the work estimate the partition balanced"}
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
+        if real_stdout is not None:
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)                     # whatever the libraries buffered goes to stderr too
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
 
 
 if __name__ == "__main__":
