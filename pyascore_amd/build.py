@@ -19,7 +19,7 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 DEVICE_SRC = ["bin_spectra.hip", "score_signatures.hip", "score_big.hip", "rank_and_localize.hip", "score_localize.hip", "tiny_batch.hip"]
 HOST_SRC = ["host.cpp", "score_table.cpp", "aux_api.cpp"]
 HEADERS = ["common.h", "device_common.hip.h", "bin_core.hip.h", "walk_core.hip.h", "score_core.hip.h",
-           "localize_core.hip.h", "localize_body.hip.h", "fused_core.hip.h", "binom_chain.h", os.path.join("..", "..", "include", "pyascore_hip.h"),
+           "localize_core.hip.h", "localize_body.hip.h", "fused_core.hip.h", "fused_pack.hip.h", "binom_chain.h", os.path.join("..", "..", "include", "pyascore_hip.h"),
            os.path.join("..", "..", "include", "pyascore_aux.h")]
 
 DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",

@@ -7,6 +7,7 @@
 #define PYA_WAVE 64
 #define PYA_NTOP 10
 #define PYA_NO_MATCH 15            /* rank value meaning "no retained peak in the window" */
+#define PYA_TABLE_PAD 4            /* +inf sentinels after the last retained peak of a staged table */
 #define PYA_MAX_L 64
 #define PYA_MAX_TYPES 8
 #define PYA_MAX_NL 4               /* distinct neutral-loss masses                         */

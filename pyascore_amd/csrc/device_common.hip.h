@@ -192,7 +192,6 @@ DEV float charge_mz(double m, int z) {
  * Retained peaks are staged in LDS sorted by m/z (float); a coarse m/z grid gives the start of
  * the scan (the grid only narrows the search, the window test itself is the reference's).
  * ------------------------------------------------------------------------------------- */
-#define PYA_TABLE_PAD 4            /* +inf sentinels after the last retained peak             */
 
 /* one retained peak in LDS: float m/z and its rank, 8 bytes so both come with one ds_read_b64 */
 struct PeakEntry {

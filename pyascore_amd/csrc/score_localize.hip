@@ -9,6 +9,7 @@
  * hand-over list and redone by the general localize instantiation (pya_launch_localize_redo).
  */
 #include "fused_core.hip.h"
+#include "fused_pack.hip.h"
 
 #ifndef FUSED_WAVES
 #define FUSED_WAVES 6
@@ -23,6 +24,83 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void pya_score_localize_kernel(
     const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
     const bool declined = fused_body<BOTH, ZM>(b, psm, lds_raw, cap, n_cap, stride, pos_cap, ent_cap, push_cap);
     if (declined && lane_id() == 0) redo_ids[atomicAdd(redo_count, 1u)] = psm;
+}
+
+/* the PSMs the packed kernel passed on (peak pool too small, a residue at or below two tolerances): a
+ * small grid strides over the list, one PSM per wavefront as above */
+template <bool BOTH, bool ZM>
+__global__ __launch_bounds__(64, FUSED_WAVES) void pya_score_localize_list_kernel(
+    BatchDev b, const uint32_t *count, const uint32_t *ids, uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap,
+    uint32_t ent_cap, uint32_t push_cap, uint32_t *redo_count, uint32_t *redo_ids) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t n = *count;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const uint32_t psm = ids[k];
+        const bool declined = fused_body<BOTH, ZM>(b, psm, lds_raw, cap, n_cap, stride, pos_cap, ent_cap, push_cap);
+        if (declined && lane_id() == 0) redo_ids[atomicAdd(redo_count, 1u)] = psm;
+        wave_lds_sync();
+    }
+}
+
+/* several PSMs per wavefront (fused_pack.hip.h) */
+#ifndef PACK_WAVES
+#define PACK_WAVES 4
+#endif
+template <bool BOTH>
+__global__ __launch_bounds__(64, PACK_WAVES) void pya_score_localize_pack_kernel(
+    BatchDev b, const uint64_t *pdesc, uint32_t n_ids, uint32_t G, uint32_t pool_cap, uint32_t n_cap, uint32_t stride,
+    uint32_t pos_cap, uint32_t push_cap, uint32_t kc, uint32_t *redo_count, uint32_t *redo_ids, uint32_t *over_count,
+    uint32_t *over_ids) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t nblk = (n_ids + G - 1) / G;
+    if (blockIdx.x >= nblk) return;
+    const uint32_t first = xcd_slot(blockIdx.x, nblk) * G;
+    fused_pack_body<BOTH>(b, pdesc, n_ids, first, G, lds_raw, pool_cap, n_cap, stride, pos_cap, push_cap, kc, redo_count,
+                          redo_ids, over_count, over_ids);
+}
+
+extern "C" size_t pya_pack_lds_bytes(uint32_t G, uint32_t pool_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t push_cap,
+                                     uint32_t kc, uint32_t both) {
+    const uint32_t ndir = both ? 2u : 1u;
+    return pack_lds_bytes(G, pool_cap, n_cap, ndir * n_cap + 4u, pos_cap, push_cap, kc, ndir);
+}
+
+extern "C" int pya_launch_fused_pack(const BatchDev *b, const uint64_t *d_ids, uint32_t n_ids, uint32_t G, uint32_t pool_cap,
+                                     uint32_t n_cap, uint32_t pos_cap, uint32_t push_cap, uint32_t kc, uint32_t both,
+                                     uint32_t *d_redo_count, uint32_t *d_redo_ids, uint32_t *d_over_count, uint32_t *d_over_ids,
+                                     hipStream_t stream) {
+    if (n_ids == 0) return 0;
+    const uint32_t ndir = both ? 2u : 1u, stride = ndir * n_cap + 4u;
+    const size_t lds = pack_lds_bytes(G, pool_cap, n_cap, stride, pos_cap, push_cap, kc, ndir);
+    const uint32_t nblk = (n_ids + G - 1) / G;
+    hipError_t e = both ? PYA_ENSURE_MAX_LDS((pya_score_localize_pack_kernel<true>)) : PYA_ENSURE_MAX_LDS((pya_score_localize_pack_kernel<false>));
+    if (e != hipSuccess) return (int)e;
+    if (both)
+        hipLaunchKernelGGL((pya_score_localize_pack_kernel<true>), dim3(nblk), dim3(64), lds, stream, *b, d_ids, n_ids, G, pool_cap,
+                           n_cap, stride, pos_cap, push_cap, kc, d_redo_count, d_redo_ids, d_over_count, d_over_ids);
+    else
+        hipLaunchKernelGGL((pya_score_localize_pack_kernel<false>), dim3(nblk), dim3(64), lds, stream, *b, d_ids, n_ids, G, pool_cap,
+                           n_cap, stride, pos_cap, push_cap, kc, d_redo_count, d_redo_ids, d_over_count, d_over_ids);
+    return (int)hipGetLastError();
+}
+
+/* what the packed launches passed on, on the one-PSM-per-wavefront kernel (charge 1) */
+extern "C" int pya_launch_fused_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
+                                     uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap,
+                                     uint32_t both, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream) {
+    if (n_max == 0) return 0;
+    const size_t lds = fused_lds_bytes(cap, n_cap, stride, pos_cap, ent_cap, push_cap, both ? 2u : 1u, false);
+    const uint32_t grid = n_max < 8192u ? n_max : 8192u;
+    hipError_t e = both ? PYA_ENSURE_MAX_LDS((pya_score_localize_list_kernel<true, false>))
+                        : PYA_ENSURE_MAX_LDS((pya_score_localize_list_kernel<false, false>));
+    if (e != hipSuccess) return (int)e;
+    if (both)
+        hipLaunchKernelGGL((pya_score_localize_list_kernel<true, false>), dim3(grid), dim3(64), lds, stream, *b, d_count, d_ids, cap,
+                           n_cap, stride, pos_cap, ent_cap, push_cap, d_redo_count, d_redo_ids);
+    else
+        hipLaunchKernelGGL((pya_score_localize_list_kernel<false, false>), dim3(grid), dim3(64), lds, stream, *b, d_count, d_ids, cap,
+                           n_cap, stride, pos_cap, ent_cap, push_cap, d_redo_count, d_redo_ids);
+    return (int)hipGetLastError();
 }
 
 extern "C" size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap,

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
-                        "fused_replay", "general_serial_replay"])
+                        "fused_replay", "general_serial_replay", "packed", "packed_8", "packed_passed_on", "packed_small_pool",
+                        "packed_always_sort", "packed_declines", "packed_replay"])
 def path(request, monkeypatch):
     """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
     assignments on the fused score + localize kernel and the other plain ones on the lean
@@ -31,6 +32,32 @@ def path(request, monkeypatch):
     monkeypatch.delenv("PYA_DEBUG", raising=False)
     monkeypatch.setenv("PYA_PLAIN_MIN", "0")       # batches under 512 PSMs skip the lean kernels by default
     monkeypatch.setenv("PYA_NO_TINY", "1")         # ... and those of up to 64 the three kernels altogether
+    # The packed fused kernel (several PSMs per wavefront, fused_pack.hip.h; opt-in with PYA_PACK=1: it measured
+    # slower than one PSM per wavefront) for plain charge-1 PSMs with few site assignments.  "packed*": on for every batch size -- four
+    # slots per wavefront, eight, everything passed on to the one-PSM-per-wavefront kernel (PYA_DEBUG=32768),
+    # a peak pool so small that most PSMs are passed on, the std::sort emulation for every slot, every slot
+    # handed over to the general localize instantiation at the start (512) or at the pairing (2048).  The
+    # other routes run without it, as before.
+    for v in ("PYA_PACK", "PYA_NO_PACK", "PYA_PACK_MIN", "PYA_PACK_GROUP_MIN", "PYA_PACK_G", "PYA_PACK_PEAKS"):
+        monkeypatch.delenv(v, raising=False)
+    if request.param.startswith("packed"):
+        monkeypatch.setenv("PYA_PACK", "1")
+        monkeypatch.setenv("PYA_PACK_MIN", "0")
+        monkeypatch.setenv("PYA_PACK_GROUP_MIN", "1")
+        if request.param == "packed_8":
+            monkeypatch.setenv("PYA_PACK_G", "8")
+        elif request.param == "packed_passed_on":
+            monkeypatch.setenv("PYA_DEBUG", "32768")
+        elif request.param == "packed_small_pool":
+            monkeypatch.setenv("PYA_PACK_PEAKS", "150")
+        elif request.param == "packed_always_sort":
+            monkeypatch.setenv("PYA_DEBUG", "1024")
+        elif request.param == "packed_declines":
+            monkeypatch.setenv("PYA_DEBUG", "512")
+        elif request.param == "packed_replay":
+            monkeypatch.setenv("PYA_DEBUG", "2048")
+        return request.param
+    monkeypatch.setenv("PYA_NO_PACK", "1")
     if request.param in ("lean_localize", "always_sort"):
         monkeypatch.setenv("PYA_NO_FUSED", "1")
     if request.param == "fused_always_sort":
