@@ -467,7 +467,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                  * peaks in input order.  A stable counting sort by window id lists them (peak
                  * indices, in the PSM's still unused slice of the retained-m/z output as scratch),
                  * then every window is emulated by the lane of its first list entry. */
-                uint16_t *list = (uint16_t *)(b.ret_mz + p0);
+                uint16_t *list = (uint16_t *)(b.ret + b.ret_off[psm]);
                 for (int base = 0; base < P; base += 64) {
                     const int i = base + lane;
                     if (i < P) {
@@ -568,10 +568,17 @@ DEV void bin_store(const BatchDev &b, uint32_t psm, int R, int status, const flo
         }
         return;
     }
-    const int64_t p0 = b.peak_off[psm];
-    for (int i = lane; i < R; i += 64) {
-        b.ret_mz[p0 + i] = r_mz[i];
-        b.ret_rank[p0 + i] = r_rank[i];
+    /* two entries per lane and 16-byte store (the table starts at an even entry: common.h) */
+    uint4 *dst = (uint4 *)(b.ret + b.ret_off[psm]);
+    const int pairs = (R + 1) >> 1;
+    for (int q = lane; q < pairs; q += 64) {
+        const int i0 = 2 * q, i1 = 2 * q + 1;
+        uint4 v;
+        v.x = __float_as_uint(r_mz[i0]);
+        v.y = (uint32_t)r_rank[i0];
+        v.z = i1 < R ? __float_as_uint(r_mz[i1]) : __float_as_uint(__builtin_huge_valf());
+        v.w = i1 < R ? (uint32_t)r_rank[i1] : (uint32_t)PYA_NO_MATCH;
+        dst[q] = v;
     }
     if (lane == 0) {
         b.ret_n[psm] = (uint32_t)R;

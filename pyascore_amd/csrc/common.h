@@ -71,15 +71,16 @@ struct BatchDev {
     const uint32_t *inv_tab;        /* same offsets: combination rank of a signature -> its index in order_tab */
     const uint32_t *binom;          /* [64][64] C(p, t), saturated: the combination rank is sum C(p_t, t)       */
     const uint64_t *desc;           /* [n_psm][PYA_DESC_WORDS] the offsets and counts above, packed (one  */
-                                    /* cache line per PSM): peak_off, pep_off, sig_off, aux_off,          */
+                                    /* cache line per PSM): ret_off, pep_off, sig_off, aux_off,           */
                                     /* L | n_aux << 16 | n_of_mod << 32 | n_sites << 48 | max_charge << 56, n_sig | order_off << 32 */
     const DevConfig *cfg;
     const float *lut;               /* score table                                          */
     const uint32_t *lut_off;        /* [lut_n_max+1] row offsets                            */
     uint32_t lut_n_max;
     /* workspace */
-    float *ret_mz;                  /* retained peaks, m/z ascending, at peak_off[psm]      */
-    uint8_t *ret_rank;
+    struct PeakEntry *ret;          /* retained peaks (float m/z, rank), m/z ascending, at ret_off[psm]: 8-byte  */
+                                    /* entries from an even (16-byte aligned) offset, so a lane moves two at a time */
+    const int64_t *ret_off;         /* [n_psm] even; room for the PSM's raw peak count rounded up to even           */
     uint32_t *ret_n;                /* [n_psm]                                              */
     uint16_t *grid;                 /* [n_psm][PYA_GRID_CELLS] m/z grid over the retained peaks (score_signatures) */
     uint32_t *redo_count;           /* spectra bin_spectra hands to its exact variant (peaks out of */
@@ -115,6 +116,13 @@ struct BatchDev {
      * build (device_common.hip.h, STAMP_T). */
     uint32_t debug;
     unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */
+};
+
+/* one retained peak: float m/z and its rank inside its window, 8 bytes so both come with one 8-byte read
+ * (two entries with one 16-byte read) from LDS and from the workspace alike */
+struct PeakEntry {
+    float mz;
+    uint32_t rank;
 };
 
 /* one tied best competitor as the scan leaves it in LDS */

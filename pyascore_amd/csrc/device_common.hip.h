@@ -193,17 +193,10 @@ DEV float charge_mz(double m, int z) {
  * the scan (the grid only narrows the search, the window test itself is the reference's).
  * ------------------------------------------------------------------------------------- */
 
-/* one retained peak in LDS: float m/z and its rank, 8 bytes so both come with one ds_read_b64 */
-struct PeakEntry {
-    float mz;
-    uint32_t rank;
-};
-
 struct PeakTable {
     const PeakEntry *e;     /* LDS, ascending m/z, n entries + PYA_TABLE_PAD (+inf, rank 15);     */
                             /* NULL = not staged: look up in the global arrays below             */
-    const float *g_mz;      /* global retained m/z of the PSM (ascending)                        */
-    const uint8_t *g_rank;
+    const PeakEntry *g_e;   /* the PSM's retained table in the workspace (ascending m/z, 16-byte aligned) */
     const uint16_t *cell;   /* LDS [PYA_GRID_CELLS]: first peak index whose cell is >= c          */
     const uint16_t *g_cell; /* the same grid in global memory (score_signatures leaves it there)  */
     int n;
@@ -218,27 +211,53 @@ struct PeakTable {
 /* LDS bytes of a staged table for up to `cap` retained peaks */
 DEV size_t peak_table_bytes(uint32_t cap) { return ((size_t)cap + PYA_TABLE_PAD) * sizeof(PeakEntry); }
 
+/* Copies R retained peaks (workspace, 16-byte aligned) into an LDS table (16-byte aligned) and appends the
+ * PYA_TABLE_PAD sentinels: two entries per lane and load, every load issued before the first store.  `nt`
+ * lanes of `tid` 0 .. nt-1 share the work (64 for a wavefront, the workgroup's size for score_big). */
+DEV void copy_peak_table(const PeakEntry *src, int R, PeakEntry *dst, int tid, int nt) {
+    const uint4 *s4 = (const uint4 *)src;
+    uint4 *d4 = (uint4 *)dst;
+    const int pairs = (R + 1) >> 1;
+    const uint32_t inf = __float_as_uint(__builtin_huge_valf());
+    for (int base = 0; base < pairs; base += 4 * nt) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = base + u * nt + tid;
+            if (q < pairs) v[u] = s4[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = base + u * nt + tid;
+            if (q < pairs) {
+                if (2 * q + 1 >= R) {                        /* the odd tail: the first sentinel */
+                    v[u].z = inf;
+                    v[u].w = PYA_NO_MATCH;
+                }
+                d4[q] = v[u];
+            }
+        }
+    }
+    const int first_pad = (R + 1) & ~1;                      /* sentinels from there to R + PYA_TABLE_PAD - 1 */
+    if (tid < PYA_TABLE_PAD) {
+        const int at = first_pad + tid;
+        if (at < R + PYA_TABLE_PAD) {
+            PeakEntry x;
+            x.mz = __builtin_huge_valf();
+            x.rank = PYA_NO_MATCH;
+            dst[at] = x;
+        }
+    }
+}
+
 /* copies the retained peaks of `psm` (written by bin_spectra) into LDS and appends sentinels */
 DEV void stage_peak_table(const BatchDev &b, uint32_t psm, PeakEntry *dst, PeakTable *t) {
-    const int lane = lane_id();
-    const int64_t p0 = b.peak_off[psm];
+    const int64_t p0 = b.ret_off[psm];
     const int R = (int)b.ret_n[psm];
-    for (int i = lane; i < R; i += 64) {
-        PeakEntry x;
-        x.mz = b.ret_mz[p0 + i];
-        x.rank = b.ret_rank[p0 + i];
-        dst[i] = x;
-    }
-    if (lane < PYA_TABLE_PAD) {
-        PeakEntry x;
-        x.mz = __builtin_huge_valf();
-        x.rank = PYA_NO_MATCH;
-        dst[R + lane] = x;
-    }
+    copy_peak_table(b.ret + p0, R, dst, lane_id(), 64);
     t->e = dst;
     t->g_cell = nullptr;
-    t->g_mz = b.ret_mz + p0;
-    t->g_rank = b.ret_rank + p0;
+    t->g_e = b.ret + p0;
     t->n = R;
     t->err = b.cfg->mz_error;
     t->half_check = b.cfg->mz_error > 0.49f;
@@ -322,12 +341,11 @@ DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
  * window is not closed by the fourth entry does a lane continue with the scalar scan. */
 /* the table of `psm` left in global memory (for kernels that make only a handful of lookups) */
 DEV void global_peak_table(const BatchDev &b, uint32_t psm, PeakTable *t) {
-    const int64_t p0 = b.peak_off[psm];
+    const int64_t p0 = b.ret_off[psm];
     t->e = nullptr;
     t->cell = nullptr;
     t->g_cell = b.grid + (size_t)psm * PYA_GRID_CELLS;
-    t->g_mz = b.ret_mz + p0;
-    t->g_rank = b.ret_rank + p0;
+    t->g_e = b.ret + p0;
     t->n = (int)b.ret_n[psm];
     t->err = b.cfg->mz_error;
     t->half_check = b.cfg->mz_error > 0.49f;
@@ -335,29 +353,23 @@ DEV void global_peak_table(const BatchDev &b, uint32_t psm, PeakTable *t) {
     t->inv_w = 0.f;
     t->nb = 0.f;
     t->last_cell = 0;
-    if (t->n > 0) grid_params(t, t->g_mz[0], t->g_mz[t->n - 1]);
+    if (t->n > 0) grid_params(t, t->g_e[0].mz, t->g_e[t->n - 1].mz);
 }
 
-/* Same window test on the global arrays.  The grid score_signatures built for this PSM gives the
- * start; the next four entries are fetched together, so a lookup is two dependent round trips to
+/* Same window test on the table in the workspace.  The grid score_signatures built for this PSM gives the
+ * (even) start; the next four entries come as two 16-byte loads, so a lookup is two dependent round trips to
  * memory instead of the ten of a binary search. */
 DEV int match_rank_global(const PeakTable &t, float f) {
     if (t.n <= 0) return PYA_NO_MATCH;
     const float lo = f - t.err;
     const float hi = f + t.err;
-    int idx = (int)t.g_cell[grid_cell(t, lo)];            /* every peak > lo has index >= idx  */
+    int idx = (int)t.g_cell[grid_cell(t, lo)];            /* every peak > lo has index >= idx (even)  */
     const int last = t.n - 1;
-    /* entries idx .. idx+3 through one address and immediate offsets; reading up to three entries
-     * past the PSM's table stays inside the plan's arena and is masked below */
-    const float *pm = t.g_mz + idx;
-    const uint8_t *pr = t.g_rank + idx;
-    float m[4];
-    int r[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        m[j] = pm[j];
-        r[j] = (int)pr[j];
-    }
+    /* reading up to three entries past the PSM's table stays inside the plan's arena and is masked below */
+    const uint4 *p4 = (const uint4 *)(t.g_e + idx);
+    const uint4 a = p4[0], c = p4[1];
+    const float m[4] = {__uint_as_float(a.x), __uint_as_float(a.z), __uint_as_float(c.x), __uint_as_float(c.z)};
+    const int r[4] = {(int)a.y, (int)a.w, (int)c.y, (int)c.w};
     int best = PYA_NO_MATCH;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -367,10 +379,10 @@ DEV int match_rank_global(const PeakTable &t, float f) {
     }
     if (idx + 3 < last && m[3] < hi) {                    /* rare: more than four entries to look at */
         for (idx += 4; idx <= last; idx++) {
-            const float p = t.g_mz[idx];
-            if (!(p < hi)) break;
-            if (p > lo && (!t.half_check || (double)f >= (double)p - 0.5)) {
-                const int rr = (int)t.g_rank[idx];
+            const PeakEntry x = t.g_e[idx];
+            if (!(x.mz < hi)) break;
+            if (x.mz > lo && (!t.half_check || (double)f >= (double)x.mz - 0.5)) {
+                const int rr = (int)x.rank;
                 best = rr < best ? rr : best;
             }
         }

@@ -319,23 +319,11 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         aux_pos = b.aux_pos[a0 + lane];
         aux_mass = b.aux_mass[a0 + lane];
     }
-    for (int i = lane; i < R; i += 64) {
-        PeakEntry e;
-        e.mz = b.ret_mz[p0 + i];
-        e.rank = b.ret_rank[p0 + i];
-        f.peaks[i] = e;
-    }
-    if (lane < PYA_TABLE_PAD) {
-        PeakEntry e;
-        e.mz = __builtin_huge_valf();
-        e.rank = PYA_NO_MATCH;
-        f.peaks[R + lane] = e;
-    }
+    copy_peak_table(b.ret + p0, R, f.peaks, lane, 64);
     PeakTable tab;
     tab.e = f.peaks;
     tab.g_cell = nullptr;
-    tab.g_mz = b.ret_mz + p0;
-    tab.g_rank = b.ret_rank + p0;
+    tab.g_e = b.ret + p0;
     tab.n = R;
     tab.err = cfg->mz_error;
     tab.half_check = cfg->mz_error > 0.49f;

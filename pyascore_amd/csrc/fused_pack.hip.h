@@ -32,7 +32,7 @@
 
 #define PACK_MAX_SLOTS 8
 #define PACK_ROUND 3                  /* competitors of a slot localised together (plus its winner) */
-#define PACK_LOAD_CHUNKS 12           /* chunks of 64 retained peaks fetched before the first is stored */
+#define PACK_LOAD_CHUNKS 6            /* chunks of 128 retained peaks fetched before the first is stored */
 
 /* slot flags */
 #define PK_ACTIVE 1u                  /* the slot holds a PSM this wavefront scores */
@@ -313,39 +313,40 @@ DEV void fused_pack_body(const BatchDev &b, const uint64_t *pdesc, uint32_t n_id
         }
     }
     STAMP_T(b, 61, );
-    /* retained peaks of all slots, laid end to end in the pool: round trip 3, up to PACK_LOAD_CHUNKS x 64 entries in
-     * flight per wavefront (LDS, not registers, limits this kernel's occupancy: the loads can have them) */
+    /* retained peaks of all slots, laid end to end in the pool: round trip 3, two entries (16 bytes) per lane and
+     * load, up to PACK_LOAD_CHUNKS x 128 entries in flight per wavefront (LDS, not registers, limits this kernel's
+     * occupancy: the loads can have them).  Slot tables start at even pool offsets and even workspace offsets. */
     {
         uint32_t pool_used = 0;
         for (uint32_t s = 0; s < G; s++)
             if (f.flags[s] & PK_ACTIVE) pool_used = f.peak_at[s] + (((uint32_t)f.R[s] + PYA_TABLE_PAD + 1u) & ~1u);
-        for (uint32_t base = 0; base < pool_used; base += 64 * PACK_LOAD_CHUNKS) {
-            float mzv[PACK_LOAD_CHUNKS];
-            uint32_t rkv[PACK_LOAD_CHUNKS];
+        const uint32_t pairs = pool_used >> 1;
+        const uint32_t inf = __float_as_uint(__builtin_huge_valf());
+        uint4 *d4 = (uint4 *)f.peaks;
+        for (uint32_t base = 0; base < pairs; base += 64 * PACK_LOAD_CHUNKS) {
+            uint4 v[PACK_LOAD_CHUNKS];
 #pragma unroll
             for (int q = 0; q < PACK_LOAD_CHUNKS; q++) {
-                const uint32_t j = base + q * 64 + (uint32_t)lane;
+                const uint32_t jp = base + q * 64 + (uint32_t)lane;    /* pair index in the pool */
+                const uint32_t j = 2u * jp;
                 uint32_t s = 0;                              /* the slot whose table holds entry j */
                 for (uint32_t t = 1; t < G; t++)
                     if ((f.flags[t] & PK_ACTIVE) && j >= f.peak_at[t]) s = t;
                 const uint32_t i = j - f.peak_at[s];
-                const bool real = j < pool_used && (f.flags[s] & PK_ACTIVE) && i < (uint32_t)f.R[s];
-                mzv[q] = __builtin_huge_valf();
-                rkv[q] = PYA_NO_MATCH;
-                if (real) {
-                    mzv[q] = b.ret_mz[f.p0[s] + i];
-                    rkv[q] = b.ret_rank[f.p0[s] + i];
+                const uint32_t Rs = (f.flags[s] & PK_ACTIVE) ? (uint32_t)f.R[s] : 0u;
+                v[q] = make_uint4(inf, PYA_NO_MATCH, inf, PYA_NO_MATCH);   /* (beyond a slot's peaks: its +inf sentinels) */
+                if (jp < pairs && i < Rs) {
+                    v[q] = ((const uint4 *)(b.ret + f.p0[s]))[i >> 1];
+                    if (i + 1 >= Rs) {
+                        v[q].z = inf;
+                        v[q].w = PYA_NO_MATCH;
+                    }
                 }
             }
 #pragma unroll
             for (int q = 0; q < PACK_LOAD_CHUNKS; q++) {
-                const uint32_t j = base + q * 64 + (uint32_t)lane;
-                if (j < pool_used) {
-                    PeakEntry e;
-                    e.mz = mzv[q];
-                    e.rank = rkv[q];
-                    f.peaks[j] = e;                          /* (beyond a slot's peaks: its +inf sentinels) */
-                }
+                const uint32_t jp = base + q * 64 + (uint32_t)lane;
+                if (jp < pairs) d4[jp] = v[q];
             }
         }
     }

@@ -321,8 +321,10 @@ struct pya_plan {
     DevBuf<uint8_t> d_pep, d_n_sites;
     DevBuf<int32_t> d_n_of_mod, d_max_charge, d_status;
     DevBuf<uint32_t> d_aux_pos, d_n_sig, d_order_off, d_ret_n, d_rec, d_sorted;
-    DevBuf<float> d_aux_mass, d_ret_mz, d_ws;
-    DevBuf<uint8_t> d_ret_rank;
+    DevBuf<float> d_aux_mass, d_ws;
+    DevBuf<PeakEntry> d_ret;             /* retained tables, 8-byte entries, every PSM's from an even offset */
+    DevBuf<int64_t> d_ret_off;
+    std::vector<int64_t> ret_off;        /* [n_psm + 1] */
     DevBuf<uint16_t> d_grid;
     DevBuf<uint32_t> d_redo3;            /* the same for localize's lean instantiation */
     DevBuf<uint32_t> d_redo;             /* [1 + n_psm]: count, then the ids bin_spectra hands to its exact variant */
@@ -603,8 +605,8 @@ void fill_dev(pya_plan *p) {
     d.lut = h->d_lut.p;
     d.lut_off = h->d_lut_off.p;
     d.lut_n_max = h->lut_uploaded_n - 1;
-    d.ret_mz = p->d_ret_mz.p;
-    d.ret_rank = p->d_ret_rank.p;
+    d.ret = p->d_ret.p;
+    d.ret_off = p->d_ret_off.p;
     d.ret_n = p->d_ret_n.p;
     d.grid = p->d_grid.p;
     d.redo_count = p->d_redo.p;
@@ -865,6 +867,16 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->peak_off[i] -= peak_base;
         p->pep_off[i] -= pep_base;
         p->aux_off[i] -= aux_base;
+    }
+    p->ret_off.resize(n + 1);
+    {
+        int64_t at = 0;                                     /* every PSM's retained table starts at an even entry */
+        for (uint64_t i = 0; i < n; i++) {
+            p->ret_off[i] = at;
+            const int64_t P = p->peak_off[i + 1] - p->peak_off[i];
+            at += ((P > 0 ? P : 0) + 1) & ~(int64_t)1;
+        }
+        p->ret_off[n] = at;
     }
     lap("copy meta");
     p->n_sites.resize(n);
@@ -1297,7 +1309,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         uint64_t *w = &p->desc[(size_t)i * PYA_DESC_WORDS];
         const uint64_t L = (uint64_t)std::max<int64_t>(0, std::min<int64_t>(p->pep_off[i + 1] - p->pep_off[i], 0xffff));
         const uint64_t na = (uint64_t)std::max<int64_t>(0, std::min<int64_t>(p->aux_off[i + 1] - p->aux_off[i], 0xffff));
-        w[0] = (uint64_t)p->peak_off[i];
+        w[0] = (uint64_t)p->ret_off[i];
         w[1] = (uint64_t)p->pep_off[i];
         w[2] = (uint64_t)p->sig_off[i];
         w[3] = (uint64_t)p->aux_off[i];
@@ -1352,6 +1364,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             if (src && bytes) ups.push_back({o, src, bytes});
             return o;
         };
+        const size_t o_ret_off = meta(p->ret_off.data(), (n + 1) * 8);
         const size_t o_peak_off = meta(p->peak_off.data(), (n + 1) * 8), o_pep_off = meta(p->pep_off.data(), (n + 1) * 8),
                      o_aux_off = meta(p->aux_off.data(), (n + 1) * 8), o_sig_off = meta(p->sig_off.data(), (n + 1) * 8),
                      o_pep = meta(p->pep.data(), p->pep.size()), o_n_sites = meta(p->n_sites.data(), n),
@@ -1384,7 +1397,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         }
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
-                     o_ret_mz = reserve((size_t)p->total_peaks * 4), o_ret_rank = reserve((size_t)p->total_peaks),
+                     o_ret = reserve((size_t)p->ret_off[n] * sizeof(PeakEntry) + 64),
                      o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_over = reserve((p->pack_ids.size() + 64) * 4), o_ws_top = reserve(n * 16),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
@@ -1428,8 +1441,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         }
         p->d_status.adopt(base + p->o_status, n);
         p->d_ret_n.adopt(base + o_ret_n, n);
-        p->d_ret_mz.adopt(base + o_ret_mz, (size_t)p->total_peaks);
-        p->d_ret_rank.adopt(base + o_ret_rank, (size_t)p->total_peaks);
+        p->d_ret.adopt(base + o_ret, (size_t)p->ret_off[n] + 8);
+        p->d_ret_off.adopt(base + o_ret_off, n + 1);
         p->d_grid.adopt(base + o_grid, n * PYA_GRID_CELLS);
         p->d_redo.adopt(base + o_redo, n + 64);
         p->d_redo3.adopt(base + o_redo3, 2 * n + 64);
@@ -1720,7 +1733,7 @@ ChunkCost chunk_costs(pya_handle *h, const pya_batch *b, uint32_t max_k) {
                 sigs = N > PYA_MAX_SIGNATURES ? 0. : (double)N;
             }
             c.io[i] = 16.0 * (double)P;
-            c.arena[i] = 5.0 * (double)P + 28.0 * sigs + (double)L + 2.0 * PYA_GRID_CELLS + 96.0 + 12.0 * max_k;
+            c.arena[i] = 8.0 * (double)(P + 1) + 8.0 + 28.0 * sigs + (double)L + 2.0 * PYA_GRID_CELLS + 96.0 + 12.0 * max_k;
         }
     };
     unsigned nt = n >= 20000 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;

@@ -73,24 +73,12 @@ __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchD
     const int L = res.L;
     PeakTable tab;
     {
-        const int64_t p0 = b.peak_off[psm];
+        const int64_t p0 = b.ret_off[psm];
         const int R = (int)b.ret_n[psm];
-        for (int i = tid; i < R; i += 64 * BIG_WAVES) {
-            PeakEntry x;
-            x.mz = b.ret_mz[p0 + i];
-            x.rank = b.ret_rank[p0 + i];
-            t_e[i] = x;
-        }
-        if (tid < PYA_TABLE_PAD) {
-            PeakEntry x;
-            x.mz = __builtin_huge_valf();
-            x.rank = PYA_NO_MATCH;
-            t_e[R + tid] = x;
-        }
+        copy_peak_table(b.ret + p0, R, t_e, tid, 64 * BIG_WAVES);
         tab.e = t_e;
         tab.g_cell = nullptr;
-        tab.g_mz = b.ret_mz + p0;
-        tab.g_rank = b.ret_rank + p0;
+        tab.g_e = b.ret + p0;
         tab.n = R;
         tab.err = cfg->mz_error;
         tab.half_check = false;                                  /* (the host sends mz_error > 0.49 elsewhere) */
