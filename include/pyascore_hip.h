@@ -115,6 +115,23 @@ typedef struct pya_results {
 int pya_create(const pya_config *cfg, pya_handle **out);
 void pya_destroy(pya_handle *h);
 int pya_add_neutral_loss(pya_handle *h, const char *group, float mass);
+/* PyAscore.score for ONE PSM with the lowest latency (Ascore.pyx:103-152; the reference's own command line
+ * calls it once per PSM, pyascore/__main__.py:129-164): no plan, no copies -- the spectrum is staged in pinned
+ * host memory the device reads directly, the PSM's scalars travel in the kernel's arguments, one wavefront runs
+ * the whole path and writes the results straight back into pinned host memory.  Results as row 0 of `out`
+ * (out->max_k <= 64).  flags: PYA_FLAG_KEEP retains the per-signature records at once; without it
+ * pya_rescore_last_keep() retains them on demand (the properties only a few callers read).  Returns
+ * PYA_ERR_STATE without an error message when the PSM needs the batch path (more than 8 fixed
+ * modifications): call pya_score_batch then. */
+int pya_score_one(pya_handle *h, const double *mz, const double *intensity, uint64_t n_peaks, const uint8_t *peptide,
+                  uint64_t peptide_len, int32_t n_of_mod, int32_t max_fragment_charge, const uint32_t *aux_pos,
+                  const float *aux_mass, uint64_t n_aux, uint32_t flags, const pya_results *out);
+int pya_rescore_last_keep(pya_handle *h);
+
+/* Re-reads the PYA_* environment switches (routes, diagnostics) into the handle.  They are read once in
+ * pya_create; this is the hook the tests use to flip a route on a live handle.  No reference counterpart. */
+int pya_reload_env(pya_handle *h);
+
 const char *pya_last_error(const pya_handle *h);
 int64_t pya_error_index(const pya_handle *h);
 

@@ -39,6 +39,10 @@ SYMBOLS = {
     "pya_create": (C.c_int, [C.POINTER(Config), C.POINTER(_vp)]),
     "pya_destroy": (None, [_vp]),
     "pya_add_neutral_loss": (C.c_int, [_vp, C.c_char_p, C.c_float]),
+    "pya_reload_env": (C.c_int, [_vp]),
+    "pya_score_one": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_int32, C.c_int32, _vp, _vp, C.c_uint64,
+                                C.c_uint32, C.POINTER(Results)]),
+    "pya_rescore_last_keep": (C.c_int, [_vp]),
     "pya_last_error": (C.c_char_p, [_vp]),
     "pya_error_index": (C.c_int64, [_vp]),
     "pya_score_batch": (C.c_int, [_vp, C.POINTER(Batch), _vp, _vp, C.c_uint32, C.POINTER(Results)]),

@@ -112,6 +112,13 @@ class PyAscore:
         if rc:
             self._raise(rc)
 
+    def reload_env(self):
+        """Re-reads the PYA_* environment switches (kernel routes, diagnostics).  The library reads them once,
+        when the scorer is created; tests that flip a route on a live scorer call this afterwards."""
+        rc = self._lib.pya_reload_env(self._h)
+        if rc:
+            self._raise(rc)
+
     def set_workspace_budget(self, n_bytes):
         """Device memory one ``score_batch`` call may hold at a time (default 6 GiB; 0 restores it).
         Bigger calls are cut into chunks of consecutive PSMs and pipelined (upload of the next chunk
@@ -142,9 +149,10 @@ class PyAscore:
         else:
             ap = np.zeros(0, np.uint32)
             am = np.zeros(0, np.float32)
-        # A batch of one through preallocated CSR scaffolding: a per-PSM loop calls this 10^5 times,
-        # and rebuilding a dozen small arrays and two ctypes structures per call costs as much as
-        # the device work.
+        # One PSM through pya_score_one (no plan, no copies: pinned spectrum block, scalars in the kernel
+        # arguments, results polled from pinned memory).  The per-signature records behind ``pep_scores`` and
+        # ``calculate_ambiguity`` are retained on demand (_ensure_kept): a loop over PSMs that reads only
+        # best_sequence / best_score / ascores / alt_sites, like the reference's command line, never pays for them.
         one = self._one
         k = max(1, int(n_of_mod))
         if one is None or one["k"] < k:
@@ -159,26 +167,47 @@ class PyAscore:
             one["results"] = _lib.Results(k, _as_ptr(one["best_score"]), _as_ptr(one["best_sig"]),
                                           _as_ptr(one["n_sig"]), _as_ptr(one["ascores"]), _as_ptr(one["alt_mask"]))
             self._one = one
-        one["peak_off"][1] = mz_arr.size
-        one["pep_off"][1] = pep.size
-        one["aux_off"][1] = ap.size
-        one["n_of_mod"][0] = n_of_mod
-        one["max_charge"][0] = max_fragment_charge
-        b = one["batch"]
-        b.pep = pep.ctypes.data
-        b.aux_pos = ap.ctypes.data
-        b.aux_mass = am.ctypes.data
         one["ascores"][:] = 0
         one["alt_mask"][:] = 0
-        rc = self._lib.pya_score_batch(self._h, C.byref(b), mz_arr.ctypes.data, int_arr.ctypes.data,
-                                       _lib.PYA_FLAG_KEEP, C.byref(one["results"]))
+        lazy = True
+        rc = _lib.PYA_ERR_STATE
+        if one["k"] <= 64:
+            rc = self._lib.pya_score_one(self._h, mz_arr.ctypes.data, int_arr.ctypes.data, mz_arr.size, pep.ctypes.data,
+                                         pep.size, int(n_of_mod), int(max_fragment_charge), ap.ctypes.data, am.ctypes.data,
+                                         ap.size, 0, C.byref(one["results"]))
+        if rc == _lib.PYA_ERR_STATE and not self._lib.pya_last_error(self._h):
+            # (more than 8 fixed modifications: a retained batch of one through the plan machinery)
+            lazy = False
+            one["peak_off"][1] = mz_arr.size
+            one["pep_off"][1] = pep.size
+            one["aux_off"][1] = ap.size
+            one["n_of_mod"][0] = n_of_mod
+            one["max_charge"][0] = max_fragment_charge
+            b = one["batch"]
+            b.pep = pep.ctypes.data
+            b.aux_pos = ap.ctypes.data
+            b.aux_mass = am.ctypes.data
+            rc = self._lib.pya_score_batch(self._h, C.byref(b), mz_arr.ctypes.data, int_arr.ctypes.data,
+                                           _lib.PYA_FLAG_KEEP, C.byref(one["results"]))
         if rc:
+            self._last = None
             self._raise(rc)
-        self._batch_n = 1
+        self._batch_n = None if lazy else 1
         self._last = dict(pep=pep, peptide=peptide, k=int(n_of_mod), aux_pos=ap.copy(), aux_mass=am.copy(),
                           best_score=float(one["best_score"][0]), best_sig=int(one["best_sig"][0]),
                           n_sig=int(one["n_sig"][0]), ascores=one["ascores"][0].copy(),
-                          alt_mask=one["alt_mask"][0].copy())
+                          alt_mask=one["alt_mask"][0].copy(), lazy=lazy)
+
+    def _ensure_kept(self):
+        """Retains the per-signature records of the last ``score()`` PSM (its inputs are still where
+        pya_score_one staged them)."""
+        last = self._last
+        if last is not None and last.get("lazy"):
+            rc = self._lib.pya_rescore_last_keep(self._h)
+            if rc:
+                self._raise(rc)
+            last["lazy"] = False
+            self._batch_n = 1
 
     def score_batch(self, batch, keep=False, skip_invalid=False):
         """Scores a CSR batch (see pyascore_amd.synth) in one call.
@@ -296,6 +325,7 @@ class PyAscore:
         last = self._last
         if last is None or last["n_sig"] <= 0:
             return []
+        self._ensure_kept()
         n = last["n_sig"]
         ns = self._n_sites(last)
         bits = np.zeros(n, np.uint64)
@@ -371,6 +401,7 @@ class PyAscore:
         (Ascore.pyx:208-230).  Inputs should come from ``pep_scores``."""
         if self._last is None:
             raise RuntimeError("calculate_ambiguity needs a scored PSM")
+        self._ensure_kept()
         from_sig = lambda s: sum(1 << j for j, v in enumerate(s) if int(v))  # noqa: E731
         rs = np.ascontiguousarray(ref_score["scores"], np.float32)
         os_ = np.ascontiguousarray(other_score["scores"], np.float32)

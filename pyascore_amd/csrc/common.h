@@ -132,6 +132,20 @@ struct PushedEntry {
     uint32_t idx;    /* its pre-sort index */
 };
 
+/* The scalars of ONE PSM, handed to pya_one_kernel in its kernel arguments (the dispatch packet is the
+ * fastest way to get a few bytes to the device: no copy, no second round trip); the wavefront writes them
+ * where the per-PSM bodies expect the batch arrays. */
+#define PYA_ONE_MAX_AUX 8
+struct OneMeta {
+    uint64_t pep[PYA_MAX_L / 8];    /* the peptide's letters */
+    uint64_t desc[6];               /* the packed descriptor (BatchDev.desc) */
+    uint32_t n_peaks, L, n_aux, n_sig, order_off, seq;
+    int32_t n_of_mod, max_charge;
+    uint32_t n_sites, pad;
+    uint32_t aux_pos[PYA_ONE_MAX_AUX];
+    float aux_mass[PYA_ONE_MAX_AUX];
+};
+
 /* LDS bytes of the batched-localisation work area (localize_core.hip.h: LocLds) */
 #define PYA_GRID_CELLS 256         /* cells of the m/z grid that accelerates the peak lookup    */
 #define PYA_LOC_SB_MAX 8           /* signatures worked on together: the winner + 7 competitors */

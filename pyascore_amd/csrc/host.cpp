@@ -13,6 +13,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -43,12 +44,19 @@ int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, u
                      uint32_t with_nl, uint32_t compact, hipStream_t stream);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap,
                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
-                        uint32_t plain, hipStream_t stream);
+                        uint32_t plain, uint32_t sort_room, hipStream_t stream);
 size_t pya_tiny_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact, uint32_t push_cap,
                           uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_tiny(const BatchDev *b, uint32_t n_psm, uint32_t cap, uint32_t prefix, uint32_t with_nl,
                     uint32_t compact, uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
                     uint32_t sb, uint32_t gtp, hipStream_t stream);
+size_t pya_one_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact, uint32_t push_cap, uint32_t n_cap,
+                         uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t use_fused, uint32_t f_n_cap, uint32_t f_stride,
+                         uint32_t f_ent_cap, uint32_t f_push_cap, uint32_t multi_z);
+int pya_launch_one(const BatchDev *b, const OneMeta *m, uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact,
+                   uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
+                   uint32_t use_fused, uint32_t f_n_cap, uint32_t f_stride, uint32_t f_ent_cap, uint32_t f_push_cap,
+                   uint32_t multi_z, int32_t *host_status, uint32_t *host_flag, hipStream_t stream);
 int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uint32_t list_cap,
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
@@ -170,7 +178,60 @@ float std_residue_mass(char c) {                       /* Types.h:7-30 */
 
 }  // namespace
 
+/* The PYA_* environment switches (route selection for the tests, diagnostics, A/B experiments).  They are
+ * read ONCE per handle, in pya_create -- a variable set in a user's shell afterwards changes nothing, and no
+ * call pays for getenv -- and again only when pya_reload_env asks for it (the tests flip routes on a live
+ * handle that way).  Defaults are the production behaviour. */
+struct Knobs {
+    bool no_plain = false, no_fused = false, no_big = false, no_tiny = false, no_prefix = false, no_chunks = false;
+    bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
+    bool host_timing = false, stamps = false, pack = false, sort_room = false;
+    uint32_t debug = 0;
+    int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64, pack_min = 512, pack_group_min = 256;
+    uint32_t pack_g = 4, pack_peaks = 208, sort_room_max = 1024;
+    int sb = -1, gtp = -1;                      /* < 0: the built-in rule */
+    double chunk_mb = 0.;                       /* 0: the default chunk size */
+    int64_t workspace_mb = 0;                   /* 0: the default budget */
+};
+static int g_knob_sb = -1, g_knob_gtp = -1;     /* (Bucket has no handle: the two A/B overrides are process-wide) */
+
+static void read_knobs(Knobs &k) {
+    auto flag = [](const char *n) { return std::getenv(n) != nullptr; };
+    auto num = [](const char *n, int64_t dflt) { const char *v = std::getenv(n); return v ? (int64_t)std::atoll(v) : dflt; };
+    k = Knobs();
+    k.no_plain = flag("PYA_NO_PLAIN");
+    k.no_fused = flag("PYA_NO_FUSED");
+    k.no_big = flag("PYA_NO_BIG");
+    k.no_tiny = flag("PYA_NO_TINY");
+    k.no_prefix = flag("PYA_NO_PREFIX");
+    k.no_chunks = flag("PYA_NO_CHUNKS");
+    k.no_upload_thread = flag("PYA_NO_UPLOAD_THREAD");
+    k.one_peak_class = flag("PYA_ONE_PEAK_CLASS");
+    k.peak_classes = flag("PYA_PEAK_CLASSES");
+    k.one_lds_class = flag("PYA_ONE_LDS_CLASS");
+    k.host_timing = flag("PYA_HOST_TIMING");
+    k.stamps = flag("PYA_STAMPS");
+    k.pack = flag("PYA_PACK") && !flag("PYA_NO_PACK");
+    k.sort_room = flag("PYA_SORT_ROOM");
+    if (const char *d = std::getenv("PYA_DEBUG")) k.debug = (uint32_t)std::strtoul(d, nullptr, 0);
+    k.plain_min = num("PYA_PLAIN_MIN", 512);
+    k.big_min_n = num("PYA_BIG_MIN_N", 1024);
+    k.tiny_max = num("PYA_TINY_MAX", 64);
+    k.pack_min = num("PYA_PACK_MIN", 512);
+    k.pack_group_min = num("PYA_PACK_GROUP_MIN", 256);
+    k.pack_g = (uint32_t)num("PYA_PACK_G", 4);
+    k.pack_peaks = (uint32_t)num("PYA_PACK_PEAKS", 208);
+    k.sort_room_max = (uint32_t)num("PYA_SORT_ROOM_MAX", 1024);
+    k.sb = (int)num("PYA_SB", -1);
+    k.gtp = (int)num("PYA_GTP", -1);
+    if (const char *e = std::getenv("PYA_CHUNK_MB")) k.chunk_mb = std::max(1.0, std::atof(e));
+    k.workspace_mb = num("PYA_WORKSPACE_MB", 0);
+    g_knob_sb = k.sb;
+    g_knob_gtp = k.gtp;
+}
+
 struct pya_handle {
+    Knobs kn;
     int device = 0;
     float bin_size = 100.f, mod_mass = 0.f, mz_error = 0.5f;
     std::string mod_group, fragment_types;
@@ -202,6 +263,20 @@ struct pya_handle {
     hipStream_t copy_stream = nullptr, run_stream = nullptr;   /* chunked calls: uploads / kernels + results */
     size_t ws_budget = 0;                      /* device bytes one pya_score_batch call may hold (0 = default) */
     std::vector<unsigned char> stage;          /* host staging of small batches: one copy each way */
+
+    /* pya_score_one: persistent pinned (device-mapped, coherent) host block + one PSM's device workspace */
+    struct One {
+        unsigned char *host = nullptr, *host_dev = nullptr;    /* the same block as the host / the device sees it */
+        DevBuf<unsigned char> ws;
+        uint32_t sig_cap = 0;                      /* signatures the workspace has room for */
+        uint32_t seq = 0;
+        hipStream_t stream = nullptr;
+        BatchDev dev;
+        OneMeta meta;                              /* of the last call (pya_rescore_last_keep replays it) */
+        bool have_last = false, last_keep = false;
+        uint32_t last_max_k = 1;
+        pya_plan *view = nullptr;                  /* what pya_get_pep_scores / pya_calculate_ambiguity read */
+    } one;
 
     std::string err;
     int64_t err_index = -1;
@@ -269,7 +344,7 @@ struct Bucket {
     /* Signatures localised together (winner included) -- LDS per wave decides the occupancy of
      * localize, the number of batches its instruction count. */
     uint32_t sb() const {
-        if (const char *o = std::getenv("PYA_SB")) return (uint32_t)std::atoi(o);   /* A/B experiments */
+        if (g_knob_sb >= 0) return (uint32_t)g_knob_sb;                            /* A/B experiments (PYA_SB) */
         /* one batch should hold the winner and one competitor per modified site; long peptides
          * have large per-signature tables, so they get fewer (measured: profiles/r01_c) */
         uint32_t v = k_max + 1;
@@ -282,7 +357,7 @@ struct Bucket {
      * so long multi-charge lists (cfg4: 228 per type) go one type at a time and the pool -- hence
      * the LDS per wave, hence the occupancy of localize -- stays small. */
     uint32_t gtp() const {
-        if (const char *o = std::getenv("PYA_GTP")) return (uint32_t)std::atoi(o);   /* A/B experiments */
+        if (g_knob_gtp >= 0) return (uint32_t)g_knob_gtp;                          /* A/B experiments (PYA_GTP) */
         uint32_t g = 0;
         while ((1u << g) < n_types) g++;
         while (g > 0 && (list_cap << g) > 256u) g--;
@@ -624,9 +699,8 @@ void fill_dev(pya_plan *p) {
     d.status = p->d_status.p;
     d.max_k = p->max_k;
     d.keep = (p->flags & PYA_FLAG_KEEP) ? 1u : 0u;
-    const char *dbg = std::getenv("PYA_DEBUG");
-    d.debug = dbg ? (uint32_t)std::strtoul(dbg, nullptr, 0) : 0u;
-    if (std::getenv("PYA_STAMPS")) {
+    d.debug = h->kn.debug;
+    if (h->kn.stamps) {
         if (!p->d_stamps.p) {
             (void)p->d_stamps.alloc(64);
             (void)hipMemset(p->d_stamps.p, 0, 64 * 8);
@@ -667,6 +741,7 @@ int pya_create(const pya_config *cfg, pya_handle **out) {
     hp->mod_group = cfg->mod_group;
     hp->fragment_types = ft;
     hp->build_letter_tables();
+    read_knobs(hp->kn);
     std::memset(hp->shape_cache, 0xff, sizeof hp->shape_cache);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -683,12 +758,21 @@ int pya_create(const pya_config *cfg, pya_handle **out) {
 void pya_destroy(pya_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->kept) pya_plan_destroy(h->kept);
+    if (h->kept) pya_plan_destroy(h->kept);                 /* (unhooks the one-PSM view if that is what it is) */
+    if (h->one.view) delete h->one.view;
+    if (h->one.host) (void)hipHostFree(h->one.host);
+    if (h->one.stream) (void)hipStreamDestroy(h->one.stream);
     for (void *ps : h->pinned_stage)
         if (ps) (void)hipHostFree(ps);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->run_stream) (void)hipStreamDestroy(h->run_stream);
     delete h;
+}
+
+int pya_reload_env(pya_handle *h) {
+    if (!h) return PYA_ERR_ARG;
+    read_knobs(h->kn);
+    return PYA_OK;
 }
 
 const char *pya_last_error(const pya_handle *h) { return h ? h->err.c_str() : "NULL handle"; }
@@ -836,7 +920,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     if (n > 0 && (!b->peak_off || !b->pep || !b->pep_off || !b->n_of_mod || !b->max_charge))
         return h->fail(PYA_ERR_ARG, -1, "NULL array in batch");
     if (n >= (1ull << 31)) return h->fail(PYA_ERR_LIMIT, -1, "more than 2^31 PSMs in one batch");
-    const bool host_timing = std::getenv("PYA_HOST_TIMING") != nullptr;
+    const bool host_timing = h->kn.host_timing;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!host_timing) return;
@@ -889,21 +973,19 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     int64_t sig_total = 0;
     /* (tiny batches are launch-bound: the lean instantiation's extra memset + hand-over launch cost
      * more than its occupancy gains there) */
-    const bool plain_on = h->cfg.n_nl == 0 && !(flags & PYA_FLAG_KEEP) && !std::getenv("PYA_NO_PLAIN") &&
-                          n >= (uint64_t)(std::getenv("PYA_PLAIN_MIN") ? std::atoi(std::getenv("PYA_PLAIN_MIN")) : 512);
+    const bool plain_on = h->cfg.n_nl == 0 && !(flags & PYA_FLAG_KEEP) && !h->kn.no_plain && n >= (uint64_t)h->kn.plain_min;
     /* Pass A (threaded for big batches): the per-letter work -- validate every PSM and count its
      * modifiable residues.  It only finds the first offending PSM; the detailed message comes from
      * the serial checks below, run for that PSM alone. */
     /* fused score + localize kernel: plain settings with one ion type per direction; C(n,k) <= 32 when
      * both directions are scored (one (signature, direction) walker per lane), <= 64 with one */
     const bool both_dirs = h->cfg.n_fwd > 0 && h->cfg.n_fwd < h->cfg.n_types;
-    const bool fused_on = plain_on && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 && !std::getenv("PYA_NO_FUSED");
+    const bool fused_on = plain_on && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 && !h->kn.no_fused;
     const uint32_t fused_max_n = both_dirs ? 32u : 64u;
     p->fused.assign(n, 0);
     /* score_big.hip: one PSM per 8-wave workgroup, fragment tree shared two levels deep */
-    static const uint64_t big_min_n = std::getenv("PYA_BIG_MIN_N") ? (uint64_t)std::atoll(std::getenv("PYA_BIG_MIN_N")) : 1024;
-    const bool big_on = h->cfg.n_nl == 0 && both_dirs && h->cfg.n_fwd == 1 && h->cfg.n_types == 2 && h->mz_error <= 0.49f &&
-                        !std::getenv("PYA_NO_BIG");
+    const uint64_t big_min_n = (uint64_t)h->kn.big_min_n;
+    const bool big_on = h->cfg.n_nl == 0 && both_dirs && h->cfg.n_fwd == 1 && h->cfg.n_types == 2 && h->mz_error <= 0.49f && !h->kn.no_big;
     p->big.assign(n, 0);
     const bool skip_invalid = (flags & PYA_FLAG_SKIP_INVALID) != 0;
     std::vector<uint8_t> bad(n, 0);
@@ -1122,7 +1204,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         /* peak classes: the median, 90th and 99th percentile and the maximum of the peak counts,
          * rounded up to 32 (one class for small batches) */
         std::vector<uint32_t> caps;
-        if (n >= 2048 && !std::getenv("PYA_ONE_PEAK_CLASS")) {
+        if (n >= 2048 && !h->kn.one_peak_class) {
             std::vector<uint32_t> pk(n);
             for (uint64_t i = 0; i < n; i++)
                 pk[i] = p->pre_status[i] ? 1u : (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
@@ -1133,7 +1215,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             }
         }
         /* classes only pay when the tail is long: every extra launch has its own ramp-up and tail */
-        if (!caps.empty() && p->peak_cap < 2 * caps[0] && !std::getenv("PYA_PEAK_CLASSES")) caps.clear();
+        if (!caps.empty() && p->peak_cap < 2 * caps[0] && !h->kn.peak_classes) caps.clear();
         caps.push_back(p->peak_cap);
         std::sort(caps.begin(), caps.end());
         caps.erase(std::unique(caps.begin(), caps.end()), caps.end());
@@ -1192,14 +1274,13 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             std::vector<uint8_t> packed(n, 0);
             p->n_fused_total = 0;
             for (uint64_t i = 0; i < n; i++) p->n_fused_total += (p->fused[i] && !p->pre_status[i]) ? 1u : 0u;
-            const uint32_t pack_g = std::getenv("PYA_PACK_G") ? (uint32_t)std::atoi(std::getenv("PYA_PACK_G")) : 4u;
+            const uint32_t pack_g = h->kn.pack_g;
             /* OFF by default (PYA_PACK=1 turns it on): measured on cfg2 / cfg3 it loses to one PSM per wavefront
              * (0.58 vs 0.40 ms, 0.68 vs 0.41 ms) although it issues half the vector instructions -- the PSMs a CU
              * holds are set by LDS per PSM either way, a packed wavefront's dependent chain of LDS and memory round
              * trips is twice as long for its three PSMs, and with 9 instead of 20 wavefronts per CU nothing hides it
              * (DESIGN.md section 9).  Kept as a tested route. */
-            const bool pack_on = fused_on && h->mz_error <= 0.49f && pack_g >= 2 && std::getenv("PYA_PACK") && !std::getenv("PYA_NO_PACK") &&
-                                 n >= (uint64_t)(std::getenv("PYA_PACK_MIN") ? std::atoi(std::getenv("PYA_PACK_MIN")) : 512);
+            const bool pack_on = fused_on && h->mz_error <= 0.49f && pack_g >= 2 && h->kn.pack && n >= (uint64_t)h->kn.pack_min;
             if (pack_on) {
                 static const uint32_t kPackClass[] = {4, 8, 16, 21, 32};
                 struct PItem { uint32_t id, cls, L; };
@@ -1219,7 +1300,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                 while (g0 < pit.size()) {
                     size_t g1 = g0;
                     while (g1 < pit.size() && pit[g1].cls == pit[g0].cls) g1++;
-                    if (g1 - g0 >= (size_t)(std::getenv("PYA_PACK_GROUP_MIN") ? std::atoi(std::getenv("PYA_PACK_GROUP_MIN")) : 256)) {   /* (a handful is not worth a launch of its own) */
+                    if (g1 - g0 >= (size_t)h->kn.pack_group_min) {   /* (a handful is not worth a launch of its own) */
                         pya_plan::PackLaunch pl = {(uint32_t)p->pack_ids.size(), (uint32_t)(g1 - g0), 0, 0, kPackClass[pit[g0].cls], 1, 8, 4};
                         uint32_t maxP = 1;
                         for (size_t t = g0; t < g1; t++) {
@@ -1231,7 +1312,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                         }
                         /* retained peaks a slot may bring: never more than its raw peaks; beyond the budget the PSM goes
                          * to the one-PSM-per-wavefront kernel (10 per 100 m/z window: ~200 for a 2000 m/z spectrum) */
-                        const uint32_t budget = (std::min<uint32_t>(maxP, std::getenv("PYA_PACK_PEAKS") ? (uint32_t)std::atoi(std::getenv("PYA_PACK_PEAKS")) : 208u) + PYA_TABLE_PAD + 1u) & ~1u;
+                        const uint32_t budget = (std::min<uint32_t>(maxP, h->kn.pack_peaks) + PYA_TABLE_PAD + 1u) & ~1u;
                         pl.G = std::min<uint32_t>(std::min<uint32_t>(pack_g, 8u), 64u / pl.n_cap);
                         while (pl.G >= 2 && pya_pack_lds_bytes(pl.G, pl.G * budget, pl.n_cap, pl.pos_cap, pl.push_cap, pl.kc, p->fused_both) > 64 * 1024) pl.G--;
                         if (pl.G >= 2) {
@@ -1275,7 +1356,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                 /* LDS classes inside the group: cut at the median and the 85th percentile of the footprint when
                  * that buys at least a fifth of the largest footprint (every launch has its own ramp-up and tail) */
                 std::vector<size_t> cuts{g0};
-                if (g1 - g0 >= 8192 && !std::getenv("PYA_ONE_LDS_CLASS")) {
+                if (g1 - g0 >= 8192 && !h->kn.one_lds_class) {
                     const size_t need_max = items[g1 - 1].need;
                     for (double q : {0.5, 0.85}) {
                         const size_t at = g0 + (size_t)(q * (double)(g1 - g0));
@@ -1502,8 +1583,8 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     const bool timing = p->flags & PYA_FLAG_TIMING;
     /* a handful of PSMs (PyAscore.score is a batch of one) is launch-bound: one fused launch, one
      * wavefront per PSM, instead of the five of the three-kernel path (tiny_batch.hip) */
-    const uint64_t tiny_max = std::getenv("PYA_TINY_MAX") ? (uint64_t)std::atoll(std::getenv("PYA_TINY_MAX")) : kTinyBatch;
-    bool tiny = !timing && p->n_psm <= tiny_max && p->n_skipped == 0 && !std::getenv("PYA_NO_TINY");
+    const uint64_t tiny_max = (uint64_t)h->kn.tiny_max;
+    bool tiny = !timing && p->n_psm <= tiny_max && p->n_skipped == 0 && !h->kn.no_tiny;
     Bucket m;                                               /* caps that cover every PSM of the batch */
     uint32_t prefix = 0, compact = 0;
     if (tiny) {
@@ -1523,7 +1604,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
             m.push_max = std::max(m.push_max, bk.push_max);
             m.z_max = std::max(m.z_max, bk.z_max);
         }
-        prefix = (m.n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
+        prefix = (m.n_cap >= 128 && !h->kn.no_prefix) ? 1u : 0u;
         compact = (h->cfg.n_nl == 0 && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 && m.z_max == 1) ? 1u : 0u;
         /* the merged caps (maxima over the buckets) can ask for more LDS than any single bucket does:
          * such a batch takes the three-kernel path, whose launches are sized per bucket */
@@ -1552,7 +1633,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     if (timing) HIPCHK(h, hipEventRecord(p->ev[1], st));
     for (const pya_plan::IdList &l : p->score_lists) {
         /* classes with C(n,k) > 64 share the walk over the first sites between signatures */
-        const uint32_t prefix = (p->buckets[l.ncls].n_cap >= 128 && !std::getenv("PYA_NO_PREFIX")) ? 1u : 0u;
+        const uint32_t prefix = (p->buckets[l.ncls].n_cap >= 128 && !h->kn.no_prefix) ? 1u : 0u;
         /* every PSM of the class on the straight-line walker: compact prefix entries */
         const uint32_t compact = (h->cfg.n_nl == 0 && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 &&
                                   p->buckets[l.ncls].z_max == 1) ? 1u : 0u;
@@ -1594,11 +1675,14 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
     for (Bucket &bk : p->buckets) {
+        /* more than sort_room_max signatures: the lean launch without room for the sort emulation (LDS ->
+         * occupancy); PSMs with a tie at the top go through the hand-over list to a second lean pass that has it */
+        const uint32_t sort_room = (bk.n_cap <= h->kn.sort_room_max || h->kn.sort_room) ? 1u : 0u;
         e = pya_launch_localize(&d, bk.d_ids.p, bk.n_plain, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(),
-                                bk.gtp(), 1u, st);
+                                bk.gtp(), 1u, sort_room, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
         e = pya_launch_localize(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
-                                bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), 0u, st);
+                                bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), 0u, 1u, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[4], st));
@@ -1650,7 +1734,7 @@ int pya_plan_check(pya_plan *p) {
     HIPCHK(h, hipStreamSynchronize(p->last_stream));
     std::vector<int32_t> st(p->n_psm);
     HIPCHK(h, hipMemcpy(st.data(), p->d_status.p, p->n_psm * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (std::getenv("PYA_HOST_TIMING")) {                  /* diagnostics: how many PSMs the lean kernels handed over */
+    if (h->kn.host_timing) {                               /* diagnostics: how many PSMs the lean kernels handed over */
         uint32_t r3 = 0, r4 = 0;
         (void)hipMemcpy(&r3, p->d_redo3.p, 4, hipMemcpyDeviceToHost);
         if (p->d_redo4.p) (void)hipMemcpy(&r4, p->d_redo4.p, 4, hipMemcpyDeviceToHost);
@@ -1682,6 +1766,7 @@ void pya_plan_destroy(pya_plan *p) {
             if (v[i]) std::fprintf(stderr, "[pya stamps] phase %2d: %12llu  %5.1f%%\n", i, v[i], 100.0 * v[i] / tot);
     }
     if (p->h->kept == p) p->h->kept = nullptr;
+    if (p->h->one.view == p) p->h->one.view = nullptr;       /* (pya_score_one's retained view of its workspace) */
     if (!p->quiesced) (void)hipDeviceSynchronize();     /* nothing may still be using the buffers */
     if (!p->h->spare_arena.p) p->arena.give_to(p->h->spare_arena);
     else if (!p->h->spare_arena2.p) p->arena.give_to(p->h->spare_arena2);
@@ -1698,7 +1783,7 @@ const size_t kDefaultBudget = (size_t)6 << 30;
 
 size_t workspace_budget(const pya_handle *h) {
     if (h->ws_budget) return h->ws_budget;
-    if (const char *e = std::getenv("PYA_WORKSPACE_MB")) return (size_t)std::max(16ll, std::atoll(e)) << 20;
+    if (h->kn.workspace_mb > 0) return (size_t)std::max<int64_t>(16, h->kn.workspace_mb) << 20;
     return kDefaultBudget;
 }
 
@@ -1926,16 +2011,28 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
     if (!out->best_score || !out->best_sig || !out->n_sig || !out->ascores || !out->alt_mask)
         return h->fail(PYA_ERR_ARG, -1, "NULL array in results");
     if (b->peak_off[b->n_psm] < b->peak_off[0]) return h->fail(PYA_ERR_ARG, -1, "peak_off is not monotone");
+    if (b->n_psm == 1 && !(flags & (PYA_FLAG_SKIP_INVALID | PYA_FLAG_TIMING))) {
+        /* a batch of one is PyAscore.score: the low-latency path (it declines what it has no room for) */
+        const bool has_aux1 = b->aux_off && b->aux_pos && b->aux_mass;
+        const int64_t a0 = has_aux1 ? b->aux_off[0] : 0, a1 = has_aux1 ? b->aux_off[1] : 0;
+        const int64_t P1 = b->peak_off[1] - b->peak_off[0], L1 = b->pep_off[1] - b->pep_off[0];
+        if (a1 >= a0 && P1 >= 0 && L1 >= 0) {
+            int rc1 = pya_score_one(h, mz + b->peak_off[0], inten + b->peak_off[0], (uint64_t)P1, b->pep + b->pep_off[0], (uint64_t)L1,
+                                    b->n_of_mod[0], b->max_charge[0], has_aux1 ? b->aux_pos + a0 : nullptr,
+                                    has_aux1 ? b->aux_mass + a0 : nullptr, (uint64_t)(a1 - a0), flags & PYA_FLAG_KEEP, out);
+            if (rc1 != PYA_ERR_STATE || !h->err.empty()) return rc1;
+        }
+    }
     {
         /* Chunking: needed when the call does not fit the device budget, worthwhile (pipelining)
          * when there is enough PCIe traffic to hide the kernels under.  A retained batch
          * (PYA_FLAG_KEEP) stays one plan: its records are queried by PSM afterwards. */
         const size_t io_total = (size_t)(b->peak_off[b->n_psm] - b->peak_off[0]) * 16;
-        if (!(flags & PYA_FLAG_KEEP) && io_total >= kChunkMin && !std::getenv("PYA_NO_CHUNKS")) {
+        if (!(flags & PYA_FLAG_KEEP) && io_total >= kChunkMin && !h->kn.no_chunks) {
             const size_t budget = workspace_budget(h);
             const ChunkCost cost = chunk_costs(h, b, out->max_k);
             double io_target = (double)kChunkTarget;
-            if (const char *e = std::getenv("PYA_CHUNK_MB")) io_target = std::max(1.0, std::atof(e)) * 1048576.0;
+            if (h->kn.chunk_mb > 0.) io_target = h->kn.chunk_mb * 1048576.0;
             std::vector<uint64_t> cuts{0};
             double io = 0, arena = 0;
             for (uint64_t i = 0; i < b->n_psm; i++) {
@@ -1953,7 +2050,7 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
             if (cuts.size() > 2) return score_batch_chunked(h, b, mz, inten, flags, out, cuts, cost.sites.data());
         }
     }
-    const bool host_timing = std::getenv("PYA_HOST_TIMING") != nullptr;
+    const bool host_timing = h->kn.host_timing;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!host_timing) return;
@@ -1969,7 +2066,7 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
     const int64_t peaks_lo = b->peak_off[0], n_peaks = b->peak_off[b->n_psm] - peaks_lo;
     std::thread uploader;
     hipError_t up_err = hipSuccess;
-    if (n_peaks > 0 && (size_t)n_peaks * 16 > kStageLimit && !std::getenv("PYA_NO_UPLOAD_THREAD")) {
+    if (n_peaks > 0 && (size_t)n_peaks * 16 > kStageLimit && !h->kn.no_upload_thread) {
         HIPCHK(h, hipSetDevice(h->device));
         if (h->io_buf.n < (size_t)n_peaks * 2) HIPCHK(h, h->io_buf.alloc((size_t)n_peaks * 2));
         io.d_mz_ext = h->io_buf.p;
@@ -2030,6 +2127,295 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
     }
     return PYA_OK;
 }
+
+} /* extern "C" */
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* pya_score_one: one PSM per call, lowest latency (tiny_batch.hip: pya_one_kernel)                        */
+/* ------------------------------------------------------------------------------------------------------ */
+namespace {
+/* layout of the pinned block: [flag 64 B | status 64 B | best_score, n_sig, best_sig 64 B | ascores 64 x 4 |
+ * alt masks 64 x 8 | m/z PYA_MAX_PEAKS x 8 | intensity PYA_MAX_PEAKS x 8] */
+const size_t kOneFlag = 0, kOneStatus = 64, kOneBest = 128, kOneAsc = 192, kOneAlt = 448, kOneMz = 1024,
+             kOneInt = kOneMz + (size_t)PYA_MAX_PEAKS * 8, kOneBytes = kOneInt + (size_t)PYA_MAX_PEAKS * 8;
+
+int one_prepare(pya_handle *h, uint32_t n_sig) {
+    pya_handle::One &o = h->one;
+    if (!o.host) {
+        HIPCHK(h, hipHostMalloc((void **)&o.host, kOneBytes, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(h, hipHostGetDevicePointer((void **)&o.host_dev, o.host, 0));
+        std::memset(o.host, 0, 1024);
+        HIPCHK(h, hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking));
+    }
+    if (!o.ws.p || o.sig_cap < n_sig) {
+        /* device workspace of one PSM: small arrays, the retained table, grid, per-signature scores / records / order */
+        const uint32_t cap = std::max<uint32_t>(1024, next_pow2(n_sig));
+        const size_t bytes = 4096 + ((size_t)PYA_MAX_PEAKS + 8) * sizeof(PeakEntry) + PYA_GRID_CELLS * 2 + 4096 +
+                             (size_t)cap * (4 + PYA_REC_WORDS * 4 + 4) + 1024;
+        HIPCHK(h, hipStreamSynchronize(o.stream));
+        HIPCHK(h, o.ws.alloc(bytes));
+        HIPCHK(h, hipMemset(o.ws.p, 0, bytes));
+        o.sig_cap = cap;
+        unsigned char *w = o.ws.p;
+        BatchDev &d = o.dev;
+        std::memset(&d, 0, sizeof d);
+        size_t at = 0;
+        auto take = [&](size_t n) { unsigned char *q = w + at; at += (n + 255) & ~(size_t)255; return q; };
+        d.peak_off = (const int64_t *)take(16);
+        d.pep_off = (const int64_t *)take(16);
+        d.aux_off = (const int64_t *)take(16);
+        d.sig_off = (const int64_t *)take(16);
+        d.ret_off = (const int64_t *)take(16);
+        d.pep = (const uint8_t *)take(PYA_MAX_L);
+        d.n_of_mod = (const int32_t *)take(4);
+        d.max_charge = (const int32_t *)take(4);
+        d.aux_pos = (const uint32_t *)take(PYA_ONE_MAX_AUX * 4);
+        d.aux_mass = (const float *)take(PYA_ONE_MAX_AUX * 4);
+        d.n_sites = (const uint8_t *)take(4);
+        d.n_sig = (const uint32_t *)take(4);
+        d.order_off = (const uint32_t *)take(4);
+        d.desc = (const uint64_t *)take(PYA_DESC_WORDS * 8);
+        d.status = (int32_t *)take(4);
+        d.ret_n = (uint32_t *)take(4);
+        d.ws_top = (uint32_t *)take(16);
+        uint32_t *redo = (uint32_t *)take(4 * 80);
+        d.redo_count = redo;
+        d.redo_ids = redo + 64;
+        d.redo3_count = redo + 66;
+        d.redo3_ids = redo + 70;
+        d.redo3b_count = redo + 67;
+        d.redo3b_ids = redo + 72;
+        d.redo4_count = redo + 68;
+        d.redo4_ids = redo + 74;
+        d.grid = (uint16_t *)take(PYA_GRID_CELLS * 2);
+        d.ret = (PeakEntry *)take(((size_t)PYA_MAX_PEAKS + 8) * sizeof(PeakEntry));
+        d.ws = (float *)take((size_t)cap * 4);
+        d.rec = (uint32_t *)take((size_t)cap * PYA_REC_WORDS * 4);
+        d.sorted_idx = (uint32_t *)take((size_t)cap * 4);
+        d.mz = (const double *)(o.host_dev + kOneMz);
+        d.inten = (const double *)(o.host_dev + kOneInt);
+        d.best_score = (float *)(o.host_dev + kOneBest);
+        d.n_sig_out = (int32_t *)(o.host_dev + kOneBest + 8);
+        d.best_sig = (uint64_t *)(o.host_dev + kOneBest + 16);
+        d.ascores = (float *)(o.host_dev + kOneAsc);
+        d.alt_mask = (uint64_t *)(o.host_dev + kOneAlt);
+    }
+    return PYA_OK;
+}
+
+/* launches the kernel for o.meta (the spectrum is in the pinned block) and waits for its results */
+int one_run(pya_handle *h, bool keep, uint32_t max_k) {
+    pya_handle::One &o = h->one;
+    const OneMeta &m = o.meta;
+    BatchDev d = o.dev;
+    d.order_tab = h->d_order.p;
+    d.inv_tab = h->d_inv.p;
+    d.binom = h->d_binom.p;
+    d.cfg = h->d_cfg.p;
+    d.lut = h->d_lut.p;
+    d.lut_off = h->d_lut_off.p;
+    d.lut_n_max = h->lut_uploaded_n - 1;
+    d.max_k = max_k;
+    d.keep = keep ? 1u : 0u;
+    d.debug = h->kn.debug & 0xffffu;
+    /* caps of this one PSM (the rules of the plan's buckets, for a bucket of one) */
+    Bucket bk;
+    const uint32_t L = m.L, z = (uint32_t)m.max_charge, k = (uint32_t)m.n_of_mod, ns = m.n_sites, N = m.n_sig;
+    const uint32_t n_uniq = (uint32_t)h->cfg.n_uniq, n_types = (uint32_t)h->cfg.n_types;
+    const uint32_t per_type = (L - 1) * z * n_uniq;
+    bk.n_cap = N;
+    bk.list_cap = next_pow2(std::max<uint32_t>(per_type, 1));
+    bk.pos_cap = std::max<uint32_t>(L - 1, 1);
+    bk.n_types = n_types;
+    bk.k_max = std::max<uint32_t>(k, 1);
+    bk.push_max = std::max<uint32_t>(k < ns ? k * (ns - k) : 1, 1);
+    bk.z_max = z;
+    const uint32_t cap = (m.n_peaks + 31u) & ~31u;
+    const uint32_t prefix = (N >= 128 && !h->kn.no_prefix) ? 1u : 0u;
+    const bool plain_types = h->cfg.n_nl == 0 && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1;
+    const uint32_t compact = (plain_types && z == 1) ? 1u : 0u;
+    const bool both = h->cfg.n_fwd > 0 && h->cfg.n_fwd < h->cfg.n_types;
+    uint32_t use_fused = 0, f_n_cap = 4, f_stride = 8, f_ent = 1, f_push = 8;
+    const uint32_t frags = (both ? 2u : 1u) * (L - 1) * z;
+    if (!keep && plain_types && !h->kn.no_fused && k < ns && N > 0 && N <= (both ? 32u : 64u) && frags <= 255u) {
+        use_fused = both ? 1u : 2u;
+        f_n_cap = (N + 3u) & ~3u;
+        f_stride = (both ? 2u : 1u) * f_n_cap + 4u;
+        f_ent = std::max<uint32_t>((L - 1) * z, 1);
+        f_push = std::max<uint32_t>(8u, bk.push_cap());
+    }
+    if (pya_one_lds_bytes(cap, prefix, h->cfg.n_nl != 0, compact, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(), use_fused,
+                          f_n_cap, f_stride, f_ent, f_push, z > 1) > kMaxLds)
+        return h->fail(PYA_ERR_LIMIT, 0, "LDS budget exceeded for this PSM");
+    volatile uint32_t *flag = (volatile uint32_t *)(o.host + kOneFlag);
+    int e = pya_launch_one(&d, &m, cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(),
+                           bk.sb(), bk.gtp(), use_fused, f_n_cap, f_stride, f_ent, f_push, z > 1 ? 1u : 0u,
+                           (int32_t *)(o.host_dev + kOneStatus), (uint32_t *)(o.host_dev + kOneFlag), o.stream);
+    if (e) return h->hip_fail((hipError_t)e, "score (one PSM) launch");
+    /* the kernel's last store is the sequence number: poll it (a stream synchronisation costs several
+     * microseconds more); give up after two seconds and ask the runtime what happened */
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; *flag != m.seq; spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            HIPCHK(h, hipStreamSynchronize(o.stream));
+            if (*flag != m.seq) return h->fail(PYA_ERR_HIP, 0, "the kernel finished without publishing its results");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    o.dev = o.dev;       /* (unchanged; d carried the per-call fields) */
+    o.last_keep = keep;
+    o.last_max_k = max_k;
+    /* a retained view for pya_get_pep_scores / pya_calculate_ambiguity */
+    if (keep) {
+        if (!o.view) o.view = new pya_plan;
+        pya_plan *p = o.view;
+        p->h = h;
+        p->flags = PYA_FLAG_KEEP;
+        p->n_psm = 1;
+        p->peak_cap = cap;
+        p->max_k = max_k;
+        p->sig_off = {0, (int64_t)N};
+        p->pep_off = {0, (int64_t)L};
+        p->n_sig = {N};
+        p->order_off = {m.order_off};
+        p->max_charge = {m.max_charge};
+        p->d_rec.adopt(d.rec, (size_t)N * PYA_REC_WORDS);
+        p->d_sorted.adopt(d.sorted_idx, N);
+        p->d_ws.adopt(d.ws, N);
+        p->dev = d;
+        p->quiesced = true;
+        p->ran = true;
+        p->last_stream = o.stream;
+        if (h->kept && h->kept != p) pya_plan_destroy(h->kept);
+        h->kept = p;
+    } else if (h->kept && h->kept == o.view) {
+        h->kept = nullptr;                                  /* the view described the previous PSM */
+    }
+    return PYA_OK;
+}
+}  // namespace
+
+extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inten, uint64_t n_peaks, const uint8_t *pep,
+                             uint64_t L, int32_t n_of_mod, int32_t max_charge, const uint32_t *aux_pos, const float *aux_mass,
+                             uint64_t n_aux, uint32_t flags, const pya_results *out) {
+    if (!h || !out) return PYA_ERR_ARG;
+    h->err.clear();
+    h->err_index = -1;
+    h->last_status.clear();
+    if (h->kn.no_tiny) return PYA_ERR_STATE;               /* (route switch of the tests: the kernel-per-stage path) */
+    if (!mz || !inten || !pep) return h->fail(PYA_ERR_ARG, -1, "NULL array");
+    if (!out->best_score || !out->best_sig || !out->n_sig || !out->ascores || !out->alt_mask)
+        return h->fail(PYA_ERR_ARG, -1, "NULL array in results");
+    if (n_aux && (!aux_pos || !aux_mass)) return h->fail(PYA_ERR_ARG, -1, "NULL fixed-modification arrays");
+    /* validation: what plan_create_impl checks for a PSM (same messages) */
+    if (n_peaks == 0) return h->fail(PYA_ERR_PSM, 0, "PSM 0: empty spectrum");
+    if (n_peaks > PYA_MAX_PEAKS) return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: %llu peaks exceed the limit of %d", (unsigned long long)n_peaks, PYA_MAX_PEAKS);
+    if (L < 1 || L > PYA_MAX_PEPTIDE_LEN)
+        return h->fail(L < 1 ? PYA_ERR_PSM : PYA_ERR_LIMIT, 0, "PSM 0: peptide length %lld outside 1..%d", (long long)L, PYA_MAX_PEPTIDE_LEN);
+    if (n_of_mod < 0) return h->fail(PYA_ERR_PSM, 0, "PSM 0: negative n_of_mod");
+    if (max_charge < 1 || max_charge > 16) return h->fail(PYA_ERR_PSM, 0, "PSM 0: max_fragment_charge %d outside 1..16", max_charge);
+    uint32_t ns = 0;
+    for (uint64_t j = 0; j < L; j++) {
+        if (!h->is_residue[pep[j]])
+            return h->fail(PYA_ERR_PSM, 0, "PSM 0: unknown residue '%c' at position %lld", (char)pep[j], (long long)(j + 1));
+        if (h->letter_modifiable((char)pep[j], (size_t)j, (size_t)L)) ns++;
+    }
+    for (uint64_t a = 0; a < n_aux; a++)
+        if (aux_pos[a] > (uint32_t)L) return h->fail(PYA_ERR_PSM, 0, "PSM 0: aux_mod_pos %u beyond the peptide", aux_pos[a]);
+    if (ns > PYA_MAX_SITES) return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: %u modifiable residues exceed %d", ns, PYA_MAX_SITES);
+    uint64_t N = 0;
+    if ((uint32_t)n_of_mod <= ns) {
+        uint64_t &cached = h->binom_cache[ns][n_of_mod];
+        if (cached == 0) cached = binom(ns, (uint32_t)n_of_mod);
+        N = cached;
+    }
+    if (N > PYA_MAX_SIGNATURES)
+        return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: C(%u,%d) site assignments exceed the limit of %d", ns, n_of_mod, PYA_MAX_SIGNATURES);
+    const uint32_t per_type = (uint32_t)(L - 1) * (uint32_t)max_charge * (uint32_t)h->cfg.n_uniq;
+    if (per_type > PYA_MAX_LIST) return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: %u fragments per ion type exceed %d", per_type, PYA_MAX_LIST);
+    if (n_aux > PYA_ONE_MAX_AUX || (uint32_t)n_of_mod > 64u) return PYA_ERR_STATE;     /* (the caller takes the batch path) */
+    if (out->max_k < (uint32_t)std::max(n_of_mod, 1)) return h->fail(PYA_ERR_ARG, -1, "results.max_k is smaller than n_of_mod");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = sync_config(h);
+    if (rc) return rc;
+    uint32_t ooff = 0;
+    if (N) {
+        uint32_t &co = h->shape_cache[ns][n_of_mod];
+        if (co == 0xffffffffu) co = shape_offset(h, ns, (uint32_t)n_of_mod);
+        ooff = co;
+    }
+    rc = ensure_lut(h, per_type * (uint32_t)h->cfg.n_types);
+    if (rc) return rc;
+    if (h->order_uploaded != h->order_tab.size() || !h->d_order.p) {
+        HIPCHK(h, h->d_order.upload(h->order_tab.data(), h->order_tab.size()));
+        HIPCHK(h, h->d_inv.upload(h->inv_tab.data(), h->inv_tab.size()));
+        if (!h->d_binom.p) {
+            std::vector<uint32_t> bt(64 * 64);
+            for (uint32_t pp = 0; pp < 64; pp++)
+                for (uint32_t t = 0; t < 64; t++) bt[pp * 64 + t] = (uint32_t)std::min<uint64_t>(binom(pp, t), 0xffffffffull);
+            HIPCHK(h, h->d_binom.upload(bt.data(), bt.size()));
+        }
+        HIPCHK(h, hipDeviceSynchronize());
+        h->order_uploaded = h->order_tab.size();
+    }
+    rc = one_prepare(h, (uint32_t)N);
+    if (rc) return rc;
+    pya_handle::One &o = h->one;
+    /* inputs: the spectrum into the pinned block, everything else into the kernel's arguments */
+    std::memcpy(o.host + kOneMz, mz, (size_t)n_peaks * 8);
+    std::memcpy(o.host + kOneInt, inten, (size_t)n_peaks * 8);
+    OneMeta &m = o.meta;
+    std::memset(&m, 0, sizeof m);
+    std::memcpy(m.pep, pep, (size_t)L);
+    m.n_peaks = (uint32_t)n_peaks;
+    m.L = (uint32_t)L;
+    m.n_aux = (uint32_t)n_aux;
+    m.n_sig = (uint32_t)N;
+    m.order_off = ooff;
+    m.seq = ++o.seq ? o.seq : ++o.seq;
+    m.n_of_mod = n_of_mod;
+    m.max_charge = max_charge;
+    m.n_sites = ns;
+    for (uint64_t a = 0; a < n_aux; a++) {
+        m.aux_pos[a] = aux_pos[a];
+        m.aux_mass[a] = aux_mass[a];
+    }
+    m.desc[0] = 0;
+    m.desc[1] = 0;
+    m.desc[2] = 0;
+    m.desc[3] = 0;
+    m.desc[4] = (uint64_t)L | (uint64_t)n_aux << 16 | (uint64_t)((uint32_t)n_of_mod & 0xffffu) << 32 | (uint64_t)ns << 48 |
+                (uint64_t)((uint32_t)max_charge & 0xffu) << 56;
+    m.desc[5] = (uint64_t)N | (uint64_t)ooff << 32;
+    o.have_last = true;
+    const uint32_t mk = out->max_k;
+    if (mk > 64) return PYA_ERR_STATE;
+    rc = one_run(h, (flags & PYA_FLAG_KEEP) != 0, mk);
+    if (rc) return rc;
+    const int32_t st = *(const int32_t *)(o.host + kOneStatus);
+    rc = check_status(h, &st, 1, false);
+    if (rc) return rc;
+    out->best_score[0] = *(const float *)(o.host + kOneBest);
+    out->n_sig[0] = *(const int32_t *)(o.host + kOneBest + 8);
+    out->best_sig[0] = *(const uint64_t *)(o.host + kOneBest + 16);
+    std::memcpy(out->ascores, o.host + kOneAsc, (size_t)mk * 4);
+    std::memcpy(out->alt_mask, o.host + kOneAlt, (size_t)mk * 8);
+    return PYA_OK;
+}
+
+/* the last pya_score_one PSM once more, retained (PYA_FLAG_KEEP): what PyAscore.pep_scores and
+ * calculate_ambiguity need; the spectrum and the scalars are still where the last call put them */
+extern "C" int pya_rescore_last_keep(pya_handle *h) {
+    if (!h) return PYA_ERR_ARG;
+    if (!h->one.have_last) return h->fail(PYA_ERR_STATE, -1, "no PSM scored with pya_score_one yet");
+    if (h->one.last_keep && h->kept == h->one.view) return PYA_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->one.meta.seq = ++h->one.seq ? h->one.seq : ++h->one.seq;
+    return one_run(h, true, h->one.last_max_k);
+}
+
+extern "C" {
 
 int pya_set_workspace_budget(pya_handle *h, uint64_t bytes) {
     if (!h) return PYA_ERR_ARG;

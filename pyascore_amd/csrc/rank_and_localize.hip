@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void pya_debug_sort_kernel(const float *keys, u
 
 extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids,
                                    uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
-                                   uint32_t sb, uint32_t gtp, uint32_t plain, hipStream_t stream) {
+                                   uint32_t sb, uint32_t gtp, uint32_t plain, uint32_t sort_room, hipStream_t stream) {
     if (n_ids == 0) return 0;
     const size_t lds = pya_localize_lds_bytes(push_cap, n_cap, pos_cap, pool_cap, sb);
     hipError_t e;
@@ -134,10 +134,8 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     if (e != hipSuccess) return (int)e;
     e = PYA_ENSURE_MAX_LDS(pya_localize_kernel<true>);
     if (e != hipSuccess) return (int)e;
-    /* more than 1024 signatures: the lean launch without room for the sort emulation (LDS -> occupancy);
-     * PSMs with a tie at the top go through the hand-over list to a second lean pass that has the room */
-    static const uint32_t room_max = getenv("PYA_SORT_ROOM_MAX") ? (uint32_t)atoi(getenv("PYA_SORT_ROOM_MAX")) : 1024u;
-    const uint32_t sort_room = (n_cap <= room_max || getenv("PYA_SORT_ROOM")) ? 1u : 0u;
+    /* sort_room = 0 (the host's choice for thousands of signatures): the lean launch without room for the sort
+     * emulation; PSMs with a tie at the top go through the hand-over list to a second lean pass that has it */
     const size_t lds_lean = sort_room ? lds : pya_localize_lds_bytes(push_cap, 0, pos_cap, pool_cap, sb);
     hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds_lean, stream, *b, d_ids, n_ids, push_cap,
                        pos_cap, pool_cap, sb, gtp, sort_room);

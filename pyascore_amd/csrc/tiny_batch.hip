@@ -11,6 +11,7 @@
 #include "bin_core.hip.h"
 #include "score_core.hip.h"
 #include "localize_body.hip.h"
+#include "fused_core.hip.h"
 
 __global__ __launch_bounds__(64) void pya_tiny_batch_kernel(BatchDev b, uint32_t n_psm, uint32_t cap, uint32_t prefix,
                                                             uint32_t with_nl, uint32_t compact, uint32_t push_cap,
@@ -59,5 +60,114 @@ extern "C" int pya_launch_tiny(const BatchDev *b, uint32_t n_psm, uint32_t cap, 
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_tiny_batch_kernel, dim3(n_psm), dim3(64), lds, stream, *b, n_psm, cap, prefix, with_nl,
                        compact, push_cap, pos_cap, pool_cap, sb, gtp);
+    return (int)hipGetLastError();
+}
+
+
+/* ---------------------------------------------------------------------------------------------------------
+ * PyAscore.score(): ONE PSM, lowest latency (Ascore.pyx:103-152 is called once per PSM by the reference's own
+ * command line, pyascore/__main__.py:129-164).  No plan, no copies: the spectrum sits in pinned host memory
+ * the device reads directly, the PSM's scalars and letters arrive in the kernel arguments, the results are
+ * written straight into pinned host memory and a sequence number behind them tells the polling host thread
+ * that they are complete.  One wavefront: bin -> (fused score + localize | score -> localize) back to back.
+ * use_fused: 0 = score_body + the general localize body (also the retained, PYA_FLAG_KEEP form),
+ *            1 = the fused body with ion types of both directions, 2 = of one direction; a PSM it hands over
+ *            is finished by the general localize body right here.
+ * ------------------------------------------------------------------------------------------------------- */
+template <bool ZM>
+__global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint32_t cap, uint32_t prefix, uint32_t with_nl,
+                                                     uint32_t compact, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap,
+                                                     uint32_t sb, uint32_t gtp, uint32_t use_fused, uint32_t f_n_cap,
+                                                     uint32_t f_stride, uint32_t f_ent_cap, uint32_t f_push_cap,
+                                                     int32_t *host_status, uint32_t *host_flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    /* the PSM's scalars into the batch arrays (all of them arrays of one PSM at offset 0) */
+    if (lane == 0) {
+        int64_t *w;
+        w = (int64_t *)b.peak_off; w[0] = 0; w[1] = (int64_t)m.n_peaks;
+        w = (int64_t *)b.pep_off;  w[0] = 0; w[1] = (int64_t)m.L;
+        w = (int64_t *)b.aux_off;  w[0] = 0; w[1] = (int64_t)m.n_aux;
+        w = (int64_t *)b.sig_off;  w[0] = 0; w[1] = (int64_t)m.n_sig;
+        w = (int64_t *)b.ret_off;  w[0] = 0;
+        ((int32_t *)b.n_of_mod)[0] = m.n_of_mod;
+        ((int32_t *)b.max_charge)[0] = m.max_charge;
+        ((uint8_t *)b.n_sites)[0] = (uint8_t)m.n_sites;
+        ((uint32_t *)b.n_sig)[0] = m.n_sig;
+        ((uint32_t *)b.order_off)[0] = m.order_off;
+        b.ws_top[1] = 0u;
+        *b.redo_count = 0u;
+    }
+    if (lane < 6) ((uint64_t *)b.desc)[lane] = m.desc[lane];
+    if (lane < PYA_MAX_L / 8) ((uint64_t *)b.pep)[lane] = m.pep[lane];
+    if (lane < PYA_ONE_MAX_AUX) {
+        ((uint32_t *)b.aux_pos)[lane] = m.aux_pos[lane];
+        ((float *)b.aux_mass)[lane] = m.aux_mass[lane];
+    }
+    __threadfence();
+    wave_lds_sync();
+    {
+        const float *r_mz;
+        const uint8_t *r_rank;
+        int status;
+        int R = bin_core<false>(b, 0, lds_raw, cap, &r_mz, &r_rank, &status);
+        if (R == PYA_BIN_REDO) {
+            wave_lds_sync();
+            R = bin_core<true>(b, 0, lds_raw, cap, &r_mz, &r_rank, &status);
+        }
+        bin_store(b, 0, R, status, r_mz, r_rank);
+    }
+    __threadfence();
+    wave_lds_sync();
+    bool general = use_fused == 0;
+    if (!general) {
+        const bool declined = use_fused == 1 ? fused_body<true, ZM>(b, 0, lds_raw, cap, f_n_cap, f_stride, pos_cap, f_ent_cap, f_push_cap)
+                                             : fused_body<false, ZM>(b, 0, lds_raw, cap, f_n_cap, f_stride, pos_cap, f_ent_cap, f_push_cap);
+        general = declined;                                  /* (wave-uniform) what it handed over is finished below */
+    } else {
+        if (prefix) score_body<true>(b, 0, lds_raw, cap, with_nl, compact);
+        else score_body<false>(b, 0, lds_raw, cap, with_nl, 0u);
+    }
+    if (general) {
+        __threadfence();
+        wave_lds_sync();
+        localize_body<false>(b, 0, lds_raw, push_cap, pos_cap, pool_cap, sb, gtp);
+    }
+    /* results are in host memory (the output arrays point there); the status, then the sequence number */
+    __threadfence();
+    wave_lds_sync();
+    if (lane == 0) {
+        *host_status = b.status[0];
+        __threadfence_system();
+        __hip_atomic_store(host_flag, m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+extern "C" size_t pya_one_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact, uint32_t push_cap,
+                                    uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t use_fused,
+                                    uint32_t f_n_cap, uint32_t f_stride, uint32_t f_ent_cap, uint32_t f_push_cap, uint32_t multi_z) {
+    size_t a = pya_tiny_lds_bytes(cap, prefix, with_nl, compact, push_cap, n_cap, pos_cap, pool_cap, sb);
+    if (use_fused) {
+        const size_t fb = fused_lds_bytes(cap, f_n_cap, f_stride, pos_cap, f_ent_cap, f_push_cap, use_fused == 1 ? 2u : 1u, multi_z != 0);
+        a = a > fb ? a : fb;
+    }
+    return a;
+}
+
+extern "C" int pya_launch_one(const BatchDev *b, const OneMeta *m, uint32_t cap, uint32_t prefix, uint32_t with_nl,
+                              uint32_t compact, uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
+                              uint32_t sb, uint32_t gtp, uint32_t use_fused, uint32_t f_n_cap, uint32_t f_stride,
+                              uint32_t f_ent_cap, uint32_t f_push_cap, uint32_t multi_z, int32_t *host_status,
+                              uint32_t *host_flag, hipStream_t stream) {
+    const size_t lds = pya_one_lds_bytes(cap, prefix, with_nl, compact, push_cap, n_cap, pos_cap, pool_cap, sb, use_fused, f_n_cap,
+                                         f_stride, f_ent_cap, f_push_cap, multi_z);
+    hipError_t e = multi_z ? PYA_ENSURE_MAX_LDS(pya_one_kernel<true>) : PYA_ENSURE_MAX_LDS(pya_one_kernel<false>);
+    if (e != hipSuccess) return (int)e;
+    if (multi_z)
+        hipLaunchKernelGGL(pya_one_kernel<true>, dim3(1), dim3(64), lds, stream, *b, *m, cap, prefix, with_nl, compact, push_cap,
+                           pos_cap, pool_cap, sb, gtp, use_fused, f_n_cap, f_stride, f_ent_cap, f_push_cap, host_status, host_flag);
+    else
+        hipLaunchKernelGGL(pya_one_kernel<false>, dim3(1), dim3(64), lds, stream, *b, *m, cap, prefix, with_nl, compact, push_cap,
+                           pos_cap, pool_cap, sb, gtp, use_fused, f_n_cap, f_stride, f_ent_cap, f_push_cap, host_status, host_flag);
     return (int)hipGetLastError();
 }

@@ -169,13 +169,16 @@ def test_equal_intensities_follow_nth_element(monkeypatch):
     for name, inten in cases.items():
         tied = dict(batch, intensity=inten)
         monkeypatch.delenv("PYA_DEBUG", raising=False)
+        gpu.reload_env()                                  # (the switches are read once per scorer)
         got = gpu.score_batch(tied)
         want = chk.score_batch(tied, got["ascores"].shape[1])
         for key in want:
             assert np.array_equal(got[key], want[key]), (name, key)
         monkeypatch.setenv("PYA_DEBUG", "128")
+        gpu.reload_env()
         forced = gpu.score_batch(tied)
         monkeypatch.delenv("PYA_DEBUG", raising=False)
+        gpu.reload_env()
         for key in got:
             assert np.array_equal(got[key], forced[key]), (name, key)
     # peaks out of m/z order AND equal intensities: the windows' input order decides
@@ -192,8 +195,10 @@ def test_equal_intensities_follow_nth_element(monkeypatch):
         assert np.array_equal(got[key], want[key]), ("shuffled", key)
     # no ties at all: the forced route must still agree with the fast one
     monkeypatch.setenv("PYA_DEBUG", "128")
+    gpu.reload_env()
     forced = gpu.score_batch(batch)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
+    gpu.reload_env()
     plain = gpu.score_batch(batch)
     for key in plain:
         assert np.array_equal(plain[key], forced[key]), key
@@ -621,14 +626,18 @@ def test_chunked_calls_equal_one_plan(monkeypatch):
     settings = synth.describe("cfg3", 1, seed=17)["settings"]
     gpu = _gpu(settings)
     monkeypatch.setenv("PYA_NO_CHUNKS", "1")
+    gpu.reload_env()                                   # (the switches are read once per scorer)
     one = gpu.score_batch(batch)
     monkeypatch.delenv("PYA_NO_CHUNKS")
+    gpu.reload_env()
     _same(gpu.score_batch(batch), one)                 # default: ~96 MB of spectra per chunk
     gpu.set_workspace_budget(48 << 20)                 # tight budget: dozens of chunks
     _same(gpu.score_batch(batch), one)
     monkeypatch.setenv("PYA_CHUNK_MB", "3")            # ... and ~100 chunks of 3 MB
+    gpu.reload_env()
     _same(gpu.score_batch(batch), one)
     monkeypatch.delenv("PYA_CHUNK_MB")
+    gpu.reload_env()
     gpu.set_workspace_budget(0)
     with pytest.raises(ValueError):
         gpu.set_workspace_budget(1000)
