@@ -25,7 +25,8 @@ def build_parser():
     p = argparse.ArgumentParser(prog="pyascore_amd", description="PTM site localisation (Ascore) on an MI355X: "
                                 "spectra (mzML / mzXML) + identifications (pepXML / mzIdentML / percolatorTXT / "
                                 "mokapotTXT) -> Scan, LocalizedSequence, PepScore, Ascores, AltSites.")
-    p.add_argument("--match_save", action="store_true", help="accepted for compatibility; nothing is dumped")
+    p.add_argument("--match_save", action="store_true",
+                   help="write dump_spectra.pkl / dump_match.pkl of the last scored PSM, as the reference's loop leaves them")
     p.add_argument("--residues", type=str, default="STY", help="residues that can carry the modification")
     p.add_argument("--mod_mass", type=float, default=79.966331, help="exact mass of the modification")
     p.add_argument("--mz_error", type=float, default=0.5, help="fragment match tolerance in m/z")
@@ -100,7 +101,8 @@ def run(args, log=print):
         for group, mass in zip(args.neutral_loss_groups.split(","), args.neutral_loss_masses.split(",")):
             ascore.add_neutral_loss(group, float(mass))
     rows = batch_cli.localize(ascore, psms, spectra, args.residues, args.mod_mass, args.hit_depth,
-                              args.max_fragment_charge, args.mod_correction_tol, args.zero_based)
+                              args.max_fragment_charge, args.mod_correction_tol, args.zero_based,
+                              match_save=args.match_save, log=lambda m: log("{} -- {}".format(stamp(), m)))
     batch_cli.write_tsv(rows, args.out_file)
     log("{} -- Ascore Completed".format(stamp()))
     return rows

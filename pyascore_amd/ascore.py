@@ -88,6 +88,8 @@ class PyAscore:
         self.device = int(device)
         self._last = None            # summary of the last score() call
         self._batch_n = None         # PSMs of the batch retained by score_batch(keep=True)
+        self._budget = 0             # set_workspace_budget (0 = the library's default, 6 GiB)
+        self._lazy_batch = None      # a retained batch too big for the device: re-scored range by range on demand
         self._one = None             # preallocated batch-of-one scaffolding of score()
 
     def __del__(self):
@@ -126,6 +128,17 @@ class PyAscore:
         rc = self._lib.pya_set_workspace_budget(self._h, int(n_bytes))
         if rc:
             self._raise(rc)
+        self._budget = int(n_bytes)
+
+    def _retained_bytes(self, arrs):
+        """Device bytes a retained (keep=True) plan of this batch holds, per PSM: 16 per raw peak (spectra) + 8 per
+        peak (retained table) + 32 per site assignment (score, count record, order) + grid, descriptor, results."""
+        from .shard import comb_table, count_sites
+        n_sites = np.clip(count_sites(arrs, self._mod_group), 0, 64)
+        k = arrs["n_of_mod"].astype(np.int64)
+        sigs = np.where((k >= 0) & (k <= n_sites), comb_table()[n_sites, np.clip(k, 0, 64)], 0.0)
+        peaks = np.diff(arrs["peak_off"]).astype(np.float64)
+        return 24.0 * peaks + 32.0 * sigs + 1024.0
 
     def score(self, mz_arr, int_arr, peptide, n_of_mod, max_fragment_charge=1, aux_mod_pos=None,
               aux_mod_mass=None):
@@ -247,13 +260,25 @@ class PyAscore:
                        _as_ptr(arrs["aux_mass"]), _as_ptr(arrs["aux_off"]))
         r = _lib.Results(max_k, _as_ptr(out["best_score"]), _as_ptr(out["best_sig"]), _as_ptr(out["n_sig"]),
                          _as_ptr(out["ascores"]), _as_ptr(out["alt_mask"]))
-        flags = (_lib.PYA_FLAG_KEEP if keep else 0) | (_lib.PYA_FLAG_SKIP_INVALID if skip_invalid else 0)
+        # A retained batch is ONE plan on the device.  When its records do not fit the workspace budget the batch is
+        # scored without them (chunked and pipelined like any big call) and batch_pep_scores() re-scores the range it
+        # is asked for, a budget's worth of PSMs at a time: the export works for any batch size.
+        self._lazy_batch = None
+        lazy_keep = False
+        if keep and n > 1:
+            budget = self._budget or (6 << 30)
+            per_psm = self._retained_bytes(dict(arrs, n_of_mod=arrs["n_of_mod"]))
+            if float(per_psm.sum()) > 0.8 * budget:
+                lazy_keep = True
+        flags = (_lib.PYA_FLAG_KEEP if keep and not lazy_keep else 0) | (_lib.PYA_FLAG_SKIP_INVALID if skip_invalid else 0)
         rc = self._lib.pya_score_batch(self._h, C.byref(b), _as_ptr(mz), _as_ptr(it), flags, C.byref(r))
         if rc:
             self._raise(rc)
         self._batch_n = n if keep else None
         if keep:
             self._last = None        # the handle's retained plan now belongs to this batch, not to score()'s PSM
+        if lazy_keep:
+            self._lazy_batch = dict(arrs, mz=mz, intensity=it, n_psm=n, per_psm=per_psm, budget=budget)
         if skip_invalid:
             out["status"] = np.zeros(n, np.int32)
             rc = self._lib.pya_last_batch_status(self._h, _as_ptr(out["status"]), n)
@@ -360,6 +385,16 @@ class PyAscore:
         begin = int(begin)
         if not 0 <= begin <= end <= self._batch_n:
             raise ValueError("PSM range outside the retained batch")
+        if self._lazy_batch is not None:
+            out = self._lazy_pep_scores(begin, end)
+        else:
+            out = self._range_pep_scores(begin, end)
+        if batch is not None:
+            rec_psm = np.repeat(np.arange(begin, end, dtype=np.int64), np.diff(out["rec_off"]))
+            out["sequence"] = self.format_batch(batch, out["sig_bits"], rec_psm=rec_psm)
+        return out
+
+    def _range_pep_scores(self, begin, end):
         off = np.zeros(end - begin + 1, np.int64)
         rc = self._lib.pya_get_pep_scores_range(self._h, begin, end, 0, _as_ptr(off), None, None, None, None, None)
         if rc:
@@ -375,9 +410,43 @@ class PyAscore:
                                                     _as_ptr(out["total_fragments"]))
             if rc:
                 self._raise(rc)
-        if batch is not None:
-            rec_psm = np.repeat(np.arange(begin, end, dtype=np.int64), np.diff(off))
-            out["sequence"] = self.format_batch(batch, out["sig_bits"], rec_psm=rec_psm)
+        return out
+
+    def _lazy_pep_scores(self, begin, end):
+        """Records of PSMs [begin, end) of a retained batch that was too big to keep on the device: the range is
+        re-scored in pieces that fit the budget, each retained, exported and dropped."""
+        from .synth import slice_batch
+        lb = self._lazy_batch
+        cost = np.concatenate([[0.0], np.cumsum(lb["per_psm"])])
+        parts, lo = [], begin
+        while lo < end:
+            hi = int(np.searchsorted(cost, cost[lo] + 0.5 * lb["budget"], side="right")) - 1
+            hi = min(max(hi, lo + 1), end)
+            sub = slice_batch(lb, lo, hi)
+            arrs = {k: np.ascontiguousarray(sub[k]) for k in ("peak_off", "pep", "pep_off", "n_of_mod", "max_charge",
+                                                              "aux_pos", "aux_mass", "aux_off")}
+            m = hi - lo
+            mk = max(1, int(arrs["n_of_mod"].max()))
+            tmp = dict(best_score=np.zeros(m, np.float32), best_sig=np.zeros(m, np.uint64), n_sig=np.zeros(m, np.int32),
+                       ascores=np.zeros((m, mk), np.float32), alt_mask=np.zeros((m, mk), np.uint64))
+            b = _lib.Batch(m, _as_ptr(arrs["peak_off"]), _as_ptr(arrs["pep"]), _as_ptr(arrs["pep_off"]),
+                           _as_ptr(arrs["n_of_mod"]), _as_ptr(arrs["max_charge"]), _as_ptr(arrs["aux_pos"]),
+                           _as_ptr(arrs["aux_mass"]), _as_ptr(arrs["aux_off"]))
+            r = _lib.Results(mk, _as_ptr(tmp["best_score"]), _as_ptr(tmp["best_sig"]), _as_ptr(tmp["n_sig"]),
+                             _as_ptr(tmp["ascores"]), _as_ptr(tmp["alt_mask"]))
+            mz = np.ascontiguousarray(sub["mz"])
+            it = np.ascontiguousarray(sub["intensity"])
+            rc = self._lib.pya_score_batch(self._h, C.byref(b), _as_ptr(mz), _as_ptr(it),
+                                           _lib.PYA_FLAG_KEEP | _lib.PYA_FLAG_SKIP_INVALID, C.byref(r))
+            if rc:
+                self._raise(rc)
+            parts.append(self._range_pep_scores(0, m))
+            lo = hi
+        off = np.concatenate([[0]] + [p["rec_off"][1:] + sum(int(q["rec_off"][-1]) for q in parts[:i])
+                                      for i, p in enumerate(parts)]).astype(np.int64)
+        out = {k: np.concatenate([p[k] for p in parts]) for k in ("sig_bits", "counts", "scores", "weighted_score",
+                                                                 "total_fragments")}
+        out["rec_off"] = off
         return out
 
     @property

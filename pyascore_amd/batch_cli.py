@@ -56,12 +56,25 @@ def psm_charge(match, spectrum):
     return max(int(z), 2)
 
 
+def save_match(spectra, match):
+    """``--match_save`` (`__main__.py:106-111`): the spectrum and the identification of a PSM as the two
+    pickle files the reference writes, in the working directory."""
+    import pickle
+    with open("dump_spectra.pkl", "wb") as dst:
+        pickle.dump([spectra], dst)
+    with open("dump_match.pkl", "wb") as dst:
+        pickle.dump([match], dst)
+
+
 def select_psms(psms, spectra_map, residues, mod_mass, hit_depth=1, max_fragment_charge=5,
-                mod_correction_tol=1.0, zero_based=False):
+                mod_correction_tol=1.0, zero_based=False, match_save=False):
     """The reference's loop header (`__main__.py:129-147`): group by scan (input sorted by scan),
     take the first ``hit_depth`` hits of a scan (negative = all), drop PSMs without an
-    unlocalised modification.  Returns (list of PSM dicts for pack_batch, list of scans)."""
+    unlocalised modification.  Returns (list of PSM dicts for pack_batch, list of scans).
+    ``match_save``: the reference dumps every PSM it is about to score over the previous one
+    (`__main__.py:148-149`), so what it leaves behind is the last one: that is what is written here."""
     picked, scans = [], []
+    last = None
     for _, group in groupby(psms, lambda m: m["scan"]):
         for ind, match in enumerate(group):
             if ind == hit_depth:
@@ -77,17 +90,22 @@ def select_psms(psms, spectra_map, residues, mod_mass, hit_depth=1, max_fragment
                                max_charge=min(max_fragment_charge, psm_charge(match, spectrum) - 1),
                                aux_pos=const_pos, aux_mass=const_masses))
             scans.append(match["scan"])
+            last = (spectrum, match)
+    if match_save and last is not None:
+        save_match(*last)
     return picked, scans
 
 
 def localize(ascore, psms, spectra_map, residues, mod_mass, hit_depth=1, max_fragment_charge=5,
-             mod_correction_tol=1.0, zero_based=False):
+             mod_correction_tol=1.0, zero_based=False, match_save=False, log=None):
     """Scores every selected PSM in one batched call and returns the TSV rows
-    ``[scan, localized_sequence, pep_score, "a;b", "1,2;3"]`` in input order."""
+    ``[scan, localized_sequence, pep_score, "a;b", "1,2;3"]`` in input order.  PSMs the library sets
+    aside (invalid, or beyond one of its documented limits) keep their row -- empty localisation, PepScore
+    nan -- and are reported through ``log`` (a callable taking one string) with their count, scans and codes."""
     if not isinstance(ascore, PyAscore):
         raise TypeError("ascore must be a pyascore_amd.PyAscore")
     picked, scans = select_psms(psms, spectra_map, residues, mod_mass, hit_depth, max_fragment_charge,
-                                mod_correction_tol, zero_based)
+                                mod_correction_tol, zero_based, match_save)
     if not picked:
         return []
     batch = pack_batch(picked)
@@ -100,6 +118,11 @@ def localize(ascore, psms, spectra_map, residues, mod_mass, hit_depth=1, max_fra
         import warnings
         warnings.warn("%d of %d PSMs were not scored (first: %s); their rows carry no localisation"
                       % (bad.size, len(picked), res["status_message"]), RuntimeWarning)
+        if log is not None:
+            shown = ", ".join("%s (code %d)" % (scans[i], int(res["status"][i])) for i in bad[:50])
+            log("%d of %d PSMs set aside (rows written with an empty LocalizedSequence and PepScore nan); first: %s"
+                % (bad.size, len(picked), res["status_message"]))
+            log("set-aside scans: %s%s" % (shown, " ..." if bad.size > 50 else ""))
     ok = (res["status"] == 0) & (res["n_sig"] > 0)
     seqs = ascore.format_batch(batch, res["best_sig"], valid=ok.astype(np.int32))   # every string in one call
     rows = []

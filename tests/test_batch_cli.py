@@ -74,6 +74,25 @@ def test_selection_follows_the_reference_loop():
     assert scans == []                                        # no PSM carries the modification of interest
 
 
+def test_match_save_leaves_the_last_scored_psm(tmp_path, monkeypatch):
+    """--match_save (`__main__.py:106-111, 148-149`): the reference dumps each PSM it is about to score over the
+    previous one; what remains is the last PSM with a variable modification, as two pickled one-element lists."""
+    import pickle
+    spectra, psms = _toy_inputs()
+    monkeypatch.chdir(tmp_path)
+    picked, scans = batch_cli.select_psms(psms, spectra, "STY", PHOSPHO, hit_depth=1, max_fragment_charge=5, match_save=True)
+    with open(tmp_path / "dump_match.pkl", "rb") as f:
+        (match,) = pickle.load(f)
+    with open(tmp_path / "dump_spectra.pkl", "rb") as f:
+        (spec,) = pickle.load(f)
+    assert match["scan"] == scans[-1] and match["peptide"] == picked[-1]["peptide"]
+    assert np.array_equal(spec["mz_values"], spectra[scans[-1]]["mz_values"])
+    # without the flag nothing is written
+    monkeypatch.chdir(tmp_path.parent)
+    batch_cli.select_psms(psms, spectra, "STY", PHOSPHO)
+    assert not (tmp_path.parent / "dump_match.pkl").exists()
+
+
 @pytest.mark.gpu
 def test_rows_match_per_psm_reference_loop(tmp_path):
     from oracle import orc
@@ -113,7 +132,12 @@ def test_one_unscorable_psm_does_not_cost_the_run_its_output():
                     mod_positions=np.array([61], np.int32), mod_masses=np.array([PHOSPHO]))
     spectra2 = dict(spectra)
     spectra2[long_psm["scan"]] = spectra[psms[0]["scan"]]
+    said = []
     with pytest.warns(RuntimeWarning, match="not scored"):
-        rows = batch_cli.localize(gpu, psms + [long_psm], spectra2, "STY", PHOSPHO, hit_depth=2, max_fragment_charge=3)
+        rows = batch_cli.localize(gpu, psms + [long_psm], spectra2, "STY", PHOSPHO, hit_depth=2, max_fragment_charge=3,
+                                  log=said.append)
+    # the run's log names how many PSMs were set aside, why, and which scans
+    assert len(said) == 2 and said[0].startswith("1 of ") and "peptide length 70" in said[0]
+    assert str(long_psm["scan"]) in said[1] and "code" in said[1]
     assert rows[:-1] == want
     assert rows[-1][0] == long_psm["scan"] and rows[-1][1] == "" and np.isnan(rows[-1][2]) and rows[-1][3:] == ["", ""]

@@ -618,6 +618,31 @@ def test_bulk_sequence_strings(case):
         gpu.format_batch(batch, res["best_sig"], rec_psm=np.full(batch["n_psm"], batch["n_psm"], np.int64))
 
 
+def test_retained_export_of_a_batch_over_the_budget():
+    """score_batch(keep=True) of a batch whose records do not fit the workspace budget: scored without
+    them, and batch_pep_scores() re-scores the range it is asked for a budget's worth at a time -- the
+    same records as the one-plan export, for the whole batch and for a range inside it."""
+    batch, settings = synth.make_batch("cfg3", n_psm=3000, seed=31)
+    gpu = _gpu(settings)
+    res = gpu.score_batch(batch, keep=True)
+    assert gpu._lazy_batch is None                     # fits the default budget: one retained plan
+    want = gpu.batch_pep_scores(batch=batch)
+    gpu.set_workspace_budget(16 << 20)                 # the records of 3000 PSMs need more than that
+    res2 = gpu.score_batch(batch, keep=True)
+    assert gpu._lazy_batch is not None
+    for key in res:
+        assert np.array_equal(res[key], res2[key]), key
+    got = gpu.batch_pep_scores(batch=batch)
+    for key in ("rec_off", "sig_bits", "counts", "scores", "weighted_score", "total_fragments"):
+        assert np.array_equal(got[key], want[key]), key
+    assert got["sequence"] == want["sequence"]
+    part = gpu.batch_pep_scores(1200, 1900)
+    a, b = int(want["rec_off"][1200]), int(want["rec_off"][1900])
+    assert np.array_equal(part["rec_off"], want["rec_off"][1200:1901] - a)
+    assert np.array_equal(part["sig_bits"], want["sig_bits"][a:b]) and np.array_equal(part["scores"], want["scores"][a:b])
+    gpu.set_workspace_budget(0)
+
+
 def test_chunked_calls_equal_one_plan(monkeypatch):
     """pya_score_batch cuts big calls into chunks that fit the device budget and pipelines them
     (upload of chunk c + 1 under the kernels of chunk c): same results as one plan for the whole
