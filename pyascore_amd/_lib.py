@@ -142,6 +142,8 @@ def load():
     _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
+        if os.environ.get("PYA_LIB_OLD") and not hasattr(lib, name):
+            continue                     # (A/B against an older build of the library: bench.py only)
         fn = getattr(lib, name)          # AttributeError = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args

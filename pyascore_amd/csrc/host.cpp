@@ -63,7 +63,13 @@ int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uin
 int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream);
 size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap);
 int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap,
-                         hipStream_t stream);
+                         uint32_t inline_on, hipStream_t stream);
+size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
+int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t push_cap,
+                                uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t *d_redo, hipStream_t stream);
+int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
+                              uint32_t pos_cap, hipStream_t stream);
+uint32_t pya_big_inline_max(void);
 size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap,
                            uint32_t both, uint32_t multi_z);
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
@@ -185,7 +191,7 @@ float std_residue_mass(char c) {                       /* Types.h:7-30 */
 struct Knobs {
     bool no_plain = false, no_fused = false, no_big = false, no_tiny = false, no_prefix = false, no_chunks = false;
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
-    bool host_timing = false, stamps = false, pack = false, sort_room = false;
+    bool host_timing = false, stamps = false, pack = false, sort_room = false, no_big_inline = false;
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64, pack_min = 512, pack_group_min = 256;
     uint32_t pack_g = 4, pack_peaks = 208, sort_room_max = 1024;
@@ -213,6 +219,7 @@ static void read_knobs(Knobs &k) {
     k.stamps = flag("PYA_STAMPS");
     k.pack = flag("PYA_PACK") && !flag("PYA_NO_PACK");
     k.sort_room = flag("PYA_SORT_ROOM");
+    k.no_big_inline = flag("PYA_NO_BIG_INLINE");
     if (const char *d = std::getenv("PYA_DEBUG")) k.debug = (uint32_t)std::strtoul(d, nullptr, 0);
     k.plain_min = num("PYA_PLAIN_MIN", 512);
     k.big_min_n = num("PYA_BIG_MIN_N", 1024);
@@ -433,6 +440,12 @@ struct pya_plan {
     std::vector<uint8_t> big;           /* [n_psm] scored by score_big.hip (thousands of site assignments, plain settings) */
     DevBuf<uint32_t> d_big_ids;
     uint32_t big_pos_cap = 1;
+    /* score_big's own localisation (summary mode, plain settings, C(n,k) <= pya_big_inline_max()): those PSMs are
+     * in no localize list; `bigloc` carries the lean localize body's caps for them, d_redo5 the ones it declines */
+    bool big_inline = false;
+    uint32_t n_big_inline = 0;
+    Bucket bigloc;
+    DevBuf<uint32_t> d_redo5;
     /* PSMs scored AND localised by the fused kernel (score_localize.hip): few site assignments, plain
      * settings.  `fusedb` carries the caps the general localize instantiation needs for the ones the
      * fused kernel hands over. */
@@ -987,6 +1000,9 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     const uint64_t big_min_n = (uint64_t)h->kn.big_min_n;
     const bool big_on = h->cfg.n_nl == 0 && both_dirs && h->cfg.n_fwd == 1 && h->cfg.n_types == 2 && h->mz_error <= 0.49f && !h->kn.no_big;
     p->big.assign(n, 0);
+    /* (summary mode with the lean localize route on: the kernel localises what it scores) */
+    const bool big_inline_ok = big_on && plain_on && !h->kn.no_big_inline;
+    const uint64_t big_inline_max = pya_big_inline_max();
     const bool skip_invalid = (flags & PYA_FLAG_SKIP_INVALID) != 0;
     std::vector<uint8_t> bad(n, 0);
     {
@@ -1130,18 +1146,23 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             /* (its count records hold the cumulative counts as bytes: at most 255 fragments) */
             const uint32_t frags = (both_dirs ? 2u : 1u) * (uint32_t)(L - 1) * (uint32_t)z;
             const bool to_fused = fused_on && N <= fused_max_n && frags <= 255u;
+            bool inl = false;
             if (big_on && z == 1 && N > big_min_n && ns >= 11) { /* (its second level shares ten sites: at least eleven) */
                 p->big[i] = 1;
                 p->big_pos_cap = std::max(p->big_pos_cap, (uint32_t)(L - 1));
+                inl = big_inline_ok && N <= big_inline_max;
             }
-            Bucket &bk = to_fused ? p->fusedb : p->buckets[bi];
+            Bucket &bk = to_fused ? p->fusedb : (inl ? p->bigloc : p->buckets[bi]);
+            if (inl) p->n_big_inline++;
             if (to_fused) {
                 p->fused[i] = 1;
                 p->fused_ent_cap = std::max(p->fused_ent_cap, (uint32_t)(L - 1) * (uint32_t)z);
             }
             /* lean localize instantiation: no neutral losses, charge 1, summary mode (it checks the
              * residue masses itself and hands back what it cannot do) */
-            if (to_fused || (plain_on && z == 1)) bk.ids.push_back((uint32_t)i);
+            if (inl) {
+                bk.ids.push_back((uint32_t)i);           /* (p->bigloc: localised by the recounting lean launch) */
+            } else if (to_fused || (plain_on && z == 1)) bk.ids.push_back((uint32_t)i);
             else bk.general_ids.push_back((uint32_t)i);
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
             bk.list_cap = std::max<uint32_t>(bk.list_cap, next_pow2(std::max<uint32_t>(per_type, 1)));
@@ -1156,6 +1177,27 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
         }
         p->ncls[i] = (uint8_t)cls_of_i;
+    }
+    if (p->n_big_inline) {
+        const Bucket &bl = p->bigloc;
+        p->big_inline = pya_localize_recount_lds_bytes((max_P + 31u) & ~31u, bl.push_cap(), bl.pos_cap, bl.pool_cap(), bl.sb()) <= 64 * 1024;
+        if (!p->big_inline) {
+            /* (caps that do not fit what score_big's dead tables leave: the separate localize kernels take them) */
+            for (uint64_t i = 0; i < n; i++) {
+                if (!p->big[i] || p->pre_status[i] || p->n_sig[i] > big_inline_max) continue;
+                Bucket &bk = p->buckets[p->ncls[i]];
+                bk.ids.push_back((uint32_t)i);                  /* (these are charge-1 PSMs: the lean list) */
+                bk.n_cap = std::max(bk.n_cap, p->n_sig[i]);
+                bk.list_cap = std::max(bk.list_cap, bl.list_cap);
+                bk.pos_cap = std::max(bk.pos_cap, bl.pos_cap);
+                bk.n_types = bl.n_types;
+                bk.k_max = std::max(bk.k_max, bl.k_max);
+                bk.push_max = std::max(bk.push_max, bl.push_max);
+                bk.z_max = std::max(bk.z_max, bl.z_max);
+            }
+            p->n_big_inline = 0;
+            p->bigloc.ids.clear();
+        }
     }
     for (Bucket &bk : p->buckets) {
         bk.n_plain = (uint32_t)bk.ids.size();
@@ -1459,6 +1501,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_pack_desc = meta(p->pack_desc.data(), p->pack_desc.size() * 8),
                      o_desc = meta(p->desc.data(), p->desc.size() * 8),
                      o_big_ids = meta(p->big_ids.data(), p->big_ids.size() * 4);
+        const size_t o_bigloc_ids = meta(p->bigloc.ids.data(), p->bigloc.ids.size() * 4);
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
             o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
@@ -1479,7 +1522,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
                      o_ret = reserve((size_t)p->ret_off[n] * sizeof(PeakEntry) + 64),
-                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_over = reserve((p->pack_ids.size() + 64) * 4), o_ws_top = reserve(n * 16),
+                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_over = reserve((p->pack_ids.size() + 64) * 4), o_redo5 = reserve(((size_t)p->n_big_inline + 64) * 4), o_ws_top = reserve(n * 16),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
@@ -1502,10 +1545,12 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_fused_ids.adopt(base + o_fused_ids, p->fused_ids.size());
         p->d_pack_desc.adopt(base + o_pack_desc, p->pack_desc.size());
         p->d_over.adopt(base + o_over, p->pack_ids.size() + 64);
+        p->d_redo5.adopt(base + o_redo5, (size_t)p->n_big_inline + 64);
         p->d_desc.adopt(base + o_desc, p->desc.size());
         p->d_big_ids.adopt(base + o_big_ids, p->big_ids.size());
         for (int i = 0; i < kNumBuckets; i++)
             p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
+        p->bigloc.d_ids.adopt(base + o_bigloc_ids, p->bigloc.ids.size());
         if (io) {
             if (own_spectra) {
                 p->d_mz.adopt(base + o_mz, (size_t)p->total_peaks);
@@ -1593,9 +1638,11 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         std::vector<const Bucket *> all;
         for (const Bucket &bk : p->buckets) all.push_back(&bk);
         all.push_back(&p->fusedb);
+        all.push_back(&p->bigloc);
         for (const Bucket *pbk : all) {
             const Bucket &bk = *pbk;
-            if (bk.ids.empty()) continue;
+            if (bk.ids.empty() && pbk != &p->bigloc) continue;
+            if (pbk == &p->bigloc && p->n_big_inline == 0) continue;
             m.n_cap = std::max(m.n_cap, bk.n_cap);
             m.list_cap = std::max(m.list_cap, bk.list_cap);
             m.pos_cap = std::max(m.pos_cap, bk.pos_cap);
@@ -1641,7 +1688,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
     }
     for (const pya_plan::IdList &l : p->big_lists) {
-        e = pya_launch_score_big(&d, p->d_big_ids.p + l.off, l.n, l.cap, p->big_pos_cap, st);
+        e = pya_launch_score_big(&d, p->d_big_ids.p + l.off, l.n, l.cap, p->big_pos_cap, p->big_inline ? 1u : 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "score_big launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
@@ -1674,6 +1721,20 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "localize (hand-over) launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
+    if (p->big_inline && !p->bigloc.ids.empty()) {
+        /* what score_big scored in its summary mode: the lean body with recounted signatures and the winner score_big
+         * named; what that declines is scored again with count records and goes to the general localize body */
+        const Bucket &bl = p->bigloc;
+        HIPCHK(h, hipMemsetAsync(p->d_redo5.p, 0, sizeof(uint32_t), st));
+        e = pya_launch_localize_recount(&d, bl.d_ids.p, (uint32_t)bl.ids.size(), p->peak_cap, bl.push_cap(), bl.pos_cap, bl.pool_cap(),
+                                        bl.sb(), bl.gtp(), p->d_redo5.p, st);
+        if (e) return h->hip_fail((hipError_t)e, "localize (recount) launch");
+        e = pya_launch_score_big_list(&d, p->d_redo5.p, p->d_redo5.p + 64, p->n_big_inline, p->peak_cap, p->big_pos_cap, st);
+        if (e) return h->hip_fail((hipError_t)e, "score_big (hand-over) launch");
+        e = pya_launch_localize_redo(&d, p->d_redo5.p, p->d_redo5.p + 64, p->n_big_inline, bl.push_cap(), (uint32_t)pya_big_inline_max(),
+                                     bl.pos_cap, bl.pool_cap(), bl.sb(), bl.gtp(), st);
+        if (e) return h->hip_fail((hipError_t)e, "localize (score_big hand-over) launch");
+    }
     for (Bucket &bk : p->buckets) {
         /* more than sort_room_max signatures: the lean launch without room for the sort emulation (LDS ->
          * occupancy); PSMs with a tie at the top go through the hand-over list to a second lean pass that has it */

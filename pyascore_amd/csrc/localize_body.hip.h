@@ -31,9 +31,20 @@ static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint3
  *                    introsort running out of depth, a non-positive residue mass.  Such PSMs are appended to a list and redone by
  *                    the general instantiation.
  *   PLAIN = false -- everything. */
+/* What a caller that has scored the PSM itself hands over instead of the workspace arrays (score_big's own
+ * localisation): the PepScores in LDS, the winner (the std::sort front it has already determined), the peak
+ * table and grid it has staged in LDS, and room for the recounted records of a batch of signatures. */
+struct InlineSrc {
+    const float *ws;          /* [N] PepScores, pre-sort order (LDS) */
+    uint32_t best_i, kmax;    /* winner's pre-sort index, its PepScore (bits) */
+    PeakTable tab;            /* staged table (tab.e, tab.cell set) */
+    uint32_t *rec_batch;      /* [sb][PYA_REC_WORDS] */
+    uint32_t *hist;           /* [sb][PYA_NTOP] */
+};
+
 template <bool PLAIN>
 DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t push_cap, uint32_t pos_cap,
-                       uint32_t pool_cap, uint32_t sb, uint32_t gtp, bool sort_room = true) {
+                       uint32_t pool_cap, uint32_t sb, uint32_t gtp, bool sort_room = true, const InlineSrc *in = nullptr) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int k = b.n_of_mod[psm];
@@ -58,7 +69,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     const int n_sites = (int)b.n_sites[psm];
     const uint64_t *order = b.order_tab + b.order_off[psm];
     const int64_t s0 = b.sig_off[psm];
-    const float *ws = b.ws + s0;
+    const float *ws = in ? in->ws : b.ws + s0;
 
     /* Ascore::isUnambiguous, cpp/Ascore.cpp:38-51 */
     if (k >= n_sites) {
@@ -80,6 +91,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     ctx.b = &b;
     ctx.cfg = cfg;
     stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, false);
+    if (in) ctx.tab = in->tab;                               /* (the caller's table in LDS: lookups stay on chip) */
     const Residues res = load_residues(b, cfg, psm);
     const uint64_t site_mask_u = res.site_mask;
     /* positive residue masses make the float32 running sum, hence every m/z list, ascending */
@@ -102,7 +114,11 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     const float ws_lane = lane < N ? ws[lane] : 0.f;       /* the first 64 scores stay in a register */
     uint32_t kmax = 0, first_max = 0xffffffffu;
     int n_max = 0;
-    {
+    if (in) {                                               /* the caller knows the winner already */
+        kmax = in->kmax;
+        n_max = 1;
+        first_max = in->best_i;
+    } else {
         const uint32_t *top = b.ws_top + (size_t)psm * 4;  /* score_signatures' summary (0 signatures = none) */
         kmax = top[0];
         n_max = (int)top[1];
@@ -131,8 +147,8 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
      * what decides this kernel's occupancy -- and most PSMs have a unique best PepScore and never
      * sort.  Big-C(n,k) launches of the lean instantiation therefore run without that room and hand the
      * PSMs with a tie at the top to the general instantiation. */
-    if (PLAIN && !sort_room && (n_max != 1 || (b.debug & 1024))) return true;
-    if (n_max != 1 || b.keep || (b.debug & 1024)) {
+    if (PLAIN && !sort_room && !in && (n_max != 1 || (b.debug & 1024))) return true;
+    if (!in && (n_max != 1 || b.keep || (b.debug & 1024))) {
         const SortLds srt = sort_carve(lds.scratch, N);
         /* (eight loads on their way before the first is stored: thousands of scores, and a wavefront
          * that makes one memory round trip per 64 of them spends its time waiting) */
@@ -268,7 +284,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     uint64_t my_alt = 0ull;
     const bool declined = loc_ascore_all<PLAIN>(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
                    best_bits, best_ws, best_i, res.site_mask,
-                   &my_asc, &my_alt, &fail);
+                   &my_asc, &my_alt, &fail, in ? in->rec_batch : nullptr, in ? in->hist : nullptr);
     if (PLAIN && declined) return true;
     STAMP_T(b, 36, false);
     if (lane < k && lds.site_tie[lane]) my_asc = 0.f < my_asc ? 0.f : my_asc;

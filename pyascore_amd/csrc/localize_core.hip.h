@@ -1165,11 +1165,63 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
  * competitors sb-1 at a time.  `rec` holds the cumulative counts score_signatures wrote, from which
  * the depth scores are read off the score table (the same reads score_signatures made).  Lane a
  * accumulates site a in *my_asc; alternative sites go to site_alt[a] (LDS). */
+/* The cumulative rank counts of signatures [from, S) of the batch, counted again instead of read from the
+ * records score_signatures writes: every (signature, direction, step) fragment of the batch's prefix tables is
+ * looked up in the peak table (LDS) and tallied.  Same running sums, same m/z arithmetic, same window test as
+ * the walkers, so the same counts; used where the records never went to memory (score_big's own localisation:
+ * thousands of site assignments, a handful of them ever looked at).  Plain settings: charge 1, one ion type
+ * per direction, no neutral losses.  rec_batch: [sb][PYA_REC_WORDS] in the records' layout; hist: [sb][PYA_NTOP]. */
+DEV void loc_recount(const LocCtx &c, int from, int S, uint32_t *rec_batch, uint32_t *hist) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    const DevConfig *cfg = c.cfg;
+    const int Lm1 = c.L - 1;
+    const int n_f = cfg->n_fwd, n_b = cfg->n_types - cfg->n_fwd;
+    const int ndir = (n_f > 0 ? 1 : 0) + (n_b > 0 ? 1 : 0);
+    for (int i = lane; i < S * PYA_NTOP; i += 64) hist[i] = 0u;
+    wave_lds_sync();
+    double Af = 0., Bf = 0., Ab = 0., Bb = 0.;
+    if (n_f > 0) type_constants(cfg->types[0], &Af, &Bf);
+    if (n_b > 0) type_constants(cfg->types[n_f], &Ab, &Bb);
+    const FastDiv divL = fastdiv_make((uint32_t)(Lm1 > 0 ? Lm1 : 1));
+    const int items = (S - from) * 2 * Lm1;
+    for (int base = 0; base < items; base += 64) {
+        const int e = base + lane;
+        if (e < items) {
+            const uint32_t sd = fastdiv((uint32_t)e, divL);
+            const int step = e - (int)sd * Lm1;
+            const int s = from + (int)(sd >> 1), d = (int)(sd & 1u);
+            if (d == 0 ? n_f > 0 : n_b > 0) {
+                const float running = w.run[(size_t)(s * 2 + d) * c.pos_cap + step];
+                const double m = ((double)running + (d ? Ab : Af)) - (d ? Bb : Bf);
+                const int rk = match_rank(c.tab, (float)(m + 1.007825));
+                if (rk < PYA_NTOP) atomicAdd(&hist[s * PYA_NTOP + rk], 1u);
+            }
+        }
+    }
+    wave_lds_sync();
+    if (lane >= from && lane < S) {
+        uint32_t cum[PYA_NTOP], acc = 0;
+#pragma unroll
+        for (int d = 0; d < PYA_NTOP; d++) {
+            acc += hist[lane * PYA_NTOP + d];
+            cum[d] = acc;
+        }
+        uint32_t *r6 = rec_batch + (size_t)lane * PYA_REC_WORDS;
+#pragma unroll
+        for (int d = 0; d < PYA_NTOP; d += 2) r6[d >> 1] = cum[d] | (cum[d + 1] << 16);
+        r6[5] = (uint32_t)(ndir * Lm1);
+    }
+    wave_lds_sync();
+}
+
+/* rec_batch / hist (LDS, optional): the counts of the batch's signatures are recounted (loc_recount) instead
+ * of read from `rec` */
 template <bool PLAIN>
 DEV bool loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, unsigned long long *site_alt,
                         const uint32_t *rec, uint64_t best_bits, float best_ws,
                         uint32_t best_i, uint64_t site_mask, float *my_asc_io, uint64_t *my_alt_io,
-                        int *fail_io) {
+                        int *fail_io, uint32_t *rec_batch = nullptr, uint32_t *hist = nullptr) {
     const int lane = lane_id();
     const BatchDev &b = *ctx.b;
     const LocLds &w = ctx.w;
@@ -1204,9 +1256,10 @@ DEV bool loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, uns
         STAMP_T(b, 27, false);
         {
             /* depth scores of signatures [have_best, S) from the recorded cumulative counts */
+            if (rec_batch) loc_recount(ctx, have_best ? 1 : 0, S, rec_batch, hist);
             for (int i = (have_best ? 10 : 0) + lane; i < S * 10; i += 64) {
                 const int s = i / 10, d = i % 10;
-                const uint32_t *r6 = rec + (size_t)w.c_pre[s] * PYA_REC_WORDS;
+                const uint32_t *r6 = rec_batch ? rec_batch + (size_t)s * PYA_REC_WORDS : rec + (size_t)w.c_pre[s] * PYA_REC_WORDS;
                 const uint32_t cum = (r6[d >> 1] >> ((d & 1) * 16)) & 0xffffu;
                 const uint32_t nf = r6[5];
                 float sc = 0.f;

@@ -67,6 +67,51 @@ __global__ __launch_bounds__(64, 2) void pya_localize_ties_kernel(BatchDev b, ui
     }
 }
 
+/* The lean localize body for PSMs score_big scored in its summary mode (thousands of site assignments): no count
+ * records exist -- the signatures the body looks at are counted again (loc_recount) -- and a tie for the best
+ * PepScore has been resolved by score_big (the score summary names the winner), so there is no sort.  The
+ * retained-peak table and the grid score_big left are staged in LDS: recount and site-determining-ion lookups
+ * stay on chip.  What the body declines (or score_big could not resolve) goes to the hand-over list. */
+__global__ __launch_bounds__(64, LOC_WAVES_PLAIN) void pya_localize_recount_kernel(
+    BatchDev b, const uint32_t *psm_ids, uint32_t n_ids, uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap,
+    uint32_t sb, uint32_t gtp, uint32_t *redo_count, uint32_t *redo_ids) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (blockIdx.x >= n_ids) return;
+    const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
+    const int lane = lane_id();
+    PeakEntry *t_e = (PeakEntry *)lds_raw;
+    uint16_t *grid = (uint16_t *)(lds_raw + ((size_t)cap + PYA_TABLE_PAD) * 8);
+    uint32_t *rec_batch = (uint32_t *)(grid + PYA_GRID_CELLS);
+    uint32_t *hist = rec_batch + PYA_LOC_SB_MAX * PYA_REC_WORDS;
+    unsigned char *rest = (unsigned char *)(hist + PYA_LOC_SB_MAX * PYA_NTOP);
+    bool declined = true;
+    const bool ok = b.status[psm] == PYA_ST_OK;
+    const uint32_t *top = b.ws_top + (size_t)psm * 4;
+    InlineSrc in;
+    in.ws = b.ws + b.sig_off[psm];
+    in.kmax = top[0];
+    in.best_i = top[2];
+    in.rec_batch = rec_batch;
+    in.hist = hist;
+    if (!ok || top[1] == 1u) {
+        if (ok) {
+            PeakTable tab;
+            stage_peak_table(b, psm, t_e, &tab);
+            ((uint64_t *)grid)[lane] = ((const uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane];
+            tab.cell = grid;
+            tab.base = 0.f;
+            tab.inv_w = 0.f;
+            tab.nb = 0.f;
+            tab.last_cell = 0;
+            wave_lds_sync();
+            if (tab.n > 0) grid_params(&tab, t_e[0].mz, t_e[tab.n - 1].mz);
+            in.tab = tab;
+        }
+        declined = localize_body<true>(b, psm, rest, push_cap, pos_cap, pool_cap, sb, gtp, true, ok ? &in : nullptr);
+    }
+    if (declined && lane == 0) redo_ids[atomicAdd(redo_count, 1u)] = psm;
+}
+
 /* PyAscore.calculate_ambiguity for PSM `psm` with caller-supplied score containers */
 __global__ __launch_bounds__(64) void pya_ambiguity_kernel(BatchDev b, uint32_t psm, uint32_t peak_cap,
                                                            uint32_t list_cap, uint64_t ref_bits,
@@ -157,6 +202,23 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_localize_redo_kernel, dim3(grid), dim3(64), lds, stream, *b, count, ids, push_cap, pos_cap,
                        pool_cap, sb, gtp);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb) {
+    return ((size_t)cap + PYA_TABLE_PAD) * 8 + PYA_GRID_CELLS * 2 + PYA_LOC_SB_MAX * (PYA_REC_WORDS + PYA_NTOP) * 4 +
+           pya_localize_lds_bytes(push_cap, 0, pos_cap, pool_cap, sb) + 64;
+}
+
+extern "C" int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
+                                           uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
+                                           uint32_t *d_redo, hipStream_t stream) {
+    if (n_ids == 0) return 0;
+    const size_t lds = pya_localize_recount_lds_bytes(cap, push_cap, pos_cap, pool_cap, sb);
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_localize_recount_kernel);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pya_localize_recount_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, cap, push_cap, pos_cap,
+                       pool_cap, sb, gtp, d_redo, d_redo + 64);
     return (int)hipGetLastError();
 }
 

@@ -22,6 +22,19 @@
 #define BIG_WAVES 8
 #define BIG_SITES1 6
 #define BIG_SITES2 10
+#define BIG_T (64 * BIG_WAVES)
+
+/* The winner among tied best PepScores, named by the kernel itself (inline mode: summary results only, C(n,k) <=
+ * pya_big_inline_max()).  Half of cfg5's PSMs tie for the best score, and which of the tied site assignments
+ * the reference reports is whatever libstdc++'s introsort leaves at the front: its emulation on ONE wavefront
+ * over 3003 scores (the lean localize kernel's second pass) took 1.13 of cfg5's 6.5 ms.  Here, once the last
+ * signature is scored, the two prefix tables and the eight rank histograms are dead -- 44 KB of the workgroup's
+ * LDS -- and become   key f32[N] | idx u16[N] | lq u16[N] | rq u16[N] | 2 KB of chunk masks and counts,
+ * on which all eight wavefronts run the left spine of the sort (wg_spine_front) and leave the winner's index in
+ * the score summary; the localize kernel then never sorts.  In this mode no count record is written either --
+ * 24 bytes x 3003 signatures x 50 000 PSMs = 3.6 GB per step on cfg5, read back for a dozen signatures per PSM:
+ * the localize kernel recounts the few signatures it looks at (localize_core.hip.h: loc_recount). */
+#define BIG_INLINE_AUX 2304
 
 /* (the level-2 table is indexed by the 10-site pattern itself; a dense table -- 638 instead of 1024
  * entries per direction for k = 5, 4 instead of 3 workgroups per CU -- was measured and lost to its
@@ -41,11 +54,144 @@ DEV void pack_counts(const uint32_t *cnt, int lane, uint64_t *lo, uint32_t *hi) 
     *hi = hist_count(cnt, lane, 8) | (hist_count(cnt, lane, 9) << 8);
 }
 
-__global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchDev b, const uint32_t *psm_ids, uint32_t n_ids,
-                                                                       uint32_t cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    if (blockIdx.x >= n_ids) return;
-    const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
+
+/* Front of libstdc++'s std::sort (descending by PepScore) over key[0..N), by the whole workgroup: the left
+ * spine of introsort's partition tree -- __unguarded_partition_pivot on [0, l) until l <= 16 -- exactly as
+ * localize_core.hip.h's sort_partition<true> runs it on one wavefront (same pivot choice, same cursor stops,
+ * same pairing, only the left part written), with the stops ranked by a scan over per-chunk ballots instead of
+ * queues.  Returns the pre-sort index of the front element; *out_of_depth when the depth limit would call for
+ * the heap sort (the caller hands the PSM over). */
+struct BigSortLds {
+    float *key;
+    uint16_t *idx, *lq, *rq;
+    unsigned long long *ml, *mr;       /* [64] stop masks per chunk of 64 positions */
+    uint32_t *cl, *cr, *ol, *orr;      /* [64] stops per chunk, and before the chunk in cursor order */
+    uint32_t *misc;                    /* [8]: nL, nR, swaps, cut, front */
+};
+DEV uint32_t wg_spine_front(const BigSortLds &s, int N, uint32_t kmax, bool *out_of_depth) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int depth = 0;
+    for (int t = N; t > 1; t >>= 1) depth++;
+    depth *= 2;
+    int l = N;
+    *out_of_depth = false;
+    if (tid < 2) s.misc[2 + tid] = 0u;
+    __syncthreads();
+    /* three barriers per partition: every thread works out the pivot for itself (the element swapped to the front
+     * is only written once everybody has taken its stops), every wavefront scans the chunk counts for itself, and
+     * every thread derives the cut for itself from the swap counter (two counters, used alternately) */
+    for (int it = 0; l > 16; it++) {
+        if (depth == 0) {
+            *out_of_depth = true;
+            return 0u;
+        }
+        depth--;
+        /* __move_median_to_first(0, 1, mid, l - 1): the pick, and the array as it looks after the swap */
+        const int mid = l / 2;
+        int pick;
+        {
+            const float a = s.key[1], bq = s.key[mid], c = s.key[l - 1];
+            if (a > bq) {
+                if (bq > c) pick = mid;
+                else if (a > c) pick = l - 1;
+                else pick = 1;
+            } else if (a > c) pick = 1;
+            else if (bq > c) pick = l - 1;
+            else pick = mid;
+        }
+        const float pv = s.key[pick], k_front = s.key[0];
+        const uint16_t i_pick = s.idx[pick], i_front = s.idx[0];
+        const int nchunks = (l + 63) >> 6;
+        for (int c = wave; c < nchunks; c += BIG_WAVES) {
+            const int p = c * 64 + lane;
+            float k = s.key[p < l ? p : l - 1];
+            k = p == pick ? k_front : k;                     /* (position 0 is no left stop and holds the pivot for the right cursor) */
+            k = p == 0 ? pv : k;
+            const unsigned long long ml = __ballot(p >= 1 && p < l && !(k > pv));
+            const unsigned long long mr = __ballot(p < l && !(pv > k));
+            if (lane == 0) {
+                s.ml[c] = ml;
+                s.mr[c] = mr;
+                s.cl[c] = (uint32_t)__popcll(ml);
+                s.cr[c] = (uint32_t)__popcll(mr);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {                                      /* the swap itself, and the other partition's counter */
+            s.key[0] = pv;
+            s.idx[0] = i_pick;
+            s.key[pick] = k_front;
+            s.idx[pick] = i_front;
+            s.misc[2 + ((it + 1) & 1)] = 0u;
+        }
+        /* stops before each chunk (left cursor ascending, right descending): every wavefront for itself */
+        int nL, nR;
+        uint32_t my_ol, my_or;
+        {
+            const int vl = lane < nchunks ? (int)s.cl[lane] : 0;
+            my_ol = (uint32_t)wave_excl_scan_i32(vl, &nL);
+            const int rc = nchunks - 1 - lane;               /* lane j takes the j-th chunk from the right */
+            const int vr = rc >= 0 ? (int)s.cr[rc] : 0;
+            my_or = (uint32_t)wave_excl_scan_i32(vr, &nR);
+        }
+        for (int c = wave; c < nchunks; c += BIG_WAVES) {
+            const unsigned long long ml = s.ml[c], mr = s.mr[c];
+            const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)my_ol, c);
+            const uint32_t orr = (uint32_t)__builtin_amdgcn_readlane((int)my_or, nchunks - 1 - c);
+            const unsigned long long below = (1ull << lane) - 1ull, above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+            if ((ml >> lane) & 1ull) s.lq[ol + (uint32_t)__popcll(ml & below)] = (uint16_t)(c * 64 + lane);
+            if ((mr >> lane) & 1ull) s.rq[orr + (uint32_t)__popcll(mr & above)] = (uint16_t)(c * 64 + lane);
+        }
+        __syncthreads();
+        const int np = nL < nR ? nL : nR;
+        /* the r-th stops are exchanged while the cursors have not met; left stops ascend and right stops descend,
+         * so the exchanged pairs are r < m_sw, their left and right positions are disjoint sets, and only the left
+         * element is written (the discarded right part keeps stale copies, as in the one-wavefront form) */
+        int mine = 0;
+        for (int r = tid; r < np; r += BIG_T) {
+            const int a = s.lq[r], bpos = s.rq[r];
+            if (a < bpos) {
+                s.key[a] = s.key[bpos];
+                s.idx[a] = s.idx[bpos];
+                mine++;
+            }
+        }
+        mine = wave_sum_i32(mine);
+        if (lane == 0 && mine) atomicAdd(&s.misc[2 + (it & 1)], (uint32_t)mine);
+        __syncthreads();
+        const int m_sw = (int)s.misc[2 + (it & 1)];
+        const int cand_l = m_sw < nL ? (int)s.lq[m_sw] : 0x7fffffff;
+        const int cand_r = m_sw >= 1 ? (int)s.rq[m_sw - 1] : l;
+        l = cand_l < cand_r ? cand_l : cand_r;
+    }
+    __syncthreads();
+    /* front of the sorted list = left-most maximum of the left-most run */
+    if (wave == 0) {
+        uint32_t pos = 0xffffffffu;
+        if (lane < l && __float_as_uint(s.key[lane]) == kmax) pos = (uint32_t)lane;
+        pos = wave_min_u32(pos);
+        if (lane == 0) s.misc[4] = s.idx[pos];
+    }
+    __syncthreads();
+    return s.misc[4];
+}
+
+__host__ __device__ static inline uint32_t pya_big_inline_max_dev() {
+    const size_t dead = 2 * 64 * sizeof(PrefixCompact) + 2 * 1024 * sizeof(PrefixCompact) + (size_t)BIG_WAVES * (PYA_NTOP / 2 * 64 * 4);
+    const size_t n = (dead - BIG_INLINE_AUX) / 10;
+    return (uint32_t)(n < 4096 ? n : 4096);                  /* (chunk masks and counts: 64 chunks of 64 positions) */
+}
+extern "C" uint32_t pya_big_inline_max(void) {
+    /* key (4) + idx, lq, rq (3 x 2) bytes per signature in what the prefix tables and histograms leave */
+    return pya_big_inline_max_dev();
+}
+
+struct BigLoc {
+    uint32_t inline_on;              /* summary results only: no count records, ties for the best score resolved here */
+};
+
+/* one PSM, one workgroup (uniform control flow: it contains workgroup barriers) */
+DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, const BigLoc &loc) {
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const int tid = (int)threadIdx.x;
@@ -65,6 +211,7 @@ __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchD
     if (b.status[psm] != PYA_ST_OK) return;                      /* (uniform over the workgroup) */
     const uint32_t N = b.n_sig[psm];
     if (N == 0) return;
+    const bool inl = loc.inline_on && !b.keep && N <= pya_big_inline_max_dev();
     /* every wavefront reads the peptide for itself (registers: site mask, length); wavefront 0 stages
      * what is shared */
     const Residues res = load_residues(b, cfg, psm);
@@ -213,7 +360,7 @@ __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchD
             } else if (ws >= 0.f && u == top_u) {
                 top_n++;
             }
-            if (b.rec) {
+            if (b.rec && !inl) {
                 uint32_t *rec = b.rec + (s0 + s) * PYA_REC_WORDS;
 #pragma unroll
                 for (int d = 0; d < PYA_NTOP; d += 2) rec[d >> 1] = cum[d] | (cum[d + 1] << 16);
@@ -222,6 +369,8 @@ __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchD
         }
         wave_lds_sync();
     }
+    /* (the PepScores are read back below by other wavefronts of this workgroup: the barriers' workgroup-scope
+     * fences order that; an agent-scope fence here -- an L2 write-back per wavefront -- doubled the kernel's time) */
     /* ---- summary of the scores over the eight wavefronts ---- */
     {
         const uint32_t kmax = wave_max_u32(top_n ? top_u : 0u);
@@ -256,18 +405,89 @@ __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchD
         t[1] = n_max;
         t[2] = first;
         if (failed) b.status[psm] = PYA_ST_LUT_RANGE;
+        tops[BIG_WAVES * 4 + 0] = kmax;                      /* (lutl's row is dead: its first words carry the summary on) */
+        tops[BIG_WAVES * 4 + 1] = n_max;
+        tops[BIG_WAVES * 4 + 2] = first;
+        tops[BIG_WAVES * 4 + 3] = failed;
+    }
+    if (!inl) return;
+    /* ---------------- the winner, right here (see the note at the top) ---------------- */
+    __syncthreads();
+    const uint32_t kmax = tops[BIG_WAVES * 4 + 0], n_max = tops[BIG_WAVES * 4 + 1];
+    if (tops[BIG_WAVES * 4 + 3] || n_max == 0) return;           /* (trial count outside the score table: localize writes "no result") */
+    if (n_max == 1 && !(b.debug & 1024u)) return;                /* a unique best PepScore: nothing to resolve */
+    /* a tie for the best PepScore: the front of std::sort decides (cpp/Ascore.cpp:141-146) */
+    BigSortLds srt;
+    srt.key = (float *)l1;                                       /* l1 | l2 | cnt_all: nothing reads them any more */
+    srt.idx = (uint16_t *)(srt.key + N);
+    srt.lq = srt.idx + N;
+    srt.rq = srt.lq + N;
+    unsigned char *aux = (unsigned char *)(((uintptr_t)(srt.rq + N) + 15) & ~(uintptr_t)15);
+    srt.ml = (unsigned long long *)aux;
+    srt.mr = srt.ml + 64;
+    srt.cl = (uint32_t *)(srt.mr + 64);
+    srt.cr = srt.cl + 64;
+    srt.ol = srt.cr + 64;
+    srt.orr = srt.ol + 64;
+    srt.misc = srt.orr + 64;
+    for (uint32_t i = (uint32_t)tid; i < N; i += BIG_T) {
+        srt.key[i] = b.ws[s0 + i];
+        srt.idx[i] = (uint16_t)i;
+    }
+    __syncthreads();
+    if (b.debug & 8u) return;
+    bool ood;
+    const uint32_t best_i = wg_spine_front(srt, (int)N, kmax, &ood);
+    if (tid == 0 && !ood) {                                      /* (out of depth: the count stays, the localize kernel hands the PSM over) */
+        uint32_t *t = b.ws_top + (size_t)psm * 4;
+        t[1] = 1u;
+        t[2] = best_i;
+    }
+}
+
+__global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchDev b, const uint32_t *psm_ids, uint32_t n_ids,
+                                                                       uint32_t cap, BigLoc loc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (blockIdx.x >= n_ids) return;
+    big_body(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, loc);
+}
+
+/* the PSMs the in-kernel localisation declined, scored again with count records for the general localize body:
+ * a small grid strides over the list */
+__global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_list_kernel(BatchDev b, const uint32_t *count, const uint32_t *ids,
+                                                                            uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t n = *count;
+    BigLoc loc = {};
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        big_body(b, ids[k], lds_raw, cap, loc);
+        __syncthreads();
     }
 }
 
 extern "C" size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap) { return score_big_lds_bytes(cap, pos_cap); }
 
-/* pos_cap: the largest L - 1 of the launch (sizes the score-table row kept in LDS) */
+/* pos_cap: the largest L - 1 of the launch (sizes the score-table row kept in LDS).  inline_on: summary mode --
+ * for PSMs of up to pya_big_inline_max() signatures no count records are written and a tie for the best score is
+ * resolved in the kernel (pya_launch_localize_recount finishes them). */
 extern "C" int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
-                                    uint32_t pos_cap, hipStream_t stream) {
+                                    uint32_t pos_cap, uint32_t inline_on, hipStream_t stream) {
     if (n_ids == 0) return 0;
     const size_t lds = score_big_lds_bytes(cap, pos_cap);
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_score_big_kernel);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pya_score_big_kernel, dim3(n_ids), dim3(64 * BIG_WAVES), lds, stream, *b, d_ids, n_ids, cap);
+    BigLoc loc = {inline_on};
+    hipLaunchKernelGGL(pya_score_big_kernel, dim3(n_ids), dim3(64 * BIG_WAVES), lds, stream, *b, d_ids, n_ids, cap, loc);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max,
+                                         uint32_t cap, uint32_t pos_cap, hipStream_t stream) {
+    if (n_max == 0) return 0;
+    const size_t lds = score_big_lds_bytes(cap, pos_cap);
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_score_big_list_kernel);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t grid = n_max < 2048u ? n_max : 2048u;
+    hipLaunchKernelGGL(pya_score_big_list_kernel, dim3(grid), dim3(64 * BIG_WAVES), lds, stream, *b, d_count, d_ids, cap);
     return (int)hipGetLastError();
 }

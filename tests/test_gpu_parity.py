@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
                         "fused_replay", "general_serial_replay", "packed", "packed_8", "packed_passed_on", "packed_small_pool",
-                        "packed_always_sort", "packed_declines", "packed_replay"])
+                        "packed_always_sort", "packed_declines", "packed_replay", "big_records"])
 def path(request, monkeypatch):
     """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
     assignments on the fused score + localize kernel and the other plain ones on the lean
@@ -38,8 +38,15 @@ def path(request, monkeypatch):
     # a peak pool so small that most PSMs are passed on, the std::sort emulation for every slot, every slot
     # handed over to the general localize instantiation at the start (512) or at the pairing (2048).  The
     # other routes run without it, as before.
-    for v in ("PYA_PACK", "PYA_NO_PACK", "PYA_PACK_MIN", "PYA_PACK_GROUP_MIN", "PYA_PACK_G", "PYA_PACK_PEAKS"):
+    for v in ("PYA_PACK", "PYA_NO_PACK", "PYA_PACK_MIN", "PYA_PACK_GROUP_MIN", "PYA_PACK_G", "PYA_PACK_PEAKS",
+              "PYA_NO_BIG_INLINE"):
         monkeypatch.delenv(v, raising=False)
+    # PSMs with thousands of site assignments (score_big): by default no count records are written, score_big
+    # names the winner among tied best scores itself and the recounting lean localize launch finishes them
+    # (every route above: "lean_declines" sends them all through its hand-over list, "always_sort" forces the
+    # workgroup sort); "big_records" is the older route (count records, sort in the localize kernels).
+    if request.param == "big_records":
+        monkeypatch.setenv("PYA_NO_BIG_INLINE", "1")
     if request.param.startswith("packed"):
         monkeypatch.setenv("PYA_PACK", "1")
         monkeypatch.setenv("PYA_PACK_MIN", "0")
