@@ -266,15 +266,37 @@ DEV int partners_in_run(const float *run, int n, int p2, float me, int side, flo
  * C-terminus (C(n,k) <= 32); otherwise one direction, one signature per lane (C(n,k) <= 64).
  * Returns true when the PSM was handed over to the general localize instantiation. */
 /* ZM: fragment charges above 1 possible (otherwise the charge loops compile away). */
+/* The retained table as bin_core has just left it in this wavefront's LDS (float m/z array, byte rank array):
+ * a caller that binned the spectrum itself passes it instead of having it read back from the workspace
+ * (score_localize.hip: pya_bin_score_localize_kernel).  Up to FUSED_LOCAL_CHUNKS x 64 retained peaks. */
+#define FUSED_LOCAL_CHUNKS 8
+struct LocalTable {
+    const float *mz;
+    const uint8_t *rank;
+    int R, status;
+};
+
 template <bool BOTH, bool ZM>
 DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t n_cap, uint32_t stride,
-                    uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap) {
+                    uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, const LocalTable *local = nullptr) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int ndir = BOTH ? 2 : 1;
     const FusedLds f = fused_carve(lds_raw, cap, n_cap, stride, pos_cap, ent_cap, push_cap, (uint32_t)ndir, ZM);
     STAMP_BEGIN();
     STAMP_T(b, 38, false);
+    /* a table handed over in LDS sits where this body's own arrays go: into registers before anything is written */
+    float lmz[FUSED_LOCAL_CHUNKS];
+    uint32_t lrk[FUSED_LOCAL_CHUNKS];
+    if (local) {
+#pragma unroll
+        for (int q = 0; q < FUSED_LOCAL_CHUNKS; q++) {
+            const int i = q * 64 + lane_id();
+            lmz[q] = i < local->R ? local->mz[i] : __builtin_huge_valf();
+            lrk[q] = i < local->R ? (uint32_t)local->rank[i] : (uint32_t)PYA_NO_MATCH;
+        }
+        wave_lds_sync();
+    }
     /* the residue table does not depend on the PSM: on its way before anything else */
     if (lane < 32) {
         f.mass_l[lane] = cfg->res_mass[lane];
@@ -288,8 +310,8 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const int zmax = ZM ? (int)(w4 >> 56) : 1;
     const int N = (int)(uint32_t)w5;
     const uint64_t *order = b.order_tab + (uint32_t)(w5 >> 32);
-    const int status = b.status[psm];
-    const int R = (int)b.ret_n[psm];
+    const int status = local ? local->status : b.status[psm];
+    const int R = local ? local->R : (int)b.ret_n[psm];
 
     const uint32_t max_k = b.max_k;
     float *out_asc = b.ascores + (size_t)psm * max_k;
@@ -319,7 +341,20 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         aux_pos = b.aux_pos[a0 + lane];
         aux_mass = b.aux_mass[a0 + lane];
     }
-    copy_peak_table(b.ret + p0, R, f.peaks, lane, 64);
+    if (local) {
+#pragma unroll
+        for (int q = 0; q < FUSED_LOCAL_CHUNKS; q++) {
+            const int i = q * 64 + lane;
+            if (i < R + PYA_TABLE_PAD) {                     /* (past the last peak: the registers hold the sentinels) */
+                PeakEntry e;
+                e.mz = lmz[q];
+                e.rank = lrk[q];
+                f.peaks[i] = e;
+            }
+        }
+    } else {
+        copy_peak_table(b.ret + p0, R, f.peaks, lane, 64);
+    }
     PeakTable tab;
     tab.e = f.peaks;
     tab.g_cell = nullptr;

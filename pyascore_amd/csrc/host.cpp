@@ -81,7 +81,12 @@ int pya_launch_fused_pack(const BatchDev *b, const uint64_t *d_pdesc, uint32_t n
                           uint32_t *d_redo_ids, uint32_t *d_over_count, uint32_t *d_over_ids, hipStream_t stream);
 int pya_launch_fused_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
                           uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
-                          uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
+                          uint32_t multi_z, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
+size_t pya_bin_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap,
+                               uint32_t both, uint32_t multi_z);
+int pya_launch_bin_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap, uint32_t stride,
+                         uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both, uint32_t multi_z,
+                         uint32_t *d_redo_count, uint32_t *d_redo_ids, uint32_t *d_binredo, hipStream_t stream);
 int pya_launch_localize_redo(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max,
                              uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
                              uint32_t gtp, hipStream_t stream);
@@ -191,7 +196,7 @@ float std_residue_mass(char c) {                       /* Types.h:7-30 */
 struct Knobs {
     bool no_plain = false, no_fused = false, no_big = false, no_tiny = false, no_prefix = false, no_chunks = false;
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
-    bool host_timing = false, stamps = false, pack = false, sort_room = false, no_big_inline = false;
+    bool host_timing = false, stamps = false, pack = false, sort_room = false, no_big_inline = false, bin_fused = false;
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64, pack_min = 512, pack_group_min = 256;
     uint32_t pack_g = 4, pack_peaks = 208, sort_room_max = 1024;
@@ -220,6 +225,7 @@ static void read_knobs(Knobs &k) {
     k.pack = flag("PYA_PACK") && !flag("PYA_NO_PACK");
     k.sort_room = flag("PYA_SORT_ROOM");
     k.no_big_inline = flag("PYA_NO_BIG_INLINE");
+    k.bin_fused = flag("PYA_BIN_FUSED");
     if (const char *d = std::getenv("PYA_DEBUG")) k.debug = (uint32_t)std::strtoul(d, nullptr, 0);
     k.plain_min = num("PYA_PLAIN_MIN", 512);
     k.big_min_n = num("PYA_BIG_MIN_N", 1024);
@@ -437,6 +443,11 @@ struct pya_plan {
     DevBuf<uint64_t> d_pack_desc;
     DevBuf<uint32_t> d_over;                 /* [64 + n]: count, then the PSMs the packed kernel passed on */
     uint32_t n_fused_total = 0;
+    /* the fused launches bin their spectra themselves (pya_bin_score_localize_kernel): those PSMs are in no bin
+     * list; d_binredo = [64 + n]: the PSMs it passes on to the list form of the fused kernel, d_redo6 = [64 + n]:
+     * those of them that pya_bin_exact_kernel has to bin first */
+    bool bin_fused = false;
+    DevBuf<uint32_t> d_binredo, d_redo6;
     std::vector<uint8_t> big;           /* [n_psm] scored by score_big.hip (thousands of site assignments, plain settings) */
     DevBuf<uint32_t> d_big_ids;
     uint32_t big_pos_cap = 1;
@@ -1236,6 +1247,10 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             std::fill(p->fused.begin(), p->fused.end(), 0);
         }
     }
+    /* OFF by default (PYA_BIN_FUSED=1): measured time-neutral -- cfg2 0.648 ms against 0.257 + 0.390 for the two kernels,
+     * both bound by vector issue, and the staging it saves is a few per cent of their instructions -- while the
+     * whole path's HBM traffic drops from 1.45x to 1.2x the algorithmic bytes. */
+    p->bin_fused = fused_on && !p->fusedb.ids.empty() && h->kn.bin_fused && !h->kn.pack;
     lap("psm loop");
     p->n_skipped = n_skipped;
     p->sig_off[n] = sig_total;
@@ -1270,7 +1285,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             size_t c = 0;
             while (caps[c] < P) c++;
             pcls[i] = (uint8_t)c;
-            cnt_bin[c]++;
+            if (!(p->fused[i] && p->bin_fused)) cnt_bin[c]++;
             if (p->fused[i]) continue;
             if (p->big[i]) cnt_big[c]++;
             else cnt_score[p->ncls[i] * nc + c]++;
@@ -1292,12 +1307,18 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             off += cnt_big[c];
         }
         p->big_ids.resize(off);
-        p->bin_ids.resize(n - n_skipped);
+        {
+            uint32_t nb = 0;
+            for (size_t c = 0; c < nc; c++) nb += cnt_bin[c];
+            p->bin_ids.resize(nb);
+        }
         p->score_ids.resize(n_score);
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;
-            pya_plan::IdList &bl = p->bin_lists[pcls[i]];
-            p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
+            if (!(p->fused[i] && p->bin_fused)) {
+                pya_plan::IdList &bl = p->bin_lists[pcls[i]];
+                p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
+            }
             if (p->fused[i]) {
                 /* (listed below) */
             } else if (p->big[i]) {
@@ -1522,7 +1543,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
                      o_ret = reserve((size_t)p->ret_off[n] * sizeof(PeakEntry) + 64),
-                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_over = reserve((p->pack_ids.size() + 64) * 4), o_redo5 = reserve(((size_t)p->n_big_inline + 64) * 4), o_ws_top = reserve(n * 16),
+                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_over = reserve((p->pack_ids.size() + 64) * 4), o_redo5 = reserve(((size_t)p->n_big_inline + 64) * 4), o_binredo = reserve(((size_t)p->n_fused_total + 64) * 4),
+                     o_redo6 = reserve(((size_t)p->n_fused_total + 64) * 4), o_ws_top = reserve(n * 16),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
@@ -1546,6 +1568,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_pack_desc.adopt(base + o_pack_desc, p->pack_desc.size());
         p->d_over.adopt(base + o_over, p->pack_ids.size() + 64);
         p->d_redo5.adopt(base + o_redo5, (size_t)p->n_big_inline + 64);
+        p->d_binredo.adopt(base + o_binredo, (size_t)p->n_fused_total + 64);
+        p->d_redo6.adopt(base + o_redo6, (size_t)p->n_fused_total + 64);
         p->d_desc.adopt(base + o_desc, p->desc.size());
         p->d_big_ids.adopt(base + o_big_ids, p->big_ids.size());
         for (int i = 0; i < kNumBuckets; i++)
@@ -1705,6 +1729,28 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
                                       p->fused_both, d.redo4_count, d.redo4_ids, p->d_over.p, p->d_over.p + 64, st);
             if (e) return h->hip_fail((hipError_t)e, "score_localize (packed) launch");
         }
+        if (p->bin_fused && !p->fused_launches.empty()) {
+            /* binning + scoring + localisation in one pass; the spectra its common-case binning declines are binned by
+             * the exact kernel (own hand-over list) and, with the very long tables, finished by the list form */
+            HIPCHK(h, hipMemsetAsync(p->d_binredo.p, 0, sizeof(uint32_t), st));
+            HIPCHK(h, hipMemsetAsync(p->d_redo6.p, 0, sizeof(uint32_t), st));
+            BatchDev d2 = d;
+            d2.redo_count = p->d_redo6.p;
+            d2.redo_ids = p->d_redo6.p + 64;
+            uint32_t any_z = 0;
+            for (const pya_plan::FusedLaunch &l : p->fused_launches) {
+                e = pya_launch_bin_fused(&d2, p->d_fused_ids.p + l.off, l.n, l.cap, l.n_cap, l.stride, l.pos_cap, l.ent_cap, l.push_cap,
+                                         p->fused_both, l.multi_z, d.redo4_count, d.redo4_ids, p->d_binredo.p, st);
+                if (e) return h->hip_fail((hipError_t)e, "bin_score_localize launch");
+                any_z |= l.multi_z;
+            }
+            e = pya_launch_bin_exact(&d2, (uint32_t)p->fused_ids.size(), p->peak_cap, st);
+            if (e) return h->hip_fail((hipError_t)e, "bin_spectra (exact, fused hand-over) launch");
+            e = pya_launch_fused_list(&d, p->d_binredo.p, p->d_binredo.p + 64, (uint32_t)p->fused_ids.size(), p->peak_cap, p->fused_n_cap,
+                                      p->fused_stride, fb.pos_cap, p->fused_ent_cap, fb.push_cap(), p->fused_both, any_z,
+                                      d.redo4_count, d.redo4_ids, st);
+            if (e) return h->hip_fail((hipError_t)e, "score_localize (bin hand-over) launch");
+        } else
         for (const pya_plan::FusedLaunch &l : p->fused_launches) {
             e = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, l.n_cap, l.stride, l.pos_cap, l.ent_cap, l.push_cap,
                                  p->fused_both, l.multi_z, d.redo4_count, d.redo4_ids, st);
@@ -1712,7 +1758,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         }
         if (!p->pack_launches.empty()) {
             e = pya_launch_fused_list(&d, p->d_over.p, p->d_over.p + 64, (uint32_t)p->pack_ids.size(), p->peak_cap, p->fused_n_cap,
-                                      p->fused_stride, fb.pos_cap, std::max(fb.pos_cap, 1u), fb.push_cap(), p->fused_both,
+                                      p->fused_stride, fb.pos_cap, std::max(fb.pos_cap, 1u), fb.push_cap(), p->fused_both, 0u,
                                       d.redo4_count, d.redo4_ids, st);
             if (e) return h->hip_fail((hipError_t)e, "score_localize (passed-on) launch");
         }

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
                         "fused_replay", "general_serial_replay", "packed", "packed_8", "packed_passed_on", "packed_small_pool",
-                        "packed_always_sort", "packed_declines", "packed_replay", "big_records"])
+                        "packed_always_sort", "packed_declines", "packed_replay", "big_records", "bin_fused",
+                        "bin_fused_exact"])
 def path(request, monkeypatch):
     """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
     assignments on the fused score + localize kernel and the other plain ones on the lean
@@ -47,6 +48,13 @@ def path(request, monkeypatch):
     # workgroup sort); "big_records" is the older route (count records, sort in the localize kernels).
     if request.param == "big_records":
         monkeypatch.setenv("PYA_NO_BIG_INLINE", "1")
+    # binning, scoring and localisation of the fused kernel's PSMs in one pass (pya_bin_score_localize_kernel;
+    # opt-in: time-neutral, less HBM traffic), without and with every spectrum forced through the exact binning
+    monkeypatch.delenv("PYA_BIN_FUSED", raising=False)
+    if request.param.startswith("bin_fused"):
+        monkeypatch.setenv("PYA_BIN_FUSED", "1")
+        if request.param == "bin_fused_exact":
+            monkeypatch.setenv("PYA_DEBUG", "128")
     if request.param.startswith("packed"):
         monkeypatch.setenv("PYA_PACK", "1")
         monkeypatch.setenv("PYA_PACK_MIN", "0")
