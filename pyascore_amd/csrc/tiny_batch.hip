@@ -106,27 +106,33 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
     }
     __threadfence();
     wave_lds_sync();
-    {
-        const float *r_mz;
-        const uint8_t *r_rank;
-        int status;
-        int R = bin_core<false>(b, 0, lds_raw, cap, &r_mz, &r_rank, &status);
-        if (R == PYA_BIN_REDO) {
-            wave_lds_sync();
-            R = bin_core<true>(b, 0, lds_raw, cap, &r_mz, &r_rank, &status);
-        }
-        bin_store(b, 0, R, status, r_mz, r_rank);
+    const float *r_mz;
+    const uint8_t *r_rank;
+    int bin_status;
+    int R = bin_core<false>(b, 0, lds_raw, cap, &r_mz, &r_rank, &bin_status);
+    if (R == PYA_BIN_REDO) {
+        wave_lds_sync();
+        R = bin_core<true>(b, 0, lds_raw, cap, &r_mz, &r_rank, &bin_status);
     }
-    __threadfence();
-    wave_lds_sync();
+    bin_store(b, 0, R, bin_status, r_mz, r_rank);            /* (the general bodies and a retained PSM read it from the workspace) */
     bool general = use_fused == 0;
-    if (!general) {
-        const bool declined = use_fused == 1 ? fused_body<true, ZM>(b, 0, lds_raw, cap, f_n_cap, f_stride, pos_cap, f_ent_cap, f_push_cap)
-                                             : fused_body<false, ZM>(b, 0, lds_raw, cap, f_n_cap, f_stride, pos_cap, f_ent_cap, f_push_cap);
+    if (!general && R <= FUSED_LOCAL_CHUNKS * 64 - PYA_TABLE_PAD) {
+        /* the fused body takes the table bin_core left in LDS: no round trip through the workspace */
+        LocalTable lt = {r_mz, r_rank, R < 0 ? 0 : R, R < 0 ? bin_status : PYA_ST_OK};
+        const bool declined = use_fused == 1 ? fused_body<true, ZM>(b, 0, lds_raw, cap, f_n_cap, f_stride, pos_cap, f_ent_cap, f_push_cap, &lt)
+                                             : fused_body<false, ZM>(b, 0, lds_raw, cap, f_n_cap, f_stride, pos_cap, f_ent_cap, f_push_cap, &lt);
         general = declined;                                  /* (wave-uniform) what it handed over is finished below */
     } else {
-        if (prefix) score_body<true>(b, 0, lds_raw, cap, with_nl, compact);
-        else score_body<false>(b, 0, lds_raw, cap, with_nl, 0u);
+        __threadfence();
+        wave_lds_sync();
+        if (!general) {
+            const bool declined = use_fused == 1 ? fused_body<true, ZM>(b, 0, lds_raw, cap, f_n_cap, f_stride, pos_cap, f_ent_cap, f_push_cap)
+                                                 : fused_body<false, ZM>(b, 0, lds_raw, cap, f_n_cap, f_stride, pos_cap, f_ent_cap, f_push_cap);
+            general = declined;
+        } else {
+            if (prefix) score_body<true>(b, 0, lds_raw, cap, with_nl, compact);
+            else score_body<false>(b, 0, lds_raw, cap, with_nl, 0u);
+        }
     }
     if (general) {
         __threadfence();
