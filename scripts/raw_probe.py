@@ -1,3 +1,4 @@
+"""Raw pya_score_one latency through ctypes, without the PyAscore wrapper (through gpurun): python scripts/raw_probe.py"""
 import os, sys, time, ctypes as C
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
