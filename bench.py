@@ -47,8 +47,10 @@ def algorithmic_bytes(batch, max_k):
 FAMILIES = {
     "pya_bin_spectra_kernel": ("pya_bin_spectra_kernel", "pya_bin_exact_kernel"),
     "pya_score_signatures_kernel": ("pya_score_signatures_kernel", "pya_score_big_kernel"),
-    "pya_score_localize_kernel": ("pya_score_localize_kernel", "pya_score_localize_pack_kernel", "pya_score_localize_list_kernel"),
-    "pya_localize_kernel": ("pya_localize_kernel", "pya_localize_ties_kernel", "pya_localize_redo_kernel"),
+    "pya_score_localize_kernel": ("pya_score_localize_kernel", "pya_score_localize_pack_kernel", "pya_score_localize_list_kernel",
+                                  "pya_bin_score_localize_kernel"),
+    "pya_localize_kernel": ("pya_localize_kernel", "pya_localize_ties_kernel", "pya_localize_redo_kernel",
+                            "pya_localize_recount_kernel", "pya_score_big_list_kernel"),
 }
 
 
@@ -78,7 +80,7 @@ def profiled_counters(cfg, kern_ms, names, default_size):
                    need at the measured issue rates (profiles/r03_valu_ceiling.md); <= 1 by construction
                    of the cost (measured at saturation);
       salu_busy    SQ_INSTS_SALU / (256 CUs x cycles): the one scalar unit of a CU issues one per cycle;
-      lanes        active lanes per vector instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 4... of 64);
+      lanes_per_valu  active lanes per vector instruction, of 64 (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU);
       lds_conflict LDS bank-conflict cycles per active LDS cycle.
     Kernel cycles = SQ_BUSY_CYCLES / 32 (the counter sums the 32 shader engines).  None when the run
     is not the profiled workload."""
@@ -126,7 +128,7 @@ def profiled_counters(cfg, kern_ms, names, default_size):
             "valu_cycles_per_inst": acc["valu_cyc"] / acc["valu"] if acc["valu"] else None,
             "valu_busy": acc["valu_cyc"] / (1024.0 * cyc) if cyc else None,
             "salu_busy": acc["salu"] / (256.0 * cyc) if cyc else None,
-            "lanes_per_valu": acc["thread_cyc"] / acc["valu"] / 4.0 if acc["valu"] and acc["thread_cyc"] else None,
+            "lanes_per_valu": acc["thread_cyc"] / acc["valu"] if acc["valu"] and acc["thread_cyc"] else None,
             "lds_conflict_share": acc["lds_conf"] / acc["lds_act"] if acc["lds_act"] else None,
             "ms_live": float(ms)}
     return {"source": os.path.relpath(path, ROOT), "families": fams, "whole_path_traffic": whole}, fams

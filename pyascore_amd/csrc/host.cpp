@@ -2370,7 +2370,6 @@ int one_run(pya_handle *h, bool keep, uint32_t max_k) {
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    o.dev = o.dev;       /* (unchanged; d carried the per-call fields) */
     o.last_keep = keep;
     o.last_max_k = max_k;
     /* a retained view for pya_get_pep_scores / pya_calculate_ambiguity */
