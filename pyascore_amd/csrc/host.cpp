@@ -65,6 +65,11 @@ size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap);
 int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap,
                          uint32_t inline_on, hipStream_t stream);
 size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
+size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc, uint32_t hs,
+                                   uint32_t pp);
+int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap, uint32_t n_cap,
+                             uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t vc, uint32_t hs, uint32_t pp,
+                             hipStream_t stream);
 int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t push_cap,
                                 uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t *d_redo, hipStream_t stream);
 int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
@@ -197,6 +202,7 @@ struct Knobs {
     bool no_plain = false, no_fused = false, no_big = false, no_tiny = false, no_prefix = false, no_chunks = false;
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
     bool host_timing = false, stamps = false, pack = false, sort_room = false, no_big_inline = false, bin_fused = false;
+    bool no_loc_hash = false;
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64, pack_min = 512, pack_group_min = 256;
     uint32_t pack_g = 4, pack_peaks = 208, sort_room_max = 1024;
@@ -226,6 +232,7 @@ static void read_knobs(Knobs &k) {
     k.sort_room = flag("PYA_SORT_ROOM");
     k.no_big_inline = flag("PYA_NO_BIG_INLINE");
     k.bin_fused = flag("PYA_BIN_FUSED");
+    k.no_loc_hash = flag("PYA_NO_LOC_HASH");
     if (const char *d = std::getenv("PYA_DEBUG")) k.debug = (uint32_t)std::strtoul(d, nullptr, 0);
     k.plain_min = num("PYA_PLAIN_MIN", 512);
     k.big_min_n = num("PYA_BIG_MIN_N", 1024);
@@ -385,6 +392,17 @@ struct Bucket {
     }
     uint32_t n_types = 1, k_max = 1;
     uint32_t z_max = 1;                 /* largest fragment charge in the bucket */
+    uint32_t pair_cap = 1;              /* largest (L - 1) * loss variants: (prefix, variant) pairs of one fragment list */
+    /* The hash route of the general localize launch (localize_hash.hip.h): ion table for the winner's list and at
+     * least one competitor's in-span ions, a grid at most half full, room for the pair lists of a typical PSM
+     * (a PSM that needs more is declined and goes to the list-based kernel). */
+    uint32_t hash_vc() const { return 2u * list_cap; }
+    uint32_t hash_hs() const { return 4u * list_cap < 64u ? 64u : 4u * list_cap; }
+    uint32_t hash_pp() const { return (8u * pair_cap + 7u) & ~7u; }
+    bool hash_ok() const {
+        return pos_cap <= 64u && hash_vc() <= 8192u &&
+               pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp()) <= 64u * 1024u;
+    }
     uint32_t push_max = 1;              /* largest k * (n_sites - k): single-move competitors of one PSM */
     uint32_t push_cap() const {
         uint32_t v = (push_max + 7u) & ~7u;
@@ -1182,6 +1200,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             bk.k_max = std::max<uint32_t>(bk.k_max, (uint32_t)k);
             bk.push_max = std::max<uint32_t>(bk.push_max, (uint32_t)k * (ns - (uint32_t)k));
             bk.z_max = std::max<uint32_t>(bk.z_max, (uint32_t)z);
+            bk.pair_cap = std::max<uint32_t>(bk.pair_cap, (uint32_t)(L - 1) * n_uniq);
         } else {
             Bucket &bk = p->buckets[0];                 /* unambiguous / empty: cheapest launch */
             bk.general_ids.push_back((uint32_t)i);
@@ -1788,6 +1807,10 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         e = pya_launch_localize(&d, bk.d_ids.p, bk.n_plain, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(),
                                 bk.gtp(), 1u, sort_room, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
+        if (!h->kn.no_loc_hash && bk.hash_ok())
+            e = pya_launch_localize_hash(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
+                                         bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), bk.hash_vc(), bk.hash_hs(), bk.hash_pp(), st);
+        else
         e = pya_launch_localize(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
                                 bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), 0u, 1u, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");

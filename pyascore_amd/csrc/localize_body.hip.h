@@ -5,6 +5,9 @@
 #include "device_common.hip.h"
 #include "localize_core.hip.h"
 
+/* the hash route: same carve-up with the fragment pool and its keep flags replaced by loc_hash_words() words */
+static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
+                                             uint32_t hs, uint32_t pp);
 static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
                                         uint32_t sb) {
     /* (the localize kernel looks peaks up in global memory: no peak table here) */
@@ -14,6 +17,17 @@ static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint3
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
+static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
+                                             uint32_t hs, uint32_t pp) {
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + 64 * 16 + 16;
+    size_t srt = n_cap ? sort_lds_bytes(n_cap) + 64 : 64;
+    size_t lst = pya_loc_lds_bytes(pos_cap, 0, sb) + 4 * loc_hash_words(vc, hs, pp);
+    return fixed + (srt > lst ? srt : lst) + 64;
+}
+
+#ifndef LOC_WAVES_HASH
+#define LOC_WAVES_HASH 4
+#endif
 #ifndef LOC_WAVES
 #define LOC_WAVES 4            /* general instantiation: 128 VGPRs */
 #endif
@@ -42,9 +56,12 @@ struct InlineSrc {
     uint32_t *hist;           /* [sb][PYA_NTOP] */
 };
 
-template <bool PLAIN>
+/* HASH (general instantiation only): the site-determining ions come from loc_site_ions_hash; pool_cap is then the
+ * number of 4-byte words of its work area (loc_hash_words(vc, hs, pp)), and a PSM it declines returns true. */
+template <bool PLAIN, bool HASH = false>
 DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t push_cap, uint32_t pos_cap,
-                       uint32_t pool_cap, uint32_t sb, uint32_t gtp, bool sort_room = true, const InlineSrc *in = nullptr) {
+                       uint32_t pool_cap, uint32_t sb, uint32_t gtp, bool sort_room = true, const InlineSrc *in = nullptr,
+                       uint32_t vc = 0, uint32_t hs = 0, uint32_t pp = 0) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int k = b.n_of_mod[psm];
@@ -282,10 +299,12 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     STAMP_T(b, 25, false);
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
-    const bool declined = loc_ascore_all<PLAIN>(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
+    HashLds hl;
+    if (HASH) hl = hash_carve(w.pool, vc, hs, pp);
+    const bool declined = loc_ascore_all<PLAIN, HASH>(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
                    best_bits, best_ws, best_i, res.site_mask,
-                   &my_asc, &my_alt, &fail, in ? in->rec_batch : nullptr, in ? in->hist : nullptr);
-    if (PLAIN && declined) return true;
+                   &my_asc, &my_alt, &fail, in ? in->rec_batch : nullptr, in ? in->hist : nullptr, HASH ? &hl : nullptr);
+    if ((PLAIN || HASH) && declined) return true;
     STAMP_T(b, 36, false);
     if (lane < k && lds.site_tie[lane]) my_asc = 0.f < my_asc ? 0.f : my_asc;
     if (lane < k) my_alt |= lds.site_alt[lane];

@@ -1161,6 +1161,8 @@ DEV bool loc_site_ions(const LocCtx &c, int S) {
     return false;
 }
 
+#include "localize_hash.hip.h"
+
 /* Ascores of every modified site of the winner (cpp/Ascore.cpp:212-254): walks the pushed
  * competitors sb-1 at a time.  `rec` holds the cumulative counts score_signatures wrote, from which
  * the depth scores are read off the score table (the same reads score_signatures made).  Lane a
@@ -1217,11 +1219,13 @@ DEV void loc_recount(const LocCtx &c, int from, int S, uint32_t *rec_batch, uint
 
 /* rec_batch / hist (LDS, optional): the counts of the batch's signatures are recounted (loc_recount) instead
  * of read from `rec` */
-template <bool PLAIN>
+/* HASH: site-determining ions by loc_site_ions_hash over *hl (it can decline: returns true, nothing written) */
+template <bool PLAIN, bool HASH = false>
 DEV bool loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, unsigned long long *site_alt,
                         const uint32_t *rec, uint64_t best_bits, float best_ws,
                         uint32_t best_i, uint64_t site_mask, float *my_asc_io, uint64_t *my_alt_io,
-                        int *fail_io, uint32_t *rec_batch = nullptr, uint32_t *hist = nullptr) {
+                        int *fail_io, uint32_t *rec_batch = nullptr, uint32_t *hist = nullptr,
+                        const HashLds *hl = nullptr) {
     const int lane = lane_id();
     const BatchDev &b = *ctx.b;
     const LocLds &w = ctx.w;
@@ -1272,7 +1276,9 @@ DEV bool loc_ascore_all(LocCtx &ctx, const PushedEntry *pushed, uint32_t np, uns
         }
         have_best = true;
         if (!(b.debug & 1)) {
-            if (loc_site_ions<PLAIN>(ctx, S)) return true;
+            if (HASH) {
+                if (loc_site_ions_hash(ctx, *hl, S)) return true;
+            } else if (loc_site_ions<PLAIN>(ctx, S)) return true;
         }
         STAMP_T(b, 35, false);
         /* one competitor per lane: the table reads of all of them are in flight together */

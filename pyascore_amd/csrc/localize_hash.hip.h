@@ -1,0 +1,518 @@
+/* localize_hash.hip.h -- site-determining ions of the general route (several fragment charges, neutral
+ * losses, any number of ion types) without generating, sorting and walking whole fragment lists.
+ *
+ * ModifiedPeptide::getSiteDeterminingIons (cpp/ModifiedPeptide.cpp:259-320) sorts every fragment of the two
+ * site assignments (all charges, all loss variants: ~230 each on cfg4) and cancels them with a greedy two-pointer
+ * walk.  The winner (list A) and a single-move competitor (list B) differ in the residues between the two sites
+ * only.  A prefix outside that span has the same loss variants in both and float32 running sums that differ
+ * by rounding, so each of its A ions has a twin in B a few ulps away -- and a run of the merged list made of
+ * twin pairs only cancels completely whatever the order inside it: the walk enters it with both cursors past
+ * everything earlier (the restart property localize_core.hip.h relies on: an ion mz_error or more above every
+ * earlier ion), the sorted A and the sorted B members are then pairwise within a few ulps, and every
+ * comparison cancels.  So only *runs that contain an ion of a differing prefix* can leave anything:
+ *   - prefixes are "in span" for (competitor, direction) when their loss variants differ or their running
+ *     sums differ by more than tau = mz_error / 8 (so the span needs no assumption about where it is);
+ *   - every in-span ion (both sides; ~60 of 230 on cfg4) asks a hash grid over the winner's ions and the
+ *     competitor's in-span ions whether anything lies within mz_error + tau + rounding of it.  Nothing
+ *     there (99.4 % on cfg4): the ion is a run of its own and is site-determining;
+ *   - otherwise the run around it is gathered exactly (twins computed, not assumed), delimited with the
+ *     walk's own arithmetic, and walked by the wavefront; the lowest in-span ion of a run does the
+ *     accounting for all of it.
+ * Nothing is sorted.  What does not fit the fixed-size tables is declined (the caller hands the PSM to the
+ * list-based instantiation).  PYA_DEBUG bits: 8192 decline everything, 16384 every in-span ion takes the
+ * exact route. */
+#ifndef PYA_LOCALIZE_HASH_H
+#define PYA_LOCALIZE_HASH_H
+/* (included by localize_core.hip.h, after loc_site_ions) */
+
+#define LH_SLOW_CAP 64
+#define LH_LISTS (2 + 4 * (PYA_LOC_SB_MAX - 1))
+
+DEV float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+DEV float wave_min_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+DEV uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t w = (uint64_t)__shfl_xor((long long)v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+/* work area (where the list-based route keeps its fragment pool): sizes are launch parameters */
+struct HashLds {
+    float *val;            /* [vc] ions of the current (type, competitor group): the winner's, then in-span B */
+    uint32_t *tab;         /* [hs / 2] open-addressing table of 16-bit slots (entry + 1), two per word        */
+    uint16_t *pairs;       /* [pp] (prefix | variant << 8) / winner pair indices, lists back to back          */
+    uint32_t *slow;        /* [LH_SLOW_CAP] items for the exact route: entry | competitor << 16 | side << 24  */
+    float *cand_val;       /* [64] */
+    uint32_t *cand_tag;    /* [64] entry | in span << 16 | side << 17 */
+    uint64_t *ispan;       /* [2 * (sb - 1)] in-span prefixes per (competitor, direction)                     */
+    uint16_t *off, *cnt;   /* [LH_LISTS] pair lists: W(d) = d, A(c, d) = 2 + 2 * cd, B(c, d) = 3 + 2 * cd      */
+    uint32_t vc, hs, pp;
+};
+
+static inline __host__ __device__ size_t loc_hash_words(uint32_t vc, uint32_t hs, uint32_t pp) {
+    return (size_t)vc + hs / 2 + (pp + 1) / 2 + LH_SLOW_CAP + 64 + 64 + 4 * PYA_LOC_SB_MAX + LH_LISTS + 2;
+}
+
+DEV HashLds hash_carve(float *base, uint32_t vc, uint32_t hs, uint32_t pp) {
+    HashLds h;
+    h.ispan = (uint64_t *)base;                                  /* (the pool starts 8-byte aligned) */
+    h.val = (float *)(h.ispan + 2 * PYA_LOC_SB_MAX);
+    h.tab = (uint32_t *)(h.val + vc);
+    h.slow = h.tab + hs / 2;
+    h.cand_val = (float *)(h.slow + LH_SLOW_CAP);
+    h.cand_tag = (uint32_t *)(h.cand_val + 64);
+    h.off = (uint16_t *)(h.cand_tag + 64);
+    h.cnt = h.off + LH_LISTS + (LH_LISTS & 1);
+    h.pairs = h.cnt + LH_LISTS + (LH_LISTS & 1);
+    h.vc = vc;
+    h.hs = hs;
+    h.pp = pp;
+    return h;
+}
+
+DEV float lh_ion(float run, float loss, bool nn, double A, double B, int z) {
+    const float x = nn ? run - loss : run;
+    const double m = ((double)x + A) - B;
+    return charge_mz(m, z);
+}
+
+DEV int lh_cell(float x, float inv_cw) { return (int)__builtin_floorf(x * inv_cw); }
+
+DEV void lh_insert(const HashLds &h, int cell, int id, int hshift) {
+    const uint32_t hmask = h.hs - 1u;
+    uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> hshift;
+    for (;;) {
+        uint32_t *wp = h.tab + (s >> 1);
+        const uint32_t sh = (s & 1u) * 16u;
+        const uint32_t old = *(volatile uint32_t *)wp;
+        if ((old >> sh) & 0xffffu) {
+            s = (s + 1u) & hmask;
+            continue;
+        }
+        if (atomicCAS(wp, old, old | ((uint32_t)(id + 1) << sh)) == old) break;
+    }
+}
+
+/* is an entry of this task (the winner's ions, the competitor's in-span ions [b_lo, b_hi)) other than `self`
+ * within `reach` of x?  Every entry whose cell is `cell` sits in the probe run that starts at its hash. */
+DEV bool lh_probe(const HashLds &h, int cell, int hshift, int self, float x, float reach, int nW, int b_lo, int b_hi) {
+    const uint32_t hmask = h.hs - 1u;
+    const uint16_t *t16 = (const uint16_t *)h.tab;
+    uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> hshift;
+    bool hit = false;
+    for (;;) {
+        const uint32_t half = t16[s];
+        if (half == 0u) break;
+        const int j = (int)half - 1;
+        const float y = h.val[j];
+        const bool mine = j < nW || (j >= b_lo && j < b_hi);
+        hit = (j != self) && mine && (__builtin_fabsf(y - x) < reach);
+        if (hit) break;
+        s = (s + 1u) & hmask;
+    }
+    return hit;
+}
+
+DEV uint32_t lh_ord(float v) {                          /* float -> unsigned with the same order */
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+/* what the exact route needs to know about the table in place */
+struct LhPass {
+    int d, zmax, c0, nW, offW, hshift;
+    double A, B;
+    float err, margin, R;
+    bool nn;
+    FastDiv divZ;
+};
+
+/* The exact route for the items of h.slow[0, nslow): the run of the merged list around each item is gathered
+ * (the winner's ions, the twins of those outside the span computed with the competitor's running sums, the
+ * competitor's in-span ions), delimited with the walk's own restart test and walked (ModifiedPeptide.cpp:291-316)
+ * by the wavefront, one candidate per lane.  The lowest in-span ion of a run accounts for the whole run.
+ * Returns true when the PSM has to be declined. */
+DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t nslow, int &staged) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    const float err = q.err, R = q.R;
+    const int zmax = q.zmax, d = q.d, nW = q.nW;
+    wave_lds_sync();
+    for (uint32_t k = 0; k < nslow; k++) {
+        const uint32_t it = h.slow[k];
+        const int id0 = (int)(it & 0xffffu), cs = (int)((it >> 16) & 0xffu), side0 = (int)(it >> 24);
+        const float x0 = h.val[id0];
+        const int cd = (cs - 1) * 2 + d;
+        const uint64_t ins = h.ispan[cd];
+        int bl = nW;
+        for (int cc = q.c0; cc < cs; cc++) bl += (int)h.cnt[3 + 2 * ((cc - 1) * 2 + d)] * zmax;
+        const int bh = bl + (int)h.cnt[3 + 2 * cd] * zmax;
+        int ncand = 0;
+        wave_lds_sync();
+        for (int base = 0; base < nW; base += 64) {
+            const int j = base + lane;
+            bool a_in = false, t_in = false;
+            float av = 0.f, tv = 0.f;
+            uint32_t isp = 0;
+            if (j < nW) {
+                av = h.val[j];
+                const float da = __builtin_fabsf(av - x0);
+                if (da < R + q.margin) {
+                    const int pair = (int)fastdiv((uint32_t)j, q.divZ), z = j - pair * zmax + 1;
+                    const uint32_t pz = h.pairs[q.offW + pair];
+                    const int p = (int)(pz & 255u), v = (int)(pz >> 8);
+                    isp = (uint32_t)((ins >> p) & 1ull);
+                    a_in = da < R;
+                    if (!isp) {
+                        tv = lh_ion(w.run[(size_t)(cs * 2 + d) * c.pos_cap + p], q.nn ? c.nl.uniq[v] : 0.f, q.nn, q.A, q.B, z);
+                        t_in = __builtin_fabsf(tv - x0) < R;
+                    }
+                }
+            }
+            const uint64_t ma = __ballot(a_in);
+            if (a_in) {
+                const int slot = ncand + __popcll(ma & lanemask_lt());
+                if (slot < 64) {
+                    h.cand_val[slot] = av;
+                    h.cand_tag[slot] = (uint32_t)j | (isp << 16);
+                }
+            }
+            ncand += __popcll(ma);
+            const uint64_t mt = __ballot(t_in);
+            if (t_in) {
+                const int slot = ncand + __popcll(mt & lanemask_lt());
+                if (slot < 64) {
+                    h.cand_val[slot] = tv;
+                    h.cand_tag[slot] = (uint32_t)j | (1u << 17);
+                }
+            }
+            ncand += __popcll(mt);
+        }
+        for (int base = bl; base < bh; base += 64) {
+            const int j = base + lane;
+            float bv = 0.f;
+            bool b_in = false;
+            if (j < bh) {
+                bv = h.val[j];
+                b_in = __builtin_fabsf(bv - x0) < R;
+            }
+            const uint64_t mb = __ballot(b_in);
+            if (b_in) {
+                const int slot = ncand + __popcll(mb & lanemask_lt());
+                if (slot < 64) {
+                    h.cand_val[slot] = bv;
+                    h.cand_tag[slot] = (uint32_t)j | (1u << 16) | (1u << 17);
+                }
+            }
+            ncand += __popcll(mb);
+        }
+        if (ncand > 64) return true;
+        wave_lds_sync();
+        const bool has = lane < ncand;
+        const float v = has ? h.cand_val[lane] : 0.f;
+        const uint32_t tag = has ? h.cand_tag[lane] : 0u;
+        const int side = (int)((tag >> 17) & 1u);
+        const bool isp = ((tag >> 16) & 1u) != 0u;
+        /* the run: everything chained to the item by gaps the walk does not restart at */
+        float lo = x0, hi = x0;
+        for (;;) {
+            const float up = (has && v > hi && !(v - hi >= err)) ? v : hi;
+            const float dn = (has && v < lo && !(lo - v >= err)) ? v : lo;
+            const float nh = wave_max_f32(up), nl = wave_min_f32(dn);
+            if (nh == hi && nl == lo) break;
+            hi = nh;
+            lo = nl;
+        }
+        /* (an ion outside the window is R or more from the item: it must not be able to chain to the run) */
+        if (!(R - (hi - x0) >= 2.f * err) || !(R - (x0 - lo) >= 2.f * err)) return true;
+        const bool member = has && v >= lo && v <= hi;
+        const uint64_t key = (member && isp) ? (((uint64_t)lh_ord(v) << 32) | ((uint64_t)side << 16) | (uint64_t)(tag & 0xffffu)) : ~0ull;
+        const uint64_t own = ((uint64_t)lh_ord(x0) << 32) | ((uint64_t)side0 << 16) | (uint64_t)id0;
+        if (wave_min_u64(key) != own) continue;          /* a lower in-span ion of the run accounts for it */
+        bool remA = member && side == 0, remB = member && side == 1, kept = false;
+        const float inf = __builtin_huge_valf();
+        for (;;) {
+            const float xa = wave_min_f32(remA ? v : inf), yb = wave_min_f32(remB ? v : inf);
+            if (xa == inf && yb == inf) break;
+            bool takeA, takeB, keep = true;
+            if (yb == inf) {
+                takeA = true;
+                takeB = false;
+            } else if (xa == inf) {
+                takeA = false;
+                takeB = true;
+            } else if (__builtin_fabsf(xa - yb) < err) {
+                takeA = takeB = true;
+                keep = false;
+            } else if (xa < yb) {
+                takeA = true;
+                takeB = false;
+            } else {
+                takeA = false;
+                takeB = true;
+            }
+            if (takeA) {
+                const int la = __builtin_ctzll(__ballot(remA && v == xa));
+                if (lane == la) {
+                    remA = false;
+                    kept = keep;
+                }
+            }
+            if (takeB) {
+                const int lb = __builtin_ctzll(__ballot(remB && v == yb));
+                if (lane == lb) {
+                    remB = false;
+                    kept = keep;
+                }
+            }
+        }
+        loc_stage_push(c, kept, v, (uint32_t)(cs * 2 + side), staged);
+    }
+    wave_lds_sync();
+    return false;
+}
+
+/* Site-determining ions of competitors 1..S-1 against the winner (entry 0): fills w.c_cnt / w.c_tr and the
+ * depth in w.c_depth, as loc_site_ions does.  Returns true when the PSM is declined (nothing to undo: the
+ * caller writes no result). */
+DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    const DevConfig *cfg = c.cfg;
+    const int T = cfg->n_types, Lm1 = c.L - 1, zmax = c.zmax;
+    const bool nn = c.nl.n_nl != 0;
+    const uint64_t types64 = load_types64(cfg);
+    const float err = cfg->mz_error;
+    if (c.b->debug & 8192u) return true;
+    /* depth of the largest score gap (Ascore.cpp:164-172) */
+    if (lane >= 1 && lane < S) {
+        float best = 0.f;
+        int depth = 0;
+        for (int d = 0; d < PYA_NTOP; d++) {
+            const float diff = w.scores[d] - w.scores[lane * 10 + d];
+            if (diff > best) {
+                best = diff;
+                depth = d;
+            }
+        }
+        w.c_depth[lane] = depth;
+    }
+    for (int i = lane; i < S * 2; i += 64) {
+        w.c_cnt[i] = 0;
+        w.c_tr[i] = 0;
+    }
+    if (Lm1 <= 0 || S < 2) {
+        wave_lds_sync();
+        return false;
+    }
+    STAMP_BEGIN();
+    /* ---- pair lists: the winner's (prefix, variant) pairs per direction; per (competitor, direction) the
+     * in-span prefixes, the winner pairs on them (A) and the competitor's pairs on them (B) ---- */
+    const float tau = err * 0.125f;
+    float runmax = 0.f;
+    uint32_t npairs = 0;
+    for (int d = 0; d < 2; d++) {
+        uint32_t pw = 0;
+        if (lane < Lm1) {
+            const size_t iw = (size_t)d * c.pos_cap + lane;
+            pw = nn ? (uint32_t)w.pmk[iw] : 1u;
+            runmax = __builtin_fmaxf(runmax, __builtin_fabsf(w.run[iw]));
+        }
+        int tot;
+        int at = (int)npairs + wave_excl_scan_i32(__popc(pw), &tot);
+        if (npairs + (uint32_t)tot > h.pp) return true;
+        while (pw) {
+            const int v = __builtin_ctz(pw);
+            pw &= pw - 1;
+            h.pairs[at++] = (uint16_t)(lane | (v << 8));
+        }
+        if (lane == 0) {
+            h.off[d] = (uint16_t)npairs;
+            h.cnt[d] = (uint16_t)tot;
+        }
+        npairs += (uint32_t)tot;
+    }
+    const int ncd = (S - 1) * 2;
+    for (int cd = 0; cd < ncd; cd++) {
+        const int cc = 1 + (cd >> 1), d = cd & 1;
+        bool in = false;
+        uint32_t pw = 0, pc = 0;
+        int cw = 0;
+        if (lane < Lm1) {
+            const size_t iw = (size_t)d * c.pos_cap + lane, ic = (size_t)(cc * 2 + d) * c.pos_cap + lane;
+            const float rw = w.run[iw], rc = w.run[ic];
+            pw = nn ? (uint32_t)w.pmk[iw] : 1u;
+            pc = nn ? (uint32_t)w.pmk[ic] : 1u;
+            cw = nn ? (int)w.cpre[iw] : lane;
+            in = pw != pc || !(__builtin_fabsf(rc - rw) <= tau);
+            runmax = __builtin_fmaxf(runmax, __builtin_fabsf(rc));
+        }
+        const uint64_t m = __ballot(in);
+        int totA, totB;
+        int atA = wave_excl_scan_i32(in ? __popc(pw) : 0, &totA);
+        int atB = wave_excl_scan_i32(in ? __popc(pc) : 0, &totB);
+        if (npairs + (uint32_t)(totA + totB) > h.pp) return true;
+        atA += (int)npairs;
+        atB += (int)npairs + totA;
+        if (in) {
+            for (int vi = 0, n = __popc(pw); vi < n; vi++) h.pairs[atA++] = (uint16_t)(cw + vi);
+            while (pc) {
+                const int v = __builtin_ctz(pc);
+                pc &= pc - 1;
+                h.pairs[atB++] = (uint16_t)(lane | (v << 8));
+            }
+        }
+        if (lane == 0) {
+            h.ispan[cd] = m;
+            h.off[2 + 2 * cd] = (uint16_t)npairs;
+            h.cnt[2 + 2 * cd] = (uint16_t)totA;
+            h.off[3 + 2 * cd] = (uint16_t)(npairs + (uint32_t)totA);
+            h.cnt[3 + 2 * cd] = (uint16_t)totB;
+        }
+        npairs += (uint32_t)(totA + totB);
+    }
+    runmax = wave_max_f32(runmax);
+    /* |twin - ion| <= tau + slop: the running sums differ by at most tau, the float32 loss subtraction and the
+     * final narrowing round by half an ulp each on either side */
+    const float slop = (runmax + 64.f) * 6e-7f;
+    const float margin = tau + slop;
+    const float reach = err + margin + slop;
+    if (!(margin + slop < 0.5f * err)) return true;          /* (huge masses against a tiny tolerance) */
+    const float qr = reach + slop;                           /* cells asked: those of x -+ qr */
+    const float inv_cw = 1.f / (2.5f * qr);
+    const int hshift = 32 - (31 - __builtin_clz(h.hs));
+    const float R = 8.f * err;                               /* window of the exact route */
+    const FastDiv divZ = fastdiv_make((uint32_t)zmax);
+    wave_lds_sync();
+    STAMP_T(*c.b, 30, false);
+    int staged = 0;
+    for (int t = 0; t < T; t++) {
+        const int d = t < cfg->n_fwd ? 0 : 1;
+        double A, B;
+        type_constants(type_at(types64, t), &A, &B);
+        const int offW = (int)h.off[d], nW = (int)h.cnt[d] * zmax;
+        if (nW > (int)h.vc) return true;
+        /* competitors go together while the table holds them, else one at a time */
+        int c0 = 1;
+        while (c0 < S) {
+            int c1 = c0, nB = 0;
+            while (c1 < S) {
+                const int n = (int)h.cnt[3 + 2 * ((c1 - 1) * 2 + d)] * zmax;
+                if (nW + nB + n > (int)h.vc) break;
+                nB += n;
+                c1++;
+            }
+            if (c1 == c0) return true;                        /* one competitor's in-span ions do not fit */
+            /* ---- table: values, then the grid ---- */
+            for (int i = lane; i < (int)(h.hs / 2); i += 64) h.tab[i] = 0u;
+            for (int i = lane; i < nW; i += 64) {
+                const int pair = (int)fastdiv((uint32_t)i, divZ), z = i - pair * zmax + 1;
+                const uint32_t pz = h.pairs[offW + pair];
+                const int p = (int)(pz & 255u), v = (int)(pz >> 8);
+                h.val[i] = lh_ion(w.run[(size_t)d * c.pos_cap + p], nn ? c.nl.uniq[v] : 0.f, nn, A, B, z);
+            }
+            {
+                int at = nW;
+                for (int cc = c0; cc < c1; cc++) {
+                    const int l = 3 + 2 * ((cc - 1) * 2 + d);
+                    const int offB = (int)h.off[l], n = (int)h.cnt[l] * zmax;
+                    for (int i = lane; i < n; i += 64) {
+                        const int pair = (int)fastdiv((uint32_t)i, divZ), z = i - pair * zmax + 1;
+                        const uint32_t pz = h.pairs[offB + pair];
+                        const int p = (int)(pz & 255u), v = (int)(pz >> 8);
+                        h.val[at + i] = lh_ion(w.run[(size_t)(cc * 2 + d) * c.pos_cap + p], nn ? c.nl.uniq[v] : 0.f, nn, A, B, z);
+                    }
+                    at += n;
+                }
+            }
+            wave_lds_sync();
+            for (int i = lane; i < nW + nB; i += 64) lh_insert(h, lh_cell(h.val[i], inv_cw), i, hshift);
+            wave_lds_sync();
+            STAMP_T(*c.b, 31, false);
+            /* ---- every in-span ion: alone within reach? ---- */
+            uint32_t nslow = 0;
+            LhPass q;
+            q.d = d;
+            q.zmax = zmax;
+            q.c0 = c0;
+            q.nW = nW;
+            q.offW = offW;
+            q.hshift = hshift;
+            q.A = A;
+            q.B = B;
+            q.err = err;
+            q.margin = margin;
+            q.R = R;
+            q.nn = nn;
+            q.divZ = divZ;
+            int b_lo = nW;
+            for (int cc = c0; cc < c1; cc++) {
+                const int cd = (cc - 1) * 2 + d;
+                const int offA = (int)h.off[2 + 2 * cd];
+                const int nA = (int)h.cnt[2 + 2 * cd] * zmax, nBc = (int)h.cnt[3 + 2 * cd] * zmax;
+                const int b_hi = b_lo + nBc;
+                for (int base = 0; base < nA + nBc; base += 64) {
+                    const int i = base + lane;
+                    const bool on = i < nA + nBc;
+                    bool hit = false;
+                    int id = 0, side = 0;
+                    float x = 0.f;
+                    if (on) {
+                        if (i < nA) {
+                            const int pair = (int)fastdiv((uint32_t)i, divZ);
+                            id = (int)h.pairs[offA + pair] * zmax + (i - pair * zmax);
+                        } else {
+                            side = 1;
+                            id = b_lo + (i - nA);
+                        }
+                        x = h.val[id];
+                        const int k0 = lh_cell(x - qr, inv_cw), k1 = lh_cell(x + qr, inv_cw);
+                        hit = lh_probe(h, k0, hshift, id, x, reach, nW, b_lo, b_hi);
+                        if (!hit && k1 != k0) hit = lh_probe(h, k1, hshift, id, x, reach, nW, b_lo, b_hi);
+                        if (c.b->debug & 16384u) hit = true;
+                    }
+                    const uint64_t hm = __ballot(hit);
+                    if (hit) {
+                        const uint32_t slot = nslow + (uint32_t)__popcll(hm & lanemask_lt());
+                        if (slot < LH_SLOW_CAP) h.slow[slot] = (uint32_t)id | ((uint32_t)cc << 16) | ((uint32_t)side << 24);
+                    }
+                    nslow += (uint32_t)__popcll(hm);
+                    loc_stage_push(c, on && !hit, x, (uint32_t)(cc * 2 + side), staged);
+                    if (nslow + 64u > LH_SLOW_CAP && nslow) {           /* (the list could overflow with the next 64 items) */
+                        if (lh_exact(c, h, q, nslow, staged)) return true;
+                        nslow = 0;
+                    }
+                }
+                b_lo = b_hi;
+            }
+            STAMP_T(*c.b, 32, false);
+            if (nslow && lh_exact(c, h, q, nslow, staged)) return true;
+            STAMP_T(*c.b, 33, false);
+            wave_lds_sync();
+            c0 = c1;
+        }
+    }
+    while (staged > 0) loc_stage_flush(c, staged);
+    wave_lds_sync();
+    STAMP_T(*c.b, 34, false);
+    return false;
+}
+
+#endif

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
                         "fused_replay", "general_serial_replay", "packed", "packed_8", "packed_passed_on", "packed_small_pool",
                         "packed_always_sort", "packed_declines", "packed_replay", "big_records", "bin_fused",
-                        "bin_fused_exact"])
+                        "bin_fused_exact", "general_lists", "hash_exact", "hash_declines"])
 def path(request, monkeypatch):
     """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
     assignments on the fused score + localize kernel and the other plain ones on the lean
@@ -27,8 +27,13 @@ def path(request, monkeypatch):
     to the general one; and with the std::sort emulation run even where a unique best PepScore makes it
     unnecessary (PYA_DEBUG=1024), without and with the fused kernel; and with the fused kernel replaying
     every (competitor, direction) task serially (PYA_DEBUG=2048); and the general instantiation with whole-task
-    serial replays instead of cluster walks (PYA_NO_PLAIN=1, PYA_DEBUG=4096)."""
+    serial replays instead of cluster walks (PYA_NO_PLAIN=1, PYA_DEBUG=4096).
+    The general instantiation finds site-determining ions with a hash grid over the ions of differing prefixes
+    (localize_hash.hip.h) by default; "general_lists" is the list-based route it replaced (PYA_NO_LOC_HASH=1, also what
+    "general_serial_replay" runs on), "hash_exact" sends every in-span ion through the exact run walk (PYA_DEBUG=16384)
+    and "hash_declines" makes the hash route decline every PSM (PYA_DEBUG=8192: hand-over list, list-based kernel)."""
     monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
+    monkeypatch.delenv("PYA_NO_LOC_HASH", raising=False)
     monkeypatch.delenv("PYA_NO_FUSED", raising=False)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
     monkeypatch.setenv("PYA_PLAIN_MIN", "0")       # batches under 512 PSMs skip the lean kernels by default
@@ -83,7 +88,17 @@ def path(request, monkeypatch):
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
     elif request.param == "general_serial_replay":
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
+        monkeypatch.setenv("PYA_NO_LOC_HASH", "1")
         monkeypatch.setenv("PYA_DEBUG", "4096")
+    elif request.param == "general_lists":
+        monkeypatch.setenv("PYA_NO_PLAIN", "1")
+        monkeypatch.setenv("PYA_NO_LOC_HASH", "1")
+    elif request.param == "hash_exact":
+        monkeypatch.setenv("PYA_NO_PLAIN", "1")
+        monkeypatch.setenv("PYA_DEBUG", "16384")
+    elif request.param == "hash_declines":
+        monkeypatch.setenv("PYA_NO_PLAIN", "1")
+        monkeypatch.setenv("PYA_DEBUG", "8192")
     elif request.param == "lean_declines":
         monkeypatch.setenv("PYA_DEBUG", "512")
     elif request.param == "always_sort":
