@@ -41,7 +41,9 @@ size_t pya_localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_ca
 int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
 int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t prefix,
-                     uint32_t with_nl, uint32_t compact, hipStream_t stream);
+                     uint32_t with_nl, uint32_t compact, uint32_t node_cap, uint32_t node_cols, uint32_t node_words,
+                     hipStream_t stream);
+size_t pya_score_node_lds_bytes(uint32_t cap, uint32_t with_nl, uint32_t node_cap, uint32_t node_cols, uint32_t node_words);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap,
                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
                         uint32_t plain, uint32_t sort_room, hipStream_t stream);
@@ -66,10 +68,10 @@ int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_id
                          uint32_t inline_on, hipStream_t stream);
 size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc, uint32_t hs,
-                                   uint32_t pp);
+                                   uint32_t pp, uint32_t tab_cap);
 int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap, uint32_t n_cap,
                              uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t vc, uint32_t hs, uint32_t pp,
-                             hipStream_t stream);
+                             uint32_t tab_cap, hipStream_t stream);
 int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t push_cap,
                                 uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t *d_redo, hipStream_t stream);
 int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
@@ -202,11 +204,12 @@ struct Knobs {
     bool no_plain = false, no_fused = false, no_big = false, no_tiny = false, no_prefix = false, no_chunks = false;
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
     bool host_timing = false, stamps = false, pack = false, sort_room = false, no_big_inline = false, bin_fused = false;
-    bool no_loc_hash = false;
+    bool no_loc_hash = false, loc_hash_lds_tab = false, no_nodes = false;
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64, pack_min = 512, pack_group_min = 256;
     uint32_t pack_g = 4, pack_peaks = 208, sort_room_max = 1024;
     int sb = -1, gtp = -1;                      /* < 0: the built-in rule */
+    int node_cap = -1;                          /* >= 0: room for that many shared nodes per direction (tests: small values force the walkers) */
     double chunk_mb = 0.;                       /* 0: the default chunk size */
     int64_t workspace_mb = 0;                   /* 0: the default budget */
 };
@@ -233,6 +236,9 @@ static void read_knobs(Knobs &k) {
     k.no_big_inline = flag("PYA_NO_BIG_INLINE");
     k.bin_fused = flag("PYA_BIN_FUSED");
     k.no_loc_hash = flag("PYA_NO_LOC_HASH");
+    k.no_nodes = flag("PYA_NO_NODES");
+    k.node_cap = (int)num("PYA_NODE_CAP", -1);
+    k.loc_hash_lds_tab = flag("PYA_LOC_HASH_LDS_TAB");
     if (const char *d = std::getenv("PYA_DEBUG")) k.debug = (uint32_t)std::strtoul(d, nullptr, 0);
     k.plain_min = num("PYA_PLAIN_MIN", 512);
     k.big_min_n = num("PYA_BIG_MIN_N", 1024);
@@ -267,6 +273,7 @@ struct pya_handle {
     DevBuf<uint32_t> d_lut_off;
 
     std::map<uint32_t, uint32_t> shape_off;   /* (n << 8 | k) -> offset into order_tab */
+    std::map<uint32_t, uint32_t> shape_cols;  /* ... -> histogram columns its shared-node route needs (shapes of <= 64 signatures) */
     std::vector<uint64_t> order_tab;
     std::vector<uint32_t> inv_tab;            /* same offsets: combination rank -> index in order_tab */
     size_t order_uploaded = 0;
@@ -393,15 +400,17 @@ struct Bucket {
     uint32_t n_types = 1, k_max = 1;
     uint32_t z_max = 1;                 /* largest fragment charge in the bucket */
     uint32_t pair_cap = 1;              /* largest (L - 1) * loss variants: (prefix, variant) pairs of one fragment list */
+    uint32_t node_words = 0;            /* largest shared-node shape table (64-bit words) among the PSMs of <= 64 signatures */
+    uint32_t node_cols = 0;             /* ... and the most histogram columns one of them needs */
     /* The hash route of the general localize launch (localize_hash.hip.h): ion table for the winner's list and at
      * least one competitor's in-span ions, a grid at most half full, room for the pair lists of a typical PSM
      * (a PSM that needs more is declined and goes to the list-based kernel). */
     uint32_t hash_vc() const { return 2u * list_cap; }
     uint32_t hash_hs() const { return 4u * list_cap < 64u ? 64u : 4u * list_cap; }
     uint32_t hash_pp() const { return (8u * pair_cap + 7u) & ~7u; }
-    bool hash_ok() const {
+    bool hash_ok(uint32_t tab_cap) const {
         return pos_cap <= 64u && hash_vc() <= 8192u &&
-               pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp()) <= 64u * 1024u;
+               pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp(), tab_cap) <= 64u * 1024u;
     }
     uint32_t push_max = 1;              /* largest k * (n_sites - k): single-move competitors of one PSM */
     uint32_t push_cap() const {
@@ -674,6 +683,38 @@ uint32_t shape_offset(pya_handle *h, uint32_t n, uint32_t k) {
             rank += binom(pos, t);
         }
         h->inv_tab[off + rank] = (uint32_t)(i - off);
+    }
+    /* Shared-node table of the shape (score_core.hip.h: score_nodes_dir), behind its order entries, for shapes of
+     * at most 64 signatures: per direction and level j (sites passed: the lowest j in direction 0, the highest j
+     * in direction 1) the signatures that are the lowest of their group -- same pattern over those sites -- and
+     * every signature's group rank as a byte. */
+    const size_t N = h->order_tab.size() - off;
+    if (N >= 1 && N <= 64) {
+        const size_t W8 = (N + 7) / 8;
+        std::vector<uint64_t> own(2 * (n + 1), 0ull), grp(2 * (n + 1) * W8, 0ull);
+        for (uint32_t dir = 0; dir < 2; dir++)
+            for (uint32_t j = 0; j <= n; j++) {
+                std::vector<uint64_t> seen;
+                uint8_t *row = (uint8_t *)(grp.data() + (size_t)(dir * (n + 1) + j) * W8);
+                for (size_t sidx = 0; sidx < N; sidx++) {
+                    const uint64_t bits = h->order_tab[off + sidx];
+                    const uint64_t pat = j == 0 ? 0ull : (dir == 0 ? (bits & ((j >= 64 ? 0ull : (1ull << j)) - 1ull)) : (bits >> (n - j)));
+                    size_t g = 0;
+                    while (g < seen.size() && seen[g] != pat) g++;
+                    if (g == seen.size()) {
+                        seen.push_back(pat);
+                        own[dir * (n + 1) + j] |= 1ull << sidx;
+                    }
+                    row[sidx] = (uint8_t)g;
+                }
+            }
+        uint32_t cols[2] = {0, 0};
+        for (uint32_t dir = 0; dir < 2; dir++)
+            for (uint32_t j = 0; j <= n; j++) cols[dir] += (uint32_t)__builtin_popcountll(own[dir * (n + 1) + j]);
+        h->shape_cols[key] = std::max(cols[0], cols[1]);
+        h->order_tab.insert(h->order_tab.end(), own.begin(), own.end());
+        h->order_tab.insert(h->order_tab.end(), grp.begin(), grp.end());
+        h->inv_tab.resize(h->order_tab.size(), 0u);
     }
     h->shape_off[key] = off;
     return off;
@@ -1201,6 +1242,11 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             bk.push_max = std::max<uint32_t>(bk.push_max, (uint32_t)k * (ns - (uint32_t)k));
             bk.z_max = std::max<uint32_t>(bk.z_max, (uint32_t)z);
             bk.pair_cap = std::max<uint32_t>(bk.pair_cap, (uint32_t)(L - 1) * n_uniq);
+            if (N <= 64) {
+                bk.node_words = std::max<uint32_t>(bk.node_words, 2u * (ns + 1u) * (1u + (uint32_t)((N + 7) / 8)));
+                auto sc = h->shape_cols.find(ns << 8 | (uint32_t)k);
+                if (sc != h->shape_cols.end()) bk.node_cols = std::max(bk.node_cols, sc->second);
+            }
         } else {
             Bucket &bk = p->buckets[0];                 /* unambiguous / empty: cheapest launch */
             bk.general_ids.push_back((uint32_t)i);
@@ -1727,7 +1773,18 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         /* every PSM of the class on the straight-line walker: compact prefix entries */
         const uint32_t compact = (h->cfg.n_nl == 0 && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 &&
                                   p->buckets[l.ncls].z_max == 1) ? 1u : 0u;
-        e = pya_launch_score(&d, p->d_score_ids.p + l.off, l.n, l.cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact, st);
+        /* general settings (neutral losses, several ion types per direction): one lookup set per distinct node of
+         * the assignment tree instead of one per signature (score_core.hip.h: score_nodes_dir) */
+        const Bucket &sbk = p->buckets[l.ncls];
+        const bool general = h->cfg.n_nl != 0 || h->cfg.n_fwd > 1 || h->cfg.n_types - h->cfg.n_fwd > 1;
+        uint32_t node_cap = 0, node_cols = std::max<uint32_t>(8u, (sbk.node_cols + 7u) & ~7u);
+        if (general && !prefix && !h->kn.no_nodes && sbk.node_words) {
+            node_cap = std::min<uint32_t>(512u, sbk.pos_cap * std::min<uint32_t>(sbk.n_cap, 64u));
+            if (h->kn.node_cap >= 0) node_cap = (uint32_t)h->kn.node_cap;
+            if (pya_score_node_lds_bytes(l.cap, h->cfg.n_nl != 0 ? 1u : 0u, node_cap, node_cols, sbk.node_words) > 64u * 1024u) node_cap = 0;
+        }
+        e = pya_launch_score(&d, p->d_score_ids.p + l.off, l.n, l.cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact, node_cap, node_cols,
+                             sbk.node_words, st);
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
     }
     for (const pya_plan::IdList &l : p->big_lists) {
@@ -1807,9 +1864,13 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         e = pya_launch_localize(&d, bk.d_ids.p, bk.n_plain, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(),
                                 bk.gtp(), 1u, sort_room, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
-        if (!h->kn.no_loc_hash && bk.hash_ok())
+        /* (PYA_LOC_HASH_LDS_TAB: the retained table staged in LDS for the lookups; measured slower on cfg4, 15.6 against
+         * 12.4 ms -- the 2 KB cost more occupancy than the global lookups cost time) */
+        const uint32_t tab_cap = (h->kn.loc_hash_lds_tab && bk.hash_ok(p->peak_cap)) ? p->peak_cap : 0u;
+        if (!h->kn.no_loc_hash && bk.hash_ok(tab_cap))
             e = pya_launch_localize_hash(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
-                                         bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), bk.hash_vc(), bk.hash_hs(), bk.hash_pp(), st);
+                                         bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), bk.hash_vc(), bk.hash_hs(), bk.hash_pp(), tab_cap,
+                                         st);
         else
         e = pya_launch_localize(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
                                 bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), 0u, 1u, st);

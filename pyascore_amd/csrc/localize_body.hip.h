@@ -7,7 +7,7 @@
 
 /* the hash route: same carve-up with the fragment pool and its keep flags replaced by loc_hash_words() words */
 static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                             uint32_t hs, uint32_t pp);
+                                             uint32_t hs, uint32_t pp, uint32_t tab_cap);
 static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
                                         uint32_t sb) {
     /* (the localize kernel looks peaks up in global memory: no peak table here) */
@@ -18,8 +18,9 @@ static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint3
 }
 
 static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                             uint32_t hs, uint32_t pp) {
-    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + 64 * 16 + 16;
+                                             uint32_t hs, uint32_t pp, uint32_t tab_cap) {
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + 64 * 16 + 16 +
+                   (tab_cap ? PYA_GRID_CELLS * 2 + ((size_t)tab_cap + PYA_TABLE_PAD) * 8 : 0);
     size_t srt = n_cap ? sort_lds_bytes(n_cap) + 64 : 64;
     size_t lst = pya_loc_lds_bytes(pos_cap, 0, sb) + 4 * loc_hash_words(vc, hs, pp);
     return fixed + (srt > lst ? srt : lst) + 64;
@@ -61,7 +62,7 @@ struct InlineSrc {
 template <bool PLAIN, bool HASH = false>
 DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t push_cap, uint32_t pos_cap,
                        uint32_t pool_cap, uint32_t sb, uint32_t gtp, bool sort_room = true, const InlineSrc *in = nullptr,
-                       uint32_t vc = 0, uint32_t hs = 0, uint32_t pp = 0) {
+                       uint32_t vc = 0, uint32_t hs = 0, uint32_t pp = 0, uint32_t tab_cap = 0) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int k = b.n_of_mod[psm];
@@ -103,11 +104,14 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     STAMP_BEGIN();
     /* only a handful of ions are matched here, so the retained-peak table is not staged in LDS:
      * that keeps this kernel's LDS small (occupancy) and saves the staging + grid build */
-    K3Lds lds = carve(lds_raw, 0, false, push_cap);
+    /* (HASH with tab_cap: the hash route looks up ~1 300 ions per PSM on cfg4-like settings, so there the table
+     * and the grid are staged as in the score kernels) */
+    const bool staged_tab = HASH && tab_cap != 0;
+    K3Lds lds = carve(lds_raw, tab_cap, staged_tab, push_cap);
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
-    stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, false);
+    stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, staged_tab);
     if (in) ctx.tab = in->tab;                               /* (the caller's table in LDS: lookups stay on chip) */
     const Residues res = load_residues(b, cfg, psm);
     const uint64_t site_mask_u = res.site_mask;

@@ -26,30 +26,38 @@
 template <bool PREFIX>
 __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
                                                                   uint32_t n_ids, uint32_t cap, uint32_t with_nl,
-                                                                  uint32_t compact) {
+                                                                  uint32_t compact, uint32_t node_cap, uint32_t node_cols,
+                                                                  uint32_t node_words) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
-    score_body<PREFIX>(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, with_nl, compact);
+    score_body<PREFIX>(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, with_nl, compact, node_cap, node_cols, node_words);
 }
 
 extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact) {
     return score_lds_bytes(cap, prefix, with_nl, compact);
 }
+extern "C" size_t pya_score_node_lds_bytes(uint32_t cap, uint32_t with_nl, uint32_t node_cap, uint32_t node_cols, uint32_t node_words) {
+    return score_lds_bytes(cap, 0, with_nl, 0, node_cap, node_cols, node_words);
+}
 
+/* node_cap != 0 (only without `prefix`): the shared-node route of score_core.hip.h with room for node_cap nodes per
+ * direction, node_cols histogram columns and a shape table of node_words 64-bit words */
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
-                                uint32_t prefix, uint32_t with_nl, uint32_t compact, hipStream_t stream) {
+                                uint32_t prefix, uint32_t with_nl, uint32_t compact, uint32_t node_cap, uint32_t node_cols,
+                                uint32_t node_words, hipStream_t stream) {
     if (n_ids == 0) return 0;
     /* spectra near the 8192-peak limit need more than the default 64 KB of dynamic LDS */
     if (!prefix) compact = 0;
-    const size_t lds = pya_score_lds_bytes(cap, prefix, with_nl, compact);
+    if (prefix) node_cap = 0;
+    const size_t lds = score_lds_bytes(cap, prefix, with_nl, compact, node_cap, node_cols, node_words);
     hipError_t e = prefix ? PYA_ENSURE_MAX_LDS(pya_score_signatures_kernel<true>)
                           : PYA_ENSURE_MAX_LDS(pya_score_signatures_kernel<false>);
     if (e != hipSuccess) return (int)e;
     if (prefix)
         hipLaunchKernelGGL(pya_score_signatures_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                           cap, with_nl, compact);
+                           cap, with_nl, compact, 0u, 64u, 0u);
     else
         hipLaunchKernelGGL(pya_score_signatures_kernel<false>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                           cap, with_nl, compact);
+                           cap, with_nl, compact, node_cap, node_cols, node_words);
     return (int)hipGetLastError();
 }

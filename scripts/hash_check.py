@@ -31,10 +31,14 @@ for cfg, nn, over in cases:
         over["mod_mass"] = mod_mass
     kind = "ref" if orc.available("ref") else "oracle"
     want = None
-    for mode, dbg in (("hash", None), ("exact", "16384"), ("declined", "8192")):
-        if dbg is None:
-            os.environ.pop("PYA_DEBUG", None)
-        else:
+    for mode, dbg in (("hash", None), ("exact", "16384"), ("declined", "8192"), ("walkers", "NO_NODES"), ("fewnodes", "NODE_CAP")):
+        for v in ("PYA_DEBUG", "PYA_NO_NODES", "PYA_NODE_CAP"):
+            os.environ.pop(v, None)
+        if dbg == "NO_NODES":
+            os.environ["PYA_NO_NODES"] = "1"
+        elif dbg == "NODE_CAP":
+            os.environ["PYA_NODE_CAP"] = "150"
+        elif dbg is not None:
             os.environ["PYA_DEBUG"] = dbg
         gpu = harness.make_scorer(PyAscore, settings)
         t = time.time(); got = gpu.score_batch(batch); dt = time.time() - t
