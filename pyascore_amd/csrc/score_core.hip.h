@@ -196,7 +196,7 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
 
     uint16_t *grid = (uint16_t *)lds_raw;                       /* [PYA_GRID_CELLS] */
     uint32_t *cnt = (uint32_t *)(grid + PYA_GRID_CELLS);        /* [PYA_NTOP / 2][64] */
-    float2 *resd = (float2 *)(cnt + PYA_NTOP / 2 * (node_cap ? node_cols : 64u));   /* [64] (the shared-node route has node_cols columns) */
+    float2 *resd = (float2 *)(cnt + PYA_NTOP / 2 * (node_cap && node_cols > 64u ? node_cols : 64u));   /* [64] (the shared-node route has node_cols columns) */
     PeakEntry *t_e = (PeakEntry *)(resd + 64);                  /* [cap + PYA_TABLE_PAD] */
     unsigned char *tail = (unsigned char *)(t_e + cap + PYA_TABLE_PAD);
     uint16_t *nl_present = nullptr;                             /* [256]          } only with */
@@ -453,7 +453,7 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
 
 static inline size_t score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact, uint32_t node_cap = 0,
                                      uint32_t node_cols = 64, uint32_t node_words = 0) {
-    return PYA_GRID_CELLS * 2 + PYA_NTOP / 2 * (node_cap ? node_cols : 64u) * 4 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8 +
+    return PYA_GRID_CELLS * 2 + PYA_NTOP / 2 * (node_cap && node_cols > 64u ? node_cols : 64u) * 4 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8 +
            (with_nl ? 512 + PYA_MAX_UNIQ * 4 + 64 : 0) +
            (prefix ? 2 * 64 * (compact ? sizeof(PrefixCompact) : sizeof(PrefixState)) : 0) +
            (node_cap ? (size_t)node_words * 8 + (size_t)node_cap * 8 + 2 * 64 * 2 + PYA_NTOP / 2 * 64 * 4 : 0) + 64;
