@@ -135,6 +135,68 @@ DEV uint32_t lh_ord(float v) {                          /* float -> unsigned wit
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+/* Surviving ions wait in a staging buffer (the 1 KB the list-based route uses for its own: 192 values + 192
+ * one-byte tags) and are looked up 128 at a time, two per lane with their memory round trips overlapped: the
+ * table stays in the workspace (staging it in LDS cost more occupancy than the lookups cost time) and a lookup
+ * is two dependent round trips. */
+#define LH_STAGE 192
+DEV void lh_stage_flush(const LocCtx &c, int &staged) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    float *sv = w.stage_val;
+    uint8_t *st = (uint8_t *)(sv + LH_STAGE);
+    STAMP_BEGIN();
+    wave_lds_sync();
+    const int take = staged < 128 ? staged : 128;
+    const bool on0 = lane < take, on1 = lane + 64 < take;
+    const float v0 = on0 ? sv[lane] : 0.f, v1 = on1 ? sv[lane + 64] : 0.f;
+    const uint32_t t0 = on0 ? st[lane] : 0u, t1 = on1 ? st[lane + 64] : 0u;
+    int r0, r1;
+    if (c.b->debug & 2u) {                                   /* (ablation: no lookups) */
+        r0 = r1 = PYA_NO_MATCH;
+    } else if (c.tab.e) {
+        r0 = match_rank_lds(c.tab, v0);
+        r1 = match_rank_lds(c.tab, v1);
+    } else {
+        match_rank_global2(c.tab, v0, v1, &r0, &r1);
+    }
+    if (on0) {
+        atomicAdd(&w.c_tr[t0], 1u);
+        if (r0 <= w.c_depth[t0 >> 1]) atomicAdd(&w.c_cnt[t0], 1u);
+    }
+    if (on1) {
+        atomicAdd(&w.c_tr[t1], 1u);
+        if (r1 <= w.c_depth[t1 >> 1]) atomicAdd(&w.c_cnt[t1], 1u);
+    }
+    wave_lds_sync();
+    const int rem = staged - take;                          /* at most 63 entries move to the front */
+    float mv = 0.f;
+    uint32_t mt = 0;
+    if (lane < rem) {
+        mv = sv[take + lane];
+        mt = st[take + lane];
+    }
+    wave_lds_sync();
+    if (lane < rem) {
+        sv[lane] = mv;
+        st[lane] = (uint8_t)mt;
+    }
+    staged = rem;
+    wave_lds_sync();
+    STAMP(*c.b, 38);
+}
+DEV void lh_stage_push(const LocCtx &c, bool kept, float val, uint32_t tag, int &staged) {
+    const LocLds &w = c.w;
+    const uint64_t km = __ballot(kept);
+    if (kept) {
+        const int slot = staged + __popcll(km & lanemask_lt());
+        w.stage_val[slot] = val;
+        ((uint8_t *)(w.stage_val + LH_STAGE))[slot] = (uint8_t)tag;
+    }
+    staged += __popcll(km);
+    if (staged >= 128) lh_stage_flush(c, staged);
+}
+
 /* what the exact route needs to know about the table in place */
 struct LhPass {
     int d, zmax, c0, nW, offW, hshift;
@@ -283,7 +345,7 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
                 }
             }
         }
-        loc_stage_push(c, kept, v, (uint32_t)(cs * 2 + side), staged);
+        lh_stage_push(c, kept, v, (uint32_t)(cs * 2 + side), staged);
     }
     wave_lds_sync();
     return false;
@@ -494,7 +556,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                         if (slot < LH_SLOW_CAP) h.slow[slot] = (uint32_t)id | ((uint32_t)cc << 16) | ((uint32_t)side << 24);
                     }
                     nslow += (uint32_t)__popcll(hm);
-                    loc_stage_push(c, on && !hit, x, (uint32_t)(cc * 2 + side), staged);
+                    lh_stage_push(c, on && !hit, x, (uint32_t)(cc * 2 + side), staged);
                     if (nslow + 64u > LH_SLOW_CAP && nslow) {           /* (the list could overflow with the next 64 items) */
                         if (lh_exact(c, h, q, nslow, staged)) return true;
                         nslow = 0;
@@ -509,7 +571,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
             c0 = c1;
         }
     }
-    while (staged > 0) loc_stage_flush(c, staged);
+    while (staged > 0) lh_stage_flush(c, staged);
     wave_lds_sync();
     STAMP_T(*c.b, 34, false);
     return false;

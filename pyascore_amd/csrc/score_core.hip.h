@@ -87,7 +87,7 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
 #pragma unroll
     for (int d = 0; d < PYA_NTOP / 2; d++) nd.priv[d * 64 + lane] = 0u;
     wave_lds_sync();
-    STAMP_T(*nd.b, 40, false);
+    STAMP_T(*nd.b, 5, false);
     /* 1. walkers: sums and loss state; group owners write the nodes */
     {
         const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
@@ -118,7 +118,7 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
         }
     }
     wave_lds_sync();
-    STAMP_T(*nd.b, 41, false);
+    STAMP_T(*nd.b, 6, false);
     /* 2. one lane per node.  The ranks of a node's lookups are bumped in the lane's own column (all lanes bumping
      * the column of a shared segment serialise on its address: 0.40 bank-conflict cycles per LDS cycle, measured)
      * and added to the segment's column once per round. */
@@ -172,7 +172,7 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
         }
     }
     wave_lds_sync();
-    STAMP_T(*nd.b, 42, false);
+    STAMP_T(*nd.b, 7, false);
     /* 3. a signature's counts = the columns of its segments */
     if (active) {
         for (int jj = 0; jj <= n_sites; jj++) {
@@ -182,7 +182,7 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
         }
     }
     wave_lds_sync();
-    STAMP_T(*nd.b, 43, false);
+    STAMP_T(*nd.b, 8, false);
     return true;
 }
 
