@@ -49,7 +49,7 @@ FAMILIES = {
     "pya_score_signatures_kernel": ("pya_score_signatures_kernel", "pya_score_big_kernel"),
     "pya_score_localize_kernel": ("pya_score_localize_kernel", "pya_score_localize_pack_kernel", "pya_score_localize_list_kernel",
                                   "pya_bin_score_localize_kernel"),
-    "pya_localize_kernel": ("pya_localize_kernel", "pya_localize_ties_kernel", "pya_localize_redo_kernel",
+    "pya_localize_kernel": ("pya_localize_kernel", "pya_localize_hash_kernel", "pya_localize_ties_kernel", "pya_localize_redo_kernel",
                             "pya_localize_recount_kernel", "pya_score_big_list_kernel"),
 }
 
