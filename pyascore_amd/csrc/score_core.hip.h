@@ -188,7 +188,8 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
 
 /* PREFIX is a template parameter so that the small-C(n,k) instantiation does not carry the
  * registers of the shared-prefix path (60 vs 77 VGPRs = 8 vs 6 waves per SIMD). */
-template <bool PREFIX>
+/* NODES: the instantiation with the shared-node route (general settings); the others do not carry its registers */
+template <bool PREFIX, bool NODES = false>
 DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t with_nl,
                     uint32_t compact, uint32_t node_cap = 0, uint32_t node_cols = 64, uint32_t node_words = 0) {
     const int lane = lane_id();
@@ -249,7 +250,7 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
      * order table */
     const int n_sites_all = __popcll(res.site_mask);
     const uint32_t ntab_words = 2u * (uint32_t)(n_sites_all + 1) * (1u + ((N + 7u) >> 3));
-    const bool node_try = !PREFIX && node_cap != 0 && N <= 64 && ntab_words <= node_words && !(b.debug & 256u) &&
+    const bool node_try = NODES && !PREFIX && node_cap != 0 && N <= 64 && ntab_words <= node_words && !(b.debug & 256u) &&
                           (env.n_nl != 0 || cfg->n_fwd > 1 || cfg->n_types - cfg->n_fwd > 1);
     if (node_try)
         for (uint32_t i = lane; i < ntab_words; i += 64) ((uint64_t *)nd.ntab)[i] = order[N + i];

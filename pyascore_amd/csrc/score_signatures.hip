@@ -26,11 +26,21 @@
 template <bool PREFIX>
 __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(BatchDev b, const uint32_t *psm_ids,
                                                                   uint32_t n_ids, uint32_t cap, uint32_t with_nl,
-                                                                  uint32_t compact, uint32_t node_cap, uint32_t node_cols,
-                                                                  uint32_t node_words) {
+                                                                  uint32_t compact) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
-    score_body<PREFIX>(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, with_nl, compact, node_cap, node_cols, node_words);
+    score_body<PREFIX>(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, with_nl, compact);
+}
+
+/* general settings (neutral losses, several ion types per direction): one lookup set per distinct node of the
+ * assignment tree (score_core.hip.h: score_nodes_dir), walkers for what does not fit */
+/* (its LDS holds it to four wavefronts per SIMD: the registers to match, no spills) */
+__global__ __launch_bounds__(64, 4) void pya_score_nodes_kernel(BatchDev b, const uint32_t *psm_ids, uint32_t n_ids,
+                                                                           uint32_t cap, uint32_t with_nl, uint32_t node_cap,
+                                                                           uint32_t node_cols, uint32_t node_words) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (blockIdx.x >= n_ids) return;
+    score_body<false, true>(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, with_nl, 0u, node_cap, node_cols, node_words);
 }
 
 extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact) {
@@ -50,14 +60,21 @@ extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32
     if (!prefix) compact = 0;
     if (prefix) node_cap = 0;
     const size_t lds = score_lds_bytes(cap, prefix, with_nl, compact, node_cap, node_cols, node_words);
+    if (node_cap) {
+        hipError_t en = PYA_ENSURE_MAX_LDS(pya_score_nodes_kernel);
+        if (en != hipSuccess) return (int)en;
+        hipLaunchKernelGGL(pya_score_nodes_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, cap, with_nl, node_cap,
+                           node_cols, node_words);
+        return (int)hipGetLastError();
+    }
     hipError_t e = prefix ? PYA_ENSURE_MAX_LDS(pya_score_signatures_kernel<true>)
                           : PYA_ENSURE_MAX_LDS(pya_score_signatures_kernel<false>);
     if (e != hipSuccess) return (int)e;
     if (prefix)
         hipLaunchKernelGGL(pya_score_signatures_kernel<true>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                           cap, with_nl, compact, 0u, 64u, 0u);
+                           cap, with_nl, compact);
     else
         hipLaunchKernelGGL(pya_score_signatures_kernel<false>, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids,
-                           cap, with_nl, compact, node_cap, node_cols, node_words);
+                           cap, with_nl, compact);
     return (int)hipGetLastError();
 }
