@@ -168,6 +168,8 @@ def test_batch_matches_golden(case, path):
     ("cfg2", 200, 207, dict(fragment_types="Zc", max_charge=3, neutral_loss=("STY", 18.01528))),
     ("cfg2", 600, 208, dict(mz_error=0.5)),
     ("cfg3", 1500, 209, dict(mz_error=0.3, max_charge=2)),
+    ("cfg4", 32, 211, dict(mz_error=0.002)),      # a tolerance below the rounding of the sums: the hash route declines, lists take over
+    ("cfg4", 32, 212, dict(mz_error=0.2)),        # a wide one: many ions with neighbours, the exact run walk
 ])
 def test_batch_matches_checker(cfg, n, seed, override, path):
     """Fresh seeded batches, HIP vs the CPU checker on this box: bit-exact everywhere."""
