@@ -68,7 +68,7 @@ int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_id
                          uint32_t inline_on, hipStream_t stream);
 size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc, uint32_t hs,
-                                   uint32_t pp, uint32_t tab_cap);
+                                   uint32_t pp, uint32_t tab_cap, uint32_t max_k);
 int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap, uint32_t n_cap,
                              uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t vc, uint32_t hs, uint32_t pp,
                              uint32_t tab_cap, hipStream_t stream);
@@ -408,9 +408,9 @@ struct Bucket {
     uint32_t hash_vc() const { return 2u * list_cap; }
     uint32_t hash_hs() const { return 4u * list_cap < 64u ? 64u : 4u * list_cap; }
     uint32_t hash_pp() const { return (8u * pair_cap + 7u) & ~7u; }
-    bool hash_ok(uint32_t tab_cap) const {
+    bool hash_ok(uint32_t tab_cap, uint32_t max_k) const {
         return pos_cap <= 64u && hash_vc() <= 8192u &&
-               pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp(), tab_cap) <= 64u * 1024u;
+               pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp(), tab_cap, max_k) <= 64u * 1024u;
     }
     uint32_t push_max = 1;              /* largest k * (n_sites - k): single-move competitors of one PSM */
     uint32_t push_cap() const {
@@ -1866,8 +1866,8 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
         /* (PYA_LOC_HASH_LDS_TAB: the retained table staged in LDS for the lookups; measured slower on cfg4, 15.6 against
          * 12.4 ms -- the 2 KB cost more occupancy than the global lookups cost time) */
-        const uint32_t tab_cap = (h->kn.loc_hash_lds_tab && bk.hash_ok(p->peak_cap)) ? p->peak_cap : 0u;
-        if (!h->kn.no_loc_hash && bk.hash_ok(tab_cap))
+        const uint32_t tab_cap = (h->kn.loc_hash_lds_tab && bk.hash_ok(p->peak_cap, p->max_k)) ? p->peak_cap : 0u;
+        if (!h->kn.no_loc_hash && bk.hash_ok(tab_cap, p->max_k))
             e = pya_launch_localize_hash(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
                                          bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), bk.hash_vc(), bk.hash_hs(), bk.hash_pp(), tab_cap,
                                          st);

@@ -7,7 +7,7 @@
 
 /* the hash route: same carve-up with the fragment pool and its keep flags replaced by loc_hash_words() words */
 static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                             uint32_t hs, uint32_t pp, uint32_t tab_cap);
+                                             uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k);
 static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
                                         uint32_t sb) {
     /* (the localize kernel looks peaks up in global memory: no peak table here) */
@@ -17,12 +17,22 @@ static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint3
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
+/* the hash route sizes the per-site and per-residue arrays by the launch (its LDS decides its occupancy) */
+static inline __host__ __device__ uint32_t hash_site_cap(uint32_t max_k) {
+    const uint32_t v = (max_k + 7u) & ~7u;
+    return v > 64u ? 64u : (v < 8u ? 8u : v);
+}
+static inline __host__ __device__ uint32_t hash_res_cap(uint32_t pos_cap) {
+    const uint32_t v = (pos_cap + 1u + 3u) & ~3u;
+    return v > 64u ? 64u : v;
+}
 static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                             uint32_t hs, uint32_t pp, uint32_t tab_cap) {
-    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + 64 * 16 + 16 +
+                                             uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k) {
+    const uint32_t site_cap = hash_site_cap(max_k), res_cap = hash_res_cap(pos_cap);
+    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + (size_t)site_cap * 16 + 16 +
                    (tab_cap ? PYA_GRID_CELLS * 2 + ((size_t)tab_cap + PYA_TABLE_PAD) * 8 : 0);
     size_t srt = n_cap ? sort_lds_bytes(n_cap) + 64 : 64;
-    size_t lst = pya_loc_lds_bytes(pos_cap, 0, sb) + 4 * loc_hash_words(vc, hs, pp);
+    size_t lst = pya_loc_lds_bytes(pos_cap, 0, sb) - (64 - res_cap) * 9 - (32 + 33) * 4 + 4 * loc_hash_words(vc, hs, pp);
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
@@ -107,7 +117,8 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     /* (HASH with tab_cap: the hash route looks up ~1 300 ions per PSM on cfg4-like settings, so there the table
      * and the grid are staged as in the score kernels) */
     const bool staged_tab = HASH && tab_cap != 0;
-    K3Lds lds = carve(lds_raw, tab_cap, staged_tab, push_cap);
+    const uint32_t site_cap = HASH ? hash_site_cap(max_k) : 64u, res_cap = HASH ? hash_res_cap(pos_cap) : 64u;
+    K3Lds lds = carve(lds_raw, tab_cap, staged_tab, push_cap, site_cap);
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
@@ -126,9 +137,11 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
 
     /* ---- sort (cpp/Ascore.cpp:141-146) ---- */
     if (lane == 0) *lds.n_pushed = 0;
-    lds.site_max[lane] = 0;
-    lds.site_tie[lane] = 0;
-    lds.site_alt[lane] = 0ull;
+    if ((uint32_t)lane < site_cap) {
+        lds.site_max[lane] = 0;
+        lds.site_tie[lane] = 0;
+        lds.site_alt[lane] = 0ull;
+    }
     /* The winner is the front of the sorted list: the largest PepScore, and among equal ones
      * whichever std::sort leaves first.  When the maximum is unique (4 PSMs in 5) no emulation is
      * needed to name it. */
@@ -284,7 +297,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
 
     STAMP_T(b, 24, false);
     /* ---- Ascores, sb-1 competitors at a time ---- */
-    ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap, sb);
+    ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap, sb, res_cap, !HASH);
     ctx.sb = (int)sb;
     ctx.gtp = (int)gtp;
     ctx.L = res.L;
@@ -294,9 +307,11 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     ctx.pos_cap = pos_cap;
     ctx.pool_cap = pool_cap;
     const LocLds &w = ctx.w;
-    w.m0[lane] = res.m0;
-    w.m1[lane] = res.m1;
-    w.nlp[lane] = (uint8_t)res.nl;
+    if ((uint32_t)lane < res_cap) {
+        w.m0[lane] = res.m0;
+        w.m1[lane] = res.m1;
+        w.nlp[lane] = (uint8_t)res.nl;
+    }
     if (lane == 0) w.sig_mask[0] = deposit_sites(best_bits, res.site_mask);
     wave_lds_sync();
 

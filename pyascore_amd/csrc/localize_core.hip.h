@@ -517,15 +517,17 @@ struct K3Lds {
     unsigned char *scratch;  /* sort arrays, later the localisation work area */
 };
 
-DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap, bool with_table = true, uint32_t push_cap = PYA_MAX_PUSHED) {
+/* site_cap: entries of the three per-site arrays (64, or the launch's largest number of modified sites rounded up) */
+DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap, bool with_table = true, uint32_t push_cap = PYA_MAX_PUSHED,
+                uint32_t site_cap = 64) {
     K3Lds k;
     k.nl_present = (uint16_t *)raw;
     k.nl_uniq = (float *)(k.nl_present + 256);
     k.pushed = (PushedEntry *)(k.nl_uniq + PYA_MAX_UNIQ);
     k.site_alt = (unsigned long long *)(k.pushed + push_cap);
-    k.site_max = (uint32_t *)(k.site_alt + 64);
-    k.site_tie = k.site_max + 64;
-    k.n_pushed = k.site_tie + 64;
+    k.site_max = (uint32_t *)(k.site_alt + site_cap);
+    k.site_tie = k.site_max + site_cap;
+    k.n_pushed = k.site_tie + site_cap;
     k.grid = (uint16_t *)(k.n_pushed + 4);
     k.t_e = (PeakEntry *)(k.grid + (with_table ? PYA_GRID_CELLS : 0));
     k.scratch = (unsigned char *)(k.t_e + (with_table ? peak_cap + PYA_TABLE_PAD : 0));
@@ -555,19 +557,22 @@ struct LocLds {
     uint32_t *t_lo, *t_off;   /* [32], [33] per task: first step of its span, items before it (lean pairing) */
 };
 
-DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, uint32_t LOC_SB) {
+/* res_cap: entries of the residue arrays (64, or the launch's longest peptide rounded up to a multiple of 4);
+ * lean_tables = false leaves the span tables of the lean pairing out (the hash route: LDS decides its occupancy) */
+DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, uint32_t LOC_SB, uint32_t res_cap = 64,
+                     bool lean_tables = true) {
     LocLds w;
     w.sig_mask = (uint64_t *)raw;
     w.m0 = (float *)(w.sig_mask + LOC_SB);
-    w.m1 = w.m0 + 64;
-    w.run = w.m1 + 64;
+    w.m1 = w.m0 + res_cap;
+    w.run = w.m1 + res_cap;
     w.scores = w.run + (size_t)LOC_SB * 2 * pos_cap;
     w.pool = w.scores + LOC_SB * 10;
     w.stage_val = w.pool + pool_cap;
     w.stage_tag = (uint32_t *)(w.stage_val + 128);
     w.t_lo = w.stage_tag + 128;
-    w.t_off = w.t_lo + 32;
-    w.tot = w.t_off + 33;
+    w.t_off = w.t_lo + (lean_tables ? 32 : 0);
+    w.tot = w.t_off + (lean_tables ? 33 : 0);
     w.c_idx = w.tot + LOC_SB * 2;
     w.c_pre = w.c_idx + LOC_SB;
     w.c_depth = (int32_t *)(w.c_pre + LOC_SB);

@@ -123,8 +123,7 @@ DEV bool lh_probe(const HashLds &h, int cell, int hshift, int self, float x, flo
         const int j = (int)half - 1;
         const float y = h.val[j];
         const bool mine = j < nW || (j >= b_lo && j < b_hi);
-        hit = (j != self) && mine && (__builtin_fabsf(y - x) < reach);
-        if (hit) break;
+        hit |= (j != self) && mine && (__builtin_fabsf(y - x) < reach);     /* (no early exit: one loop condition) */
         s = (s + 1u) & hmask;
     }
     return hit;

@@ -219,8 +219,8 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
 }
 
 extern "C" size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                              uint32_t hs, uint32_t pp, uint32_t tab_cap) {
-    return localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, tab_cap);
+                                              uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k) {
+    return localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, tab_cap, max_k);
 }
 
 /* general PSMs: the hash route first, then whatever it declined on the list-based instantiation */
@@ -232,7 +232,7 @@ extern "C" int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids
     if (e != hipSuccess) return (int)e;
     e = PYA_ENSURE_MAX_LDS(pya_localize_hash_kernel);
     if (e != hipSuccess) return (int)e;
-    const size_t lds_hash = localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, tab_cap);
+    const size_t lds_hash = localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, tab_cap, b->max_k);
     hipLaunchKernelGGL(pya_localize_hash_kernel, dim3(n_ids), dim3(64), lds_hash, stream, *b, d_ids, n_ids, push_cap, pos_cap, sb,
                        vc, hs, pp, tab_cap);
     e = hipGetLastError();
