@@ -68,10 +68,10 @@ int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_id
                          uint32_t inline_on, hipStream_t stream);
 size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc, uint32_t hs,
-                                   uint32_t pp, uint32_t tab_cap, uint32_t max_k);
+                                   uint32_t pp, uint32_t tab_cap, uint32_t max_k, uint32_t n_nl);
 int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap, uint32_t n_cap,
                              uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t vc, uint32_t hs, uint32_t pp,
-                             uint32_t tab_cap, hipStream_t stream);
+                             uint32_t tab_cap, uint32_t n_nl, hipStream_t stream);
 int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t push_cap,
                                 uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t *d_redo, hipStream_t stream);
 int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
@@ -213,7 +213,7 @@ struct Knobs {
     double chunk_mb = 0.;                       /* 0: the default chunk size */
     int64_t workspace_mb = 0;                   /* 0: the default budget */
 };
-static int g_knob_sb = -1, g_knob_gtp = -1;     /* (Bucket has no handle: the two A/B overrides are process-wide) */
+static int g_knob_sb = -1, g_knob_gtp = -1, g_knob_hash_pp = -1;     /* (Bucket has no handle: the two A/B overrides are process-wide) */
 
 static void read_knobs(Knobs &k) {
     auto flag = [](const char *n) { return std::getenv(n) != nullptr; };
@@ -254,6 +254,7 @@ static void read_knobs(Knobs &k) {
     k.workspace_mb = num("PYA_WORKSPACE_MB", 0);
     g_knob_sb = k.sb;
     g_knob_gtp = k.gtp;
+    g_knob_hash_pp = (int)num("PYA_HASH_PP", -1);
 }
 
 struct pya_handle {
@@ -399,22 +400,30 @@ struct Bucket {
     }
     uint32_t n_types = 1, k_max = 1;
     uint32_t z_max = 1;                 /* largest fragment charge in the bucket */
+    uint32_t list_max = 1;              /* longest fragment list of one (signature, ion type) */
     uint32_t pair_cap = 1;              /* largest (L - 1) * loss variants: (prefix, variant) pairs of one fragment list */
     uint32_t node_words = 0;            /* largest shared-node shape table (64-bit words) among the PSMs of <= 64 signatures */
     uint32_t node_cols = 0;             /* ... and the most histogram columns one of them needs */
     /* The hash route of the general localize launch (localize_hash.hip.h): ion table for the winner's list and at
      * least one competitor's in-span ions, a grid at most half full, room for the pair lists of a typical PSM
      * (a PSM that needs more is declined and goes to the list-based kernel). */
-    uint32_t hash_vc() const { return 2u * list_cap; }
-    uint32_t hash_hs() const { return 4u * list_cap < 64u ? 64u : 4u * list_cap; }
-    uint32_t hash_pp() const { return (8u * pair_cap + 7u) & ~7u; }
-    bool hash_ok(uint32_t tab_cap, uint32_t max_k) const {
+    uint32_t hash_vc() const { return (2u * list_max + 15u) & ~15u; }
+    uint32_t hash_hs() const {
+        uint32_t v = 64u;
+        while (v < 2u * hash_vc()) v <<= 1;
+        return v;
+    }
+    /* one direction's pair lists at a time: the winner's and, per competitor of a batch, its in-span pairs on both sides
+     * -- room for the worst case, so the hash route never declines for lack of it (PYA_HASH_PP: a smaller multiple of
+     * pair_cap, for the tests of the hand-over) */
+    uint32_t hash_pp() const { return ((g_knob_hash_pp > 0 ? (uint32_t)g_knob_hash_pp : 1u + 2u * (sb() - 1u)) * pair_cap + 7u) & ~7u; }
+    bool hash_ok(uint32_t tab_cap, uint32_t max_k, uint32_t n_nl) const {
         return pos_cap <= 64u && hash_vc() <= 8192u &&
-               pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp(), tab_cap, max_k) <= 64u * 1024u;
+               pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp(), tab_cap, max_k, n_nl) <= 64u * 1024u;
     }
     uint32_t push_max = 1;              /* largest k * (n_sites - k): single-move competitors of one PSM */
     uint32_t push_cap() const {
-        uint32_t v = (push_max + 7u) & ~7u;
+        uint32_t v = (push_max + 3u) & ~3u;
         return v > PYA_MAX_PUSHED ? PYA_MAX_PUSHED : v;
     }
 };
@@ -1242,6 +1251,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             bk.push_max = std::max<uint32_t>(bk.push_max, (uint32_t)k * (ns - (uint32_t)k));
             bk.z_max = std::max<uint32_t>(bk.z_max, (uint32_t)z);
             bk.pair_cap = std::max<uint32_t>(bk.pair_cap, (uint32_t)(L - 1) * n_uniq);
+            bk.list_max = std::max<uint32_t>(bk.list_max, per_type);
             if (N <= 64) {
                 bk.node_words = std::max<uint32_t>(bk.node_words, 2u * (ns + 1u) * (1u + (uint32_t)((N + 7) / 8)));
                 auto sc = h->shape_cols.find(ns << 8 | (uint32_t)k);
@@ -1866,11 +1876,12 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
         /* (PYA_LOC_HASH_LDS_TAB: the retained table staged in LDS for the lookups; measured slower on cfg4, 15.6 against
          * 12.4 ms -- the 2 KB cost more occupancy than the global lookups cost time) */
-        const uint32_t tab_cap = (h->kn.loc_hash_lds_tab && bk.hash_ok(p->peak_cap, p->max_k)) ? p->peak_cap : 0u;
-        if (!h->kn.no_loc_hash && bk.hash_ok(tab_cap, p->max_k))
+        const uint32_t nnl = (uint32_t)h->cfg.n_nl;
+        const uint32_t tab_cap = (h->kn.loc_hash_lds_tab && bk.hash_ok(p->peak_cap, p->max_k, nnl)) ? p->peak_cap : 0u;
+        if (!h->kn.no_loc_hash && bk.hash_ok(tab_cap, p->max_k, nnl))
             e = pya_launch_localize_hash(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
                                          bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), bk.hash_vc(), bk.hash_hs(), bk.hash_pp(), tab_cap,
-                                         st);
+                                         nnl, st);
         else
         e = pya_launch_localize(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
                                 bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), 0u, 1u, st);

@@ -7,7 +7,7 @@
 
 /* the hash route: same carve-up with the fragment pool and its keep flags replaced by loc_hash_words() words */
 static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                             uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k);
+                                             uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k, uint32_t n_nl);
 static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
                                         uint32_t sb) {
     /* (the localize kernel looks peaks up in global memory: no peak table here) */
@@ -19,23 +19,28 @@ static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint3
 
 /* the hash route sizes the per-site and per-residue arrays by the launch (its LDS decides its occupancy) */
 static inline __host__ __device__ uint32_t hash_site_cap(uint32_t max_k) {
-    const uint32_t v = (max_k + 7u) & ~7u;
-    return v > 64u ? 64u : (v < 8u ? 8u : v);
+    const uint32_t v = (max_k + 3u) & ~3u;
+    return v > 64u ? 64u : (v < 4u ? 4u : v);
 }
+/* entries of the staged neutral-loss state table: the state packs two bits per distinct loss mass */
+static inline __host__ __device__ uint32_t hash_nl_cap(uint32_t n_nl) { return n_nl >= 4u ? 256u : (n_nl == 0u ? 4u : 1u << (2u * n_nl)); }
 static inline __host__ __device__ uint32_t hash_res_cap(uint32_t pos_cap) {
     const uint32_t v = (pos_cap + 1u + 3u) & ~3u;
     return v > 64u ? 64u : v;
 }
 static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                             uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k) {
+                                             uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k, uint32_t n_nl) {
     const uint32_t site_cap = hash_site_cap(max_k), res_cap = hash_res_cap(pos_cap);
-    size_t fixed = 512 + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + (size_t)site_cap * 16 + 16 +
+    size_t fixed = 2 * (size_t)hash_nl_cap(n_nl) + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + (size_t)site_cap * 16 + 16 +
                    (tab_cap ? PYA_GRID_CELLS * 2 + ((size_t)tab_cap + PYA_TABLE_PAD) * 8 : 0);
     size_t srt = n_cap ? sort_lds_bytes(n_cap) + 64 : 64;
-    size_t lst = pya_loc_lds_bytes(pos_cap, 0, sb) - (64 - res_cap) * 9 - (32 + 33) * 4 + 4 * loc_hash_words(vc, hs, pp);
+    /* (residue arrays by the launch, no span tables, 128 one-byte staging tags instead of 128 words) */
+    size_t lst = pya_loc_lds_bytes(pos_cap, 0, sb) - (64 - res_cap) * 9 - (32 + 33) * 4 - (128 - 32) * 4 + 4 * loc_hash_words(vc, hs, pp, sb);
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
+/* (five wavefronts per SIMD -- 96 registers, ~60 spilled -- and the LDS trimmed to 8 KB to match were measured:
+ * 10.8-11.7 ms on cfg4 against 10.4 with four and no spills) */
 #ifndef LOC_WAVES_HASH
 #define LOC_WAVES_HASH 4
 #endif
@@ -118,7 +123,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
      * and the grid are staged as in the score kernels) */
     const bool staged_tab = HASH && tab_cap != 0;
     const uint32_t site_cap = HASH ? hash_site_cap(max_k) : 64u, res_cap = HASH ? hash_res_cap(pos_cap) : 64u;
-    K3Lds lds = carve(lds_raw, tab_cap, staged_tab, push_cap, site_cap);
+    K3Lds lds = carve(lds_raw, tab_cap, staged_tab, push_cap, site_cap, HASH ? hash_nl_cap((uint32_t)cfg->n_nl) : 256u);
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
@@ -319,7 +324,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     float my_asc = __builtin_huge_valf();     /* lane a keeps site a */
     uint64_t my_alt = 0ull;
     HashLds hl;
-    if (HASH) hl = hash_carve(w.pool, vc, hs, pp);
+    if (HASH) hl = hash_carve(w.pool, vc, hs, pp, sb);
     const bool declined = loc_ascore_all<PLAIN, HASH>(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
                    best_bits, best_ws, best_i, res.site_mask,
                    &my_asc, &my_alt, &fail, in ? in->rec_batch : nullptr, in ? in->hist : nullptr, HASH ? &hl : nullptr);

@@ -515,14 +515,16 @@ struct K3Lds {
     uint32_t *n_pushed;      /* [4]  */
     uint16_t *grid;          /* [PYA_GRID_CELLS] */
     unsigned char *scratch;  /* sort arrays, later the localisation work area */
+    uint32_t nl_cap;         /* entries of nl_present staged (256, or 4^(distinct loss masses) in the hash route) */
 };
 
 /* site_cap: entries of the three per-site arrays (64, or the launch's largest number of modified sites rounded up) */
 DEV K3Lds carve(unsigned char *raw, uint32_t peak_cap, bool with_table = true, uint32_t push_cap = PYA_MAX_PUSHED,
-                uint32_t site_cap = 64) {
+                uint32_t site_cap = 64, uint32_t nl_cap = 256) {
     K3Lds k;
+    k.nl_cap = nl_cap;
     k.nl_present = (uint16_t *)raw;
-    k.nl_uniq = (float *)(k.nl_present + 256);
+    k.nl_uniq = (float *)(k.nl_present + nl_cap);
     k.pushed = (PushedEntry *)(k.nl_uniq + PYA_MAX_UNIQ);
     k.site_alt = (unsigned long long *)(k.pushed + push_cap);
     k.site_max = (uint32_t *)(k.site_alt + site_cap);
@@ -570,7 +572,7 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, ui
     w.pool = w.scores + LOC_SB * 10;
     w.stage_val = w.pool + pool_cap;
     w.stage_tag = (uint32_t *)(w.stage_val + 128);
-    w.t_lo = w.stage_tag + 128;
+    w.t_lo = w.stage_tag + (lean_tables ? 128 : 32);          /* (the hash route keeps one-byte tags) */
     w.t_off = w.t_lo + (lean_tables ? 32 : 0);
     w.tot = w.t_off + (lean_tables ? 33 : 0);
     w.c_idx = w.tot + LOC_SB * 2;
@@ -592,7 +594,7 @@ DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, u
     else global_peak_table(b, psm, tab);
     nl->n_nl = cfg->n_nl;
     if (nl->n_nl) {
-        for (int i = lane; i < 256; i += 64) k.nl_present[i] = cfg->present[i];
+        for (int i = lane; i < (int)k.nl_cap; i += 64) k.nl_present[i] = cfg->present[i];
         if (lane < PYA_MAX_UNIQ) k.nl_uniq[lane] = cfg->uniq[lane];
     }
     nl->present = k.nl_present;

@@ -26,7 +26,7 @@
 /* (included by localize_core.hip.h, after loc_site_ions) */
 
 #define LH_SLOW_CAP 64
-#define LH_LISTS (2 + 4 * (PYA_LOC_SB_MAX - 1))
+#define LH_LISTS (2 * PYA_LOC_SB_MAX)     /* 1 + 2 per competitor, rounded up to even */
 
 DEV float wave_max_f32(float v) {
 #pragma unroll
@@ -59,28 +59,29 @@ struct HashLds {
     uint32_t *tab;         /* [hs / 2] open-addressing table of 16-bit slots (entry + 1), two per word        */
     uint16_t *pairs;       /* [pp] (prefix | variant << 8) / winner pair indices, lists back to back          */
     uint32_t *slow;        /* [LH_SLOW_CAP] items for the exact route: entry | competitor << 16 | side << 24  */
-    float *cand_val;       /* [64] */
-    uint32_t *cand_tag;    /* [64] entry | in span << 16 | side << 17 */
-    uint64_t *ispan;       /* [2 * (sb - 1)] in-span prefixes per (competitor, direction)                     */
-    uint16_t *off, *cnt;   /* [LH_LISTS] pair lists: W(d) = d, A(c, d) = 2 + 2 * cd, B(c, d) = 3 + 2 * cd      */
+    float *cand_val;       /* [LH_CAND_CAP] */
+    uint32_t *cand_tag;    /* [LH_CAND_CAP] entry | in span << 16 | side << 17 */
+    uint64_t *ispan;       /* [sb] in-span prefixes per competitor, current direction                         */
+    uint16_t *off, *cnt;   /* [LH_LISTS] pair lists of the current direction: W = 0, A(c) = 1 + 2 (c - 1), B(c) = 2 + 2 (c - 1) */
     uint32_t vc, hs, pp;
 };
 
-static inline __host__ __device__ size_t loc_hash_words(uint32_t vc, uint32_t hs, uint32_t pp) {
-    return (size_t)vc + hs / 2 + (pp + 1) / 2 + LH_SLOW_CAP + 64 + 64 + 4 * PYA_LOC_SB_MAX + LH_LISTS + 2;
+#define LH_CAND_CAP 32
+static inline __host__ __device__ size_t loc_hash_words(uint32_t vc, uint32_t hs, uint32_t pp, uint32_t sb) {
+    return (size_t)vc + hs / 2 + (pp + 1) / 2 + LH_SLOW_CAP + 2 * LH_CAND_CAP + 2 * sb + LH_LISTS + 2;
 }
 
-DEV HashLds hash_carve(float *base, uint32_t vc, uint32_t hs, uint32_t pp) {
+DEV HashLds hash_carve(float *base, uint32_t vc, uint32_t hs, uint32_t pp, uint32_t sb) {
     HashLds h;
     h.ispan = (uint64_t *)base;                                  /* (the pool starts 8-byte aligned) */
-    h.val = (float *)(h.ispan + 2 * PYA_LOC_SB_MAX);
+    h.val = (float *)(h.ispan + sb);
     h.tab = (uint32_t *)(h.val + vc);
     h.slow = h.tab + hs / 2;
     h.cand_val = (float *)(h.slow + LH_SLOW_CAP);
-    h.cand_tag = (uint32_t *)(h.cand_val + 64);
-    h.off = (uint16_t *)(h.cand_tag + 64);
-    h.cnt = h.off + LH_LISTS + (LH_LISTS & 1);
-    h.pairs = h.cnt + LH_LISTS + (LH_LISTS & 1);
+    h.cand_tag = (uint32_t *)(h.cand_val + LH_CAND_CAP);
+    h.off = (uint16_t *)(h.cand_tag + LH_CAND_CAP);
+    h.cnt = h.off + LH_LISTS;
+    h.pairs = h.cnt + LH_LISTS;
     h.vc = vc;
     h.hs = hs;
     h.pp = pp;
@@ -134,38 +135,23 @@ DEV uint32_t lh_ord(float v) {                          /* float -> unsigned wit
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-/* Surviving ions wait in a staging buffer (the 1 KB the list-based route uses for its own: 192 values + 192
- * one-byte tags) and are looked up 128 at a time, two per lane with their memory round trips overlapped: the
- * table stays in the workspace (staging it in LDS cost more occupancy than the lookups cost time) and a lookup
- * is two dependent round trips. */
-#define LH_STAGE 192
+/* Surviving ions wait in a staging buffer (128 values + 128 one-byte tags) and are looked up 64 at a time, one
+ * per lane, in the workspace table.  (Staging the table in LDS cost more occupancy than the lookups cost time;
+ * two lookups per lane with overlapped round trips, and no lookups at all -- PYA_DEBUG=2 -- leave the kernel's
+ * time unchanged: it is bound by issue at the occupancy its LDS allows, not by these loads.) */
+#define LH_STAGE 128
 DEV void lh_stage_flush(const LocCtx &c, int &staged) {
     const int lane = lane_id();
     const LocLds &w = c.w;
     float *sv = w.stage_val;
     uint8_t *st = (uint8_t *)(sv + LH_STAGE);
-    STAMP_BEGIN();
     wave_lds_sync();
-    const int take = staged < 128 ? staged : 128;
-    const bool on0 = lane < take, on1 = lane + 64 < take;
-    const float v0 = on0 ? sv[lane] : 0.f, v1 = on1 ? sv[lane + 64] : 0.f;
-    const uint32_t t0 = on0 ? st[lane] : 0u, t1 = on1 ? st[lane + 64] : 0u;
-    int r0, r1;
-    if (c.b->debug & 2u) {                                   /* (ablation: no lookups) */
-        r0 = r1 = PYA_NO_MATCH;
-    } else if (c.tab.e) {
-        r0 = match_rank_lds(c.tab, v0);
-        r1 = match_rank_lds(c.tab, v1);
-    } else {
-        match_rank_global2(c.tab, v0, v1, &r0, &r1);
-    }
-    if (on0) {
-        atomicAdd(&w.c_tr[t0], 1u);
-        if (r0 <= w.c_depth[t0 >> 1]) atomicAdd(&w.c_cnt[t0], 1u);
-    }
-    if (on1) {
-        atomicAdd(&w.c_tr[t1], 1u);
-        if (r1 <= w.c_depth[t1 >> 1]) atomicAdd(&w.c_cnt[t1], 1u);
+    const int take = staged < 64 ? staged : 64;
+    if (lane < take) {
+        const uint32_t tg = st[lane];
+        const int r = (c.b->debug & 2u) ? PYA_NO_MATCH : match_rank(c.tab, sv[lane]);     /* (2: ablation, no lookups) */
+        atomicAdd(&w.c_tr[tg], 1u);
+        if (r <= w.c_depth[tg >> 1]) atomicAdd(&w.c_cnt[tg], 1u);
     }
     wave_lds_sync();
     const int rem = staged - take;                          /* at most 63 entries move to the front */
@@ -182,7 +168,6 @@ DEV void lh_stage_flush(const LocCtx &c, int &staged) {
     }
     staged = rem;
     wave_lds_sync();
-    STAMP(*c.b, 38);
 }
 DEV void lh_stage_push(const LocCtx &c, bool kept, float val, uint32_t tag, int &staged) {
     const LocLds &w = c.w;
@@ -193,7 +178,7 @@ DEV void lh_stage_push(const LocCtx &c, bool kept, float val, uint32_t tag, int 
         ((uint8_t *)(w.stage_val + LH_STAGE))[slot] = (uint8_t)tag;
     }
     staged += __popcll(km);
-    if (staged >= 128) lh_stage_flush(c, staged);
+    if (staged >= 64) lh_stage_flush(c, staged);
 }
 
 /* what the exact route needs to know about the table in place */
@@ -220,11 +205,10 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
         const uint32_t it = h.slow[k];
         const int id0 = (int)(it & 0xffffu), cs = (int)((it >> 16) & 0xffu), side0 = (int)(it >> 24);
         const float x0 = h.val[id0];
-        const int cd = (cs - 1) * 2 + d;
-        const uint64_t ins = h.ispan[cd];
+        const uint64_t ins = h.ispan[cs - 1];
         int bl = nW;
-        for (int cc = q.c0; cc < cs; cc++) bl += (int)h.cnt[3 + 2 * ((cc - 1) * 2 + d)] * zmax;
-        const int bh = bl + (int)h.cnt[3 + 2 * cd] * zmax;
+        for (int cc = q.c0; cc < cs; cc++) bl += (int)h.cnt[2 + 2 * (cc - 1)] * zmax;
+        const int bh = bl + (int)h.cnt[2 + 2 * (cs - 1)] * zmax;
         int ncand = 0;
         wave_lds_sync();
         for (int base = 0; base < nW; base += 64) {
@@ -250,7 +234,7 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
             const uint64_t ma = __ballot(a_in);
             if (a_in) {
                 const int slot = ncand + __popcll(ma & lanemask_lt());
-                if (slot < 64) {
+                if (slot < LH_CAND_CAP) {
                     h.cand_val[slot] = av;
                     h.cand_tag[slot] = (uint32_t)j | (isp << 16);
                 }
@@ -259,7 +243,7 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
             const uint64_t mt = __ballot(t_in);
             if (t_in) {
                 const int slot = ncand + __popcll(mt & lanemask_lt());
-                if (slot < 64) {
+                if (slot < LH_CAND_CAP) {
                     h.cand_val[slot] = tv;
                     h.cand_tag[slot] = (uint32_t)j | (1u << 17);
                 }
@@ -277,14 +261,14 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
             const uint64_t mb = __ballot(b_in);
             if (b_in) {
                 const int slot = ncand + __popcll(mb & lanemask_lt());
-                if (slot < 64) {
+                if (slot < LH_CAND_CAP) {
                     h.cand_val[slot] = bv;
                     h.cand_tag[slot] = (uint32_t)j | (1u << 16) | (1u << 17);
                 }
             }
             ncand += __popcll(mb);
         }
-        if (ncand > 64) return true;
+        if (ncand > LH_CAND_CAP) return true;
         wave_lds_sync();
         const bool has = lane < ncand;
         const float v = has ? h.cand_val[lane] : 0.f;
@@ -350,6 +334,73 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
     return false;
 }
 
+/* Pair lists of one direction (built when the ion types change direction: one direction's lists at a time halve
+ * the room they need): list 0 = the winner's (prefix | variant << 8) pairs; per competitor cc the in-span prefixes
+ * (h.ispan[cc - 1]: loss variants differ, or running sums differ by more than tau), list 1 + 2 (cc - 1) = the
+ * winner's pair indices on them (A), list 2 + 2 (cc - 1) = the competitor's pairs on them (B).  True = no room. */
+DEV bool lh_build_lists(const LocCtx &c, const HashLds &h, int S, int d, float tau, bool nn) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    const int Lm1 = c.L - 1;
+    uint32_t npairs = 0;
+    {
+        uint32_t pw = 0;
+        if (lane < Lm1) pw = nn ? (uint32_t)w.pmk[(size_t)d * c.pos_cap + lane] : 1u;
+        int tot;
+        int at = wave_excl_scan_i32(__popc(pw), &tot);
+        if ((uint32_t)tot > h.pp) return true;
+        while (pw) {
+            const int v = __builtin_ctz(pw);
+            pw &= pw - 1;
+            h.pairs[at++] = (uint16_t)(lane | (v << 8));
+        }
+        if (lane == 0) {
+            h.off[0] = 0;
+            h.cnt[0] = (uint16_t)tot;
+        }
+        npairs = (uint32_t)tot;
+    }
+    for (int cc = 1; cc < S; cc++) {
+        bool in = false;
+        uint32_t pw = 0, pc = 0;
+        int cw = 0;
+        if (lane < Lm1) {
+            const size_t iw = (size_t)d * c.pos_cap + lane, ic = (size_t)(cc * 2 + d) * c.pos_cap + lane;
+            const float rw = w.run[iw], rc = w.run[ic];
+            pw = nn ? (uint32_t)w.pmk[iw] : 1u;
+            pc = nn ? (uint32_t)w.pmk[ic] : 1u;
+            cw = nn ? (int)w.cpre[iw] : lane;
+            in = pw != pc || !(__builtin_fabsf(rc - rw) <= tau);
+        }
+        const uint64_t m = __ballot(in);
+        int totA, totB;
+        int atA = wave_excl_scan_i32(in ? __popc(pw) : 0, &totA);
+        int atB = wave_excl_scan_i32(in ? __popc(pc) : 0, &totB);
+        if (npairs + (uint32_t)(totA + totB) > h.pp) {
+            return true;
+        }
+        atA += (int)npairs;
+        atB += (int)npairs + totA;
+        if (in) {
+            for (int vi = 0, n = __popc(pw); vi < n; vi++) h.pairs[atA++] = (uint16_t)(cw + vi);
+            while (pc) {
+                const int v = __builtin_ctz(pc);
+                pc &= pc - 1;
+                h.pairs[atB++] = (uint16_t)(lane | (v << 8));
+            }
+        }
+        if (lane == 0) {
+            h.ispan[cc - 1] = m;
+            h.off[1 + 2 * (cc - 1)] = (uint16_t)npairs;
+            h.cnt[1 + 2 * (cc - 1)] = (uint16_t)totA;
+            h.off[2 + 2 * (cc - 1)] = (uint16_t)(npairs + (uint32_t)totA);
+            h.cnt[2 + 2 * (cc - 1)] = (uint16_t)totB;
+        }
+        npairs += (uint32_t)(totA + totB);
+    }
+    return false;
+}
+
 /* Site-determining ions of competitors 1..S-1 against the winner (entry 0): fills w.c_cnt / w.c_tr and the
  * depth in w.c_depth, as loc_site_ions does.  Returns true when the PSM is declined (nothing to undo: the
  * caller writes no result). */
@@ -384,70 +435,12 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
         return false;
     }
     STAMP_BEGIN();
-    /* ---- pair lists: the winner's (prefix, variant) pairs per direction; per (competitor, direction) the
-     * in-span prefixes, the winner pairs on them (A) and the competitor's pairs on them (B) ---- */
+    /* largest running sum (for the rounding allowance below) */
     const float tau = err * 0.125f;
     float runmax = 0.f;
-    uint32_t npairs = 0;
-    for (int d = 0; d < 2; d++) {
-        uint32_t pw = 0;
-        if (lane < Lm1) {
-            const size_t iw = (size_t)d * c.pos_cap + lane;
-            pw = nn ? (uint32_t)w.pmk[iw] : 1u;
-            runmax = __builtin_fmaxf(runmax, __builtin_fabsf(w.run[iw]));
-        }
-        int tot;
-        int at = (int)npairs + wave_excl_scan_i32(__popc(pw), &tot);
-        if (npairs + (uint32_t)tot > h.pp) return true;
-        while (pw) {
-            const int v = __builtin_ctz(pw);
-            pw &= pw - 1;
-            h.pairs[at++] = (uint16_t)(lane | (v << 8));
-        }
-        if (lane == 0) {
-            h.off[d] = (uint16_t)npairs;
-            h.cnt[d] = (uint16_t)tot;
-        }
-        npairs += (uint32_t)tot;
-    }
-    const int ncd = (S - 1) * 2;
-    for (int cd = 0; cd < ncd; cd++) {
-        const int cc = 1 + (cd >> 1), d = cd & 1;
-        bool in = false;
-        uint32_t pw = 0, pc = 0;
-        int cw = 0;
-        if (lane < Lm1) {
-            const size_t iw = (size_t)d * c.pos_cap + lane, ic = (size_t)(cc * 2 + d) * c.pos_cap + lane;
-            const float rw = w.run[iw], rc = w.run[ic];
-            pw = nn ? (uint32_t)w.pmk[iw] : 1u;
-            pc = nn ? (uint32_t)w.pmk[ic] : 1u;
-            cw = nn ? (int)w.cpre[iw] : lane;
-            in = pw != pc || !(__builtin_fabsf(rc - rw) <= tau);
-            runmax = __builtin_fmaxf(runmax, __builtin_fabsf(rc));
-        }
-        const uint64_t m = __ballot(in);
-        int totA, totB;
-        int atA = wave_excl_scan_i32(in ? __popc(pw) : 0, &totA);
-        int atB = wave_excl_scan_i32(in ? __popc(pc) : 0, &totB);
-        if (npairs + (uint32_t)(totA + totB) > h.pp) return true;
-        atA += (int)npairs;
-        atB += (int)npairs + totA;
-        if (in) {
-            for (int vi = 0, n = __popc(pw); vi < n; vi++) h.pairs[atA++] = (uint16_t)(cw + vi);
-            while (pc) {
-                const int v = __builtin_ctz(pc);
-                pc &= pc - 1;
-                h.pairs[atB++] = (uint16_t)(lane | (v << 8));
-            }
-        }
-        if (lane == 0) {
-            h.ispan[cd] = m;
-            h.off[2 + 2 * cd] = (uint16_t)npairs;
-            h.cnt[2 + 2 * cd] = (uint16_t)totA;
-            h.off[3 + 2 * cd] = (uint16_t)(npairs + (uint32_t)totA);
-            h.cnt[3 + 2 * cd] = (uint16_t)totB;
-        }
-        npairs += (uint32_t)(totA + totB);
+    for (int i = lane; i < S * 2 * Lm1; i += 64) {
+        const int sd = i / Lm1, p = i - sd * Lm1;
+        runmax = __builtin_fmaxf(runmax, __builtin_fabsf(w.run[(size_t)sd * c.pos_cap + p]));
     }
     runmax = wave_max_f32(runmax);
     /* |twin - ion| <= tau + slop: the running sums differ by at most tau, the float32 loss subtraction and the
@@ -463,19 +456,25 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
     const FastDiv divZ = fastdiv_make((uint32_t)zmax);
     wave_lds_sync();
     STAMP_T(*c.b, 30, false);
-    int staged = 0;
+    int staged = 0, lists_dir = -1;
     for (int t = 0; t < T; t++) {
         const int d = t < cfg->n_fwd ? 0 : 1;
+        if (d != lists_dir) {
+            wave_lds_sync();
+            if (lh_build_lists(c, h, S, d, tau, nn)) return true;
+            lists_dir = d;
+            wave_lds_sync();
+        }
         double A, B;
         type_constants(type_at(types64, t), &A, &B);
-        const int offW = (int)h.off[d], nW = (int)h.cnt[d] * zmax;
+        const int offW = (int)h.off[0], nW = (int)h.cnt[0] * zmax;
         if (nW > (int)h.vc) return true;
         /* competitors go together while the table holds them, else one at a time */
         int c0 = 1;
         while (c0 < S) {
             int c1 = c0, nB = 0;
             while (c1 < S) {
-                const int n = (int)h.cnt[3 + 2 * ((c1 - 1) * 2 + d)] * zmax;
+                const int n = (int)h.cnt[2 + 2 * (c1 - 1)] * zmax;
                 if (nW + nB + n > (int)h.vc) break;
                 nB += n;
                 c1++;
@@ -492,7 +491,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
             {
                 int at = nW;
                 for (int cc = c0; cc < c1; cc++) {
-                    const int l = 3 + 2 * ((cc - 1) * 2 + d);
+                    const int l = 2 + 2 * (cc - 1);
                     const int offB = (int)h.off[l], n = (int)h.cnt[l] * zmax;
                     for (int i = lane; i < n; i += 64) {
                         const int pair = (int)fastdiv((uint32_t)i, divZ), z = i - pair * zmax + 1;
@@ -525,9 +524,8 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
             q.divZ = divZ;
             int b_lo = nW;
             for (int cc = c0; cc < c1; cc++) {
-                const int cd = (cc - 1) * 2 + d;
-                const int offA = (int)h.off[2 + 2 * cd];
-                const int nA = (int)h.cnt[2 + 2 * cd] * zmax, nBc = (int)h.cnt[3 + 2 * cd] * zmax;
+                const int offA = (int)h.off[1 + 2 * (cc - 1)];
+                const int nA = (int)h.cnt[1 + 2 * (cc - 1)] * zmax, nBc = (int)h.cnt[2 + 2 * (cc - 1)] * zmax;
                 const int b_hi = b_lo + nBc;
                 for (int base = 0; base < nA + nBc; base += 64) {
                     const int i = base + lane;

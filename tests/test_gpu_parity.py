@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
                         "fused_replay", "general_serial_replay", "packed", "packed_8", "packed_passed_on", "packed_small_pool",
                         "packed_always_sort", "packed_declines", "packed_replay", "big_records", "bin_fused",
-                        "bin_fused_exact", "general_lists", "hash_exact", "hash_declines", "hash_lds_table", "score_walkers", "score_few_nodes"])
+                        "bin_fused_exact", "general_lists", "hash_exact", "hash_declines", "hash_lds_table", "hash_small_lists", "score_walkers", "score_few_nodes"])
 def path(request, monkeypatch):
     """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
     assignments on the fused score + localize kernel and the other plain ones on the lean
@@ -35,6 +35,10 @@ def path(request, monkeypatch):
     monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
     monkeypatch.delenv("PYA_NO_LOC_HASH", raising=False)
     monkeypatch.delenv("PYA_LOC_HASH_LDS_TAB", raising=False)
+    monkeypatch.delenv("PYA_HASH_PP", raising=False)
+    if request.param == "hash_small_lists":        # room for the pair lists of short spans only: a share of the PSMs is handed over
+        monkeypatch.setenv("PYA_NO_PLAIN", "1")
+        monkeypatch.setenv("PYA_HASH_PP", "2")
     if request.param == "hash_lds_table":          # the hash route with the retained table staged in LDS (opt-in: measured slower)
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
         monkeypatch.setenv("PYA_LOC_HASH_LDS_TAB", "1")
