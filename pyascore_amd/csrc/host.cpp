@@ -42,8 +42,9 @@ int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uin
 int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t prefix,
                      uint32_t with_nl, uint32_t compact, uint32_t node_cap, uint32_t node_cols, uint32_t node_words,
-                     hipStream_t stream);
-size_t pya_score_node_lds_bytes(uint32_t cap, uint32_t with_nl, uint32_t node_cap, uint32_t node_cols, uint32_t node_words);
+                     uint32_t res_cap, uint32_t nl_cap, hipStream_t stream);
+size_t pya_score_node_lds_bytes(uint32_t cap, uint32_t with_nl, uint32_t node_cap, uint32_t node_cols, uint32_t node_words,
+                                uint32_t res_cap, uint32_t nl_cap);
 int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap,
                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
                         uint32_t plain, uint32_t sort_room, hipStream_t stream);
@@ -1788,13 +1789,18 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         const Bucket &sbk = p->buckets[l.ncls];
         const bool general = h->cfg.n_nl != 0 || h->cfg.n_fwd > 1 || h->cfg.n_types - h->cfg.n_fwd > 1;
         uint32_t node_cap = 0, node_cols = std::max<uint32_t>(8u, (sbk.node_cols + 7u) & ~7u);
+        /* (the node kernel's LDS decides its occupancy: residue and loss-state tables by the launch, room for 320 nodes
+         * per direction -- cfg4's shape needs 186 on average, 328 at most; a direction with more is walked) */
+        const uint32_t res_cap = std::min<uint32_t>(64u, (sbk.pos_cap + 1u + 3u) & ~3u);
+        const uint32_t nnl_s = (uint32_t)h->cfg.n_nl, nl_cap = nnl_s >= 4u ? 256u : (nnl_s == 0u ? 4u : 1u << (2u * nnl_s));
         if (general && !prefix && !h->kn.no_nodes && sbk.node_words) {
-            node_cap = std::min<uint32_t>(512u, sbk.pos_cap * std::min<uint32_t>(sbk.n_cap, 64u));
-            if (h->kn.node_cap >= 0) node_cap = (uint32_t)h->kn.node_cap;
-            if (pya_score_node_lds_bytes(l.cap, h->cfg.n_nl != 0 ? 1u : 0u, node_cap, node_cols, sbk.node_words) > 64u * 1024u) node_cap = 0;
+            node_cap = std::min<uint32_t>(320u, (sbk.pos_cap * std::min<uint32_t>(sbk.n_cap, 64u) + 1u) & ~1u);
+            if (h->kn.node_cap >= 0) node_cap = (uint32_t)h->kn.node_cap & ~1u;
+            if (pya_score_node_lds_bytes(l.cap, h->cfg.n_nl != 0 ? 1u : 0u, node_cap, node_cols, sbk.node_words, res_cap, nl_cap) > 64u * 1024u)
+                node_cap = 0;
         }
         e = pya_launch_score(&d, p->d_score_ids.p + l.off, l.n, l.cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact, node_cap, node_cols,
-                             sbk.node_words, st);
+                             sbk.node_words, res_cap, nl_cap, st);
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
     }
     for (const pya_plan::IdList &l : p->big_lists) {

@@ -54,7 +54,8 @@ struct PrefixCompact {
  * at level j; then bytes grp[dir][j][s] (rows padded to 8) = rank of the group of s among the groups of level j. */
 struct NodeLds {
     const uint64_t *ntab;   /* LDS copy of the shape table */
-    uint2 *node;            /* [node_cap] {running sum bits, loss state | column << 16} */
+    float *run;             /* [node_cap] running sum of the node's fragment */
+    uint16_t *info;         /* [node_cap] loss state | histogram column << 8 */
     uint16_t *nb;           /* [64] first node of every step */
     uint16_t *sb;           /* [64] first column of every level */
     uint32_t *priv;         /* [PYA_NTOP / 2][64] a column per lane for the lookups of its node */
@@ -80,7 +81,7 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
     int nnodes, ncol;
     const int nbase = wave_excl_scan_i32(G, &nnodes);
     const int sbase = wave_excl_scan_i32(lane <= n_sites ? __popcll(own[lane]) : 0, &ncol);
-    if ((uint32_t)nnodes > nd.node_cap || (uint32_t)ncol > nd.ncols) return false;
+    if ((uint32_t)nnodes > nd.node_cap || (uint32_t)ncol > nd.ncols || ncol > 255) return false;
     if (lane < Lm1) nd.nb[lane] = (uint16_t)nbase;
     if (lane <= n_sites) nd.sb[lane] = (uint16_t)sbase;
     for (uint32_t i = lane; i < (PYA_NTOP / 2) * nd.ncols; i += 64) e.cnt[i] = 0u;
@@ -114,7 +115,11 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
                 segb = nd.sb[j];
             }
             if (active) nfrag += nvar * (uint32_t)(my_types * e.zmax);
-            if (owner) nd.node[(uint32_t)nd.nb[step] + g] = make_uint2(__float_as_uint(running), nl_state | ((segb + g) << 16));
+            if (owner) {
+                const uint32_t at = (uint32_t)nd.nb[step] + g;
+                nd.run[at] = running;
+                nd.info[at] = (uint16_t)(nl_state | ((segb + g) << 8));
+            }
         }
     }
     wave_lds_sync();
@@ -127,9 +132,9 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
     for (int base = 0; base < nnodes; base += 64) {
         const int i = base + lane;
         const bool on_n = i < nnodes;
-        const uint2 ent = on_n ? nd.node[i] : make_uint2(0u, 0u);
-        const float running = __uint_as_float(ent.x);
-        uint32_t pm = on_n ? (e.n_nl ? (uint32_t)e.nl_present[ent.y & 255u] : 1u) : 0u;
+        const float running = on_n ? nd.run[i] : 0.f;
+        const uint32_t inf = on_n ? (uint32_t)nd.info[i] : 0u;
+        uint32_t pm = on_n ? (e.n_nl ? (uint32_t)e.nl_present[inf & 255u] : 1u) : 0u;
         while (__any(pm != 0)) {
             const bool on = pm != 0;
             const int v = on ? __builtin_ctz(pm) : 0;
@@ -163,7 +168,7 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
                 }
             }
         }
-        uint32_t *col = e.cnt + (ent.y >> 16);
+        uint32_t *col = e.cnt + (inf >> 8);
 #pragma unroll
         for (int d = 0; d < PYA_NTOP / 2; d++) {
             const uint32_t c = mine[d * 64];
@@ -191,21 +196,22 @@ DEV bool score_nodes_dir(const WalkEnv &e, const PeakTable &tab, const NodeLds &
 /* NODES: the instantiation with the shared-node route (general settings); the others do not carry its registers */
 template <bool PREFIX, bool NODES = false>
 DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t with_nl,
-                    uint32_t compact, uint32_t node_cap = 0, uint32_t node_cols = 64, uint32_t node_words = 0) {
+                    uint32_t compact, uint32_t node_cap = 0, uint32_t node_cols = 64, uint32_t node_words = 0,
+                    uint32_t res_cap = 64, uint32_t nl_cap = 256) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
 
     uint16_t *grid = (uint16_t *)lds_raw;                       /* [PYA_GRID_CELLS] */
     uint32_t *cnt = (uint32_t *)(grid + PYA_GRID_CELLS);        /* [PYA_NTOP / 2][64] */
     float2 *resd = (float2 *)(cnt + PYA_NTOP / 2 * (node_cap && node_cols > 64u ? node_cols : 64u));   /* [64] (the shared-node route has node_cols columns) */
-    PeakEntry *t_e = (PeakEntry *)(resd + 64);                  /* [cap + PYA_TABLE_PAD] */
+    PeakEntry *t_e = (PeakEntry *)(resd + res_cap);             /* [cap + PYA_TABLE_PAD] (res_cap, nl_cap: 64 and 256, or what the launch needs) */
     unsigned char *tail = (unsigned char *)(t_e + cap + PYA_TABLE_PAD);
     uint16_t *nl_present = nullptr;                             /* [256]          } only with */
     float *nl_uniq = nullptr;                                   /* [PYA_MAX_UNIQ] } neutral   */
     uint8_t *resn = nullptr;                                    /* [64]           } losses    */
     if (with_nl) {
         nl_present = (uint16_t *)tail;
-        nl_uniq = (float *)(nl_present + 256);
+        nl_uniq = (float *)(nl_present + nl_cap);
         resn = (uint8_t *)(nl_uniq + PYA_MAX_UNIQ);
         tail = resn + 64;
     }
@@ -213,8 +219,9 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     PrefixCompact *prc = (PrefixCompact *)tail;                 /* ... or this when `compact`  */
     NodeLds nd;                                                 /* ... or the shared-node tables (never with PREFIX) */
     nd.ntab = (const uint64_t *)tail;
-    nd.node = (uint2 *)(tail + (size_t)node_words * 8);
-    nd.nb = (uint16_t *)(nd.node + node_cap);
+    nd.run = (float *)(tail + (size_t)node_words * 8);
+    nd.info = (uint16_t *)(nd.run + node_cap);
+    nd.nb = nd.info + node_cap;                                 /* (node_cap is even) */
     nd.sb = nd.nb + 64;
     nd.priv = (uint32_t *)(nd.sb + 64);
     nd.b = &b;
@@ -242,7 +249,7 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     env.resn = resn;
     env.cnt = cnt;
     if (env.n_nl) {
-        for (int i = lane; i < 256; i += 64) nl_present[i] = cfg->present[i];
+        for (int i = lane; i < (int)nl_cap; i += 64) nl_present[i] = cfg->present[i];
         if (lane < PYA_MAX_UNIQ) nl_uniq[lane] = cfg->uniq[lane];
     }
     stage_residues(res, resd, resn);
@@ -453,11 +460,11 @@ DEV void score_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
 }
 
 static inline size_t score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact, uint32_t node_cap = 0,
-                                     uint32_t node_cols = 64, uint32_t node_words = 0) {
-    return PYA_GRID_CELLS * 2 + PYA_NTOP / 2 * (node_cap && node_cols > 64u ? node_cols : 64u) * 4 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8 +
-           (with_nl ? 512 + PYA_MAX_UNIQ * 4 + 64 : 0) +
+                                     uint32_t node_cols = 64, uint32_t node_words = 0, uint32_t res_cap = 64, uint32_t nl_cap = 256) {
+    return PYA_GRID_CELLS * 2 + PYA_NTOP / 2 * (node_cap && node_cols > 64u ? node_cols : 64u) * 4 + (size_t)res_cap * 8 +
+           ((size_t)cap + PYA_TABLE_PAD) * 8 + (with_nl ? 2 * (size_t)nl_cap + PYA_MAX_UNIQ * 4 + 64 : 0) +
            (prefix ? 2 * 64 * (compact ? sizeof(PrefixCompact) : sizeof(PrefixState)) : 0) +
-           (node_cap ? (size_t)node_words * 8 + (size_t)node_cap * 8 + 2 * 64 * 2 + PYA_NTOP / 2 * 64 * 4 : 0) + 64;
+           (node_cap ? (size_t)node_words * 8 + (size_t)node_cap * 6 + 2 * 64 * 2 + PYA_NTOP / 2 * 64 * 4 : 0) + 64;
 }
 
 #endif

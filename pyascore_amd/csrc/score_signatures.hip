@@ -34,37 +34,45 @@ __global__ __launch_bounds__(64, SCORE_WAVES) void pya_score_signatures_kernel(B
 
 /* general settings (neutral losses, several ion types per direction): one lookup set per distinct node of the
  * assignment tree (score_core.hip.h: score_nodes_dir), walkers for what does not fit */
-/* (its LDS holds it to four wavefronts per SIMD: the registers to match, no spills) */
-__global__ __launch_bounds__(64, 4) void pya_score_nodes_kernel(BatchDev b, const uint32_t *psm_ids, uint32_t n_ids,
+/* (its time is inversely proportional to its occupancy -- 5.3 / 5.9 / 6.3 ms on cfg4 with 16 / 14 / 12 wavefronts per CU --
+ * so its LDS is sized by the launch to fit five per SIMD, and the registers follow: 96 with a handful of spills) */
+__global__ __launch_bounds__(64, 5) void pya_score_nodes_kernel(BatchDev b, const uint32_t *psm_ids, uint32_t n_ids,
                                                                            uint32_t cap, uint32_t with_nl, uint32_t node_cap,
-                                                                           uint32_t node_cols, uint32_t node_words) {
+                                                                           uint32_t node_cols, uint32_t node_words, uint32_t res_cap,
+                                                                           uint32_t nl_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
-    score_body<false, true>(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, with_nl, 0u, node_cap, node_cols, node_words);
+    score_body<false, true>(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, with_nl, 0u, node_cap, node_cols, node_words,
+                            res_cap, nl_cap);
 }
 
 extern "C" size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact) {
     return score_lds_bytes(cap, prefix, with_nl, compact);
 }
-extern "C" size_t pya_score_node_lds_bytes(uint32_t cap, uint32_t with_nl, uint32_t node_cap, uint32_t node_cols, uint32_t node_words) {
-    return score_lds_bytes(cap, 0, with_nl, 0, node_cap, node_cols, node_words);
+extern "C" size_t pya_score_node_lds_bytes(uint32_t cap, uint32_t with_nl, uint32_t node_cap, uint32_t node_cols, uint32_t node_words,
+                                           uint32_t res_cap, uint32_t nl_cap) {
+    return score_lds_bytes(cap, 0, with_nl, 0, node_cap, node_cols, node_words, res_cap, nl_cap);
 }
 
 /* node_cap != 0 (only without `prefix`): the shared-node route of score_core.hip.h with room for node_cap nodes per
  * direction, node_cols histogram columns and a shape table of node_words 64-bit words */
 extern "C" int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                                 uint32_t prefix, uint32_t with_nl, uint32_t compact, uint32_t node_cap, uint32_t node_cols,
-                                uint32_t node_words, hipStream_t stream) {
+                                uint32_t node_words, uint32_t res_cap, uint32_t nl_cap, hipStream_t stream) {
     if (n_ids == 0) return 0;
     /* spectra near the 8192-peak limit need more than the default 64 KB of dynamic LDS */
     if (!prefix) compact = 0;
     if (prefix) node_cap = 0;
-    const size_t lds = score_lds_bytes(cap, prefix, with_nl, compact, node_cap, node_cols, node_words);
+    if (!node_cap) {
+        res_cap = 64;
+        nl_cap = 256;
+    }
+    const size_t lds = score_lds_bytes(cap, prefix, with_nl, compact, node_cap, node_cols, node_words, res_cap, nl_cap);
     if (node_cap) {
         hipError_t en = PYA_ENSURE_MAX_LDS(pya_score_nodes_kernel);
         if (en != hipSuccess) return (int)en;
         hipLaunchKernelGGL(pya_score_nodes_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, cap, with_nl, node_cap,
-                           node_cols, node_words);
+                           node_cols, node_words, res_cap, nl_cap);
         return (int)hipGetLastError();
     }
     hipError_t e = prefix ? PYA_ENSURE_MAX_LDS(pya_score_signatures_kernel<true>)
