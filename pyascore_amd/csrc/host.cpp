@@ -1262,6 +1262,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             Bucket &bk = p->buckets[0];                 /* unambiguous / empty: cheapest launch */
             bk.general_ids.push_back((uint32_t)i);
             bk.n_cap = std::max<uint32_t>(bk.n_cap, (uint32_t)N);
+            /* (its peptide still goes through the score kernel of this class, whose residue table is sized by pos_cap) */
+            bk.pos_cap = std::max<uint32_t>(bk.pos_cap, (uint32_t)std::max<int64_t>(L - 1, 1));
         }
         p->ncls[i] = (uint8_t)cls_of_i;
     }
