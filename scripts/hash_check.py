@@ -20,6 +20,10 @@ cases = [("cfg4", n, {}),
          ("cfg2", n, dict(mz_error=0.5)),
          ("cfg4", n, dict(mod_mass=57.02146)),          # glycine: in-span ions land on other prefixes' ions
          ("cfg4", n, dict(mz_error=0.2)),
+         ("cfg4", n, dict(mz_error=0.01)),              # tau and the rounding allowance are of the same order
+         ("cfg4", n, dict(mz_error=0.007)),
+         ("cfg4", n, dict(mz_error=0.005)),             # ... and here the route declines (allowance > tolerance / 2)
+         ("cfg4", n, dict(mz_error=1.5)),               # everything has neighbours
          ("cfg3", 2 * n, {})]
 bad_total = 0
 for cfg, nn, over in cases:
