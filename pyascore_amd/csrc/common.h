@@ -111,9 +111,12 @@ struct BatchDev {
      * pya_bin_exact_kernel, 512 the lean localize instantiation declines every PSM, 1024 the
      * std::sort emulation runs even for a unique best PepScore, 2048 the fused kernel replays every
      * (competitor, direction) task with the serial walk (and pairs ions over whole lists, not spans),
-     * 4096 the general localize instantiation replays a task with a doubly partnered ion serially
-     * instead of walking its clusters in parallel.  Bits 16..31: truncation point of the diagnostic
-     * build (device_common.hip.h, STAMP_T). */
+     * 4096 the list-based general localize instantiation replays a task with a doubly partnered ion serially
+     * instead of walking its clusters in parallel, 8192 the hash route of the general localize declines every
+     * PSM (hand-over list, list-based kernel), 16384 it sends every in-span ion through the exact run walk,
+     * 256 score_signatures walks every signature under general settings (no shared tree nodes), 0x8000 the
+     * packed fused kernel passes every slot on.  Ablation: 2 the hash route looks no surviving ion up.
+     * Bits 16..31: truncation point of the diagnostic build (device_common.hip.h, STAMP_T). */
     uint32_t debug;
     unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */
 };

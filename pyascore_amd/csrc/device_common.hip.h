@@ -390,51 +390,6 @@ DEV int match_rank_global(const PeakTable &t, float f) {
     return best;
 }
 
-/* two lookups in the workspace table with their memory round trips overlapped (grid cells together, then the
- * entries together); same result as match_rank_global for each */
-DEV void match_rank_global2(const PeakTable &t, float f0, float f1, int *r0, int *r1) {
-    if (t.n <= 0) {
-        *r0 = PYA_NO_MATCH;
-        *r1 = PYA_NO_MATCH;
-        return;
-    }
-    const float lo0 = f0 - t.err, hi0 = f0 + t.err, lo1 = f1 - t.err, hi1 = f1 + t.err;
-    const int c0 = grid_cell(t, lo0), c1 = grid_cell(t, lo1);
-    const int i0 = (int)t.g_cell[c0], i1 = (int)t.g_cell[c1];
-    const int last = t.n - 1;
-    const uint4 *p0 = (const uint4 *)(t.g_e + i0), *p1 = (const uint4 *)(t.g_e + i1);
-    const uint4 a0 = p0[0], b0 = p0[1], a1 = p1[0], b1 = p1[1];
-    int best[2] = {PYA_NO_MATCH, PYA_NO_MATCH};
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const uint4 a = q ? a1 : a0, c = q ? b1 : b0;
-        const float lo = q ? lo1 : lo0, hi = q ? hi1 : hi0, f = q ? f1 : f0;
-        int idx = q ? i1 : i0;
-        const float m[4] = {__uint_as_float(a.x), __uint_as_float(a.z), __uint_as_float(c.x), __uint_as_float(c.z)};
-        const int r[4] = {(int)a.y, (int)a.w, (int)c.y, (int)c.w};
-        int bq = PYA_NO_MATCH;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            bool in = idx + j <= last && m[j] > lo && m[j] < hi;
-            if (t.half_check) in = in && (double)f >= (double)m[j] - 0.5;
-            bq = in && r[j] < bq ? r[j] : bq;
-        }
-        if (idx + 3 < last && m[3] < hi) {                    /* rare: more than four entries to look at */
-            for (idx += 4; idx <= last; idx++) {
-                const PeakEntry x = t.g_e[idx];
-                if (!(x.mz < hi)) break;
-                if (x.mz > lo && (!t.half_check || (double)f >= (double)x.mz - 0.5)) {
-                    const int rr = (int)x.rank;
-                    bq = rr < bq ? rr : bq;
-                }
-            }
-        }
-        best[q] = bq;
-    }
-    *r0 = best[0];
-    *r1 = best[1];
-}
-
 /* Four entries from the even index at or below `idx`, as two 16-byte reads: the LDS serves a
  * ds_read_b128 in 4 cycles and a ds_read2_b64 (what four 8-byte entries from an odd index become) in
  * 8, and the lookups of a walk are what fills the LDS pipe.  An entry below idx sits in an earlier
