@@ -87,9 +87,15 @@ __host__ __device__ static inline size_t fused_sort_bytes(uint32_t n) {
  * has no use for them -- a task with a doubly partnered ion, which its residue-mass condition all but
  * rules out, is handed to the general kernel instead of being replayed here -- and without them the
  * post region is no larger than the walk region it overlays: a fifth more wavefronts per CU on cfg2. */
+/* entries of the three per-site arrays: a PSM's modified sites number at most its single-move competitors (k <= k (n - k)
+ * for an ambiguous PSM), which push_cap bounds */
+__host__ __device__ static inline uint32_t fused_site_cap(uint32_t push_cap) {
+    const uint32_t v = (push_cap + 3u) & ~3u;
+    return v > 64u ? 64u : (v < 4u ? 4u : v);
+}
 __host__ __device__ static inline size_t fused_post_bytes(uint32_t n_cap, uint32_t push_cap, uint32_t ent_cap, uint32_t ndir,
                                                           bool multi_z) {
-    return fused_align16(fused_sort_bytes(n_cap)) + (size_t)push_cap * 16 + 64 * 8 + 64 * 4 * 2 + 16 +
+    return fused_align16(fused_sort_bytes(n_cap)) + (size_t)push_cap * 16 + (size_t)fused_site_cap(push_cap) * 16 + 16 +
            (size_t)(1 + FUSED_ROUND) * 40 + (size_t)FUSED_ROUND * (16 * ndir + 4 + 4) + 16 + 64 +
            (multi_z ? fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap * 4) +
                           fused_align16((size_t)FUSED_ROUND * ndir * 2 * ent_cap)
@@ -124,12 +130,13 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
     size_t q = o + fused_align16(fused_sort_bytes(n_cap));
     f.pushed = (PushedEntry *)(raw + q);
     q += (size_t)push_cap * sizeof(PushedEntry);
+    const size_t sc = fused_site_cap(push_cap);
     f.site_alt = (unsigned long long *)(raw + q);
-    q += 64 * 8;
+    q += sc * 8;
     f.site_max = (uint32_t *)(raw + q);
-    q += 64 * 4;
+    q += sc * 4;
     f.site_tie = (uint32_t *)(raw + q);
-    q += 64 * 4;
+    q += sc * 4;
     f.n_pushed = (uint32_t *)(raw + q);
     q += 16;
     f.sc = (float *)(raw + q);
@@ -478,9 +485,11 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         const uint64_t at_max = __ballot(sig_lane && u == kmax);
         best_i = (uint32_t)__builtin_ctzll(at_max);
         if (lane == 0) *f.n_pushed = 0;
-        f.site_max[lane] = 0;
-        f.site_tie[lane] = 0;
-        f.site_alt[lane] = 0ull;
+        if ((uint32_t)lane < fused_site_cap(push_cap)) {
+            f.site_max[lane] = 0;
+            f.site_tie[lane] = 0;
+            f.site_alt[lane] = 0ull;
+        }
         if (__popcll(at_max) != 1 || (b.debug & 1024)) {
             const SortLds srt = sort_carve(f.sort_raw, N);
             if (sig_lane) {
