@@ -205,7 +205,7 @@ struct Knobs {
     bool no_plain = false, no_fused = false, no_big = false, no_tiny = false, no_prefix = false, no_chunks = false;
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
     bool host_timing = false, stamps = false, pack = false, sort_room = false, no_big_inline = false, bin_fused = false;
-    bool no_loc_hash = false, loc_hash_lds_tab = false, no_nodes = false;
+    bool no_loc_hash = false, loc_hash_lds_tab = false, no_nodes = false, recount_lds_tab = false;
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64, pack_min = 512, pack_group_min = 256;
     uint32_t pack_g = 4, pack_peaks = 208, sort_room_max = 1024;
@@ -238,6 +238,7 @@ static void read_knobs(Knobs &k) {
     k.bin_fused = flag("PYA_BIN_FUSED");
     k.no_loc_hash = flag("PYA_NO_LOC_HASH");
     k.no_nodes = flag("PYA_NO_NODES");
+    k.recount_lds_tab = flag("PYA_RECOUNT_LDS_TAB");
     k.node_cap = (int)num("PYA_NODE_CAP", -1);
     k.loc_hash_lds_tab = flag("PYA_LOC_HASH_LDS_TAB");
     if (const char *d = std::getenv("PYA_DEBUG")) k.debug = (uint32_t)std::strtoul(d, nullptr, 0);
@@ -1866,7 +1867,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
          * named; what that declines is scored again with count records and goes to the general localize body */
         const Bucket &bl = p->bigloc;
         HIPCHK(h, hipMemsetAsync(p->d_redo5.p, 0, sizeof(uint32_t), st));
-        e = pya_launch_localize_recount(&d, bl.d_ids.p, (uint32_t)bl.ids.size(), p->peak_cap, bl.push_cap(), bl.pos_cap, bl.pool_cap(),
+        e = pya_launch_localize_recount(&d, bl.d_ids.p, (uint32_t)bl.ids.size(), h->kn.recount_lds_tab ? p->peak_cap : 0u, bl.push_cap(), bl.pos_cap, bl.pool_cap(),
                                         bl.sb(), bl.gtp(), p->d_redo5.p, st);
         if (e) return h->hip_fail((hipError_t)e, "localize (recount) launch");
         e = pya_launch_score_big_list(&d, p->d_redo5.p, p->d_redo5.p + 64, p->n_big_inline, p->peak_cap, p->big_pos_cap, st);

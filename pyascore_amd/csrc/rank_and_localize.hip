@@ -92,9 +92,11 @@ __global__ __launch_bounds__(64, LOC_WAVES_PLAIN) void pya_localize_recount_kern
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
     const int lane = lane_id();
+    /* cap = 0: the table and the grid stay in the workspace (lookups are a small share of this kernel, and its time
+     * follows its occupancy: 13.3 KB = 12 wavefronts per CU with the table staged, 9.9 KB = 16 without) */
     PeakEntry *t_e = (PeakEntry *)lds_raw;
-    uint16_t *grid = (uint16_t *)(lds_raw + ((size_t)cap + PYA_TABLE_PAD) * 8);
-    uint32_t *rec_batch = (uint32_t *)(grid + PYA_GRID_CELLS);
+    uint16_t *grid = (uint16_t *)(lds_raw + (cap ? ((size_t)cap + PYA_TABLE_PAD) * 8 : 0));
+    uint32_t *rec_batch = (uint32_t *)(grid + (cap ? PYA_GRID_CELLS : 0));
     uint32_t *hist = rec_batch + PYA_LOC_SB_MAX * PYA_REC_WORDS;
     unsigned char *rest = (unsigned char *)(hist + PYA_LOC_SB_MAX * PYA_NTOP);
     bool declined = true;
@@ -107,7 +109,11 @@ __global__ __launch_bounds__(64, LOC_WAVES_PLAIN) void pya_localize_recount_kern
     in.rec_batch = rec_batch;
     in.hist = hist;
     if (!ok || top[1] == 1u) {
-        if (ok) {
+        if (ok && !cap) {
+            PeakTable tab;
+            global_peak_table(b, psm, &tab);
+            in.tab = tab;
+        } else if (ok) {
             PeakTable tab;
             stage_peak_table(b, psm, t_e, &tab);
             ((uint64_t *)grid)[lane] = ((const uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane];
@@ -247,7 +253,7 @@ extern "C" int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids
 }
 
 extern "C" size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb) {
-    return ((size_t)cap + PYA_TABLE_PAD) * 8 + PYA_GRID_CELLS * 2 + PYA_LOC_SB_MAX * (PYA_REC_WORDS + PYA_NTOP) * 4 +
+    return (cap ? ((size_t)cap + PYA_TABLE_PAD) * 8 + PYA_GRID_CELLS * 2 : 0) + PYA_LOC_SB_MAX * (PYA_REC_WORDS + PYA_NTOP) * 4 +
            pya_localize_lds_bytes(push_cap, 0, pos_cap, pool_cap, sb) + 64;
 }
 
