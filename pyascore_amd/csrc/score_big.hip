@@ -288,6 +288,8 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         l1[dir * 64 + lane] = pc;
     }
     __syncthreads();
+    STAMP_BEGIN();
+    STAMP_T(b, 9, );
     /* ---- level 2: the patterns of the first 10 sites that a signature can have (at most k modified,
      * enough sites left for the rest), resumed from level 1 ---- */
     for (int base = 0; base < 2 * 1024; base += 64 * BIG_WAVES) {
@@ -312,6 +314,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         wave_lds_sync();
     }
     __syncthreads();
+    STAMP_T(b, 10, );
     /* ---- the signatures: resume from the level-2 patterns, walk the rest of both directions ---- */
     int lut_fail = 0;
     uint32_t top_u = 0, top_n = 0, top_i = 0xffffffffu;
@@ -369,6 +372,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         }
         wave_lds_sync();
     }
+    STAMP_T(b, 11, );
     /* (the PepScores are read back below by other wavefronts of this workgroup: the barriers' workgroup-scope
      * fences order that; an agent-scope fence here -- an L2 write-back per wavefront -- doubled the kernel's time) */
     /* ---- summary of the scores over the eight wavefronts ---- */
@@ -438,6 +442,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     if (b.debug & 8u) return;
     bool ood;
     const uint32_t best_i = wg_spine_front(srt, (int)N, kmax, &ood);
+    STAMP_T(b, 12, );
     if (tid == 0 && !ood) {                                      /* (out of depth: the count stays, the localize kernel hands the PSM over) */
         uint32_t *t = b.ws_top + (size_t)psm * 4;
         t[1] = 1u;
