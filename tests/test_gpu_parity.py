@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
                         "fused_replay", "general_serial_replay", "packed", "packed_8", "packed_passed_on", "packed_small_pool",
                         "packed_always_sort", "packed_declines", "packed_replay", "big_records", "bin_fused",
-                        "bin_fused_exact", "general_lists", "hash_exact", "hash_declines", "hash_lds_table", "hash_small_lists", "score_walkers", "score_few_nodes"])
+                        "bin_fused_exact", "general_lists", "hash_exact", "hash_declines", "hash_lds_table", "hash_small_lists", "score_walkers", "score_few_nodes", "recount_lds_table"])
 def path(request, monkeypatch):
     """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
     assignments on the fused score + localize kernel and the other plain ones on the lean
@@ -36,6 +36,11 @@ def path(request, monkeypatch):
     monkeypatch.delenv("PYA_NO_LOC_HASH", raising=False)
     monkeypatch.delenv("PYA_LOC_HASH_LDS_TAB", raising=False)
     monkeypatch.delenv("PYA_HASH_PP", raising=False)
+    # the recounting lean localize launch (PSMs score_big scored) with the retained table staged in LDS instead of left in
+    # the workspace (time-neutral; the default keeps the LDS)
+    monkeypatch.delenv("PYA_RECOUNT_LDS_TAB", raising=False)
+    if request.param == "recount_lds_table":
+        monkeypatch.setenv("PYA_RECOUNT_LDS_TAB", "1")
     if request.param == "hash_small_lists":        # room for the pair lists of short spans only: a share of the PSMs is handed over
         monkeypatch.setenv("PYA_NO_PLAIN", "1")
         monkeypatch.setenv("PYA_HASH_PP", "2")
