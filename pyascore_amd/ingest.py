@@ -108,6 +108,45 @@ class MassCorrector:
             out_mass.extend(m)
         return np.array(out_pos), np.array(out_mass)
 
+    def correct_numpy(self, peptide, positions, masses):
+        """The reference's deprecated array form (id_parsers.py:133-180), kept for callers that still use it: the
+        first reported modification is tried as an n-terminal one (at position 0; folded into the first residue's
+        mass at position 1; or merged with a modification of the first residue, in which case the n-terminal part
+        is split off and -- as in the reference -- subtracted from ``masses[0]`` in place); every other reported
+        mass must equal residue + known modification within ``mz_tol`` or a ValueError names the offenders.
+        Returns (positions array, masses array)."""
+        positions = np.asarray(positions)
+        if positions.size == 0:
+            return np.array([]), np.array([])
+        inf = float("inf")
+        out_pos, out_mass = [], []
+        first = peptide[0]
+        n_mod = self.mod_mass_dict.get("n", inf)
+        res0 = STD_AA_MASS.get(first, inf)
+        if positions[0] == 0 and _close(masses[0], n_mod, self.mz_tol):
+            out_pos.append(0.)
+            out_mass.append(n_mod)
+            positions, masses = positions[1:], masses[1:]
+        elif positions[0] == 1 and _close(masses[0], res0 + n_mod, self.mz_tol):
+            out_pos.append(0.)
+            out_mass.append(n_mod)
+            positions, masses = positions[1:], masses[1:]
+        elif positions[0] == 1 and _close(masses[0], res0 + self.mod_mass_dict.get(first, inf) + n_mod, self.mz_tol):
+            out_pos.append(0)
+            out_mass.append(n_mod)
+            masses[0] -= n_mod
+        if positions.size > 0:
+            on_residue = [int(p) for p in positions if p != 0]
+            std = np.array([STD_AA_MASS.get(peptide[p - 1], inf) for p in on_residue])
+            mods = np.array([self.mod_mass_dict.get(peptide[p - 1], inf) for p in on_residue])
+            ok = np.isclose(masses, std + mods, rtol=0., atol=self.mz_tol)
+            if np.any(~ok):
+                raise ValueError("Unrecognized mod at positions, {}, with masses, {}".format(
+                    positions[np.where(~ok)], np.asarray(masses)[np.where(~ok)]))
+            out_pos.extend(positions)
+            out_mass.extend(mods)
+        return np.array(out_pos), np.array(out_mass)
+
 
 # ------------------------------------------------------------------------------------------------
 # XML helpers

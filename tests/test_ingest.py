@@ -325,3 +325,33 @@ def test_command_line_end_to_end(tmp_path):
                                     str(tmp_path / "b.tsv")]), log=lambda *_: None)
     first_hits = [r for i, r in enumerate(want) if i == 0 or want[i - 1][0] != r[0]]
     assert rows2 == first_hits
+
+
+def test_mass_corrector_numpy_form():
+    """MassCorrector.correct_numpy, the reference's deprecated array form (id_parsers.py:133-180), on cases whose
+    answers follow from its rules by hand: residue + modification masses come back as the known modification;
+    an n-terminal acetylation reported at position 0, folded into residue 1, or merged with a modification of
+    residue 1 is split off; an unknown mass is an error that names position and mass."""
+    from pyascore_amd.ingest import MassCorrector, STD_AA_MASS, COMMON_MODS
+    mc = MassCorrector(mz_tol=1.5)
+    ser, met, n_ac = STD_AA_MASS["S"], STD_AA_MASS["M"], COMMON_MODS["n"]
+    # empty
+    pos, mass = mc.correct_numpy("PEPTIDE", np.array([]), np.array([]))
+    assert pos.size == 0 and mass.size == 0
+    # two modified residues, masses reported as residue + (rounded) modification
+    pos, mass = mc.correct_numpy("ASMK", np.array([2, 3]), np.array([ser + 79.97, met + 16.0]))
+    assert pos.tolist() == [2, 3] and np.allclose(mass, [COMMON_MODS["S"], COMMON_MODS["M"]], rtol=0, atol=1e-12)
+    # n-terminal modification reported at position 0
+    pos, mass = mc.correct_numpy("SAK", np.array([0, 1]), np.array([42.01, ser + 79.97]))
+    assert pos.tolist() == [0, 1] and np.allclose(mass, [n_ac, COMMON_MODS["S"]], rtol=0, atol=1e-12)
+    # ... folded into the first residue's mass
+    pos, mass = mc.correct_numpy("AMK", np.array([1, 2]), np.array([STD_AA_MASS["A"] + 42.01, met + 15.99]))
+    assert pos.tolist() == [0, 2] and np.allclose(mass, [n_ac, COMMON_MODS["M"]], rtol=0, atol=1e-12)
+    # ... merged with a modification of the first residue: split, and the caller's mass loses the n-terminal part
+    reported = np.array([ser + 79.966331 + n_ac])
+    pos, mass = mc.correct_numpy("SAK", np.array([1]), reported)
+    assert pos.tolist() == [0, 1] and np.allclose(mass, [n_ac, COMMON_MODS["S"]], rtol=0, atol=1e-12)
+    assert abs(reported[0] - (ser + 79.966331)) < 1e-9
+    # an unknown mass
+    with pytest.raises(ValueError, match="Unrecognized mod at positions"):
+        mc.correct_numpy("ASK", np.array([2]), np.array([ser + 120.0]))
