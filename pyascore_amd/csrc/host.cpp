@@ -411,13 +411,14 @@ struct Bucket {
      * (a PSM that needs more is declined and goes to the list-based kernel). */
     uint32_t hash_vc() const { return (2u * list_max + 15u) & ~15u; }
     uint32_t hash_hs() const {
-        uint32_t v = 64u;
-        while (v < 2u * hash_vc()) v <<= 1;
+        uint32_t v = 64u;                              /* (a third full at most: 10.15 against 10.45 ms on cfg4 with half) */
+        while (v < 3u * hash_vc()) v <<= 1;
         return v;
     }
     /* one direction's pair lists at a time: the winner's and, per competitor of a batch, its in-span pairs on both sides
-     * -- room for the worst case, so the hash route never declines for lack of it (PYA_HASH_PP: a smaller multiple of
-     * pair_cap, for the tests of the hand-over) */
+     * -- room for the worst case, so the hash route never declines for lack of it (PYA_HASH_PP: another multiple of
+     * pair_cap, for the tests of the hand-over; 6 instead of 7 measured 4 % slower on cfg4 at the same occupancy: where
+     * the arrays behind the lists land in the LDS banks) */
     uint32_t hash_pp() const { return ((g_knob_hash_pp > 0 ? (uint32_t)g_knob_hash_pp : 1u + 2u * (sb() - 1u)) * pair_cap + 7u) & ~7u; }
     bool hash_ok(uint32_t tab_cap, uint32_t max_k, uint32_t n_nl) const {
         return pos_cap <= 64u && hash_vc() <= 8192u &&

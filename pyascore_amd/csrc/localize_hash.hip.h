@@ -450,7 +450,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
     const float reach = err + margin + slop;
     if (!(margin + slop < 0.5f * err)) return true;          /* (huge masses against a tiny tolerance) */
     const float qr = reach + slop;                           /* cells asked: those of x -+ qr */
-    const float inv_cw = 1.f / (2.5f * qr);
+    const float inv_cw = 1.f / (16.f * qr);                 /* (wide cells: an ion's window lies in one cell seven times out of eight, and cells stay almost empty) */
     const int hshift = 32 - (31 - __builtin_clz(h.hs));
     const float R = 8.f * err;                               /* window of the exact route */
     const FastDiv divZ = fastdiv_make((uint32_t)zmax);
