@@ -2,25 +2,33 @@
 
     python -m pyascore_amd.build [--force]
 
-Device code (*.hip) is compiled by hipcc for gfx950 only; the host side (host.cpp,
-score_table.cpp) by g++ so the float32 score-table chain is evaluated by the same compiler
-family and libm as the reference (DESIGN.md "Exactness").  -ffp-contract=off everywhere.
+Device code (*.hip) is compiled by hipcc for gfx950 only; the host side (*.cpp) by g++ so the float32
+score-table chain is evaluated by the same compiler family and libm as the reference (DESIGN.md
+"Exactness").  -ffp-contract=off everywhere.
+
+What makes an object stale is CONTENT, not a hand-kept header list and not time stamps: every compile
+writes the compiler's own dependency list (-MD), and `<obj>.flags` keeps the flags and a SHA-256 over
+the bytes of every file of that list inside this repository.  An object is rebuilt when that record
+differs from what the tree holds now.  The library carries `tree_digest()` — a SHA-256 over every file
+under csrc/ and include/ — in `pya_version()`, so a test can prove that the binary it ran is the
+source it sees (tests/test_c_abi.py, tests/test_gpu_parity.py).
 """
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 import sys
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.realpath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libpyascore_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-DEVICE_SRC = ["bin_spectra.hip", "score_signatures.hip", "score_big.hip", "rank_and_localize.hip", "score_localize.hip", "tiny_batch.hip"]
-HOST_SRC = ["host.cpp", "score_table.cpp", "aux_api.cpp"]
-HEADERS = ["common.h", "device_common.hip.h", "bin_core.hip.h", "walk_core.hip.h", "score_core.hip.h",
-           "localize_core.hip.h", "localize_body.hip.h", "fused_core.hip.h", "fused_pack.hip.h", "binom_chain.h", os.path.join("..", "..", "include", "pyascore_hip.h"),
-           os.path.join("..", "..", "include", "pyascore_aux.h")]
+SOURCE_EXT = (".hip", ".cpp", ".h")
+VERSION_SRC = "version.cpp"          # compiled at every link with the tree digest as a macro
 
 DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
                 "-fno-fast-math", "-Wall", "-Wno-unused-function"]
@@ -28,25 +36,73 @@ HOST_FLAGS = ["-O2", "-fPIC", "-pthread", "-std=c++17", "-ffp-contract=off", "-W
               "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")]
 
 
-def _stale(target, deps, flags=None):
-    """Older than a dependency, or built with other flags (kept in <target>.flags)."""
-    if not os.path.exists(target):
+def source_files():
+    """Every source file of the library: csrc/ and include/, sorted by repository-relative path."""
+    out = []
+    for d in (CSRC, INCLUDE):
+        for name in os.listdir(d):
+            if name.endswith(SOURCE_EXT):
+                out.append(os.path.join(d, name))
+    return sorted(out, key=lambda p: os.path.relpath(p, ROOT))
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        rel = os.path.relpath(p, ROOT).replace(os.sep, "/")
+        with open(p, "rb") as f:
+            body = f.read()
+        h.update(rel.encode() + b"\0" + str(len(body)).encode() + b"\0" + body)
+    return h.hexdigest()
+
+
+def tree_digest():
+    """SHA-256 over (path, bytes) of every file under csrc/ and include/ with a source extension."""
+    return _digest(source_files())
+
+
+def _deps_of(obj):
+    """The files of this repository the compiler read for `obj` (from its -MD output), or None."""
+    try:
+        with open(obj + ".d") as f:
+            text = f.read()
+    except OSError:
+        return None
+    words = text.replace("\\\n", " ").split()
+    deps = set()
+    for w in words:
+        if w.endswith(":"):
+            continue
+        p = os.path.realpath(w)
+        if p.startswith(ROOT + os.sep):
+            deps.add(p)
+    return sorted(deps)
+
+
+def _record(flags, deps):
+    return " ".join(flags) + "\n" + _digest(deps) + "\n"
+
+
+def _stale(obj, flags):
+    if not os.path.exists(obj):
         return True
-    if flags is not None:
-        try:
-            with open(target + ".flags") as f:
-                if f.read() != " ".join(flags):
-                    return True
-        except OSError:
-            return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    deps = _deps_of(obj)
+    if deps is None or any(not os.path.exists(d) for d in deps):
+        return True
+    try:
+        with open(obj + ".flags") as f:
+            return f.read() != _record(flags, deps)
+    except OSError:
+        return True
 
 
 def _compile(cmd, flags, src, obj):
-    _run(cmd + flags + ["-c", src, "-o", obj])
+    for stale in (obj, obj + ".flags"):
+        if os.path.exists(stale):
+            os.remove(stale)
+    _run(cmd + flags + ["-MD", "-MF", obj + ".d", "-c", src, "-o", obj])
     with open(obj + ".flags", "w") as f:
-        f.write(" ".join(flags))
+        f.write(_record(flags, _deps_of(obj)))
 
 
 def _run(cmd):
@@ -56,26 +112,32 @@ def _run(cmd):
 
 def build(force=False):
     dflags = list(DEVICE_FLAGS)
-    if os.environ.get("PYA_LOC_WAVES"):         # A/B experiments on the localize kernel's occupancy target
-        dflags.append("-DLOC_WAVES=" + os.environ["PYA_LOC_WAVES"])
-    if os.environ.get("PYA_DEFS"):              # other -D switches for A/B builds
+    if os.environ.get("PYA_DEFS"):              # -D switches for A/B builds
         dflags += os.environ["PYA_DEFS"].split()
     if os.environ.get("PYA_BUILD_STAMPS"):      # diagnostic build with in-kernel phase stamps
         dflags.append("-DPYA_STAMPS")
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objs = []
-    for src in DEVICE_SRC:
-        s, o = os.path.join(CSRC, src), os.path.join(CSRC, src + ".o")
-        if force or _stale(o, [s] + hdrs, dflags):
-            _compile([HIPCC], dflags, s, o)
+    jobs, objs = [], []
+    for name in sorted(os.listdir(CSRC)):
+        if name == VERSION_SRC or not name.endswith((".hip", ".cpp")):
+            continue
+        s, o = os.path.join(CSRC, name), os.path.join(CSRC, name + ".o")
+        cmd, flags = ([HIPCC], dflags) if name.endswith(".hip") else (["g++"], HOST_FLAGS)
+        if force or _stale(o, flags):
+            jobs.append((cmd, flags, s, o))
         objs.append(o)
-    for src in HOST_SRC:
-        s, o = os.path.join(CSRC, src), os.path.join(CSRC, src + ".o")
-        if force or _stale(o, [s] + hdrs, HOST_FLAGS):
-            _compile(["g++"], HOST_FLAGS, s, o)
-        objs.append(o)
-    if force or _stale(LIB, objs):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        for fut in [pool.submit(_compile, *j) for j in jobs]:
+            fut.result()
+    # the version object names the tree it was linked from; it is stale whenever anything changed
+    digest = tree_digest()
+    vflags = HOST_FLAGS + ['-DPYA_TREE_DIGEST="%s"' % digest]
+    vs, vo = os.path.join(CSRC, VERSION_SRC), os.path.join(CSRC, VERSION_SRC + ".o")
+    relink = force or bool(jobs) or not os.path.exists(LIB)
+    if relink or _stale(vo, vflags):
+        _compile(["g++"], vflags, vs, vo)
+        relink = True
+    if relink:
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + [vo])
     return LIB
 
 

@@ -808,7 +808,6 @@ void fill_dev(pya_plan *p) {
 
 extern "C" {
 
-const char *pya_version(void) { return "pyascore_hip 0.1.0 (gfx950)"; }
 
 int pya_create(const pya_config *cfg, pya_handle **out) {
     if (!cfg || !out) return PYA_ERR_ARG;

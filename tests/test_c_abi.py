@@ -43,6 +43,33 @@ def test_version_string(lib):
     assert b"gfx950" in lib.pya_version()
 
 
+def test_library_names_the_tree_it_was_built_from(lib):
+    """pya_version() carries the SHA-256 of every file under csrc/ and include/ (build.py:tree_digest)."""
+    from pyascore_amd import build
+    assert ("src=" + build.tree_digest()).encode() in lib.pya_version()
+
+
+def test_every_object_was_compiled_from_the_files_in_the_tree(lib):
+    """Each object's record (flags + SHA-256 over the compiler's own dependency list) matches the tree now,
+    the dependency lists cover every header under csrc/ and include/, and the library is not older than
+    its objects."""
+    from pyascore_amd import build, _lib
+    objs = sorted(f for f in os.listdir(build.CSRC) if f.endswith(".o"))
+    srcs = sorted(f + ".o" for f in os.listdir(build.CSRC) if f.endswith((".hip", ".cpp")))
+    assert objs == srcs
+    seen = set()
+    for o in objs:
+        path = os.path.join(build.CSRC, o)
+        deps = build._deps_of(path)
+        assert deps, o
+        seen.update(deps)
+        rec = open(path + ".flags").read().split("\n")
+        assert rec[1] == build._digest(deps), "%s is stale" % o
+        assert os.path.getmtime(_lib.LIB_PATH) >= os.path.getmtime(path), o
+    unused = [p for p in build.source_files() if p not in seen]
+    assert not unused, "in the tree digest but read by no compile: %s" % unused
+
+
 def test_fails_loudly_without_device(lib):
     import torch
     if torch.cuda.is_available():

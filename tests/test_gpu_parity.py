@@ -14,6 +14,20 @@ from pyascore_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+def test_loaded_library_is_built_from_this_tree():
+    """The library this suite runs names the SHA-256 of csrc/ + include/ it was linked from (csrc/version.cpp);
+    recomputed from the tree on this box it must be the same, and every object's own record (flags + digest of
+    the compiler's dependency list) must match too: a stale object cannot pass for HEAD."""
+    from pyascore_amd import _lib, build
+    lib = _lib.load()
+    assert ("src=" + build.tree_digest()).encode() in lib.pya_version(), lib.pya_version()
+    for name in sorted(os.listdir(build.CSRC)):
+        if name.endswith((".hip", ".cpp")):
+            obj = os.path.join(build.CSRC, name + ".o")
+            deps = build._deps_of(obj)
+            assert deps and open(obj + ".flags").read().split("\n")[1] == build._digest(deps), name
+
+
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
                         "fused_replay", "general_serial_replay", "packed", "packed_8", "packed_passed_on", "packed_small_pool",
                         "packed_always_sort", "packed_declines", "packed_replay", "big_records", "bin_fused",
