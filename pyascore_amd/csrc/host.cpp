@@ -83,18 +83,6 @@ size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
                      uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
                      uint32_t multi_z, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
-size_t pya_pack_lds_bytes(uint32_t G, uint32_t pool_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t push_cap, uint32_t kc, uint32_t both);
-int pya_launch_fused_pack(const BatchDev *b, const uint64_t *d_pdesc, uint32_t n_ids, uint32_t G, uint32_t pool_cap, uint32_t n_cap,
-                          uint32_t pos_cap, uint32_t push_cap, uint32_t kc, uint32_t both, uint32_t *d_redo_count,
-                          uint32_t *d_redo_ids, uint32_t *d_over_count, uint32_t *d_over_ids, hipStream_t stream);
-int pya_launch_fused_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
-                          uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
-                          uint32_t multi_z, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
-size_t pya_bin_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap,
-                               uint32_t both, uint32_t multi_z);
-int pya_launch_bin_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap, uint32_t stride,
-                         uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both, uint32_t multi_z,
-                         uint32_t *d_redo_count, uint32_t *d_redo_ids, uint32_t *d_binredo, hipStream_t stream);
 int pya_launch_localize_redo(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max,
                              uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
                              uint32_t gtp, hipStream_t stream);
@@ -204,11 +192,11 @@ float std_residue_mass(char c) {                       /* Types.h:7-30 */
 struct Knobs {
     bool no_plain = false, no_fused = false, no_big = false, no_tiny = false, no_prefix = false, no_chunks = false;
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
-    bool host_timing = false, stamps = false, pack = false, sort_room = false, no_big_inline = false, bin_fused = false;
-    bool no_loc_hash = false, loc_hash_lds_tab = false, no_nodes = false, recount_lds_tab = false;
+    bool host_timing = false, stamps = false, sort_room = false, no_big_inline = false;
+    bool no_loc_hash = false, no_nodes = false;
     uint32_t debug = 0;
-    int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64, pack_min = 512, pack_group_min = 256;
-    uint32_t pack_g = 4, pack_peaks = 208, sort_room_max = 1024;
+    int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64;
+    uint32_t sort_room_max = 1024;
     int sb = -1, gtp = -1;                      /* < 0: the built-in rule */
     int node_cap = -1;                          /* >= 0: room for that many shared nodes per direction (tests: small values force the walkers) */
     double chunk_mb = 0.;                       /* 0: the default chunk size */
@@ -232,23 +220,15 @@ static void read_knobs(Knobs &k) {
     k.one_lds_class = flag("PYA_ONE_LDS_CLASS");
     k.host_timing = flag("PYA_HOST_TIMING");
     k.stamps = flag("PYA_STAMPS");
-    k.pack = flag("PYA_PACK") && !flag("PYA_NO_PACK");
     k.sort_room = flag("PYA_SORT_ROOM");
     k.no_big_inline = flag("PYA_NO_BIG_INLINE");
-    k.bin_fused = flag("PYA_BIN_FUSED");
     k.no_loc_hash = flag("PYA_NO_LOC_HASH");
     k.no_nodes = flag("PYA_NO_NODES");
-    k.recount_lds_tab = flag("PYA_RECOUNT_LDS_TAB");
     k.node_cap = (int)num("PYA_NODE_CAP", -1);
-    k.loc_hash_lds_tab = flag("PYA_LOC_HASH_LDS_TAB");
     if (const char *d = std::getenv("PYA_DEBUG")) k.debug = (uint32_t)std::strtoul(d, nullptr, 0);
     k.plain_min = num("PYA_PLAIN_MIN", 512);
     k.big_min_n = num("PYA_BIG_MIN_N", 1024);
     k.tiny_max = num("PYA_TINY_MAX", 64);
-    k.pack_min = num("PYA_PACK_MIN", 512);
-    k.pack_group_min = num("PYA_PACK_GROUP_MIN", 256);
-    k.pack_g = (uint32_t)num("PYA_PACK_G", 4);
-    k.pack_peaks = (uint32_t)num("PYA_PACK_PEAKS", 208);
     k.sort_room_max = (uint32_t)num("PYA_SORT_ROOM_MAX", 1024);
     k.sb = (int)num("PYA_SB", -1);
     k.gtp = (int)num("PYA_GTP", -1);
@@ -472,21 +452,7 @@ struct pya_plan {
         uint32_t off, n, cap, multi_z, n_cap, stride, pos_cap, ent_cap, push_cap;
     };
     std::vector<FusedLaunch> fused_launches;
-    /* launches of the packed fused kernel (fused_pack.hip.h): several PSMs per wavefront, per C(n,k) class */
-    struct PackLaunch {
-        uint32_t off, n, G, pool_cap, n_cap, pos_cap, push_cap, kc;
-    };
-    std::vector<PackLaunch> pack_launches;
-    std::vector<uint32_t> pack_ids;
-    std::vector<uint64_t> pack_desc;         /* [n][8] the packed PSMs' descriptors in launch order + their ids */
-    DevBuf<uint64_t> d_pack_desc;
-    DevBuf<uint32_t> d_over;                 /* [64 + n]: count, then the PSMs the packed kernel passed on */
     uint32_t n_fused_total = 0;
-    /* the fused launches bin their spectra themselves (pya_bin_score_localize_kernel): those PSMs are in no bin
-     * list; d_binredo = [64 + n]: the PSMs it passes on to the list form of the fused kernel, d_redo6 = [64 + n]:
-     * those of them that pya_bin_exact_kernel has to bin first */
-    bool bin_fused = false;
-    DevBuf<uint32_t> d_binredo, d_redo6;
     std::vector<uint8_t> big;           /* [n_psm] scored by score_big.hip (thousands of site assignments, plain settings) */
     DevBuf<uint32_t> d_big_ids;
     uint32_t big_pos_cap = 1;
@@ -1326,10 +1292,6 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             std::fill(p->fused.begin(), p->fused.end(), 0);
         }
     }
-    /* OFF by default (PYA_BIN_FUSED=1): measured time-neutral -- cfg2 0.648 ms against 0.257 + 0.390 for the two kernels,
-     * both bound by vector issue, and the staging it saves is a few per cent of their instructions -- while the
-     * whole path's HBM traffic drops from 1.45x to 1.2x the algorithmic bytes. */
-    p->bin_fused = fused_on && !p->fusedb.ids.empty() && h->kn.bin_fused && !h->kn.pack;
     lap("psm loop");
     p->n_skipped = n_skipped;
     p->sig_off[n] = sig_total;
@@ -1364,7 +1326,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             size_t c = 0;
             while (caps[c] < P) c++;
             pcls[i] = (uint8_t)c;
-            if (!(p->fused[i] && p->bin_fused)) cnt_bin[c]++;
+            cnt_bin[c]++;
             if (p->fused[i]) continue;
             if (p->big[i]) cnt_big[c]++;
             else cnt_score[p->ncls[i] * nc + c]++;
@@ -1394,7 +1356,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->score_ids.resize(n_score);
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;
-            if (!(p->fused[i] && p->bin_fused)) {
+            {
                 pya_plan::IdList &bl = p->bin_lists[pcls[i]];
                 p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
             }
@@ -1409,71 +1371,14 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             }
         }
             {
-            /* ---- launches of the packed fused kernel (several PSMs per wavefront, fused_pack.hip.h): fragment
-             * charge 1, mz_error <= 0.49, and few enough site assignments that at least two PSMs share a
-             * wavefront; one launch per C(n,k) class, slots per wavefront = 64 / class size (at most pack_g) ---- */
             const uint32_t ndir = both_dirs ? 2u : 1u;
-            std::vector<uint8_t> packed(n, 0);
             p->n_fused_total = 0;
             for (uint64_t i = 0; i < n; i++) p->n_fused_total += (p->fused[i] && !p->pre_status[i]) ? 1u : 0u;
-            const uint32_t pack_g = h->kn.pack_g;
-            /* OFF by default (PYA_PACK=1 turns it on): measured on cfg2 / cfg3 it loses to one PSM per wavefront
-             * (0.58 vs 0.40 ms, 0.68 vs 0.41 ms) although it issues half the vector instructions -- the PSMs a CU
-             * holds are set by LDS per PSM either way, a packed wavefront's dependent chain of LDS and memory round
-             * trips is twice as long for its three PSMs, and with 9 instead of 20 wavefronts per CU nothing hides it
-             * (DESIGN.md section 9).  Kept as a tested route. */
-            const bool pack_on = fused_on && h->mz_error <= 0.49f && pack_g >= 2 && h->kn.pack && n >= (uint64_t)h->kn.pack_min;
-            if (pack_on) {
-                static const uint32_t kPackClass[] = {4, 8, 16, 21, 32};
-                struct PItem { uint32_t id, cls, L; };
-                std::vector<PItem> pit;
-                for (uint64_t i = 0; i < n; i++) {
-                    if (!p->fused[i] || p->pre_status[i] || p->max_charge[i] != 1) continue;
-                    const uint32_t N = p->n_sig[i];
-                    uint32_t c = 0;
-                    while (c < 5 && kPackClass[c] < N) c++;
-                    if (c >= 5 || 64u / kPackClass[c] < 2u) continue;            /* one PSM per wavefront anyway */
-                    pit.push_back({(uint32_t)i, c, (uint32_t)(p->pep_off[i + 1] - p->pep_off[i])});
-                }
-                std::sort(pit.begin(), pit.end(), [](const PItem &a, const PItem &b2) {
-                    return a.cls != b2.cls ? a.cls < b2.cls : (a.L != b2.L ? a.L < b2.L : a.id < b2.id);
-                });
-                size_t g0 = 0;
-                while (g0 < pit.size()) {
-                    size_t g1 = g0;
-                    while (g1 < pit.size() && pit[g1].cls == pit[g0].cls) g1++;
-                    if (g1 - g0 >= (size_t)h->kn.pack_group_min) {   /* (a handful is not worth a launch of its own) */
-                        pya_plan::PackLaunch pl = {(uint32_t)p->pack_ids.size(), (uint32_t)(g1 - g0), 0, 0, kPackClass[pit[g0].cls], 1, 8, 4};
-                        uint32_t maxP = 1;
-                        for (size_t t = g0; t < g1; t++) {
-                            const uint32_t id = pit[t].id, kk = (uint32_t)p->n_of_mod[id], ns = p->n_sites[id];
-                            pl.pos_cap = std::max(pl.pos_cap, pit[t].L - 1);
-                            pl.push_cap = std::max(pl.push_cap, std::min<uint32_t>(PYA_MAX_PUSHED, (kk * (ns - kk) + 7u) & ~7u));
-                            pl.kc = std::max(pl.kc, (kk + 3u) & ~3u);
-                            maxP = std::max(maxP, (uint32_t)(p->peak_off[id + 1] - p->peak_off[id]));
-                        }
-                        /* retained peaks a slot may bring: never more than its raw peaks; beyond the budget the PSM goes
-                         * to the one-PSM-per-wavefront kernel (10 per 100 m/z window: ~200 for a 2000 m/z spectrum) */
-                        const uint32_t budget = (std::min<uint32_t>(maxP, h->kn.pack_peaks) + PYA_TABLE_PAD + 1u) & ~1u;
-                        pl.G = std::min<uint32_t>(std::min<uint32_t>(pack_g, 8u), 64u / pl.n_cap);
-                        while (pl.G >= 2 && pya_pack_lds_bytes(pl.G, pl.G * budget, pl.n_cap, pl.pos_cap, pl.push_cap, pl.kc, p->fused_both) > 64 * 1024) pl.G--;
-                        if (pl.G >= 2) {
-                            pl.pool_cap = pl.G * budget;
-                            for (size_t t = g0; t < g1; t++) {
-                                p->pack_ids.push_back(pit[t].id);
-                                packed[pit[t].id] = 1;
-                            }
-                            p->pack_launches.push_back(pl);
-                        }
-                    }
-                    g0 = g1;
-                }
-            }
             /* ---- launches of the fused kernel ---- */
             struct Item { uint32_t id, group; size_t need; uint32_t n_cap, pos, ent, push; };
             std::vector<Item> items;
             for (uint64_t i = 0; i < n; i++) {
-                if (!p->fused[i] || p->pre_status[i] || packed[i]) continue;
+                if (!p->fused[i] || p->pre_status[i]) continue;
                 Item it;
                 it.id = (uint32_t)i;
                 const uint32_t z = (uint32_t)p->max_charge[i], Lm1 = (uint32_t)(p->pep_off[i + 1] - p->pep_off[i] - 1);
@@ -1540,13 +1445,6 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                (uint64_t)((uint32_t)p->max_charge[i] & 0xffu) << 56;
         w[5] = (uint64_t)p->n_sig[i] | (uint64_t)p->order_off[i] << 32;
     }
-    p->pack_desc.resize(p->pack_ids.size() * 8);
-    for (size_t t = 0; t < p->pack_ids.size(); t++) {
-        const uint32_t id = p->pack_ids[t];
-        std::memcpy(&p->pack_desc[t * 8], &p->desc[(size_t)id * PYA_DESC_WORDS], PYA_DESC_WORDS * 8);
-        p->pack_desc[t * 8 + 6] = id;
-        p->pack_desc[t * 8 + 7] = 0;
-    }
     lap("id lists");
     rc = ensure_lut(h, lut_need);
     if (rc) return rc;
@@ -1598,7 +1496,6 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_bin_ids = meta(p->bin_ids.data(), p->bin_ids.size() * 4),
                      o_score_ids = meta(p->score_ids.data(), p->score_ids.size() * 4),
                      o_fused_ids = meta(p->fused_ids.data(), p->fused_ids.size() * 4),
-                     o_pack_desc = meta(p->pack_desc.data(), p->pack_desc.size() * 8),
                      o_desc = meta(p->desc.data(), p->desc.size() * 8),
                      o_big_ids = meta(p->big_ids.data(), p->big_ids.size() * 4);
         const size_t o_bigloc_ids = meta(p->bigloc.ids.data(), p->bigloc.ids.size() * 4);
@@ -1622,8 +1519,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d2h_bytes = total - p->o_status;
         const size_t o_ret_n = reserve(n * 4),
                      o_ret = reserve((size_t)p->ret_off[n] * sizeof(PeakEntry) + 64),
-                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_over = reserve((p->pack_ids.size() + 64) * 4), o_redo5 = reserve(((size_t)p->n_big_inline + 64) * 4), o_binredo = reserve(((size_t)p->n_fused_total + 64) * 4),
-                     o_redo6 = reserve(((size_t)p->n_fused_total + 64) * 4), o_ws_top = reserve(n * 16),
+                     o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_redo5 = reserve(((size_t)p->n_big_inline + 64) * 4), o_ws_top = reserve(n * 16),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
@@ -1644,11 +1540,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_bin_ids.adopt(base + o_bin_ids, p->bin_ids.size());
         p->d_score_ids.adopt(base + o_score_ids, p->score_ids.size());
         p->d_fused_ids.adopt(base + o_fused_ids, p->fused_ids.size());
-        p->d_pack_desc.adopt(base + o_pack_desc, p->pack_desc.size());
-        p->d_over.adopt(base + o_over, p->pack_ids.size() + 64);
         p->d_redo5.adopt(base + o_redo5, (size_t)p->n_big_inline + 64);
-        p->d_binredo.adopt(base + o_binredo, (size_t)p->n_fused_total + 64);
-        p->d_redo6.adopt(base + o_redo6, (size_t)p->n_fused_total + 64);
         p->d_desc.adopt(base + o_desc, p->desc.size());
         p->d_big_ids.adopt(base + o_big_ids, p->big_ids.size());
         for (int i = 0; i < kNumBuckets; i++)
@@ -1812,50 +1704,14 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
     if (p->n_fused_total) {
-        /* few site assignments, plain settings: scored and localised in one pass (score_localize.hip) -- several
-         * PSMs per wavefront where they are small enough (fused_pack.hip.h), one per wavefront otherwise; what
-         * the packed kernel passes on goes to the one-per-wavefront kernel, what either hands over goes through
-         * the general localize instantiation */
+        /* few site assignments, plain settings: scored and localised in one pass (score_localize.hip), one PSM per
+         * wavefront; what it hands over goes through the general localize instantiation */
         HIPCHK(h, hipMemsetAsync(d.redo4_count, 0, sizeof(uint32_t), st));
         const Bucket &fb = p->fusedb;
-        if (!p->pack_launches.empty()) HIPCHK(h, hipMemsetAsync(p->d_over.p, 0, sizeof(uint32_t), st));
-        for (const pya_plan::PackLaunch &l : p->pack_launches) {
-            e = pya_launch_fused_pack(&d, p->d_pack_desc.p + (size_t)l.off * 8, l.n, l.G, l.pool_cap, l.n_cap, l.pos_cap, l.push_cap, l.kc,
-                                      p->fused_both, d.redo4_count, d.redo4_ids, p->d_over.p, p->d_over.p + 64, st);
-            if (e) return h->hip_fail((hipError_t)e, "score_localize (packed) launch");
-        }
-        if (p->bin_fused && !p->fused_launches.empty()) {
-            /* binning + scoring + localisation in one pass; the spectra its common-case binning declines are binned by
-             * the exact kernel (own hand-over list) and, with the very long tables, finished by the list form */
-            HIPCHK(h, hipMemsetAsync(p->d_binredo.p, 0, sizeof(uint32_t), st));
-            HIPCHK(h, hipMemsetAsync(p->d_redo6.p, 0, sizeof(uint32_t), st));
-            BatchDev d2 = d;
-            d2.redo_count = p->d_redo6.p;
-            d2.redo_ids = p->d_redo6.p + 64;
-            uint32_t any_z = 0;
-            for (const pya_plan::FusedLaunch &l : p->fused_launches) {
-                e = pya_launch_bin_fused(&d2, p->d_fused_ids.p + l.off, l.n, l.cap, l.n_cap, l.stride, l.pos_cap, l.ent_cap, l.push_cap,
-                                         p->fused_both, l.multi_z, d.redo4_count, d.redo4_ids, p->d_binredo.p, st);
-                if (e) return h->hip_fail((hipError_t)e, "bin_score_localize launch");
-                any_z |= l.multi_z;
-            }
-            e = pya_launch_bin_exact(&d2, (uint32_t)p->fused_ids.size(), p->peak_cap, st);
-            if (e) return h->hip_fail((hipError_t)e, "bin_spectra (exact, fused hand-over) launch");
-            e = pya_launch_fused_list(&d, p->d_binredo.p, p->d_binredo.p + 64, (uint32_t)p->fused_ids.size(), p->peak_cap, p->fused_n_cap,
-                                      p->fused_stride, fb.pos_cap, p->fused_ent_cap, fb.push_cap(), p->fused_both, any_z,
-                                      d.redo4_count, d.redo4_ids, st);
-            if (e) return h->hip_fail((hipError_t)e, "score_localize (bin hand-over) launch");
-        } else
         for (const pya_plan::FusedLaunch &l : p->fused_launches) {
             e = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, l.n_cap, l.stride, l.pos_cap, l.ent_cap, l.push_cap,
                                  p->fused_both, l.multi_z, d.redo4_count, d.redo4_ids, st);
             if (e) return h->hip_fail((hipError_t)e, "score_localize launch");
-        }
-        if (!p->pack_launches.empty()) {
-            e = pya_launch_fused_list(&d, p->d_over.p, p->d_over.p + 64, (uint32_t)p->pack_ids.size(), p->peak_cap, p->fused_n_cap,
-                                      p->fused_stride, fb.pos_cap, std::max(fb.pos_cap, 1u), fb.push_cap(), p->fused_both, 0u,
-                                      d.redo4_count, d.redo4_ids, st);
-            if (e) return h->hip_fail((hipError_t)e, "score_localize (passed-on) launch");
         }
         e = pya_launch_localize_redo(&d, d.redo4_count, d.redo4_ids, p->n_fused_total, fb.push_cap(), fb.n_cap,
                                      fb.pos_cap, fb.pool_cap(), fb.sb(), fb.gtp(), st);
@@ -1867,7 +1723,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
          * named; what that declines is scored again with count records and goes to the general localize body */
         const Bucket &bl = p->bigloc;
         HIPCHK(h, hipMemsetAsync(p->d_redo5.p, 0, sizeof(uint32_t), st));
-        e = pya_launch_localize_recount(&d, bl.d_ids.p, (uint32_t)bl.ids.size(), h->kn.recount_lds_tab ? p->peak_cap : 0u, bl.push_cap(), bl.pos_cap, bl.pool_cap(),
+        e = pya_launch_localize_recount(&d, bl.d_ids.p, (uint32_t)bl.ids.size(), 0u, bl.push_cap(), bl.pos_cap, bl.pool_cap(),
                                         bl.sb(), bl.gtp(), p->d_redo5.p, st);
         if (e) return h->hip_fail((hipError_t)e, "localize (recount) launch");
         e = pya_launch_score_big_list(&d, p->d_redo5.p, p->d_redo5.p + 64, p->n_big_inline, p->peak_cap, p->big_pos_cap, st);
@@ -1883,10 +1739,8 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         e = pya_launch_localize(&d, bk.d_ids.p, bk.n_plain, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(),
                                 bk.gtp(), 1u, sort_room, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
-        /* (PYA_LOC_HASH_LDS_TAB: the retained table staged in LDS for the lookups; measured slower on cfg4, 15.6 against
-         * 12.4 ms -- the 2 KB cost more occupancy than the global lookups cost time) */
         const uint32_t nnl = (uint32_t)h->cfg.n_nl;
-        const uint32_t tab_cap = (h->kn.loc_hash_lds_tab && bk.hash_ok(p->peak_cap, p->max_k, nnl)) ? p->peak_cap : 0u;
+        const uint32_t tab_cap = 0u;
         if (!h->kn.no_loc_hash && bk.hash_ok(tab_cap, p->max_k, nnl))
             e = pya_launch_localize_hash(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
                                          bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), bk.hash_vc(), bk.hash_hs(), bk.hash_pp(), tab_cap,
@@ -1949,11 +1803,8 @@ int pya_plan_check(pya_plan *p) {
         uint32_t r3 = 0, r4 = 0;
         (void)hipMemcpy(&r3, p->d_redo3.p, 4, hipMemcpyDeviceToHost);
         if (p->d_redo4.p) (void)hipMemcpy(&r4, p->d_redo4.p, 4, hipMemcpyDeviceToHost);
-        uint32_t ov = 0;
-        if (p->d_over.p && !p->pack_launches.empty()) (void)hipMemcpy(&ov, p->d_over.p, 4, hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "[pya plan] handed over: %u by the lean localize instantiation (last bucket), %u of %u by the fused kernels; "
-                     "%u of %zu passed on by the packed kernel (%zu launches)\n", r3, r4, p->n_fused_total, ov, p->pack_ids.size(),
-                     p->pack_launches.size());
+        std::fprintf(stderr, "[pya plan] handed over: %u by the lean localize instantiation (last bucket), %u of %u by the fused kernel\n",
+                     r3, r4, p->n_fused_total);
     }
     const bool skip = (p->flags & PYA_FLAG_SKIP_INVALID) != 0;
     if (skip) h->last_status = st;

@@ -29,117 +29,52 @@ def test_loaded_library_is_built_from_this_tree():
 
 
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
-                        "fused_replay", "general_serial_replay", "packed", "packed_8", "packed_passed_on", "packed_small_pool",
-                        "packed_always_sort", "packed_declines", "packed_replay", "big_records", "bin_fused",
-                        "bin_fused_exact", "general_lists", "hash_exact", "hash_declines", "hash_lds_table", "hash_small_lists", "score_walkers", "score_few_nodes", "recount_lds_table"])
+                        "fused_replay", "general_serial_replay", "big_records", "general_lists", "hash_exact", "hash_declines",
+                        "hash_small_lists", "score_walkers", "score_few_nodes"])
 def path(request, monkeypatch):
-    """Batches run six times: plain PSMs (no neutral losses, fragment charge 1) with few site
-    assignments on the fused score + localize kernel and the other plain ones on the lean
-    instantiation of the localize kernel (default); without the fused kernel (PYA_NO_FUSED=1); every
-    PSM on the general instantiation (PYA_NO_PLAIN=1); with the fused kernel and the lean
-    instantiation declining every PSM (PYA_DEBUG=512), which sends them through their hand-over lists
-    to the general one; and with the std::sort emulation run even where a unique best PepScore makes it
-    unnecessary (PYA_DEBUG=1024), without and with the fused kernel; and with the fused kernel replaying
-    every (competitor, direction) task serially (PYA_DEBUG=2048); and the general instantiation with whole-task
-    serial replays instead of cluster walks (PYA_NO_PLAIN=1, PYA_DEBUG=4096).
-    The general instantiation finds site-determining ions with a hash grid over the ions of differing prefixes
-    (localize_hash.hip.h) by default; "general_lists" is the list-based route it replaced (PYA_NO_LOC_HASH=1, also what
-    "general_serial_replay" runs on), "hash_exact" sends every in-span ion through the exact run walk (PYA_DEBUG=16384)
-    and "hash_declines" makes the hash route decline every PSM (PYA_DEBUG=8192: hand-over list, list-based kernel)."""
-    monkeypatch.delenv("PYA_NO_PLAIN", raising=False)
-    monkeypatch.delenv("PYA_NO_LOC_HASH", raising=False)
-    monkeypatch.delenv("PYA_LOC_HASH_LDS_TAB", raising=False)
-    monkeypatch.delenv("PYA_HASH_PP", raising=False)
-    # the recounting lean localize launch (PSMs score_big scored) with the retained table staged in LDS instead of left in
-    # the workspace (time-neutral; the default keeps the LDS)
-    monkeypatch.delenv("PYA_RECOUNT_LDS_TAB", raising=False)
-    if request.param == "recount_lds_table":
-        monkeypatch.setenv("PYA_RECOUNT_LDS_TAB", "1")
-    if request.param == "hash_small_lists":        # room for the pair lists of short spans only: a share of the PSMs is handed over
-        monkeypatch.setenv("PYA_NO_PLAIN", "1")
-        monkeypatch.setenv("PYA_HASH_PP", "2")
-    if request.param == "hash_lds_table":          # the hash route with the retained table staged in LDS (opt-in: measured slower)
-        monkeypatch.setenv("PYA_NO_PLAIN", "1")
-        monkeypatch.setenv("PYA_LOC_HASH_LDS_TAB", "1")
-    # score_signatures under general settings (neutral losses, several ion types per direction) looks every distinct
-    # node of the assignment tree up once (score_core.hip.h: score_nodes_dir); "score_walkers" is one walker per
-    # signature as before (PYA_NO_NODES=1), "score_few_nodes" leaves room for 150 nodes per direction, so that
-    # some PSMs / directions fall back to the walkers inside the kernel.
-    monkeypatch.delenv("PYA_NO_NODES", raising=False)
-    monkeypatch.delenv("PYA_NODE_CAP", raising=False)
-    if request.param == "score_walkers":
-        monkeypatch.setenv("PYA_NO_NODES", "1")
-    if request.param == "score_few_nodes":
-        monkeypatch.setenv("PYA_NODE_CAP", "150")
-    monkeypatch.delenv("PYA_NO_FUSED", raising=False)
-    monkeypatch.delenv("PYA_DEBUG", raising=False)
-    monkeypatch.setenv("PYA_PLAIN_MIN", "0")       # batches under 512 PSMs skip the lean kernels by default
-    monkeypatch.setenv("PYA_NO_TINY", "1")         # ... and those of up to 64 the three kernels altogether
-    # The packed fused kernel (several PSMs per wavefront, fused_pack.hip.h; opt-in with PYA_PACK=1: it measured
-    # slower than one PSM per wavefront) for plain charge-1 PSMs with few site assignments.  "packed*": on for every batch size -- four
-    # slots per wavefront, eight, everything passed on to the one-PSM-per-wavefront kernel (PYA_DEBUG=32768),
-    # a peak pool so small that most PSMs are passed on, the std::sort emulation for every slot, every slot
-    # handed over to the general localize instantiation at the start (512) or at the pairing (2048).  The
-    # other routes run without it, as before.
-    for v in ("PYA_PACK", "PYA_NO_PACK", "PYA_PACK_MIN", "PYA_PACK_GROUP_MIN", "PYA_PACK_G", "PYA_PACK_PEAKS",
+    """Every batch runs on every route a PSM can take (results stay exact on all of them):
+    fused                  plain PSMs (no neutral losses, one ion type per direction) with few site assignments on the
+                           fused score + localize kernel, the other plain ones on the lean localize instantiation (default)
+    lean_localize          without the fused kernel (PYA_NO_FUSED=1)
+    general_localize       every PSM on the general instantiation (PYA_NO_PLAIN=1): hash route for site-determining ions
+    lean_declines          the fused kernel and the lean instantiation decline every PSM (PYA_DEBUG=512): hand-over lists
+    always_sort            the std::sort emulation runs even for a unique best PepScore (PYA_DEBUG=1024), without / with
+    fused_always_sort      the fused kernel
+    fused_replay           the fused kernel replays every (competitor, direction) task serially (PYA_DEBUG=2048)
+    general_serial_replay  the list-based general instantiation with whole-task serial replays (PYA_DEBUG=4096)
+    general_lists          the list-based general route the hash route replaced (PYA_NO_LOC_HASH=1)
+    hash_exact             the hash route sends every in-span ion through the exact run walk (PYA_DEBUG=16384)
+    hash_declines          the hash route declines every PSM (PYA_DEBUG=8192: hand-over list, list-based kernel)
+    hash_small_lists       room for the pair lists of short spans only (PYA_HASH_PP=2): a share of the PSMs is handed over
+    score_walkers          score_signatures under general settings with one walker per signature (PYA_NO_NODES=1)
+    score_few_nodes        ... with room for 150 shared nodes per direction: some directions fall back to the walkers
+    big_records            PSMs with thousands of site assignments on the older route (count records, sort in localize)
+    (Routes measured slower and deleted in round 4 -- several PSMs per wavefront, binning inside the fused kernel, the
+    hash / recount launches with the retained table staged in LDS -- are described in DESIGN.md section 10.)"""
+    for v in ("PYA_NO_PLAIN", "PYA_NO_LOC_HASH", "PYA_HASH_PP", "PYA_NO_NODES", "PYA_NODE_CAP", "PYA_NO_FUSED", "PYA_DEBUG",
               "PYA_NO_BIG_INLINE"):
         monkeypatch.delenv(v, raising=False)
-    # PSMs with thousands of site assignments (score_big): by default no count records are written, score_big
-    # names the winner among tied best scores itself and the recounting lean localize launch finishes them
-    # (every route above: "lean_declines" sends them all through its hand-over list, "always_sort" forces the
-    # workgroup sort); "big_records" is the older route (count records, sort in the localize kernels).
-    if request.param == "big_records":
-        monkeypatch.setenv("PYA_NO_BIG_INLINE", "1")
-    # binning, scoring and localisation of the fused kernel's PSMs in one pass (pya_bin_score_localize_kernel;
-    # opt-in: time-neutral, less HBM traffic), without and with every spectrum forced through the exact binning
-    monkeypatch.delenv("PYA_BIN_FUSED", raising=False)
-    if request.param.startswith("bin_fused"):
-        monkeypatch.setenv("PYA_BIN_FUSED", "1")
-        if request.param == "bin_fused_exact":
-            monkeypatch.setenv("PYA_DEBUG", "128")
-    if request.param.startswith("packed"):
-        monkeypatch.setenv("PYA_PACK", "1")
-        monkeypatch.setenv("PYA_PACK_MIN", "0")
-        monkeypatch.setenv("PYA_PACK_GROUP_MIN", "1")
-        if request.param == "packed_8":
-            monkeypatch.setenv("PYA_PACK_G", "8")
-        elif request.param == "packed_passed_on":
-            monkeypatch.setenv("PYA_DEBUG", "32768")
-        elif request.param == "packed_small_pool":
-            monkeypatch.setenv("PYA_PACK_PEAKS", "150")
-        elif request.param == "packed_always_sort":
-            monkeypatch.setenv("PYA_DEBUG", "1024")
-        elif request.param == "packed_declines":
-            monkeypatch.setenv("PYA_DEBUG", "512")
-        elif request.param == "packed_replay":
-            monkeypatch.setenv("PYA_DEBUG", "2048")
-        return request.param
-    monkeypatch.setenv("PYA_NO_PACK", "1")
-    if request.param in ("lean_localize", "always_sort"):
-        monkeypatch.setenv("PYA_NO_FUSED", "1")
-    if request.param == "fused_always_sort":
-        monkeypatch.setenv("PYA_DEBUG", "1024")
-    if request.param == "fused_replay":            # every task of the fused kernel through its serial replay
-        monkeypatch.setenv("PYA_DEBUG", "2048")
-    if request.param == "general_localize":
-        monkeypatch.setenv("PYA_NO_PLAIN", "1")
-    elif request.param == "general_serial_replay":
-        monkeypatch.setenv("PYA_NO_PLAIN", "1")
-        monkeypatch.setenv("PYA_NO_LOC_HASH", "1")
-        monkeypatch.setenv("PYA_DEBUG", "4096")
-    elif request.param == "general_lists":
-        monkeypatch.setenv("PYA_NO_PLAIN", "1")
-        monkeypatch.setenv("PYA_NO_LOC_HASH", "1")
-    elif request.param == "hash_exact":
-        monkeypatch.setenv("PYA_NO_PLAIN", "1")
-        monkeypatch.setenv("PYA_DEBUG", "16384")
-    elif request.param == "hash_declines":
-        monkeypatch.setenv("PYA_NO_PLAIN", "1")
-        monkeypatch.setenv("PYA_DEBUG", "8192")
-    elif request.param == "lean_declines":
-        monkeypatch.setenv("PYA_DEBUG", "512")
-    elif request.param == "always_sort":
-        monkeypatch.setenv("PYA_DEBUG", "1024")
+    monkeypatch.setenv("PYA_PLAIN_MIN", "0")       # batches under 512 PSMs skip the lean kernels by default
+    monkeypatch.setenv("PYA_NO_TINY", "1")         # ... and those of up to 64 the three kernels altogether
+    env = {
+        "fused": {},
+        "lean_localize": {"PYA_NO_FUSED": "1"},
+        "general_localize": {"PYA_NO_PLAIN": "1"},
+        "lean_declines": {"PYA_DEBUG": "512"},
+        "always_sort": {"PYA_NO_FUSED": "1", "PYA_DEBUG": "1024"},
+        "fused_always_sort": {"PYA_DEBUG": "1024"},
+        "fused_replay": {"PYA_DEBUG": "2048"},
+        "general_serial_replay": {"PYA_NO_PLAIN": "1", "PYA_NO_LOC_HASH": "1", "PYA_DEBUG": "4096"},
+        "general_lists": {"PYA_NO_PLAIN": "1", "PYA_NO_LOC_HASH": "1"},
+        "hash_exact": {"PYA_NO_PLAIN": "1", "PYA_DEBUG": "16384"},
+        "hash_declines": {"PYA_NO_PLAIN": "1", "PYA_DEBUG": "8192"},
+        "hash_small_lists": {"PYA_NO_PLAIN": "1", "PYA_HASH_PP": "2"},
+        "score_walkers": {"PYA_NO_NODES": "1"},
+        "score_few_nodes": {"PYA_NODE_CAP": "150"},
+        "big_records": {"PYA_NO_BIG_INLINE": "1"},
+    }[request.param]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     return request.param
 
 
