@@ -4,8 +4,6 @@
 #define PYA_BIN_CORE_H
 #include "device_common.hip.h"
 
-/* LDS bytes the binning stage needs for a spectrum of up to `cap` peaks (cap multiple of 32) */
-DEV size_t bin_lds_bytes(uint32_t cap) { return (size_t)cap * (8 + 4 + 2 + 1); }
 
 /* ---------------------------------------------------------------------------------------
  * Exact top-n_top selection of one window when intensities tie (Spectra.cpp:24-41): libstdc++'s
@@ -166,17 +164,243 @@ DEV void run_exact_ranks(const R &r, int len, uint8_t *rank_out) {
  * into `lds` and hold the retained peaks (ascending float32 m/z, rank inside their window);
  * returns their count, or -1 with *status set.  Ends with an LDS sync.
  *
- * EXACT = false is the common case -- peaks in m/z order, no two equal intensities inside a
- * window -- and returns PYA_BIN_REDO for everything else; EXACT = true handles everything (any
- * peak order, ties resolved as std::nth_element + std::sort do).  Two instantiations in two
- * kernels, because the rare paths would otherwise double the registers of the common one. */
+ * Two bodies in two kernels, because the rare paths would otherwise double the registers of the common one:
+ * bin_fast takes the common case -- peaks in m/z order, at most 64 windows, finite non-negative intensities, no
+ * two intensities inside a window's top n_top that agree in their leading 20 mantissa bits -- and returns
+ * PYA_BIN_REDO for everything else; bin_exact handles everything (any peak order, ties resolved as
+ * std::nth_element + std::sort do). */
 #define PYA_BIN_REDO (-2)
 #ifndef BIN_BLOCK
 #define BIN_BLOCK 6
 #endif
-template <bool EXACT>
-DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
+#define PYA_BIN_FAST_WINDOWS 64    /* window ids the composite key has room for */
+#define PYA_BIN_KEY_BITS 25        /* intensity bits of the composite key: 5 exponent + 20 mantissa bits below the largest */
+
+/* whole-wave DPP shifts (GFX9): lane i takes the value of lane i - 1 / i + 1; lane 0 / 63 take `edge`.  One
+ * vector move where __shfl_up / __shfl_down are an LDS permute with its address arithmetic.
+ * (scripts/dpp_probe.hip checks the semantics on the device.) */
+DEV uint32_t lane_prev_u32(uint32_t x, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+DEV uint32_t lane_next_u32(uint32_t x, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+DEV double lane_next_f64(double x, double edge) {
+    const uint64_t xb = (uint64_t)__double_as_longlong(x), eb = (uint64_t)__double_as_longlong(edge);
+    const uint32_t lo = lane_next_u32((uint32_t)xb, (uint32_t)eb), hi = lane_next_u32((uint32_t)(xb >> 32), (uint32_t)(eb >> 32));
+    return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32)));
+}
+DEV double first_lane_f64(double x) {
+    const uint64_t xb = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xb >> 32));
+    return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32)));
+}
+
+/* LDS of one wavefront of the binning stage: 15 bytes per peak (cap a multiple of 32) and the window table */
+#define PYA_BIN_WAVE_BYTES(cap) ((((size_t)(cap) * 15 + 63) & ~(size_t)63) + 256)
+
+/* The common case.  LDS (PYA_BIN_WAVE_BYTES):
+ *   ckey u32[2 cap]  one composite key per peak, (63 - window) << 25 | intensity key, then zeros for the longest window
+ *   mzf  f32[cap]    float m/z per peak; the retained m/z are compacted into it in place
+ *   win  u16[cap]    window of the peak
+ *   rank u8 [cap]    ranks of the retained peaks (output)
+ *   wtab u16[2][64]  first and last peak of every window
+ * A sorted spectrum's windows are runs of consecutive peaks, so a peak's rank is the number of run mates that are more
+ * intense.  The mates are read from the run's first peak on, straight through its end, for as many steps as the
+ * longest run of the spectrum has peaks -- the same trip count for every lane, no per-lane bounds: what follows a run
+ * in LDS belongs to later windows (or is the zero padding), and the window field makes all of that compare below
+ * every peak of this run.  The intensity key is the high word of the float64 intensity (sign 0, order-preserving)
+ * minus a base that leaves room for 2^32 of dynamic range below the spectrum's most intense peak; "more intense" is
+ * then the sign of a 32-bit difference: subtract, shift, add -- three instructions of the cheap class per mate
+ * (profiles/r03_valu_ceiling.md) where a float64 compare with its masks took four of the expensive one.
+ * Keys that are equal (intensities that agree in 20 mantissa bits, or lie 2^32 below the maximum) make the counts of a
+ * window fall short of len (len - 1) / 2, which the deficit notices; only if such a peak ranks inside the top n_top
+ * does it matter, and then the spectrum is handed over (as equal intensities at the top always were). */
+DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
                  const uint8_t **out_rank, int *status) {
+    const int lane = lane_id();
+    uint32_t *ckey = (uint32_t *)lds;
+    float *s_mzf = (float *)(ckey + 2 * (size_t)cap);
+    uint16_t *s_win = (uint16_t *)(s_mzf + cap);
+    uint8_t *o_rank = (uint8_t *)(s_win + cap);
+    uint16_t *w_first = (uint16_t *)(lds + (((size_t)cap * 15 + 63) & ~(size_t)63));
+    uint16_t *w_last = w_first + PYA_BIN_FAST_WINDOWS;
+
+    STAMP_BEGIN();
+    STAMP_T(b, 1, -1);
+    const int64_t p0 = b.peak_off[psm];
+    const uint32_t P = (uint32_t)(b.peak_off[psm + 1] - p0);
+    const double *mz = b.mz + p0;
+    const double *inten = b.inten + p0;
+    const float bin_size = b.cfg->bin_size;
+    const double bsd = (double)bin_size, inv_bs = 1. / bsd;
+    const double mn = mz[0], mx = mz[P - 1];                /* a sorted spectrum has its extremes at the ends */
+    *status = PYA_ST_OK;
+    /* window bounds from the extremes (Spectra.cpp:46-48) */
+    const float min_mz = (float)(__builtin_floor(mn / 100.) * 100.);
+    const float max_mz = (float)(__builtin_ceil(mx / 100.) * 100.);
+    const float nb_f = __builtin_ceilf((max_mz - min_mz) / bin_size);        /* float arithmetic, :48 */
+    const bool ok = nb_f >= 1.f && nb_f <= 65535.f;
+    const uint32_t n_bins = ok ? (uint32_t)nb_f : 1u;
+    /* (more windows than the keys and the window table have room for: handed over below; until then the ids stay
+     * inside the table) */
+    const int last_win = (int)(n_bins < PYA_BIN_FAST_WINDOWS ? n_bins : PYA_BIN_FAST_WINDOWS) - 1;
+    /* window id of one peak (double arithmetic, Spectra.cpp:55-58): floor((v - min) / bin_size) as the
+     * reference's double division gives it, without the division: every multiple k * bin_size
+     * (k < 2^16, bin_size a float) is exact in double, so the rounded quotient reaches k exactly when
+     * the true one does and the floor equals the mathematical one -- which a reciprocal estimate plus
+     * an exact remainder (fma) pins down. */
+    auto window_of = [&](double v) -> uint32_t {
+        const double x = v - (double)min_mz;
+        const double q = __builtin_floor(x * inv_bs);
+        const double r = __builtin_fma(-q, bsd, x);
+        int qi = (int)q;
+        qi += r >= bsd ? 1 : 0;
+        qi -= r < 0. ? 1 : 0;
+        return (uint32_t)(qi > last_win ? last_win : qi);
+    };
+    constexpr uint32_t U = BIN_BLOCK;
+    constexpr uint32_t KMAX = (1u << PYA_BIN_KEY_BITS) - 1u;
+    w_first[lane] = 0xffffu;                                  /* (no peak) */
+    /* only the high word of an intensity is needed here (the keys; sign, infinity and NaN show in it too) */
+    const uint32_t *inten_hi = (const uint32_t *)inten + 1;
+    uint32_t maxhw = 0;
+    int bad = 0;
+    /* (a spectrum of more than one block: the later blocks' intensities once more, for the key base) */
+    for (uint32_t i = 64 * U + (uint32_t)lane; i < P; i += 64) {
+        const uint32_t hw = inten_hi[2 * i];
+        bad |= hw >= 0x7ff00000u ? 1 : 0;
+        maxhw = hw > maxhw ? hw : maxhw;
+    }
+    /* m/z order: every peak against the next lane's below (one vector compare per 64 peaks), and the pairs that
+     * straddle two chunks here: lane j looks at peaks 64 j + 63 and 64 j + 64 */
+    uint64_t uns = 0;                                        /* lanes that saw a larger m/z before a smaller one (scalar) */
+    for (uint32_t j = (uint32_t)lane; 64 * j + 64 < P; j += 64) uns |= __ballot(mz[64 * j + 63] > mz[64 * j + 64]);
+    uint32_t carry_w = 0x1ffffu, keybase = 0;
+    /* The sweep that bins the peaks, checks the order and builds the keys.  The spectrum comes in blocks of
+     * 64 * BIN_BLOCK peaks whose loads are ALL issued before the first of them is used: a wavefront's time here is
+     * HBM round trips, and a load-use-load-use loop makes one per 64 peaks instead of one per block. */
+    for (uint32_t base = 0; base < P; base += 64 * U) {
+        double v[U];
+        uint32_t hw[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t i = base + u * 64 + (uint32_t)lane;       /* (past the end: the last peak again) */
+            const uint32_t ic = i < P ? i : P - 1;
+            v[u] = mz[ic];
+            hw[u] = inten_hi[2 * ic];
+        }
+        if (base == 0) {
+            uint32_t m = maxhw;
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {                      /* (clamped lanes repeat the last peak) */
+                bad |= hw[u] >= 0x7ff00000u ? 1 : 0;
+                m = hw[u] > m ? hw[u] : m;
+            }
+            m = wave_max_u32(m);
+            keybase = m > KMAX ? m - KMAX : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            /* (one chunk at a time: interleaving them costs the registers and the occupancy) */
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t cbase = base + u * 64;
+            if (cbase < P) {
+                const uint32_t i = cbase + (uint32_t)lane;
+                const bool in = i < P;
+                const double x = v[u];
+                uns |= __ballot(x > lane_next_f64(x, x));         /* (lane 63, and the last peak, against themselves) */
+                const uint32_t w = in ? window_of(x) : 0x10000u;
+                const uint32_t pw = lane_prev_u32(w, carry_w);
+                carry_w = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);
+                const uint32_t k = (hw[u] > keybase ? hw[u] : keybase) - keybase;
+                if (pw != w) {                                    /* a window starts here (or the spectrum has ended) */
+                    if (in) w_first[w] = (uint16_t)i;
+                    if (pw < 0x10000u) w_last[pw] = (uint16_t)(i - 1);
+                }
+                if (in) {
+                    ckey[i] = ((63u - w) << PYA_BIN_KEY_BITS) | k;
+                    s_mzf[i] = (float)x;
+                    s_win[i] = (uint16_t)w;
+                    if (i == P - 1) w_last[w] = (uint16_t)i;
+                }
+            }
+        }
+    }
+    if (uns) return PYA_BIN_REDO;                            /* peaks out of m/z order */
+    if (!ok) {
+        *status = nb_f > 65535.f ? PYA_ST_TOO_MANY_BINS : PYA_ST_NO_BINS;
+        return -1;
+    }
+    if (__any(bad) || n_bins > PYA_BIN_FAST_WINDOWS || (b.debug & 128)) return PYA_BIN_REDO;
+    wave_lds_sync();
+    const uint32_t wf = w_first[lane], wl = w_last[lane];
+    const uint32_t mylen = wf != 0xffffu ? wl - wf + 1u : 0u;
+    const uint32_t maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(mylen));   /* (a scalar trip count) */
+    const uint32_t trips = (maxlen + 1u) & ~1u;               /* mates are read two at a time */
+    for (uint32_t q = (uint32_t)lane; q < trips; q += 64) ckey[P + q] = 0u;  /* (index < 2 cap: P + trips <= 2 P, and a single window stops at P) */
+    wave_lds_sync();
+    STAMP_T(b, 2, -1);
+
+    /* ranks (Spectra.cpp:24-41) and, in the same sweep, the retained peaks in ascending m/z */
+    uint32_t total = 0;
+    int deficit = 0;
+    for (uint32_t base = 0; base < P; base += 64) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool in = i < P;
+        const uint32_t me = in ? ckey[i] : 0u;
+        const uint32_t lo = in ? (uint32_t)w_first[s_win[i]] : 0u;
+        const float mzf = in ? s_mzf[i] : 0.f;
+        const uint32_t *src = ckey + lo;
+        uint32_t cnt = 0;
+        if (!(b.debug & 32))
+#pragma unroll 4
+        for (uint32_t t = 0; t < trips; t += 2) {
+            const uint32_t o0 = src[t], o1 = src[t + 1];
+            cnt += (me - o0) >> 31;                          /* keys are below 2^31: the sign says "more intense" */
+            cnt += (me - o1) >> 31;
+        }
+        deficit += in ? (int)cnt - (int)(i - lo) : 0;        /* 0 over a window whose keys all differ */
+        const bool keep = in && cnt < PYA_NTOP;
+        const uint64_t m = __ballot(keep);
+        if (keep && !(b.debug & 64)) {
+            const uint32_t pos = total + (uint32_t)__popcll(m & lanemask_lt());
+            s_mzf[pos] = mzf;                                /* pos <= i: in place */
+            o_rank[pos] = (uint8_t)cnt;
+        }
+        total += (uint32_t)__popcll(m);
+    }
+    if (wave_sum_i32(deficit) != 0 && !(b.debug & 32)) {
+        /* equal keys somewhere: they matter only for a peak inside its window's top n_top */
+        bool hot = false;
+        for (uint32_t base = 0; base < P; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            const bool in = i < P;
+            const uint32_t me = in ? ckey[i] : 0u;
+            const uint32_t *src = ckey + (in ? (uint32_t)w_first[s_win[i]] : 0u);
+            int cnt = 0, eq = 0;
+            for (uint32_t t = 0; t < trips; t++) {
+                const uint32_t o = src[t];
+                cnt += o > me ? 1 : 0;
+                eq += o == me ? 1 : 0;                       /* (the peak itself included) */
+            }
+            hot = hot || (in && cnt < PYA_NTOP && eq > 1);
+        }
+        if (__any(hot)) return PYA_BIN_REDO;
+    }
+    wave_lds_sync();
+    STAMP_T(b, 4, -1);
+    *out_mz = s_mzf;
+    *out_rank = o_rank;
+    return (b.debug & 64) ? 0 : (int)total;
+}
+
+/* The general body (see above): any peak order, any number of windows, equal intensities resolved as
+ * std::nth_element + std::sort resolve them.  LDS: inten f64[cap] | mzf f32[cap] | window u16[cap] | rank u8[cap]
+ * (+ 192 bytes of window starts behind it). */
+DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
+                  const uint8_t **out_rank, int *status) {
     const int lane = lane_id();
     double *s_inten = (double *)lds;
     float *s_mzf = (float *)(s_inten + cap);
@@ -267,10 +491,8 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                     if (lane == 63) nx = after;
                     if (i < P) {
                         const double x = v[u];
-                        if (EXACT) {                         /* (the common-case kernel hands unsorted spectra over) */
-                            tmn = x < tmn ? x : tmn;
-                            tmx = x > tmx ? x : tmx;
-                        }
+                        tmn = x < tmn ? x : tmn;
+                        tmx = x > tmx ? x : tmx;
                         uns |= (x > nx) ? 1 : 0;
                         s_inten[i] = it[u];
                         s_mzf[i] = (float)x;
@@ -280,7 +502,6 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             }
         }
         unsorted = __any(uns);
-        if (!EXACT && unsorted) return PYA_BIN_REDO;
         bool redo = !ok;
         if (unsorted) {
             tmn = wave_min_f64(tmn);
@@ -299,7 +520,6 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             for (int i = lane; i < P; i += 64) s_bin[i] = window_of(mz[i]);
         }
     }
-    if (!EXACT && (unsorted || (b.debug & 128))) return PYA_BIN_REDO;
     wave_lds_sync();
     STAMP_T(b, 2, -1);
 
@@ -310,95 +530,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
      * runs in lock step -- a wave-uniform loop without per-lane exit tests; positions past the end
      * of a shorter run are clamped to the lane's own peak, which never counts. */
     if (!(b.debug & 32)) {
-        /* Fast sweep: count the strictly more intense run mates only (one compare and one
-         * add-with-carry per mate).  Without equal intensities inside a window that IS the rank;
-         * with them the counts of a window no longer add up to len*(len-1)/2, which the check
-         * after the sweep notices, and the exact sweep below redoes the spectrum. */
-        if (!EXACT) {
-          /* Sweep 0 ranks (strictly-more-intense mates).  Only if its counts reveal equal intensities
-           * somewhere does sweep 1 look where: equal peaks that all rank below the top n_top of
-           * their window are dropped whatever the library calls do with them, so the spectrum is
-           * handed over only when a peak ranked inside the top n_top has an equal (count-like
-           * intensities tie all the time among the weak peaks, hardly ever at the top). */
-          bool hot = false;
-          for (int sweep = 0; sweep < 2; sweep++) {
-            int carry_lo = 0, deficit = 0;
-            for (int base = 0; base < P; base += 64) {
-                const int i = base + lane;
-                const bool in = i < P;
-                const uint32_t w = in ? (uint32_t)s_bin[i] : 0x10000u;
-                const uint32_t pw = (in && i > 0) ? (uint32_t)s_bin[i - 1] : 0x10001u;
-                const double me = s_inten[in ? i : 0];
-                const uint64_t starts = __ballot(in && pw != w);
-                const uint64_t upto = lanemask_lt() | (1ull << lane);
-                const uint64_t le = starts & upto, gt = starts & ~upto;
-                /* where does the run that is still open at the end of this chunk stop? */
-                int run_end = P - 1;
-                for (int nb = base + 64; nb < P; nb += 64) {
-                    const int j = nb + lane;
-                    const uint64_t m2 = __ballot(j < P && s_bin[j] != s_bin[j - 1]);
-                    if (m2) {
-                        run_end = nb + __builtin_ctzll(m2) - 1;
-                        break;
-                    }
-                }
-                const int lo = le ? base + 63 - __builtin_clzll(le) : carry_lo;
-                const int hi = gt ? base + __builtin_ctzll(gt) - 1 : run_end;
-                const int len = in ? hi - lo + 1 : 0;
-                /* longest run that reaches into this chunk, from the ballot of the run starts: scalar work */
-                int t_max = 0, t_min = 0x7fffffff;            /* ... and the shortest: below it no lane needs the length test */
-                {
-                    uint64_t m = starts;
-                    int prev = carry_lo;
-                    if (m & 1ull) {
-                        prev = base;
-                        m &= ~1ull;
-                    }
-                    while (m) {
-                        const int p = base + __builtin_ctzll(m);
-                        t_max = p - prev > t_max ? p - prev : t_max;
-                        t_min = p - prev < t_min ? p - prev : t_min;
-                        prev = p;
-                        m &= m - 1;
-                    }
-                    t_max = run_end - prev + 1 > t_max ? run_end - prev + 1 : t_max;
-                    t_min = run_end - prev + 1 < t_min ? run_end - prev + 1 : t_min;
-                }
-                carry_lo = __builtin_amdgcn_readlane(lo, 63);
-                /* mates are read at lo + t straight through the end of the lane's run (whatever
-                 * follows in LDS is masked by t < len), so the address is one running pointer */
-                const double *src = s_inten + (in ? lo : 0);
-                int cnt = 0;
-                const int t_end = __builtin_amdgcn_readfirstlane(t_max);
-                const int t_all = __builtin_amdgcn_readfirstlane(t_min);
-                if (sweep == 0) {
-#pragma unroll 4
-                    for (int t = 0; t < t_all; t++) cnt += (int)(src[t] > me);   /* every run of the chunk reaches this far */
-#pragma unroll 4
-                    for (int t = t_all; t < t_end; t++) {
-                        const double o = src[t];                  /* unconditional: no branch around the read */
-                        cnt += (int)((t < len) & (o > me));
-                    }
-                    deficit += in ? (len - 1) - 2 * cnt : 0;
-                    if (in) s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
-                } else {
-#pragma unroll 4
-                    for (int t = 0; t < t_end; t++) {
-                        const double o = src[t];
-                        cnt += (int)((t < len) & (o == me));      /* counts the peak itself too */
-                    }
-                    hot = hot || (in && s_rank[i] < PYA_NTOP && cnt > 1);
-                }
-            }
-            if (sweep == 0) {
-                if (wave_sum_i32(deficit) == 0) break;            /* no two equal intensities in any window */
-            } else if (__any(hot)) {
-                return PYA_BIN_REDO;                              /* a tie inside some window's top n_top */
-            }
-          }
-        }
-        if (!EXACT) {
-        } else if (!unsorted) {
+        if (!unsorted) {
             /* Which equally intense peaks of a window are retained, and in which rank order, is
              * whatever std::nth_element + std::sort leave: one lane per window emulates them
              * serially on the window's (intensity, index) pairs in place -- up to 64 windows at a
@@ -532,7 +664,7 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             }
             total += __popcll(m);
         }
-    } else if (EXACT) {
+    } else {
         /* general order: position = number of retained peaks with a smaller (m/z, index) */
         for (int base = 0; base < P; base += 64) {
             int i = base + lane;
@@ -556,6 +688,13 @@ DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     *out_mz = o_mz;
     *out_rank = o_rank;
     return total;
+}
+
+template <bool EXACT>
+DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
+                 const uint8_t **out_rank, int *status) {
+    if (EXACT) return bin_exact(b, psm, lds, cap, out_mz, out_rank, status);
+    return bin_fast(b, psm, lds, cap, out_mz, out_rank, status);
 }
 
 /* retained table of one spectrum (or its error status) to global memory */

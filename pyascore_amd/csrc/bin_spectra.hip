@@ -6,8 +6,8 @@
  * order plus their intensity rank inside their window -- exactly the information the match
  * cache of the reference holds (ModifiedPeptide.cpp:126-142).
  *
- * HBM traffic: reads 16 B per raw peak once (coalesced, 8 B per lane), writes 5 B per retained
- * peak.  Everything else lives in LDS: intensity (f64) and window id (u16) per peak.
+ * HBM traffic: reads 16 B per raw peak once (coalesced, 8 B per lane), writes 8 B per retained
+ * peak.  Everything else lives in LDS (bin_core.hip.h).
  *
  * Two kernels: pya_bin_spectra_kernel takes the common case (peaks in m/z order, no two equal
  * intensities inside a window) and appends every other spectrum to a list that
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDe
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t slot = xcd_slot(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
     if (slot >= n_ids) return;
-    unsigned char *lds_raw = lds_all + (size_t)wave * (((size_t)cap * 15 + 63) & ~(size_t)63);
+    unsigned char *lds_raw = lds_all + (size_t)wave * PYA_BIN_WAVE_BYTES(cap);
     const uint32_t psm = psm_ids[slot];
     const float *r_mz;
     const uint8_t *r_rank;
@@ -55,12 +55,12 @@ __global__ __launch_bounds__(64) void pya_bin_exact_kernel(BatchDev b, uint32_t 
     }
 }
 
-extern "C" size_t pya_bin_lds_bytes(uint32_t cap) { return (size_t)cap * (8 + 4 + 2 + 1) + 64; }
+extern "C" size_t pya_bin_lds_bytes(uint32_t cap) { return PYA_BIN_WAVE_BYTES(cap); }
 
 extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                               hipStream_t stream) {
     if (n_ids == 0) return 0;
-    const size_t per_wave = (((size_t)cap * 15 + 63) & ~(size_t)63);
+    const size_t per_wave = PYA_BIN_WAVE_BYTES(cap);
     const uint32_t nw = per_wave * BIN_WAVES <= 64 * 1024 ? BIN_WAVES : 1;
     size_t lds = nw * per_wave;
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_bin_spectra_kernel);

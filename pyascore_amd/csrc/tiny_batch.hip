@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void pya_tiny_batch_kernel(BatchDev b, uint32_t
 extern "C" size_t pya_tiny_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact,
                                      uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
                                      uint32_t sb) {
-    size_t a = (((size_t)cap * 15 + 63) & ~(size_t)63) + 192;
+    size_t a = PYA_BIN_WAVE_BYTES(cap);       /* (covers the exact body's 192 bytes of window starts too) */
     size_t s = score_lds_bytes(cap, prefix, with_nl, prefix ? compact : 0u);
     size_t l = localize_lds_bytes(push_cap, n_cap, pos_cap, pool_cap, sb);
     a = a > s ? a : s;

@@ -208,6 +208,77 @@ def test_equal_intensities_follow_nth_element(monkeypatch):
         assert np.array_equal(plain[key], forced[key]), key
 
 
+def test_binning_keys_and_their_hand_overs(monkeypatch):
+    """The common-case binning ranks with 31-bit composite keys (window | high word of the intensity, 20 mantissa
+    bits, 2^32 of dynamic range below the spectrum's maximum: bin_core.hip.h, bin_fast) and hands over what they cannot
+    decide.  Every regime against the checker: intensities that differ only below the key's precision, at the top of
+    their windows and among the weak peaks; zero, denormal and huge intensities in one spectrum; negative and -0.0
+    intensities; more than 64 windows (small bin_size); a whole spectrum inside one window; spectra of more than one
+    384-peak block; and the forced general route (PYA_DEBUG=128) agreeing with the default on all of them."""
+    batch, settings = synth.make_batch("cfg2", n_psm=300, seed=4242)
+    it = batch["intensity"]
+    rng = np.random.default_rng(9)
+    ulp = np.spacing(it)
+    near = it.copy()                                                   # pairs a few ulps apart: equal keys, different doubles
+    idx = rng.permutation(it.size)
+    half = it.size // 2
+    near[idx[:half]] = np.floor(it[idx[:half]] / 64.0) * 64.0 + 1.0
+    near[idx[:half]] += ulp[idx[:half]] * rng.integers(0, 4, half)
+    top = it.copy()                                                    # the most intense peaks of every spectrum a few ulps apart
+    for i in range(batch["n_psm"]):
+        a, b = batch["peak_off"][i], batch["peak_off"][i + 1]
+        order = a + np.argsort(it[a:b])[::-1][:40]
+        top[order] = 50000.0 + np.spacing(50000.0) * rng.integers(0, 6, order.size)
+    wide = it.copy()
+    wide[idx[: it.size // 5]] = 0.0
+    wide[idx[it.size // 5: it.size // 4]] = 5e-324
+    wide[idx[it.size // 4: it.size // 3]] *= 1e-30
+    wide[idx[it.size // 3: it.size // 2]] *= 1e30
+    neg = it.copy()
+    neg[idx[: it.size // 10]] *= -1.0
+    neg[idx[it.size // 10: it.size // 8]] = -0.0
+    cases = {"near": near, "top": top, "wide": wide, "negative": neg}
+    gpu, chk = _gpu(settings), _checker(settings)
+
+    def both(b2, name, g=gpu, c=chk):
+        monkeypatch.delenv("PYA_DEBUG", raising=False)
+        g.reload_env()
+        got = g.score_batch(b2)
+        want = c.score_batch(b2, got["ascores"].shape[1])
+        for key in want:
+            assert np.array_equal(got[key], want[key]), (name, key)
+        monkeypatch.setenv("PYA_DEBUG", "128")
+        g.reload_env()
+        forced = g.score_batch(b2)
+        monkeypatch.delenv("PYA_DEBUG", raising=False)
+        g.reload_env()
+        for key in got:
+            assert np.array_equal(got[key], forced[key]), (name, "forced", key)
+
+    for name, inten in cases.items():
+        both(dict(batch, intensity=inten), name)
+    # a whole spectrum inside one 100 m/z window (one run of ~330 peaks), and spectra of several blocks
+    squeezed = dict(batch, mz=400.0 + (batch["mz"] - 100.0) / 20.0)
+    both(squeezed, "one window")
+    # spectra of several 384-peak blocks: the peaks of five spectra merged under the first one's peptide
+    po = batch["peak_off"]
+    mzs, its, offs = [], [], [0]
+    for j in range(0, 200, 5):
+        m, t = batch["mz"][po[j]:po[j + 5]], it[po[j]:po[j + 5]]
+        o = np.argsort(m, kind="stable")
+        mzs.append(m[o]); its.append(t[o]); offs.append(offs[-1] + m.size)
+    pick = np.arange(0, 200, 5)
+    L = int(batch["pep_off"][1] - batch["pep_off"][0])
+    big = dict(batch, n_psm=pick.size, mz=np.concatenate(mzs), intensity=np.concatenate(its),
+               peak_off=np.asarray(offs, np.int64), pep=batch["pep"].reshape(-1, L)[pick].ravel().copy(),
+               pep_off=np.arange(pick.size + 1, dtype=np.int64) * L, n_of_mod=batch["n_of_mod"][pick].copy(),
+               max_charge=batch["max_charge"][pick].copy(), aux_off=np.zeros(pick.size + 1, np.int64))
+    both(big, "blocks")
+    # more than 64 windows: bin_size 10
+    fine = dict(settings, bin_size=10.0)
+    both(batch, "bin_size 10", _gpu(fine), _checker(fine))
+
+
 @pytest.mark.parametrize("case", ["synth_cfg3", "edge_nl", "velos_zprec", "ties_cfg2"])
 def test_bulk_pep_scores_match_golden(case):
     """pya_get_pep_scores_range: every localisation of every PSM of a retained batch
