@@ -45,15 +45,15 @@
  * pointers through integers to align them hides the address space from the compiler, which then
  * emits FLAT accesses -- slower, and waited for together with every global load in flight):
  *   grid u16[256]
- *   walk region   cnt u32[5][64] | peaks PeakEntry[cap + 4]                     (dead after the walk)
+ *   walk region   cum u32[16][4] | peaks PeakEntry[cap + 4]                     (dead after the walk)
  *   post region   (same bytes) sort arrays, pushed competitors, per-site maxima / ties / alternative
  *                 sites, depth scores and counters of a round
  *   kept          resd float2[pos_cap + 1] | rkl u8[ent_cap][stride] | rec u32[n_cap][3] | wsl f32[n_cap]
- *                 | mass f32[32] | flags u32[32] | selm f32[(1 + FUSED_ROUND) * ndir][ent_cap]
+ *                 | mass f32[32] | flags u32[32] | site_pos u8[pos_cap + 1] | selm f32[(1 + FUSED_ROUND) * ndir][ent_cap]
  *                 (pos_cap = L - 1, ent_cap = (L - 1) x charges: list entries per (signature, direction)) */
 struct FusedLds {
     uint16_t *grid;
-    uint32_t *cnt;
+    uint4 *cum_lut;          /* [16] rank -> increments of the ten cumulative counts, a byte each (see fused_cum_entry) */
     PeakEntry *peaks;
     float2 *resd;
     uint8_t *rkl;
@@ -61,6 +61,7 @@ struct FusedLds {
     float *wsl;
     float *mass_l;
     uint32_t *flag_l;
+    uint8_t *site_pos;       /* [pos_cap + 1] residue of the j-th modifiable one */
     float *selm;
     /* post region */
     unsigned char *sort_raw;   /* sort_carve(sort_raw, N): the std::sort emulation's work area */
@@ -102,14 +103,14 @@ __host__ __device__ static inline size_t fused_post_bytes(uint32_t n_cap, uint32
                     : 0);
 }
 __host__ __device__ static inline size_t fused_walk_bytes(uint32_t cap) {
-    return PYA_NTOP / 2 * 64 * 4 + ((size_t)cap + PYA_TABLE_PAD) * 8;
+    return 16 * 16 + ((size_t)cap + PYA_TABLE_PAD) * 8;
 }
 /* pos_cap = largest L - 1 of the launch, ent_cap = largest (L - 1) x charges: list entries per
  * (signature, direction) */
 __host__ __device__ static inline size_t fused_kept_bytes(uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap,
                                                           uint32_t ndir) {
     return fused_align16(((size_t)pos_cap + 1) * 8) + fused_align16((size_t)ent_cap * stride) + (size_t)n_cap * 16 + 256 +
-           (size_t)(1 + FUSED_ROUND) * ndir * ent_cap * 4;
+           fused_align16((size_t)pos_cap + 1) + (size_t)(1 + FUSED_ROUND) * ndir * ent_cap * 4;
 }
 __host__ __device__ static inline size_t fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap,
                                                          uint32_t ent_cap, uint32_t push_cap, uint32_t ndir, bool multi_z) {
@@ -123,8 +124,8 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
     FusedLds f;
     f.grid = (uint16_t *)raw;
     size_t o = PYA_GRID_CELLS * 2;
-    f.cnt = (uint32_t *)(raw + o);
-    f.peaks = (PeakEntry *)(raw + o + PYA_NTOP / 2 * 64 * 4);
+    f.cum_lut = (uint4 *)(raw + o);
+    f.peaks = (PeakEntry *)(raw + o + 16 * 16);
     /* post region over the walk region */
     f.sort_raw = raw + o;
     size_t q = o + fused_align16(fused_sort_bytes(n_cap));
@@ -169,18 +170,44 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
     o += (size_t)n_cap * 4;
     f.mass_l = (float *)(raw + o);
     f.flag_l = (uint32_t *)(raw + o + 128);
-    f.selm = (float *)(raw + o + 256);
+    f.site_pos = (uint8_t *)(raw + o + 256);
+    f.selm = (float *)(raw + o + 256 + fused_align16((size_t)pos_cap + 1));
     return f;
 }
 
+/* Cumulative counts (Ascore.cpp:115-118: counts[d] = fragments matched at rank <= d) are kept in three registers per
+ * walker, a byte per depth (a PSM of this kernel has at most 255 fragments per site assignment): a fragment that
+ * matched rank r adds 1 to the bytes d >= r, which is one 16-byte LDS read of the entry below and three adds of the
+ * cheap class -- where bumping a histogram column in LDS took four instructions of the expensive class and an LDS
+ * atomic, and the scores then had to sum the histogram up.  Entry 15 (no match) is all zeros. */
+DEV uint4 fused_cum_entry(uint32_t r) {
+    const uint32_t full = 0x01010101u;
+    uint4 e;
+    e.x = r < 4u ? full << (8u * r) : 0u;
+    e.y = r <= 4u ? full : (r < 8u ? full << (8u * (r - 4u)) : 0u);
+    e.z = r <= 8u ? 0x0101u : (r == 9u ? 0x0100u : 0u);
+    e.w = 0u;
+    if (r >= (uint32_t)PYA_NTOP) e.x = e.y = e.z = 0u;
+    return e;
+}
+struct CumCounts {
+    uint32_t a, b, c;        /* depths 0-3 | 4-7 | 8-9 */
+    DEV void add(const uint4 &e) {
+        a += e.x;
+        b += e.y;
+        c += e.z;
+    }
+    DEV uint32_t at(int d) const { return ((d < 4 ? a : (d < 8 ? b : c)) >> ((d & 3) * 8)) & 0xffu; }
+};
+
 /* the straight-line walker of walk_core.hip.h that also records the rank every fragment matched in
  * column `w` of rkl (entry step * zmax + z - 1); A, B: the ion-type offsets of the lane's direction.
- * Lanes without a walker run the same code: they bump their own histogram column by zero and
+ * Lanes without a walker run the same code: their counts are never read and they
  * record into a spare column (`w` = stride - 1 for them) -- no per-lane branches in the loop.
  * BZ: no direction subtracts an offset (every ion type but z / Z), so that instruction is left out. */
 template <bool BZ>
-DEV void walk_record_steps(const float2 *&rp, int rstride, StepBits &bits, float &running, uint32_t *col, const PeakTable &tab,
-                           int zmax, double A, double B, bool active, uint8_t *&ro, int stride, int count) {
+DEV void walk_record_steps(const float2 *&rp, int rstride, StepBits &bits, float &running, const uint4 *lut, CumCounts &cum,
+                           const PeakTable &tab, int zmax, double A, double B, uint8_t *&ro, int stride, int count) {
     for (int i = 0; i < count; i++, rp += rstride) {
         const float2 mm = *rp;
         running = (bits.next() ? mm.y : mm.x) + running;     /* ModifiedPeptide.cpp:385-389 */
@@ -189,19 +216,19 @@ DEV void walk_record_steps(const float2 *&rp, int rstride, StepBits &bits, float
             const Look k = look4(tab, charge_mz(m, z));
             int rk = k.best;
             if (k.more()) rk = look_rest(tab, k);
-            hist_bump(col, active, rk);
+            cum.add(lut[rk]);
             *ro = (uint8_t)rk;
         }
     }
 }
-DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, int L, int zmax, uint64_t resmask, int dir,
-                     double A, double B, bool all_b_zero, bool active, uint8_t *rkl, int stride, int w) {
+DEV CumCounts walk_record(const float2 *resd, const uint4 *lut, const PeakTable &tab, int L, int zmax, uint64_t resmask, int dir,
+                          double A, double B, bool all_b_zero, uint8_t *rkl, int stride, int w) {
     const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
     const float2 *rp = resd + (dir ? L - 1 : 0);
     const int rstride = dir ? -1 : 1;
-    uint32_t *col = cnt + lane_id();
     uint8_t *ro = rkl + w;
     float running = 0.f;
+    CumCounts cum = {0u, 0u, 0u};
     if (tab.half_check) {                                    /* mz_error > 0.49: the lookup with the extra test */
         const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
         for (int step = 0; step + 1 < L; step++, rp += rstride) {
@@ -212,11 +239,11 @@ DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, in
             const double m = ((double)running + A) - B;
             for (int z = 1; z <= zmax; z++, ro += stride) {
                 const int rk = match_rank_lds(tab, charge_mz(m, z));
-                hist_bump(col, active, rk);
+                cum.add(lut[rk]);
                 *ro = (uint8_t)rk;
             }
         }
-        return;
+        return cum;
     }
     const uint64_t M = msb_first_from(tmask, 0);
     const int n = L - 1;
@@ -224,9 +251,10 @@ DEV void walk_record(const float2 *resd, uint32_t *cnt, const PeakTable &tab, in
         StepBits bits = {seg ? (uint32_t)M : (uint32_t)(M >> 32)};
         int c = (n < seg * 32 + 32 ? n : seg * 32 + 32) - seg * 32;
         if (c < 0) c = 0;
-        if (all_b_zero) walk_record_steps<true>(rp, rstride, bits, running, col, tab, zmax, A, B, active, ro, stride, c);
-        else walk_record_steps<false>(rp, rstride, bits, running, col, tab, zmax, A, B, active, ro, stride, c);
+        if (all_b_zero) walk_record_steps<true>(rp, rstride, bits, running, lut, cum, tab, zmax, A, B, ro, stride, c);
+        else walk_record_steps<false>(rp, rstride, bits, running, lut, cum, tab, zmax, A, B, ro, stride, c);
     }
+    return cum;
 }
 
 /* the same walk without lookups: fragment m/z of one signature and direction to out[z-1][step] */
@@ -247,6 +275,26 @@ DEV void walk_mz_only(const float2 *resd, int L, int zmax, uint64_t resmask, int
             const double m = ((double)running + A) - B;
             out[step] = (float)(m + 1.007825);
             for (int z = 2; z <= zmax; z++) out[(z - 1) * Lm1 + step] = charge_mz(m, z);
+        }
+    }
+}
+
+/* ... and its first half alone: the float32 running sums (charge 1: a second, wave-wide pass turns them into m/z) */
+DEV void walk_sums_only(const float2 *resd, int L, uint64_t resmask, int dir, float *out) {
+    const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
+    const uint64_t M = msb_first_from(tmask, 0);
+    const float2 *rp = resd + (dir ? L - 1 : 0);
+    const int rstride = dir ? -1 : 1;
+    const int Lm1 = L - 1;
+    float running = 0.f;
+    int step = 0;
+    for (int seg = 0; seg < 2; seg++) {
+        StepBits bits = {seg ? (uint32_t)M : (uint32_t)(M >> 32)};
+        const int end = Lm1 < seg * 32 + 32 ? Lm1 : seg * 32 + 32;
+        for (; step < end; step++, rp += rstride) {
+            const float2 mm = *rp;
+            running = (bits.next() ? mm.y : mm.x) + running;
+            out[step] = running;
         }
     }
 }
@@ -405,12 +453,12 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         }
         site_mask = __ballot(modifiable);
         if (in) f.resd[lane] = make_float2(m0, m1);
+        if (modifiable) f.site_pos[__popcll(site_mask & lanemask_lt())] = (uint8_t)lane;
     }
     STAMP_T(b, 49, false);
     grid_build(&tab, f.grid);
     STAMP_T(b, 50, false);
-#pragma unroll
-    for (int d = 0; d < PYA_NTOP / 2; d++) f.cnt[d * 64 + lane] = 0u;
+    if (lane < 16) f.cum_lut[lane] = fused_cum_entry((uint32_t)lane);
     const int Lm1 = L - 1;
     const uint64_t resmask = deposit_sites(bits, site_mask);
     const int w = !active ? (int)stride - 1 : (BOTH ? (lane >> 5) * N + s : s);   /* this lane's column of the rank lists (last: spare) */
@@ -423,8 +471,22 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const bool wide = !__any(lane < L && !(m0 > wide_min && m1 > wide_min));
     wave_lds_sync();
     STAMP_T(b, 40, false);
-    walk_record(f.resd, f.cnt, tab, L, zmax, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, Bf == 0. && Bb == 0., active, f.rkl,
-                (int)stride, w);
+    CumCounts cum = walk_record(f.resd, f.cum_lut, tab, L, zmax, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, Bf == 0. && Bb == 0.,
+                                f.rkl, (int)stride, w);
+    if (BOTH) {                                             /* a signature's two directions: the backward walker's counts to the forward one */
+        uint32_t *r3 = f.rec + (size_t)s * 3;
+        if (active && lane >= 32) {
+            r3[0] = cum.a;
+            r3[1] = cum.b;
+            r3[2] = cum.c;
+        }
+        wave_lds_sync();
+        if (active && lane < 32) {
+            cum.a += r3[0];
+            cum.b += r3[1];
+            cum.c += r3[2];
+        }
+    }
     wave_lds_sync();
     STAMP_T(b, 41, false);
 
@@ -432,20 +494,13 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     int fail = 0;
     float ws = 0.f;
     if (active && (!BOTH || lane < 32)) {
-        /* cumulative counts over rank (Ascore.cpp:115-118) and scores (Ascore.cpp:123-139) */
-        uint32_t cum[PYA_NTOP];
-        uint32_t acc = 0;
-#pragma unroll
-        for (int d = 0; d < PYA_NTOP; d++) {
-            acc += hist_count(f.cnt, lane, d) + (BOTH ? hist_count(f.cnt, lane + 32, d) : 0u);
-            cum[d] = acc;
-        }
+        /* scores from the cumulative counts (Ascore.cpp:123-139) */
         ws = -1.f;
         if (nfrag <= b.lut_n_max) {
             double sum = 0.;
 #pragma unroll
             for (int d = 0; d < PYA_NTOP; d++) {
-                const float sc = lut_score(b, (uint32_t)d, cum[d], nfrag);
+                const float sc = lut_score(b, (uint32_t)d, cum.at(d), nfrag);
                 const float prod = cfg->weights[d] * sc;                  /* float product ...   */
                 sum = sum + (double)prod;                                 /* ... double sum      */
             }
@@ -453,10 +508,10 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         } else {
             fail = 1;
         }
-        uint32_t *r3 = f.rec + (size_t)s * 3;              /* counts <= 126: a byte each */
-        r3[0] = cum[0] | cum[1] << 8 | cum[2] << 16 | cum[3] << 24;
-        r3[1] = cum[4] | cum[5] << 8 | cum[6] << 16 | cum[7] << 24;
-        r3[2] = cum[8] | cum[9] << 8;
+        uint32_t *r3 = f.rec + (size_t)s * 3;              /* (the counts as they are: a byte each) */
+        r3[0] = cum.a;
+        r3[1] = cum.b;
+        r3[2] = cum.c;
         f.wsl[s] = ws;
     }
     if (__any(fail)) {                                      /* trial count outside the score table */
@@ -468,7 +523,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         }
         return false;
     }
-    wave_lds_sync();                                        /* cnt / peaks are free from here on */
+    wave_lds_sync();                                        /* the count table and the peaks are free from here on */
     STAMP_T(b, 42, false);
 
     bool declined = !presorted || (b.debug & 512);
@@ -518,7 +573,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             if ((double)__builtin_fabsf(best_ws - my_ws) < 1e-6) {
                 /* ties the winner: Ascore 0 (Ascore.cpp:159-161), no ion work needed */
                 f.site_tie[a] = 1u;
-                atomicOr(&f.site_alt[a], 1ull << nth_set_bit(site_mask, __builtin_ctzll(came)));
+                atomicOr(&f.site_alt[a], 1ull << f.site_pos[__builtin_ctzll(came)]);
             } else {
                 const uint32_t slot = atomicAdd(f.n_pushed, 1u);
                 if (slot < push_cap) {
@@ -551,8 +606,22 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             const int sg = lane / ndir, d = lane - sg * ndir;
             const uint64_t sb = sg == 0 ? best_bits : f.pushed[e0 + sg - 1].bits;
             const int dd = BOTH ? d : (cfg->n_fwd > 0 ? 0 : 1);
-            walk_mz_only(f.resd, L, zmax, deposit_sites(sb, site_mask), dd, dd ? Ab : Af, dd ? Bb : Bf,
-                         f.selm + (size_t)lane * ent_cap);
+            if (ZM) walk_mz_only(f.resd, L, zmax, deposit_sites(sb, site_mask), dd, dd ? Ab : Af, dd ? Bb : Bf,
+                                 f.selm + (size_t)lane * ent_cap);
+            else walk_sums_only(f.resd, L, deposit_sites(sb, site_mask), dd, f.selm + (size_t)lane * ent_cap);
+        }
+        if (!ZM) {
+            /* charge 1: the few lanes above leave the running sums; every lane turns a share of them into m/z
+             * (ModifiedPeptide.cpp:570-591), instead of the few doing the float64 arithmetic step by step */
+            wave_lds_sync();
+            const int l0 = e0 == 0 ? 0 : ndir, nl = S * ndir - l0;
+            for (int i = lane; i < nl * Lm1; i += 64) {
+                const int lq = (int)fastdiv((uint32_t)i, divL), st = i - lq * Lm1;
+                const int dd = BOTH ? ((l0 + lq) & 1) : (cfg->n_fwd > 0 ? 0 : 1);
+                float *at = f.selm + (size_t)(l0 + lq) * ent_cap + st;
+                const double m = ((double)*at + (dd ? Ab : Af)) - (dd ? Bb : Bf);
+                *at = (float)(m + 1.007825);
+            }
         }
         /* depth scores of the winner and the competitors, read off the score table */
         for (int i = (e0 == 0 ? 0 : 10) + lane; i < S * 10; i += 64) {
@@ -566,18 +635,30 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
             const PushedEntry pe = f.pushed[e0 + lane];
             const uint64_t gone = best_bits & ~pe.bits, came = pe.bits & ~best_bits;
             const int a = __popcll(best_bits & (gone - 1));
-            atomicOr(&f.site_alt[a], 1ull << nth_set_bit(site_mask, __builtin_ctzll(came)));
+            atomicOr(&f.site_alt[a], 1ull << f.site_pos[__builtin_ctzll(came)]);
             f.c_site[lane] = (uint32_t)a;
-            float best = 0.f;                               /* depth of the largest score gap (Ascore.cpp:164-172) */
-            int depth = 0;
-            for (int d = 0; d < PYA_NTOP; d++) {
-                const float diff = f.sc[d] - f.sc[(lane + 1) * 10 + d];
-                if (diff > best) {
-                    best = diff;
-                    depth = d;
-                }
+        }
+        {
+            /* depth of the largest score gap (Ascore.cpp:164-172: the first depth whose gap is the largest, 0 when no gap
+             * is positive), one lane per (competitor, depth): a positive gap's bit pattern orders like its value, the
+             * largest goes through an LDS maximum and a ballot names the first depth that has it */
+            const int c = lane >> 4, d = lane & 15;
+            const bool on = c < nc && d < PYA_NTOP;
+            uint32_t key = 0;
+            if (on) {
+                const float diff = f.sc[d] - f.sc[(c + 1) * 10 + d];
+                key = diff > 0.f ? __float_as_uint(diff) : 0u;
             }
-            f.c_depth[lane] = depth;
+            if (lane < nc) f.c_depth[lane] = 0;
+            wave_lds_sync();
+            if (on && key) atomicMax((uint32_t *)&f.c_depth[c], key);
+            wave_lds_sync();
+            const uint64_t at_max = __ballot(on && key && key == (uint32_t)f.c_depth[c]);
+            wave_lds_sync();
+            if (lane < nc) {
+                const uint32_t m16 = (uint32_t)(at_max >> (16 * lane)) & 0xffffu;
+                f.c_depth[lane] = m16 ? __builtin_ctz(m16) : 0;
+            }
         }
         if (lane < nc * ndir * 2) {
             f.c_tr[lane] = 0;
@@ -614,8 +695,8 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
                 const int c = lane / ndir, d = lane - c * ndir;
                 const int dd = BOTH ? d : (cfg->n_fwd > 0 ? 0 : 1);
                 const uint64_t diff = best_bits ^ f.pushed[e0 + c].bits;            /* site indices */
-                const int r_lo = nth_set_bit(site_mask, __builtin_ctzll(diff));
-                const int r_hi = nth_set_bit(site_mask, 63 - __builtin_clzll(diff));
+                const int r_lo = (int)f.site_pos[__builtin_ctzll(diff)];
+                const int r_hi = (int)f.site_pos[63 - __builtin_clzll(diff)];
                 const int lo = dd ? L - 1 - r_hi : r_lo, hi = dd ? L - 1 - r_lo : r_hi;
                 f.t_lo[lane] = (uint32_t)lo;
                 f.t_off[lane] = (uint32_t)(2 * (hi - lo));       /* both sides */
