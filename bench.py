@@ -74,11 +74,11 @@ def profiled_counters(cfg, kern_ms, names, default_size):
     (profiles/*_rocprof_<cfg>/pmc_summary.csv, separate --pmc passes, scripts/profile.sh):
       traffic      HBM bytes per step, 2 x FETCH_SIZE + WRITE_SIZE (KB counters; gfx950's FETCH_SIZE tallies
                    128-byte requests as 64: MI355X_MICROARCH.md, HBM section);
-      hbm_actual   that over the family's live HIP-event duration, GB/s;
+      hbm_actual   that over the family's duration IN THE PROFILED RUN (kernel_stats.csv of the same directory:
+                   counters and durations of one build on one box; `ms_profiled` beside this run's `ms_live`), GB/s;
       valu_busy    SQ_INSTS_VALU x the measured cost of a vector instruction of the kernel's own mix
-                   / (1024 SIMDs x the kernel's cycles): the share of SIMD time its vector instructions
-                   need at the measured issue rates (profiles/r03_valu_ceiling.md); <= 1 by construction
-                   of the cost (measured at saturation);
+                   / (1024 SIMDs x the kernel's cycles in the profiled run): the share of SIMD time its vector
+                   instructions need at the measured issue rates (profiles/r03_valu_ceiling.md);
       salu_busy    SQ_INSTS_SALU / (256 CUs x cycles): the one scalar unit of a CU issues one per cycle;
       lanes_per_valu  active lanes per vector instruction, of 64 (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU);
       lds_conflict LDS bank-conflict cycles per active LDS cycle.
@@ -99,17 +99,27 @@ def profiled_counters(cfg, kern_ms, names, default_size):
                 per_kernel.setdefault(row["kernel"], {})[row["counter"]] = float(row.get("per_step") or row["mean_value"])
     except OSError:
         return None, None
+    # the profiled run's own kernel durations (rocprofv3 --kernel-trace --stats of the same command: scripts/profile.sh
+    # runs 10 steps + 2 warm-up steps)
+    prof_ns = {}
+    try:
+        with open(os.path.join(dirs[-1], "kernel_stats.csv"), newline="") as f:
+            for row in csv.DictReader(f):
+                prof_ns[row["Name"].split("(")[0].replace("void ", "").strip()] = float(row["TotalDurationNs"]) / 12.0
+    except (OSError, KeyError, ValueError):
+        prof_ns = {}
     cost, cost_default = valu_costs()
     fams = {}
     whole = 0.0
     for fam_name, ms in zip(names, kern_ms):
         members = FAMILIES.get(fam_name, (fam_name,))
         acc = {"traffic": 0.0, "valu_cyc": 0.0, "valu": 0.0, "salu": 0.0, "cycles": 0.0, "thread_cyc": 0.0,
-               "lds_conf": 0.0, "lds_act": 0.0, "kernels": []}
+               "lds_conf": 0.0, "lds_act": 0.0, "kernels": [], "ms_prof": 0.0}
         for kname, c in per_kernel.items():
             if kname.split("<")[0] not in members or "FETCH_SIZE" not in c:
                 continue
             acc["kernels"].append(kname)
+            acc["ms_prof"] += prof_ns.get(kname, 0.0) * 1e-6
             acc["traffic"] += (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0
             acc["valu"] += c.get("SQ_INSTS_VALU", 0.0)
             acc["valu_cyc"] += c.get("SQ_INSTS_VALU", 0.0) * (cost.get(kname) or cost_default)
@@ -124,7 +134,8 @@ def profiled_counters(cfg, kern_ms, names, default_size):
         cyc = acc["cycles"]
         fams[fam_name] = {
             "kernels": sorted(acc["kernels"]), "traffic": acc["traffic"],
-            "hbm_actual": acc["traffic"] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            "hbm_actual": acc["traffic"] / (acc["ms_prof"] * 1e-3) / 1e9 if acc["ms_prof"] > 0 else None,
+            "ms_profiled": acc["ms_prof"] or None,
             "valu_cycles_per_inst": acc["valu_cyc"] / acc["valu"] if acc["valu"] else None,
             "valu_busy": acc["valu_cyc"] / (1024.0 * cyc) if cyc else None,
             "salu_busy": acc["salu"] / (256.0 * cyc) if cyc else None,
@@ -265,6 +276,9 @@ def main():
                     "(default: the config's size, e.g. 1M for cfg3)")
     ap.add_argument("--max-charge", type=int, default=None,
                     help="override the config's max fragment charge (real 3+/4+ precursors are scored at 2/3)")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="timed blocks of --steps steps each (every block bracketed by barrier + synchronize); the line "
+                         "reports the MEDIAN block, and every block's ms per step beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true",
                     help="skip the host-array legs (profiling runs: only the timed device-resident steps launch kernels)")
@@ -348,28 +362,42 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    pipe.reset_stats()
-    kern_ms = np.zeros(4)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.step()
-        kern_ms += np.asarray(plan.timings_ms())           # HIP events on the launch stream
-    pipe.drain()                                           # every gather of the timed steps has landed
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # A timed block = EXACTLY --steps steps between barrier + synchronize on both sides.  One block of a 0.6 ms step is
+    # 30 ms of wall time, which a clock ramp or a noisy neighbour can move by 10 %: several blocks are timed, the
+    # median one is the line's value, all of them are listed.
+    blocks = []
+    for _ in range(max(1, args.blocks)):
+        pipe.reset_stats()
+        k_ms = np.zeros(4)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.step()
+            k_ms += np.asarray(plan.timings_ms())          # HIP events on the launch stream
+        pipe.drain()                                       # every gather of the timed steps has landed
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if use_dist:                                       # (the slowest rank's time, the same on every rank)
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_own, el = el, float(t.item())
+        else:
+            el_own = el
+        blocks.append((el, el_own, k_ms / max(args.steps, 1), pipe.gather_wait_s))
     plan.check()
-    kern_ms /= max(args.steps, 1)
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    elapsed, elapsed_own, kern_ms, gather_wait_s = blocks[order[len(order) // 2]]
+    block_ms = [1e3 * b[0] / max(args.steps, 1) for b in blocks]
 
     per_rank = None
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_own, elapsed = elapsed, float(t.item())
         # what every rank measured, so that the first real scaling run explains itself: per-rank kernel
         # family times, time spent waiting for gathers, own wall time, shard size and work estimate
-        mine = torch.tensor(list(kern_ms) + [1e3 * pipe.gather_wait_s / max(args.steps, 1), 1e3 * elapsed_own / max(args.steps, 1),
+        mine = torch.tensor(list(kern_ms) + [1e3 * gather_wait_s / max(args.steps, 1), 1e3 * elapsed_own / max(args.steps, 1),
                                              float(hi - lo), float(weights[lo:hi].sum())], dtype=torch.float64, device=dev)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -419,6 +447,9 @@ def main():
             "metric": METRIC, "value": total * args.steps / elapsed, "unit": "PSMs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
+            "blocks": {"n": len(block_ms), "ms_per_step": block_ms, "min": min(block_ms), "max": max(block_ms),
+                       "note": "every block is exactly `steps` steps between barrier + synchronize; value / ms_per_step / "
+                               "kernel_ms are the median block's"},
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32/f64 scalar + i32 counts",
             "data": "synthetic (SURVEY.md 8(d) generator, job seed 1000, spectra per 16k-PSM block)",
             "config": {"workload": "%s: %d PSMs over %d GPU(s), work-balanced contiguous shards" % (args.config, total, world),

@@ -145,6 +145,8 @@ int pya_score_batch(pya_handle *h, const pya_batch *batch, const double *mz,
  * cut into chunks of consecutive PSMs and pipelined: the upload of chunk c + 1 runs under the kernels
  * and the result copy of chunk c.  Results do not depend on the cut. */
 int pya_set_workspace_budget(pya_handle *h, uint64_t bytes);
+/* the budget in force (the value set, PYA_WORKSPACE_MB, or the default of 6 GiB) */
+uint64_t pya_get_workspace_budget(const pya_handle *h);
 
 /* per-PSM status codes (PYA_PSM_*) of the last pya_score_batch call on this handle; n must equal
  * that batch's n_psm.  All zeros unless PYA_FLAG_SKIP_INVALID let PSMs be set aside. */

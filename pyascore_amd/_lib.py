@@ -47,6 +47,7 @@ SYMBOLS = {
     "pya_error_index": (C.c_int64, [_vp]),
     "pya_score_batch": (C.c_int, [_vp, C.POINTER(Batch), _vp, _vp, C.c_uint32, C.POINTER(Results)]),
     "pya_set_workspace_budget": (C.c_int, [_vp, C.c_uint64]),
+    "pya_get_workspace_budget": (C.c_uint64, [_vp]),
     "pya_last_batch_status": (C.c_int, [_vp, _vp, C.c_uint64]),
     "pya_plan_create": (C.c_int, [_vp, C.POINTER(Batch), C.c_uint32, C.POINTER(_vp)]),
     "pya_plan_run": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(Results)]),

@@ -110,6 +110,7 @@ class PyAscore:
         (Ascore.pyx:81-99).  Upper case = unmodified residue, lower case = modified residue."""
         if not isinstance(group, str):
             raise TypeError("Argument 'group' has incorrect type (expected str)")
+        self._ensure_kept()      # (the last score() PSM's records, if they are still to be produced: under the old settings)
         rc = self._lib.pya_add_neutral_loss(self._h, group.encode("utf8"), float(mass))
         if rc:
             self._raise(rc)
@@ -117,6 +118,7 @@ class PyAscore:
     def reload_env(self):
         """Re-reads the PYA_* environment switches (kernel routes, diagnostics).  The library reads them once,
         when the scorer is created; tests that flip a route on a live scorer call this afterwards."""
+        self._ensure_kept()
         rc = self._lib.pya_reload_env(self._h)
         if rc:
             self._raise(rc)
@@ -204,6 +206,7 @@ class PyAscore:
                                            _lib.PYA_FLAG_KEEP, C.byref(one["results"]))
         if rc:
             self._last = None
+            self._batch_n = None
             self._raise(rc)
         self._batch_n = None if lazy else 1
         self._last = dict(pep=pep, peptide=peptide, k=int(n_of_mod), aux_pos=ap.copy(), aux_mass=am.copy(),
@@ -233,6 +236,9 @@ class PyAscore:
         a documented limit of this implementation does not fail the call; it gets best_score -1,
         n_sig -1 and a non-zero code in the extra ``status`` array (include/pyascore_hip.h PYA_PSM_*),
         and ``status_message`` describes the first such PSM."""
+        # the records behind pep_scores / calculate_ambiguity of the last score() PSM are produced on demand by
+        # replaying what score() staged in the library: before another call reuses that staging, produce them
+        self._ensure_kept()
         n = int(batch["n_psm"])
         mz = np.ascontiguousarray(batch["mz"], np.float64)
         it = np.ascontiguousarray(batch["intensity"], np.float64)
@@ -266,10 +272,12 @@ class PyAscore:
         self._lazy_batch = None
         lazy_keep = False
         if keep and n > 1:
-            budget = self._budget or (6 << 30)
-            per_psm = self._retained_bytes(dict(arrs, n_of_mod=arrs["n_of_mod"]))
-            if float(per_psm.sum()) > 0.8 * budget:
-                lazy_keep = True
+            budget = int(self._lib.pya_get_workspace_budget(self._h))
+            try:
+                per_psm = self._retained_bytes(dict(arrs, n_of_mod=arrs["n_of_mod"]))
+                lazy_keep = float(per_psm.sum()) > 0.8 * budget
+            except (IndexError, ValueError):
+                lazy_keep = False            # malformed offsets: the library's own validation reports them
         flags = (_lib.PYA_FLAG_KEEP if keep and not lazy_keep else 0) | (_lib.PYA_FLAG_SKIP_INVALID if skip_invalid else 0)
         rc = self._lib.pya_score_batch(self._h, C.byref(b), _as_ptr(mz), _as_ptr(it), flags, C.byref(r))
         if rc:
@@ -278,6 +286,8 @@ class PyAscore:
         if keep:
             self._last = None        # the handle's retained plan now belongs to this batch, not to score()'s PSM
         if lazy_keep:
+            # (references, not copies: a batch this size is gigabytes.  The arrays must not be modified before
+            # batch_pep_scores() has been read -- it re-scores the ranges it is asked for from them.)
             self._lazy_batch = dict(arrs, mz=mz, intensity=it, n_psm=n, per_psm=per_psm, budget=budget)
         if skip_invalid:
             out["status"] = np.zeros(n, np.int32)

@@ -832,6 +832,7 @@ void pya_destroy(pya_handle *h) {
 int pya_reload_env(pya_handle *h) {
     if (!h) return PYA_ERR_ARG;
     read_knobs(h->kn);
+    h->one.have_last = false;        /* (a replay of the last pya_score_one PSM would run under other switches) */
     return PYA_OK;
 }
 
@@ -843,6 +844,7 @@ int pya_add_neutral_loss(pya_handle *h, const char *group, float mass) {
     std::map<char, float> saved = h->nl;
     for (const char *c = group; *c; c++) h->nl[*c] = mass;     /* ModifiedPeptide.cpp:99-103 */
     h->cfg_dirty = true;
+    h->one.have_last = false;        /* (a replay of the last pya_score_one PSM would score it under the new settings) */
     int rc = build_dev_config(h);
     if (rc) {
         h->nl = saved;
@@ -2073,7 +2075,10 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
     if (!out->best_score || !out->best_sig || !out->n_sig || !out->ascores || !out->alt_mask)
         return h->fail(PYA_ERR_ARG, -1, "NULL array in results");
     if (b->peak_off[b->n_psm] < b->peak_off[0]) return h->fail(PYA_ERR_ARG, -1, "peak_off is not monotone");
-    if (b->n_psm == 1 && !(flags & (PYA_FLAG_SKIP_INVALID | PYA_FLAG_TIMING))) {
+    /* (not while the records of a pya_score_one PSM are retained in the one-PSM workspace: this call would overwrite
+     * what pya_get_pep_scores / pya_calculate_ambiguity still read there) */
+    const bool one_view_live = h->kept && h->kept == h->one.view;
+    if (b->n_psm == 1 && !(flags & (PYA_FLAG_SKIP_INVALID | PYA_FLAG_TIMING)) && !one_view_live) {
         /* a batch of one is PyAscore.score: the low-latency path (it declines what it has no room for) */
         const bool has_aux1 = b->aux_off && b->aux_pos && b->aux_mass;
         const int64_t a0 = has_aux1 ? b->aux_off[0] : 0, a1 = has_aux1 ? b->aux_off[1] : 0;
@@ -2082,6 +2087,9 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
             int rc1 = pya_score_one(h, mz + b->peak_off[0], inten + b->peak_off[0], (uint64_t)P1, b->pep + b->pep_off[0], (uint64_t)L1,
                                     b->n_of_mod[0], b->max_charge[0], has_aux1 ? b->aux_pos + a0 : nullptr,
                                     has_aux1 ? b->aux_mass + a0 : nullptr, (uint64_t)(a1 - a0), flags & PYA_FLAG_KEEP, out);
+            /* the one-PSM staging now holds THIS PSM: pya_rescore_last_keep must not replay it as the caller's last
+             * pya_score_one PSM (it fails with PYA_ERR_STATE instead) */
+            if (!(flags & PYA_FLAG_KEEP)) h->one.have_last = false;
             if (rc1 != PYA_ERR_STATE || !h->err.empty()) return rc1;
         }
     }
@@ -2215,6 +2223,9 @@ int one_prepare(pya_handle *h, uint32_t n_sig) {
         const size_t bytes = 4096 + ((size_t)PYA_MAX_PEAKS + 8) * sizeof(PeakEntry) + PYA_GRID_CELLS * 2 + 4096 +
                              (size_t)cap * (4 + PYA_REC_WORDS * 4 + 4) + 1024;
         HIPCHK(h, hipStreamSynchronize(o.stream));
+        /* the retained view (if any) points into the allocation that goes away */
+        if (o.view && h->kept == o.view) h->kept = nullptr;
+        o.last_keep = false;
         HIPCHK(h, o.ws.alloc(bytes));
         HIPCHK(h, hipMemset(o.ws.p, 0, bytes));
         o.sig_cap = cap;
@@ -2477,6 +2488,8 @@ extern "C" int pya_rescore_last_keep(pya_handle *h) {
 }
 
 extern "C" {
+
+uint64_t pya_get_workspace_budget(const pya_handle *h) { return h ? (uint64_t)workspace_budget(h) : 0; }
 
 int pya_set_workspace_budget(pya_handle *h, uint64_t bytes) {
     if (!h) return PYA_ERR_ARG;

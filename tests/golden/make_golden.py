@@ -132,8 +132,8 @@ def main():
     run_case("velos_z1", settings(), velos_psms("z1"))
     run_case("velos_zprec", settings(), velos_psms("zprec"))
     run_case("velos_nl", settings(nl=[("ST", 18.01528)]), velos_psms("zprec"))
-    for cfg, n, seed in (("cfg1", 16, 11), ("cfg2", 64, 12), ("cfg3", 160, 13), ("cfg4", 8, 14),
-                         ("cfg5", 2, 15)):
+    for cfg, n, seed in (("cfg1", 16, 11), ("cfg2", 64, 12), ("cfg3", 160, 13), ("cfg4", 64, 14),
+                         ("cfg5", 16, 15)):
         s, b = synth_case(cfg, n, seed)
         run_case("synth_" + cfg, s, b)
     run_case("edge_default", settings(mz_error=0.05), edge_psms(rng, 0.05))

@@ -663,6 +663,49 @@ def test_retained_batch_invalidates_single_psm_state():
     assert len(gpu.pep_scores) == 20
 
 
+def test_lazy_records_belong_to_the_psm_that_was_scored():
+    """score(A) produces A's per-signature records only when pep_scores is read (a replay of what score() staged in
+    the library).  Whatever reuses that staging in between -- a batch of one PSM B, a change of the settings, a reload
+    of the switches -- must not make the replay return another PSM's records, or A's under other settings."""
+    batch, settings = synth.make_batch("cfg3", n_psm=24, seed=31)
+    chk = _checker(settings)
+
+    def want_scores(i):
+        chk.score(**synth.unpack_psm(batch, i))
+        return [(int(np.dot(r["signature"], 1 << np.arange(len(r["signature"])))), float(r["weighted_score"]),
+                 list(map(int, r["counts"]))) for r in chk.pep_scores]
+
+    def got_scores(g):
+        return [(int(np.dot(r["signature"], 1 << np.arange(len(r["signature"])))), float(r["weighted_score"]),
+                 list(map(int, r["counts"]))) for r in g.pep_scores]
+
+    a, bi = 3, 17
+    one_b = {k: v for k, v in synth.make_slice_of(batch, bi, bi + 1).items()} if hasattr(synth, "make_slice_of") else None
+    if one_b is None:                                       # a batch holding PSM `bi` alone
+        po, pe = batch["peak_off"], batch["pep_off"]
+        one_b = dict(n_psm=1, mz=batch["mz"][po[bi]:po[bi + 1]].copy(), intensity=batch["intensity"][po[bi]:po[bi + 1]].copy(),
+                     peak_off=np.array([0, po[bi + 1] - po[bi]], np.int64), pep=batch["pep"][pe[bi]:pe[bi + 1]].copy(),
+                     pep_off=np.array([0, pe[bi + 1] - pe[bi]], np.int64), n_of_mod=batch["n_of_mod"][bi:bi + 1].copy(),
+                     max_charge=batch["max_charge"][bi:bi + 1].copy(), aux_pos=np.zeros(0, np.uint32),
+                     aux_mass=np.zeros(0, np.float32), aux_off=np.zeros(2, np.int64))
+    gpu = _gpu(settings)
+    gpu.score(**synth.unpack_psm(batch, a))
+    out = gpu.score_batch(one_b)                            # reuses the one-PSM path of the library
+    assert out["n_sig"][0] == len(want_scores(bi))
+    assert got_scores(gpu) == want_scores(a)                # A's records, not B's read with A's shape
+    # ... and after a change of the settings the records are still those of the settings A was scored with
+    gpu.score(**synth.unpack_psm(batch, a))
+    gpu.add_neutral_loss("STY", 97.9769)
+    assert got_scores(gpu) == want_scores(a)
+    # the C ABI itself: a replay after the staging was reused fails instead of answering for the wrong PSM
+    from pyascore_amd import _lib
+    gpu2 = _gpu(settings)
+    gpu2.score(**synth.unpack_psm(batch, a))
+    gpu2._last["lazy"] = False                              # (skip the Python side's own precaution)
+    gpu2.score_batch(one_b)
+    assert gpu2._lib.pya_rescore_last_keep(gpu2._h) == _lib.PYA_ERR_STATE
+
+
 def test_drop_in_import_name():
     """`from pyascore import PyAscore` (reference pyascore/__init__.py:17) gives the HIP scorer."""
     import pyascore
