@@ -50,10 +50,16 @@ extern "C" {
 #define PYA_ERR_LIMIT (-4)  /* a PSM exceeds a documented limit of this implementation   */
 #define PYA_ERR_STATE (-5)  /* call sequence error (e.g. no retained batch)              */
 
-/* documented limits (DESIGN.md "Limits") */
-#define PYA_MAX_PEPTIDE_LEN 64
-#define PYA_MAX_SITES 63
-#define PYA_MAX_SIGNATURES 15000
+/* documented limits (DESIGN.md "Limits").  The FAST_* values are what the fast kernels take; a PSM beyond one of
+ * them (and inside the limits above it) is scored by the general kernel (csrc/general_psm.hip): same results, the
+ * reference's algorithm at a fraction of the speed. */
+#define PYA_MAX_PEPTIDE_LEN 255
+#define PYA_MAX_SITES 63                   /* (the reference's own limit: cpp/Ascore.cpp:91-94 keys a signature by a long) */
+#define PYA_MAX_SIGNATURES (1 << 22)       /* C(n_sites, n_of_mod) */
+#define PYA_MAX_FRAGMENTS_PER_TYPE 8192    /* (L - 1) x charges x neutral-loss sums */
+#define PYA_FAST_PEPTIDE_LEN 64
+#define PYA_FAST_SIGNATURES 15000
+#define PYA_FAST_FRAGMENTS_PER_TYPE 2048
 #define PYA_MAX_PEAKS 8192
 #define PYA_MAX_FRAGMENT_TYPES 8
 #define PYA_MAX_NL_VALUES 4
@@ -109,7 +115,9 @@ typedef struct pya_results {
     uint64_t *best_sig;         /* [n_psm]  sig bits of the best localisation            */
     int32_t *n_sig;             /* [n_psm]  number of localisations scored               */
     float *ascores;             /* [n_psm * max_k]  +inf where unambiguous               */
-    uint64_t *alt_mask;         /* [n_psm * max_k]                                       */
+    uint64_t *alt_mask;         /* [n_psm * max_k] alternative sites of every modified site: bit p = residue p of the
+                                 * peptide (0-based) for peptides of up to 64 residues; for longer ones (general
+                                 * kernel) bit j = the j-th modifiable residue (pya_count_sites gives its position) */
 } pya_results;
 
 int pya_create(const pya_config *cfg, pya_handle **out);

@@ -469,11 +469,21 @@ class PyAscore:
     def alt_sites(self):
         if self._last is None:
             return []
-        out = []
-        for j in range(self._last["k"]):
-            m = int(self._last["alt_mask"][j])
-            out.append(np.array([p + 1 for p in range(64) if (m >> p) & 1], dtype=np.uint32))
-        return out
+        return [np.array(self.alt_positions(self._last["alt_mask"][j], self._last["pep"]), dtype=np.uint32)
+                for j in range(self._last["k"])]
+
+    def alt_positions(self, mask, pep):
+        """1-based peptide positions named by one ``alt_mask`` word of a PSM with the letters ``pep`` (bytes / uint8
+        array).  Bit p = residue p for peptides of up to 64 residues; for longer ones (scored by the general kernel)
+        bit j = the j-th modifiable residue (include/pyascore_hip.h: pya_results.alt_mask)."""
+        m = int(mask)
+        pep = np.frombuffer(bytes(pep), dtype=np.uint8) if not isinstance(pep, np.ndarray) else np.ascontiguousarray(pep, np.uint8)
+        if pep.size <= 64:
+            return [p + 1 for p in range(64) if (m >> p) & 1]
+        ns = C.c_int32(0)
+        pos = np.zeros(_lib.PYA_MAX_PEPTIDE_LEN, np.uint8)
+        self._lib.pya_count_sites(self._h, _as_ptr(pep), pep.size, C.byref(ns), _as_ptr(pos))
+        return [int(pos[j]) + 1 for j in range(min(int(ns.value), 64)) if (m >> j) & 1]
 
     def calculate_ambiguity(self, ref_score, other_score):
         """Calculate ambiguity between 2 competing localizations of the last scored PSM

@@ -132,7 +132,7 @@ def localize(ascore, psms, spectra_map, residues, mod_mass, hit_depth=1, max_fra
             continue
         k = psm["n_of_mod"]
         ascores = ";".join(str(s) for s in res["ascores"][i, :k])
-        alts = ";".join(",".join(str(p + 1) for p in range(64) if (int(m) >> p) & 1)
+        alts = ";".join(",".join(str(q) for q in ascore.alt_positions(m, psm["peptide"].encode("utf8")))
                         for m in res["alt_mask"][i, :k])
         rows.append([scans[i], seqs[i], float(res["best_score"][i]), ascores, alts])
     return rows

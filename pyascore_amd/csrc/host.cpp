@@ -83,6 +83,10 @@ size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
                      uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
                      uint32_t multi_z, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
+size_t pya_general_lds_bytes(uint32_t l_cap, uint32_t list_cap);
+size_t pya_general_scratch_bytes(uint32_t n_cap, uint32_t push_cap);
+int pya_launch_general(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch, uint64_t scratch_stride,
+                       uint32_t n_cap, uint32_t push_cap, uint32_t l_cap, uint32_t list_cap, hipStream_t stream);
 int pya_launch_localize_redo(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max,
                              uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
                              uint32_t gtp, hipStream_t stream);
@@ -91,7 +95,7 @@ int pya_launch_localize_redo(const BatchDev *b, const uint32_t *d_count, const u
 namespace {
 
 const size_t kMaxLds = 160 * 1024;
-const uint32_t kBucketLimits[] = {64, 512, 4096, PYA_MAX_SIGNATURES};
+const uint32_t kBucketLimits[] = {64, 512, 4096, PYA_FAST_SIGNATURES};
 const int kNumBuckets = 4;
 const uint64_t kTinyBatch = 64;         /* up to this many PSMs go through the fused single-launch kernel */
 const size_t kStageLimit = 1u << 20;   /* batches whose transfers are smaller than this go through one staged copy */
@@ -453,6 +457,14 @@ struct pya_plan {
     };
     std::vector<FusedLaunch> fused_launches;
     uint32_t n_fused_total = 0;
+    /* PSMs beyond a limit of the fast kernels (peptide > 64 residues, > 15 000 site assignments, > 2 048 fragments per ion
+     * type): binned like every other one, then scored and localised by the general kernel (general_psm.hip) */
+    std::vector<uint8_t> gen;           /* [n_psm] */
+    std::vector<uint32_t> gen_ids;
+    DevBuf<uint32_t> d_gen_ids;
+    DevBuf<unsigned char> d_gen_scratch;
+    uint32_t gen_n_cap = 1, gen_push_cap = 1, gen_l_cap = 1, gen_list_cap = 1;
+    size_t gen_stride = 0;
     std::vector<uint8_t> big;           /* [n_psm] scored by score_big.hip (thousands of site assignments, plain settings) */
     DevBuf<uint32_t> d_big_ids;
     uint32_t big_pos_cap = 1;
@@ -1049,6 +1061,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
     const uint64_t big_min_n = (uint64_t)h->kn.big_min_n;
     const bool big_on = h->cfg.n_nl == 0 && both_dirs && h->cfg.n_fwd == 1 && h->cfg.n_types == 2 && h->mz_error <= 0.49f && !h->kn.no_big;
     p->big.assign(n, 0);
+    p->gen.assign(n, 0);
     /* (summary mode with the lean localize route on: the kernel localises what it scores) */
     const bool big_inline_ok = big_on && plain_on && !h->kn.no_big_inline;
     const uint64_t big_inline_max = pya_big_inline_max();
@@ -1167,9 +1180,15 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             continue;
         }
         const uint32_t per_type = (uint32_t)(L - 1) * (uint32_t)z * n_uniq;
-        if (per_type > PYA_MAX_LIST) {
+        if (per_type > PYA_MAX_FRAGMENTS_PER_TYPE) {
             int rc2 = reject(PYA_ERR_LIMIT, i, "PSM %llu: %u fragments per ion type exceed %d", (unsigned long long)i,
-                             per_type, PYA_MAX_LIST);
+                             per_type, PYA_MAX_FRAGMENTS_PER_TYPE);
+            if (rc2) return rc2;
+            continue;
+        }
+        if ((uint64_t)per_type * n_types > PYA_MAX_LUT_N) {
+            int rc2 = reject(PYA_ERR_LIMIT, i, "PSM %llu: up to %llu theoretical fragments per site assignment; the score table covers %d",
+                             (unsigned long long)i, (unsigned long long)per_type * n_types, PYA_MAX_LUT_N);
             if (rc2) return rc2;
             continue;
         }
@@ -1187,6 +1206,16 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         max_P = std::max<uint32_t>(max_P, (uint32_t)P);
         lut_need = std::max(lut_need, per_type * n_types);
         if ((uint32_t)k > max_k) max_k = (uint32_t)k;
+        if (L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) {
+            /* beyond a limit of the fast kernels: the general kernel takes the PSM whole */
+            p->gen[i] = 1;
+            p->gen_ids.push_back((uint32_t)i);
+            p->gen_n_cap = std::max<uint32_t>(p->gen_n_cap, (uint32_t)N);
+            p->gen_push_cap = std::max<uint32_t>(p->gen_push_cap, (uint32_t)k <= ns ? (uint32_t)k * (ns - (uint32_t)k) : 0u);
+            p->gen_l_cap = std::max<uint32_t>(p->gen_l_cap, (uint32_t)L);
+            p->gen_list_cap = std::max<uint32_t>(p->gen_list_cap, per_type);
+            continue;
+        }
         int cls_of_i = 0;
         if (N > 0 && (uint32_t)k < ns) {
             int bi = 0;
@@ -1329,7 +1358,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             while (caps[c] < P) c++;
             pcls[i] = (uint8_t)c;
             cnt_bin[c]++;
-            if (p->fused[i]) continue;
+            if (p->fused[i] || p->gen[i]) continue;
             if (p->big[i]) cnt_big[c]++;
             else cnt_score[p->ncls[i] * nc + c]++;
         }
@@ -1362,8 +1391,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                 pya_plan::IdList &bl = p->bin_lists[pcls[i]];
                 p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
             }
-            if (p->fused[i]) {
-                /* (listed below) */
+            if (p->fused[i] || p->gen[i]) {
+                /* (listed below / in gen_ids) */
             } else if (p->big[i]) {
                 pya_plan::IdList &gl = p->big_lists[pcls[i]];
                 p->big_ids[gl.off + gl.n++] = (uint32_t)i;
@@ -1470,6 +1499,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             return h->fail(PYA_ERR_LIMIT, (int64_t)bk.ids[0], "LDS budget exceeded (%zu bytes) for the bucket of PSM %u",
                            need, bk.ids[0]);
     }
+    if (!p->gen_ids.empty() && pya_general_lds_bytes(p->gen_l_cap, p->gen_list_cap) > kMaxLds)
+        return h->fail(PYA_ERR_LIMIT, (int64_t)p->gen_ids[0], "LDS budget exceeded for the general kernel (PSM %u)", p->gen_ids[0]);
     lap("tables");
     /* One device allocation for everything (hipMalloc is ~100 us a call), laid out so that what
      * goes up and what comes back are each one contiguous range. */
@@ -1501,6 +1532,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_desc = meta(p->desc.data(), p->desc.size() * 8),
                      o_big_ids = meta(p->big_ids.data(), p->big_ids.size() * 4);
         const size_t o_bigloc_ids = meta(p->bigloc.ids.data(), p->bigloc.ids.size() * 4);
+        const size_t o_gen_ids = meta(p->gen_ids.data(), p->gen_ids.size() * 4);
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
             o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
@@ -1524,6 +1556,9 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_redo5 = reserve(((size_t)p->n_big_inline + 64) * 4), o_ws_top = reserve(n * 16),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
+        p->gen_push_cap = (p->gen_push_cap + 3u) & ~3u;
+        p->gen_stride = p->gen_ids.empty() ? 0 : (pya_general_scratch_bytes(p->gen_n_cap, p->gen_push_cap) + 255) & ~(size_t)255;
+        const size_t o_gen_scratch = reserve(p->gen_ids.size() * p->gen_stride);
         if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
             HIPCHK(h, p->arena.alloc(total));
         unsigned char *base = p->arena.p;
@@ -1548,6 +1583,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         for (int i = 0; i < kNumBuckets; i++)
             p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
         p->bigloc.d_ids.adopt(base + o_bigloc_ids, p->bigloc.ids.size());
+        p->d_gen_ids.adopt(base + o_gen_ids, p->gen_ids.size());
+        p->d_gen_scratch.adopt(base + o_gen_scratch, p->gen_ids.size() * p->gen_stride);
         if (io) {
             if (own_spectra) {
                 p->d_mz.adopt(base + o_mz, (size_t)p->total_peaks);
@@ -1626,7 +1663,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     /* a handful of PSMs (PyAscore.score is a batch of one) is launch-bound: one fused launch, one
      * wavefront per PSM, instead of the five of the three-kernel path (tiny_batch.hip) */
     const uint64_t tiny_max = (uint64_t)h->kn.tiny_max;
-    bool tiny = !timing && p->n_psm <= tiny_max && p->n_skipped == 0 && !h->kn.no_tiny;
+    bool tiny = !timing && p->n_psm <= tiny_max && p->n_skipped == 0 && !h->kn.no_tiny && p->gen_ids.empty();
     Bucket m;                                               /* caps that cover every PSM of the batch */
     uint32_t prefix = 0, compact = 0;
     if (tiny) {
@@ -1751,6 +1788,11 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         e = pya_launch_localize(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
                                 bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), 0u, 1u, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
+    }
+    if (!p->gen_ids.empty()) {
+        e = pya_launch_general(&d, p->d_gen_ids.p, (uint32_t)p->gen_ids.size(), p->d_gen_scratch.p, p->gen_stride, p->gen_n_cap,
+                               p->gen_push_cap, p->gen_l_cap, p->gen_list_cap, st);
+        if (e) return h->hip_fail((hipError_t)e, "general kernel launch");
     }
     if (timing) HIPCHK(h, hipEventRecord(p->ev[4], st));
     p->last_stream = st;
@@ -2405,7 +2447,10 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     if (N > PYA_MAX_SIGNATURES)
         return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: C(%u,%d) site assignments exceed the limit of %d", ns, n_of_mod, PYA_MAX_SIGNATURES);
     const uint32_t per_type = (uint32_t)(L - 1) * (uint32_t)max_charge * (uint32_t)h->cfg.n_uniq;
-    if (per_type > PYA_MAX_LIST) return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: %u fragments per ion type exceed %d", per_type, PYA_MAX_LIST);
+    if (per_type > PYA_MAX_FRAGMENTS_PER_TYPE)
+        return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: %u fragments per ion type exceed %d", per_type, PYA_MAX_FRAGMENTS_PER_TYPE);
+    /* (beyond a limit of the fast kernels: the caller takes the batch path, which has the general kernel) */
+    if (L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) return PYA_ERR_STATE;
     if (n_aux > PYA_ONE_MAX_AUX || (uint32_t)n_of_mod > 64u) return PYA_ERR_STATE;     /* (the caller takes the batch path) */
     if (out->max_k < (uint32_t)std::max(n_of_mod, 1)) return h->fail(PYA_ERR_ARG, -1, "results.max_k is smaller than n_of_mod");
     HIPCHK(h, hipSetDevice(h->device));
@@ -2575,6 +2620,9 @@ int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits, cons
     if (psm >= p->n_psm) return h->fail(PYA_ERR_ARG, -1, "PSM index out of range");
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t L = p->pep_off[psm + 1] - p->pep_off[psm];
+    if (L > PYA_FAST_PEPTIDE_LEN)
+        return h->fail(PYA_ERR_LIMIT, (int64_t)psm, "calculate_ambiguity: peptides of more than %d residues are scored by the general "
+                       "kernel only (their Ascores are in the results)", PYA_FAST_PEPTIDE_LEN);
     const uint32_t list_cap = next_pow2(std::max<uint32_t>(1, (uint32_t)(L - 1) * (uint32_t)p->max_charge[psm] *
                                                                   (uint32_t)h->cfg.n_uniq));
     float host_scores[2 * PYA_NTOP];

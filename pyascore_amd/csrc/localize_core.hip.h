@@ -14,14 +14,45 @@
  * into as the pass pairs them.  (Listing every stop -- 4 more bytes per element -- made the sort room
  * 10 bytes per signature, and that room decides how many wavefronts a CU holds while thousands of
  * scores are sorted: 30 KB -> 19 KB for 3003.) */
-struct SortLds {
+template <typename IdxT, bool GLOBAL>
+struct SortAreaT {
+    typedef IdxT idx_t;
     float *key;          /* [N] */
-    uint16_t *idx;       /* [N] */
+    IdxT *idx;           /* [N] */
     uint64_t *lmask;     /* [N / 64 + 2] stops of the left cursor, chunk by chunk from the left   */
     uint64_t *rmask;     /* [N / 64 + 2] stops of the right cursor, chunk by chunk from the right */
-    uint16_t *lq, *rq;   /* [qmask + 1] each: positions of the stops being paired                */
+    IdxT *lq, *rq;       /* [qmask + 1] each: positions of the stops being paired                */
     int qmask;           /* 127; 63 when there are at most 64 elements (no stop index reaches 64) */
+    /* lanes hand data to each other through the arrays: LDS (the kernels' own sorts), or the workspace in global
+     * memory (general_psm.hip: any number of site assignments, 32-bit positions) */
+    DEV void sync() const {
+        if (GLOBAL) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            wave_lds_sync();
+        }
+    }
 };
+typedef SortAreaT<uint16_t, false> SortLds;
+typedef SortAreaT<uint32_t, true> SortGlobal;
+/* work area of a sort of N elements in global memory: key f32[N] | idx u32[N] | masks u64[2 (N / 64 + 2)] | queues u32[2][128] */
+__host__ __device__ static inline size_t sort_global_bytes(size_t n) {
+    return ((n * 8 + 15) & ~(size_t)15) + (n / 64 + 2) * 16 + 2 * 128 * 4;
+}
+DEV SortGlobal sort_carve_global(unsigned char *raw, int N) {
+    SortGlobal s;
+    s.key = (float *)raw;
+    s.idx = (uint32_t *)(s.key + N);
+    unsigned char *m = raw + (((size_t)N * 8 + 15) & ~(size_t)15);
+    s.lmask = (uint64_t *)m;
+    s.rmask = s.lmask + (N / 64 + 2);
+    s.lq = (uint32_t *)(s.rmask + (N / 64 + 2));
+    s.rq = s.lq + 128;
+    s.qmask = N <= 64 ? 63 : 127;
+    return s;
+}
 __host__ __device__ static inline size_t sort_lds_bytes(size_t n) {
     if (n <= 64) return (n * 10 + 15) & ~(size_t)15;      /* two plain lists of n stops, no masks */
     return ((n * 6 + 15) & ~(size_t)15) + (n / 64 + 2) * 16 + 2 * 128 * 2;
@@ -46,17 +77,19 @@ DEV SortLds sort_carve(unsigned char *raw, int N) {
     return s;
 }
 
-DEV void sort_swap(const SortLds &s, int i, int j) {
+template <class S>
+DEV void sort_swap(const S &s, int i, int j) {
     float k = s.key[i];
     s.key[i] = s.key[j];
     s.key[j] = k;
-    uint16_t t = s.idx[i];
+    typename S::idx_t t = s.idx[i];
     s.idx[i] = s.idx[j];
     s.idx[j] = t;
 }
 
 /* libstdc++ __adjust_heap / __push_heap with comp(a,b) = key[a] > key[b]; lane 0 only */
-DEV void heap_adjust(const SortLds &s, int first, int hole, int len, float vk, uint16_t vi) {
+template <class S>
+DEV void heap_adjust(const S &s, int first, int hole, int len, float vk, typename S::idx_t vi) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -84,19 +117,20 @@ DEV void heap_adjust(const SortLds &s, int first, int hole, int len, float vk, u
 }
 
 /* __partial_sort(first, last, last) = make_heap + sort_heap; lane 0 only */
-DEV void heap_sort_serial(const SortLds &s, int first, int last) {
+template <class S>
+DEV void heap_sort_serial(const S &s, int first, int last) {
     int len = last - first;
     if (len < 2) return;
     for (int parent = (len - 2) / 2;; parent--) {
         float vk = s.key[first + parent];
-        uint16_t vi = s.idx[first + parent];
+        typename S::idx_t vi = s.idx[first + parent];
         heap_adjust(s, first, parent, len, vk, vi);
         if (parent == 0) break;
     }
     while (last - first > 1) {
         --last;
         float vk = s.key[last];
-        uint16_t vi = s.idx[last];
+        typename S::idx_t vi = s.idx[last];
         s.key[last] = s.key[first];
         s.idx[last] = s.idx[first];
         heap_adjust(s, first, 0, last - first, vk, vi);
@@ -110,8 +144,9 @@ DEV void heap_sort_serial(const SortLds &s, int first, int last) {
  * read four chunks before they use the first: one LDS round trip per 256 elements, not per 64. */
 /* SMALL_ONLY: the caller never has more than 64 elements (the fused kernel): the general path is not
  * compiled in -- its arrays would cost that kernel a scratch allocation. */
-template <bool LEFT_ONLY, bool SMALL_ONLY = false>
-DEV int sort_partition(const SortLds &s, int f, int l) {
+template <bool LEFT_ONLY, bool SMALL_ONLY = false, class S>
+DEV int sort_partition(const S &s, int f, int l) {
+    typedef typename S::idx_t idx_t;
     const int lane = lane_id();
     const int mid = f + (l - f) / 2;
     /* __move_median_to_first(f, f+1, mid, l-1) */
@@ -125,9 +160,9 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
         } else if (a > c) pick = f + 1;
         else if (b > c) pick = l - 1;
         else pick = mid;
-        wave_lds_sync();
+        s.sync();
         if (lane == 0) sort_swap(s, f, pick);
-        wave_lds_sync();
+        s.sync();
     }
     const float pv = s.key[f];
     if (SMALL_ONLY || s.qmask == 63) {
@@ -137,10 +172,10 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
         const float kl = s.key[il < l ? il : l - 1], kr = s.key[ir >= f ? ir : f];
         const bool stop_l = il < l && !(kl > pv), stop_r = ir >= f && !(pv > kr);
         const uint64_t ml = __ballot(stop_l), mr = __ballot(stop_r);
-        if (stop_l) s.lq[__popcll(ml & lanemask_lt())] = (uint16_t)il;
-        if (stop_r) s.rq[__popcll(mr & lanemask_lt())] = (uint16_t)ir;
+        if (stop_l) s.lq[__popcll(ml & lanemask_lt())] = (idx_t)il;
+        if (stop_r) s.rq[__popcll(mr & lanemask_lt())] = (idx_t)ir;
         const int nL = __popcll(ml), nR = __popcll(mr);
-        wave_lds_sync();
+        s.sync();
         const int np = nL < nR ? nL : nR;
         int a = 0, b = 0;
         if (lane < np) {
@@ -149,7 +184,7 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
         }
         const bool sw = lane < np && a < b;
         const float ka = s.key[a], kb = s.key[b];
-        const uint16_t ia = s.idx[a], ib = s.idx[b];
+        const idx_t ia = s.idx[a], ib = s.idx[b];
         if (sw) {
             s.key[a] = kb;
             s.idx[a] = ib;
@@ -161,7 +196,7 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
         const int m_sw = __popcll(__ballot(sw));
         const int cand_l = m_sw < nL ? (int)s.lq[m_sw] : 0x7fffffff;
         const int cand_r = m_sw >= 1 ? (int)s.rq[m_sw - 1] : l;
-        wave_lds_sync();
+        s.sync();
         return cand_l < cand_r ? cand_l : cand_r;
     }
     if (SMALL_ONLY) return l;                               /* (not reached) */
@@ -206,7 +241,7 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
             }
         }
     }
-    wave_lds_sync();
+    s.sync();
     /* Pair the r-th stops; they are exchanged while the cursors have not met (the left stops ascend, the
      * right ones descend: once a pair has met, all later ones have).  The stops of a chunk are unpacked
      * into the queues -- entry r at slot r mod 128 (mod 64 for at most 64 elements) -- just ahead of the block of 64 pairs that needs them. */
@@ -217,7 +252,7 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
             const uint64_t mv = s.lmask[lc];
             const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mv >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mv);
-            if ((m >> lane) & 1ull) s.lq[(lprod + __popcll(m & lanemask_lt())) & s.qmask] = (uint16_t)(f + 1 + lc * 64 + lane);
+            if ((m >> lane) & 1ull) s.lq[(lprod + __popcll(m & lanemask_lt())) & s.qmask] = (idx_t)(f + 1 + lc * 64 + lane);
             lprod += __popcll(m);
             lc++;
         }
@@ -227,7 +262,7 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
             const uint64_t mv = s.rmask[rc];
             const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mv >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mv);
-            if ((m >> lane) & 1ull) s.rq[(rprod + __popcll(m & lanemask_lt())) & s.qmask] = (uint16_t)(l - 1 - rc * 64 - lane);
+            if ((m >> lane) & 1ull) s.rq[(rprod + __popcll(m & lanemask_lt())) & s.qmask] = (idx_t)(l - 1 - rc * 64 - lane);
             rprod += __popcll(m);
             rc++;
         }
@@ -235,7 +270,7 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
     for (int r0 = 0; r0 < np; r0 += 64) {
         unpack_left(r0 + 63);
         unpack_right(r0 + 63);
-        wave_lds_sync();
+        s.sync();
         const int r = r0 + lane;
         int a = 0, b = 0;
         if (r < np) {
@@ -244,7 +279,7 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
         }
         const bool sw = r < np && a < b;
         const float ka = s.key[a], kb = s.key[b];
-        const uint16_t ia = s.idx[a], ib = s.idx[b];
+        const idx_t ia = s.idx[a], ib = s.idx[b];
         if (sw) {
             s.key[a] = kb;
             s.idx[a] = ib;
@@ -255,17 +290,17 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
         }
         const int n_sw = __popcll(__ballot(sw));
         m_sw += n_sw;
-        wave_lds_sync();
+        s.sync();
         if (n_sw < 64) break;                              /* the cursors have met (or the pairs ran out) */
     }
     int cand_l = 0x7fffffff;
     if (m_sw < nL) {
         unpack_left(m_sw);
-        wave_lds_sync();
+        s.sync();
         cand_l = (int)s.lq[m_sw & s.qmask];
     }
     const int cand_r = m_sw >= 1 ? (int)s.rq[(m_sw - 1) & s.qmask] : l;
-    wave_lds_sync();
+    s.sync();
     return cand_l < cand_r ? cand_l : cand_r;
 }
 
@@ -273,8 +308,8 @@ DEV int sort_partition(const SortLds &s, int f, int l) {
  * (or heap-sorted runs) exactly as libstdc++ leaves it before __final_insertion_sort. */
 /* PLAIN (the lean instantiation of the localize kernel, see rank_and_localize.hip) gives up --
  * returns true -- where the depth limit would call for the serial heap sort. */
-template <bool PLAIN, bool SMALL_ONLY = false>
-DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only, int *front_len = nullptr) {
+template <bool PLAIN, bool SMALL_ONLY = false, class S>
+DEV bool sort_introsort_loop(const S &s, int N, bool spine_only, int *front_len = nullptr) {
     if (front_len) *front_len = N;
     if (N <= 16) return false;
     const int lane = lane_id();
@@ -288,16 +323,16 @@ DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only, int *fron
         while (l > 16) {
             if (d == 0) {
                 if (PLAIN) return true;
-                wave_lds_sync();
+                s.sync();
                 if (lane == 0) heap_sort_serial(s, 0, l);   /* (stale right parts do not reach in here) */
-                wave_lds_sync();
+                s.sync();
                 break;
             }
             d--;
             l = sort_partition<true, SMALL_ONLY>(s, 0, l);
         }
         if (front_len) *front_len = l;
-        wave_lds_sync();
+        s.sync();
         return false;
     }
     /* explicit stack, one entry per lane */
@@ -311,9 +346,9 @@ DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only, int *fron
         while (l - f > 16) {
             if (d == 0) {
                 if (PLAIN) return true;
-                wave_lds_sync();
+                s.sync();
                 if (lane == 0) heap_sort_serial(s, f, l);
-                wave_lds_sync();
+                s.sync();
                 break;
             }
             d--;
@@ -323,12 +358,13 @@ DEV bool sort_introsort_loop(const SortLds &s, int N, bool spine_only, int *fron
             l = cut;
         }
     }
-    wave_lds_sync();
+    s.sync();
     return false;
 }
 
 /* final position of element i after the closing (stable) insertion sort */
-DEV int sort_final_pos(const SortLds &s, int i, int N) {
+template <class S>
+DEV int sort_final_pos(const S &s, int i, int N) {
     const float me = s.key[i];
     int pos = i;
     const int lo = i - 15 < 0 ? 0 : i - 15;

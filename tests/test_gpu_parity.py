@@ -571,7 +571,9 @@ def test_largest_spectra_and_limits():
     with pytest.raises(ValueError, match="8192"):
         s.score(np.sort(rng.uniform(100.0, 3000.0, 8193)), np.ones(8193), "ASTK", 1)
     with pytest.raises(ValueError, match="length"):
-        s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 65, 0)
+        s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 256, 0)
+    s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 65, 0)          # (the general kernel: 65 to 255 residues)
+    assert s.best_sequence == "A" * 65
     with pytest.raises(ValueError, match="site assignments"):
         s.score(np.array([100.5, 200.5]), np.ones(2), "STSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTST", 12)
 
@@ -615,7 +617,7 @@ def test_skip_invalid_sets_psms_aside():
     mzs = np.sort(rng.uniform(150.0, 1500.0, 200))
     its = rng.lognormal(5, 1, 200)
     odd = [
-        dict(mz=mzs, intensity=its, peptide="A" * 30 + "STY" * 14, n_of_mod=2, max_charge=1),          # 72 residues
+        dict(mz=mzs, intensity=its, peptide="A" * 200 + "STY" * 20, n_of_mod=2, max_charge=1),         # 260 residues
         dict(mz=mzs, intensity=its, peptide="PEPTIXDESK", n_of_mod=1, max_charge=1),                     # unknown residue
         dict(mz=np.zeros(0), intensity=np.zeros(0), peptide="PEPTIDESK", n_of_mod=1, max_charge=1),      # empty spectrum
         dict(mz=mzs, intensity=its, peptide="ST" * 20, n_of_mod=12, max_charge=1),                       # C(40,12) assignments
@@ -645,6 +647,77 @@ def test_skip_invalid_sets_psms_aside():
     assert np.array_equal(got["alt_mask"][keep][:, :k], alone["alt_mask"])
     # a clean batch reports all zeros
     assert not gpu.score_batch(good, skip_invalid=True)["status"].any()
+
+
+def _long_batch(L, n_sites, n_mod, n, seed, **over):
+    return synth.make_batch("cfg2", n_psm=n, seed=seed, L=L, n_sites=n_sites, n_mod=n_mod, **over)
+
+
+def _same_psm_by_psm(gpu, chk, batch, records=True):
+    """score() + every property, PSM by PSM (the batch form of the checker packs alternative sites into 64-bit residue
+    masks, which peptides of more than 64 residues do not fit), and the retained records in one bulk call per side."""
+    for i in range(batch["n_psm"]):
+        kw = synth.unpack_psm(batch, i)
+        gpu.score(**kw)
+        chk.score(**kw)
+        assert gpu.best_sequence == chk.best_sequence, i
+        assert np.float32(gpu.best_score) == np.float32(chk.best_score), i
+        assert np.array_equal(gpu.ascores, chk.ascores), i
+        ga, ca = gpu.alt_sites, chk.alt_sites
+        assert len(ga) == len(ca) and all(np.array_equal(a, b) for a, b in zip(ga, ca)), i
+        if records:
+            raw = chk.raw_pep_scores()
+            bits = (raw["signature"].astype(np.uint64) << np.arange(raw["signature"].shape[1], dtype=np.uint64)).sum(axis=1)
+            got = gpu.batch_pep_scores() if gpu._batch_n else {k: np.zeros(0) for k in ("sig_bits", "counts", "scores", "weighted_score", "total_fragments")}
+            if gpu._batch_n is None:
+                gpu._ensure_kept()
+                got = gpu.batch_pep_scores()
+            assert np.array_equal(got["sig_bits"], bits.astype(np.uint64)), i
+            for key in ("counts", "scores", "weighted_score", "total_fragments"):
+                assert np.array_equal(got[key], raw[key]), (i, key)
+
+
+@pytest.mark.parametrize("L,n_sites,n_mod,over", [
+    (65, 4, 2, {}), (100, 6, 2, dict(max_charge=2)), (180, 5, 3, {}), (255, 4, 1, {}),
+    (90, 5, 2, dict(fragment_types="yb", mz_error=0.5)),
+    (70, 4, 2, dict(fragment_types="bycz", max_charge=2, mz_error=0.02, neutral_loss=("sty", 97.9769))),
+])
+def test_general_kernel_long_peptides(L, n_sites, n_mod, over):
+    """Peptides of 65 to 255 residues (the reference takes any length: cpp/ModifiedPeptide.cpp:24-57) are scored by the
+    general kernel (csrc/general_psm.hip), whole: counts, PepScores, the sorted order, Ascores and alternative sites
+    equal the reference's."""
+    batch, settings = _long_batch(L, n_sites, n_mod, 6, 1000 + L, **over)
+    _same_psm_by_psm(_gpu(settings), _checker(settings), batch)
+
+
+def test_general_kernel_many_site_assignments_and_long_lists():
+    """More than 15 000 site assignments (C(20,5) = 15 504, C(17,8) = 24 310: the std::sort emulation in global memory,
+    32-bit positions) and more than 2 048 fragments per ion type (neutral losses x eight charges) -- in one batch with
+    ordinary PSMs, which keep their fast kernels; then the big ones' retained records."""
+    big1, settings = _long_batch(40, 20, 5, 3, 71)
+    big2, _ = _long_batch(30, 17, 8, 2, 72)
+    small, _ = synth.make_batch("cfg2", n_psm=40, seed=73)
+    psms = []
+    for bt in (small, big1, big2):
+        for i in range(bt["n_psm"]):
+            kw = synth.unpack_psm(bt, i)
+            psms.append(dict(mz=kw["mz_arr"], intensity=kw["int_arr"], peptide=kw["peptide"], n_of_mod=kw["n_of_mod"],
+                             max_charge=kw["max_fragment_charge"]))
+    rng = np.random.default_rng(3)
+    order = rng.permutation(len(psms))
+    batch = synth.pack_batch([psms[i] for i in order])
+    gpu, chk = _gpu(settings), _checker(settings)
+    got = gpu.score_batch(batch, skip_invalid=True)
+    assert not got["status"].any()
+    want = chk.score_batch(batch, got["ascores"].shape[1])
+    for key in ("n_sig", "best_sig", "best_score", "alt_mask", "ascores"):
+        assert np.array_equal(got[key], want[key]), key
+    assert sorted(np.unique(got["n_sig"])) == [20, 15504, 24310]
+    _same_psm_by_psm(gpu, chk, big1)
+    # long fragment lists: two neutral losses and eight fragment charges on one ion type
+    st = dict(settings, fragment_types="b", mz_error=0.02, neutral_losses=[["sty", 97.9769], ["ST", 18.01528]])
+    lists, _ = synth.make_batch("cfg2", n_psm=4, seed=74, L=60, n_sites=5, n_mod=2, max_charge=8)
+    _same_psm_by_psm(_gpu(st), _checker(st), lists)
 
 
 def test_retained_batch_invalidates_single_psm_state():
