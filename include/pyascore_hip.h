@@ -63,7 +63,8 @@ extern "C" {
 #define PYA_MAX_PEAKS 8192
 #define PYA_MAX_FRAGMENT_TYPES 8
 #define PYA_MAX_NL_VALUES 4
-#define PYA_N_TOP 10
+#define PYA_N_TOP 10                       /* the value everything is built for (the reference's command line passes 10) */
+#define PYA_MAX_N_TOP 16                   /* 11..16: every PSM of the scorer goes through the general kernel            */
 
 #define PYA_FLAG_KEEP 1u    /* retain per-signature records for pya_get_pep_scores /     */
                             /* pya_calculate_ambiguity                                    */
@@ -86,7 +87,7 @@ typedef struct pya_plan pya_plan;
 
 typedef struct pya_config {
     float bin_size;             /* m/z width of a peak window                            */
-    uint32_t n_top;             /* peaks retained per window; must be 10                 */
+    uint32_t n_top;             /* peaks retained per window = depths scored: 10..16     */
     const char *mod_group;      /* e.g. "STY"; 'n' / 'c' allow the termini               */
     float mod_mass;
     float mz_error;             /* Da                                                    */
@@ -177,15 +178,15 @@ void pya_plan_destroy(pya_plan *plan);
 /* all localisations of PSM `psm` of the last pya_score_batch(..., PYA_FLAG_KEEP, ...), in the
  * reference's sorted order; arrays sized for `cap` records; returns the record count in *n */
 int pya_get_pep_scores(pya_handle *h, uint64_t psm, uint64_t cap, uint64_t *n, uint64_t *sig_bits,
-                       int32_t *counts /* cap x 10 */, float *scores /* cap x 10 */,
+                       int32_t *counts /* cap x n_top */, float *scores /* cap x n_top */,
                        float *weighted_score, int32_t *total_fragments);
 /* the same for PSMs [psm_begin, psm_end) in one call (three device copies for the whole range):
  * rec_off[psm_end - psm_begin + 1] receives the CSR offsets of the PSMs' records; with cap == 0 only
  * rec_off is filled (size query), otherwise the arrays must hold rec_off[last] records.
  * (pep_scores of a whole batch, Ascore.pyx:241-252 at scale) */
 int pya_get_pep_scores_range(pya_handle *h, uint64_t psm_begin, uint64_t psm_end, uint64_t cap,
-                             int64_t *rec_off, uint64_t *sig_bits, int32_t *counts /* cap x 10 */,
-                             float *scores /* cap x 10 */, float *weighted_score,
+                             int64_t *rec_off, uint64_t *sig_bits, int32_t *counts /* cap x n_top */,
+                             float *scores /* cap x n_top */, float *weighted_score,
                              int32_t *total_fragments);
 int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits,
                             const float *ref_scores, float ref_weighted, uint64_t other_bits,

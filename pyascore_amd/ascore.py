@@ -4,7 +4,7 @@ include/pyascore_hip.h.  Same constructor, ``add_neutral_loss``, ``score``, prop
 ``calculate_ambiguity``; plus ``score_batch`` (``score`` is a batch of one).
 
 Deviations, all towards *more* defined behaviour: inputs the reference
-would abort or read out of bounds on (unknown residue, empty spectrum, ``n_top != 10``,
+would abort or read out of bounds on (unknown residue, empty spectrum, ``n_top < 10``,
 ``max_fragment_charge < 1``, mismatched array lengths) raise ``ValueError`` here.
 """
 import ctypes as C
@@ -55,7 +55,8 @@ class PyAscore:
     bin_size : float
         Size in MZ of each bin
     n_top : int
-        Number of top peaks to retain in each bin (this implementation requires 10)
+        Number of top peaks to retain in each bin: 10 (what everything is built for and the reference's command
+        line passes) to 16 (every PSM then goes through the general kernel: same results, far slower)
     mod_group : str
         Residues that can carry the unlocalized modification, e.g. "STY" ('n'/'c' = termini)
     mod_mass : float
@@ -86,6 +87,7 @@ class PyAscore:
         if rc:
             self._raise(rc)
         self.device = int(device)
+        self._n_top = int(n_top)
         self._last = None            # summary of the last score() call
         self._batch_n = None         # PSMs of the batch retained by score_batch(keep=True)
         self._budget = 0             # set_workspace_budget (0 = the library's default, 6 GiB)
@@ -364,8 +366,8 @@ class PyAscore:
         n = last["n_sig"]
         ns = self._n_sites(last)
         bits = np.zeros(n, np.uint64)
-        counts = np.zeros((n, 10), np.int32)
-        scores = np.zeros((n, 10), np.float32)
+        counts = np.zeros((n, self._n_top), np.int32)
+        scores = np.zeros((n, self._n_top), np.float32)
         ws = np.zeros(n, np.float32)
         nfrag = np.zeros(n, np.int32)
         got = C.c_uint64()
@@ -385,8 +387,8 @@ class PyAscore:
     def batch_pep_scores(self, begin=0, end=None, batch=None):
         """All localisations of PSMs [begin, end) of the last ``score_batch(..., keep=True)``, in the
         reference's sorted order, as CSR arrays (bulk form of ``pep_scores``, Ascore.pyx:241-252):
-        dict(rec_off i64[n+1], sig_bits u64[R] (bit j = j-th modifiable residue), counts i32[R, 10],
-        scores f32[R, 10], weighted_score f32[R], total_fragments i32[R]); records of PSM i are
+        dict(rec_off i64[n+1], sig_bits u64[R] (bit j = j-th modifiable residue), counts i32[R, n_top],
+        scores f32[R, n_top], weighted_score f32[R], total_fragments i32[R]); records of PSM i are
         rows rec_off[i - begin] : rec_off[i - begin + 1].  With ``batch`` (the scored batch) the
         records' ``sequence`` strings are added, all formatted in one library call."""
         if self._batch_n is None:
@@ -410,8 +412,8 @@ class PyAscore:
         if rc:
             self._raise(rc)
         total = int(off[-1])
-        out = dict(rec_off=off, sig_bits=np.zeros(total, np.uint64), counts=np.zeros((total, 10), np.int32),
-                   scores=np.zeros((total, 10), np.float32), weighted_score=np.zeros(total, np.float32),
+        out = dict(rec_off=off, sig_bits=np.zeros(total, np.uint64), counts=np.zeros((total, self._n_top), np.int32),
+                   scores=np.zeros((total, self._n_top), np.float32), weighted_score=np.zeros(total, np.float32),
                    total_fragments=np.zeros(total, np.int32))
         if total:
             rc = self._lib.pya_get_pep_scores_range(self._h, begin, end, total, _as_ptr(off),

@@ -130,13 +130,13 @@ DEV void run_insertion_sort(const R &r, int first, int last) {
     }
 }
 /* Ranks of one window whose len elements sit in r in input order: rank_out[element id] = rank
- * inside the window, PYA_NO_MATCH for the ones that are not retained. */
+ * inside the window, 255 for the ones that are not retained; ntop = peaks retained per window (DevConfig.n_top). */
 template <class R>
-DEV void run_exact_ranks(const R &r, int len, uint8_t *rank_out) {
-    for (int e = 0; e < len; e++) rank_out[r.id(e)] = PYA_NO_MATCH;
-    if (len > PYA_NTOP) {                                      /* std::nth_element(begin, begin + 9, end) */
+DEV void run_exact_ranks(const R &r, int len, uint8_t *rank_out, int ntop) {
+    for (int e = 0; e < len; e++) rank_out[r.id(e)] = 255;
+    if (len > ntop) {                                          /* std::nth_element(begin, begin + n_top - 1, end) */
         int first = 0, last = len;
-        const int nth = PYA_NTOP - 1;
+        const int nth = ntop - 1;
         int depth = 0;
         for (int t = len; t > 1; t >>= 1) depth++;
         depth *= 2;
@@ -155,7 +155,7 @@ DEV void run_exact_ranks(const R &r, int len, uint8_t *rank_out) {
         }
         if (!done) run_insertion_sort(r, first, last);
     }
-    const int n = len < PYA_NTOP ? len : PYA_NTOP;             /* resize(n_top); std::sort */
+    const int n = len < ntop ? len : ntop;                     /* resize(n_top); std::sort */
     run_insertion_sort(r, 0, n);
     for (int q = 0; q < n; q++) rank_out[r.id(q)] = (uint8_t)q;
 }
@@ -234,6 +234,7 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     const double *mz = b.mz + p0;
     const double *inten = b.inten + p0;
     const float bin_size = b.cfg->bin_size;
+    const int ntop = b.cfg->n_top;                           /* peaks retained per window */
     const double bsd = (double)bin_size, inv_bs = 1. / bsd;
     const double mn = mz[0], mx = mz[P - 1];                /* a sorted spectrum has its extremes at the ends */
     *status = PYA_ST_OK;
@@ -362,7 +363,7 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             cnt += (me - o1) >> 31;
         }
         deficit += in ? (int)cnt - (int)(i - lo) : 0;        /* 0 over a window whose keys all differ */
-        const bool keep = in && cnt < PYA_NTOP;
+        const bool keep = in && cnt < (uint32_t)ntop;
         const uint64_t m = __ballot(keep);
         if (keep && !(b.debug & 64)) {
             const uint32_t pos = total + (uint32_t)__popcll(m & lanemask_lt());
@@ -385,7 +386,7 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                 cnt += o > me ? 1 : 0;
                 eq += o == me ? 1 : 0;                       /* (the peak itself included) */
             }
-            hot = hot || (in && cnt < PYA_NTOP && eq > 1);
+            hot = hot || (in && cnt < ntop && eq > 1);
         }
         if (__any(hot)) return PYA_BIN_REDO;
     }
@@ -423,6 +424,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
      * (Spectra.cpp:46-47 use min_element / max_element). */
     const DevConfig *cfg_ = cfg;
     const float bin_size = cfg_->bin_size;
+    const int ntop = cfg_->n_top;
     const double bsd = (double)bin_size, inv_bs = 1. / bsd;
     double mn = mz[0], mx = mz[P - 1];
     float min_mz = 0.f;
@@ -572,7 +574,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
                     r.key = s_inten + lo;
                     r.idx = s_bin + lo;
                     for (int e = 0; e < len; e++) r.idx[e] = (uint16_t)e;
-                    run_exact_ranks(r, len, s_rank + lo);
+                    run_exact_ranks(r, len, s_rank + lo, ntop);
                 }
                 wave_lds_sync();
             }
@@ -591,7 +593,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
                         cnt += (o > me || (o == me && j < i)) ? 1 : 0;
                         tie |= (o == me) ? 1 : 0;
                     }
-                    s_rank[i] = (uint8_t)(cnt < PYA_NTOP ? cnt : PYA_NO_MATCH);
+                    s_rank[i] = (uint8_t)(cnt < ntop ? cnt : 255);
                 }
             }
             if (__any(tie)) {
@@ -636,7 +638,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
                         RunIndirect r;
                         r.idx = list + q;
                         r.key = s_inten;
-                        run_exact_ranks(r, hi - q + 1, s_rank);
+                        run_exact_ranks(r, hi - q + 1, s_rank, ntop);
                     }
                 }
                 __threadfence();
@@ -655,7 +657,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
     } else if (!unsorted) {
         for (int base = 0; base < P; base += 64) {
             int i = base + lane;
-            bool keep = i < P && s_rank[i] < PYA_NTOP;
+            bool keep = i < P && s_rank[i] < ntop;
             uint64_t m = __ballot(keep);
             if (keep) {
                 int pos = total + __popcll(m & lanemask_lt());
@@ -668,12 +670,12 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
         /* general order: position = number of retained peaks with a smaller (m/z, index) */
         for (int base = 0; base < P; base += 64) {
             int i = base + lane;
-            bool keep = i < P && s_rank[i] < PYA_NTOP;
+            bool keep = i < P && s_rank[i] < ntop;
             if (keep) {
                 float me = s_mzf[i];
                 int pos = 0;
                 for (int j = 0; j < P; j++) {
-                    if (s_rank[j] >= PYA_NTOP) continue;
+                    if (s_rank[j] >= ntop) continue;
                     float o = s_mzf[j];
                     pos += (o < me || (o == me && j < i)) ? 1 : 0;
                 }

@@ -5,7 +5,8 @@
 #include <stdint.h>
 
 #define PYA_WAVE 64
-#define PYA_NTOP 10
+#define PYA_NTOP 10                /* peaks retained per window / depths the fast kernels are built for              */
+#define PYA_NTOP_MAX 16            /* ... the binning and the general kernel take (DevConfig.n_top)                   */
 #define PYA_NO_MATCH 15            /* rank value meaning "no retained peak in the window" */
 #define PYA_TABLE_PAD 4            /* +inf sentinels after the last retained peak of a staged table */
 #define PYA_MAX_L 64
@@ -47,6 +48,7 @@ struct DevConfig {
     uint16_t present[256];          /* NL stack state (2 bits per class, saturating at 2)   */
                                     /*   -> bit set of uniq[] values that exist             */
     float weights[PYA_NTOP];        /* Ascore.cpp:16-18                                     */
+    int32_t n_top;                  /* peaks retained per window = depths scored (Ascore.pyx:64-67); 10 unless the general kernel runs everything */
 };
 
 /* device pointers + scalars of one launch family; passed by value as kernel argument */

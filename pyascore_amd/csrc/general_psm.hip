@@ -11,6 +11,9 @@
  *   single-move competitors, the best of every modified site   cpp/Ascore.cpp:212-254
  *   site-determining ions: both lists, sorted, greedy walk     cpp/ModifiedPeptide.cpp:259-320
  *   Ascores                                                    cpp/Ascore.cpp:157-210
+ * n_top (peaks retained per window = depths scored) is a run-time value here, 10 to 16: such depths are counted and
+ * scored, the first ten weighted, all of them searched for the depth of an Ascore (Ascore.cpp:15-36, :123-139, :164-172);
+ * a scorer created with n_top > 10 sends every PSM here.
  * Binning is not repeated: the PSM's spectrum goes through bin_spectra like every other one.  The host sends a PSM
  * here only when it exceeds a limit of the fast kernels (host.cpp: plan_create_impl); a batch of ordinary PSMs never
  * launches this kernel.  Speed is not a goal: the lookups are binary searches in the workspace table, the lists are
@@ -53,13 +56,13 @@ struct GenLds {
     unsigned long long *site_alt;    /* [64] */
     float *site_asc;             /* [64] */
     uint32_t *misc;              /* [16] counters */
-    float *sc;                   /* [2][PYA_NTOP] depth scores of the two signatures */
+    float *sc;                   /* [2][PYA_NTOP_MAX] depth scores of the two signatures */
     float *la, *lb, *sa, *sb;    /* [list_cap] each: the two lists, unsorted and sorted */
     uint8_t *ha, *hb;            /* [list_cap] the sorted ion matched a peak of rank <= depth */
 };
 __host__ __device__ static inline size_t gen_lds_bytes(uint32_t l_cap, uint32_t list_cap) {
     const size_t lc = (l_cap + 3u) & ~3u;
-    return lc * (4 + 4 + 2 * 4 + 2 * 4 + 2 * 2 + 3) + 64 + 512 + PYA_MAX_UNIQ * 4 + 64 * (4 + 4 + 8 + 4) + 64 + 2 * PYA_NTOP * 4 + 8 +
+    return lc * (4 + 4 + 2 * 4 + 2 * 4 + 2 * 2 + 3) + 64 + 512 + PYA_MAX_UNIQ * 4 + 64 * (4 + 4 + 8 + 4) + 64 + 2 * PYA_NTOP_MAX * 4 + 8 +
            (size_t)list_cap * (4 * 4 + 2) + 64;
 }
 DEV GenLds gen_carve(unsigned char *raw, uint32_t l_cap, uint32_t list_cap) {
@@ -76,7 +79,7 @@ DEV GenLds gen_carve(unsigned char *raw, uint32_t l_cap, uint32_t list_cap) {
     g.site_asc = (float *)(g.site_tie + 64);
     g.misc = (uint32_t *)(g.site_asc + 64);
     g.sc = (float *)(g.misc + 16);
-    g.la = g.sc + 2 * PYA_NTOP + 2;
+    g.la = g.sc + 2 * PYA_NTOP_MAX + 2;
     g.lb = g.la + list_cap;
     g.sa = g.lb + list_cap;
     g.sb = g.sa + list_cap;
@@ -198,6 +201,8 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
     const bool half_check = err > 0.49f;
     const int T = cfg->n_types, n_fwd = cfg->n_fwd;
     const uint64_t types64 = load_types64(cfg);
+    const int ntop = cfg->n_top;                               /* 10..PYA_NTOP_MAX */
+    const uint32_t rec_words = (uint32_t)(ntop + 1) / 2u + 1u;    /* count record: ntop 16-bit counts + the fragment total (host.cpp: rec_words) */
 
     /* ---- residues (ModifiedPeptide.cpp:24-79) ---- */
     for (int i = lane; i < L; i += 64) {
@@ -249,9 +254,9 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
     int fail = 0;
     for (int s = lane; s < N; s += 64) {
         const uint64_t bits = order[s];
-        uint32_t cnt[PYA_NTOP];
+        uint32_t cnt[PYA_NTOP_MAX];
 #pragma unroll
-        for (int d = 0; d < PYA_NTOP; d++) cnt[d] = 0;
+        for (int d = 0; d < PYA_NTOP_MAX; d++) cnt[d] = 0;
         uint32_t nfrag = 0;
         for (int dir = 0; dir < 2; dir++) {
             const int t0 = dir ? n_fwd : 0, t1 = dir ? T : n_fwd;
@@ -278,16 +283,16 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
                         const double m = ((double)x + A) - B;
                         for (int z = 1; z <= zmax; z++) {
                             const int rk = gen_match_rank(tab, R, charge_mz(m, z), err, half_check);
-                            if (rk < PYA_NTOP) cnt[rk]++;
+                            if (rk < ntop) cnt[rk]++;
                             nfrag++;
                         }
                     }
                 }
             }
         }
-        uint32_t cum[PYA_NTOP], acc = 0;
+        uint32_t cum[PYA_NTOP_MAX], acc = 0;
 #pragma unroll
-        for (int d = 0; d < PYA_NTOP; d++) {
+        for (int d = 0; d < PYA_NTOP_MAX; d++) {
             acc += cnt[d];
             cum[d] = acc;
         }
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
             double sum = 0.;
 #pragma unroll
             for (int d = 0; d < PYA_NTOP; d++) {
-                const float sc = b.lut[lut_row(nfrag) + (uint32_t)d * (nfrag + 1) + cum[d]];
+                const float sc = b.lut[b.lut_off[nfrag] + (uint32_t)d * (nfrag + 1) + cum[d]];   /* (the first ten depths are weighted) */
                 const float prod = cfg->weights[d] * sc;          /* float product ... */
                 sum = sum + (double)prod;                         /* ... double sum    */
             }
@@ -305,10 +310,11 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
             fail = 1;
         }
         b.ws[s0 + s] = ws;
-        uint32_t *r6 = b.rec + (size_t)(s0 + s) * PYA_REC_WORDS;
+        uint32_t *r6 = b.rec + (size_t)(s0 + s) * rec_words;
 #pragma unroll
-        for (int d = 0; d < PYA_NTOP; d += 2) r6[d >> 1] = cum[d] | (cum[d + 1] << 16);
-        r6[5] = nfrag;
+        for (int d = 0; d < PYA_NTOP_MAX; d += 2)
+            if (d < ntop) r6[d >> 1] = cum[d] | ((d + 1 < ntop ? cum[d + 1] : 0u) << 16);
+        r6[rec_words - 1] = nfrag;
     }
     if (__any(fail)) {
         if (lane == 0) {
@@ -424,18 +430,20 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
         const int came_j = __builtin_ctzll(came);
         if (lane == 0) g.site_alt[a] |= 1ull << (L <= 64 ? (int)g.site_pos[came_j] : came_j);
         /* depth scores of the two from the recorded counts; depth of the largest gap (first one, 0 when none is positive) */
-        if (lane < 2 * PYA_NTOP) {
-            const int which = lane / PYA_NTOP, d = lane - which * PYA_NTOP;
-            const uint32_t *r6 = b.rec + (size_t)(s0 + (which ? pe.idx : best_i)) * PYA_REC_WORDS;
-            const uint32_t cumd = (r6[d >> 1] >> ((d & 1) * 16)) & 0xffffu, nf = r6[5];
-            g.sc[lane] = b.lut[lut_row(nf) + (uint32_t)d * (nf + 1) + cumd];
+        if (lane < 2 * PYA_NTOP_MAX) {
+            const int which = lane / PYA_NTOP_MAX, d = lane - which * PYA_NTOP_MAX;
+            if (d < ntop) {
+                const uint32_t *r6 = b.rec + (size_t)(s0 + (which ? pe.idx : best_i)) * rec_words;
+                const uint32_t cumd = (r6[d >> 1] >> ((d & 1) * 16)) & 0xffffu, nf = r6[rec_words - 1];
+                g.sc[lane] = b.lut[b.lut_off[nf] + (uint32_t)d * (nf + 1) + cumd];
+            }
         }
         gen_sync();
         int depth = 0;
         {
             float bestd = 0.f;
-            for (int d = 0; d < PYA_NTOP; d++) {
-                const float diff = g.sc[d] - g.sc[PYA_NTOP + d];
+            for (int d = 0; d < ntop; d++) {
+                const float diff = g.sc[d] - g.sc[PYA_NTOP_MAX + d];
                 if (diff > bestd) {
                     bestd = diff;
                     depth = d;
@@ -502,8 +510,8 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
             if (tr0 > b.lut_n_max || tr1 > b.lut_n_max) {
                 fail = 1;
             } else {
-                const float sc0 = b.lut[lut_row(tr0) + (uint32_t)depth * (tr0 + 1) + c0];
-                const float sc1 = b.lut[lut_row(tr1) + (uint32_t)depth * (tr1 + 1) + c1];
+                const float sc0 = b.lut[b.lut_off[tr0] + (uint32_t)depth * (tr0 + 1) + c0];
+                const float sc1 = b.lut[b.lut_off[tr1] + (uint32_t)depth * (tr1 + 1) + c1];
                 const float asc = sc0 - sc1;
                 g.site_asc[a] = asc < g.site_asc[a] ? asc : g.site_asc[a];
             }

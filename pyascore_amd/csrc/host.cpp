@@ -247,6 +247,8 @@ struct pya_handle {
     Knobs kn;
     int device = 0;
     float bin_size = 100.f, mod_mass = 0.f, mz_error = 0.5f;
+    uint32_t n_top = PYA_NTOP;                /* 10: the fast kernels; 11..16: every PSM through the general kernel */
+    uint32_t rec_words() const { return (n_top + 1u) / 2u + 1u; }   /* count record: n_top 16-bit counts + the fragment total */
     std::string mod_group, fragment_types;
     std::map<char, float> nl;                 /* letter -> neutral loss (ModifiedPeptide.h:19) */
     DevConfig cfg;
@@ -604,6 +606,7 @@ int build_dev_config(pya_handle *h) {
     for (float x : w) sum += x;
     float fs = (float)sum;
     for (int i = 0; i < PYA_NTOP; i++) c.weights[i] = w[i] / fs;
+    c.n_top = (int32_t)h->n_top;
     return PYA_OK;
 }
 
@@ -623,9 +626,9 @@ int ensure_lut(pya_handle *h, uint32_t n_max) {
                        "assignment; the score table covers %u", n_max, PYA_MAX_LUT_N);
     if (h->lut_uploaded_n > n_max) return PYA_OK;
     uint32_t target = std::max<uint32_t>(n_max, 128);
-    pya_score_table_extend(h->mz_error, PYA_NTOP, target, h->lut, h->lut_off);
+    pya_score_table_extend(h->mz_error, h->n_top, target, h->lut, h->lut_off);
     for (size_t n = 0; n < h->lut_off.size(); n++)             /* the kernels compute row offsets */
-        if (h->lut_off[n] != 5u * (uint32_t)n * ((uint32_t)n + 1u))
+        if (h->lut_off[n] != h->n_top * (uint32_t)n * ((uint32_t)n + 1u) / 2u)
             return h->fail(PYA_ERR_STATE, -1, "score table rows are not dense");
     HIPCHK(h, h->d_lut.upload(h->lut.data(), h->lut.size()));
     HIPCHK(h, h->d_lut_off.upload(h->lut_off.data(), h->lut_off.size()));
@@ -794,9 +797,14 @@ int pya_create(const pya_config *cfg, pya_handle **out) {
     *out = h.get();                                    /* so the caller can read the message */
     pya_handle *hp = h.release();
     if (!cfg->mod_group || !cfg->fragment_types) return hp->fail(PYA_ERR_ARG, -1, "NULL string in config");
-    if (cfg->n_top != PYA_NTOP)
-        return hp->fail(PYA_ERR_ARG, -1, "n_top must be %d (the PepScore weights are %d long, "
-                        "Ascore.cpp:16-18); got %u", PYA_NTOP, PYA_NTOP, cfg->n_top);
+    /* n_top peaks retained per window = depths scored.  Below 10 the reference's weighted sum reads past its scores
+     * (cpp/Ascore.cpp:135-137: undefined); above 10 it retains, counts and scores n_top depths, weights the first ten
+     * and searches all of them for the depth of an Ascore (:15-36, :123-139, :164-172) -- the general kernel does that,
+     * for every PSM of such a scorer. */
+    if (cfg->n_top < PYA_NTOP || cfg->n_top > PYA_NTOP_MAX)
+        return hp->fail(PYA_ERR_ARG, -1, "n_top must be %d..%d (the PepScore weights are %d long, Ascore.cpp:16-18; "
+                        "below that the reference reads past its scores); got %u", PYA_NTOP, PYA_NTOP_MAX, PYA_NTOP, cfg->n_top);
+    hp->n_top = cfg->n_top;
     if (!(cfg->bin_size > 0.f)) return hp->fail(PYA_ERR_ARG, -1, "bin_size must be positive");
     if (!(cfg->mz_error > 0.f) || !(cfg->mz_error < 50.f))
         return hp->fail(PYA_ERR_ARG, -1, "mz_error must be in (0, 50)");
@@ -1206,8 +1214,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         max_P = std::max<uint32_t>(max_P, (uint32_t)P);
         lut_need = std::max(lut_need, per_type * n_types);
         if ((uint32_t)k > max_k) max_k = (uint32_t)k;
-        if (L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) {
-            /* beyond a limit of the fast kernels: the general kernel takes the PSM whole */
+        if (L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE || h->n_top != PYA_NTOP) {
+            /* beyond a limit of the fast kernels (or n_top > 10): the general kernel takes the PSM whole */
             p->gen[i] = 1;
             p->gen_ids.push_back((uint32_t)i);
             p->gen_n_cap = std::max<uint32_t>(p->gen_n_cap, (uint32_t)N);
@@ -1554,7 +1562,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         const size_t o_ret_n = reserve(n * 4),
                      o_ret = reserve((size_t)p->ret_off[n] * sizeof(PeakEntry) + 64),
                      o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_redo5 = reserve(((size_t)p->n_big_inline + 64) * 4), o_ws_top = reserve(n * 16),
-                     o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * PYA_REC_WORDS * 4),
+                     o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * h->rec_words() * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
         p->gen_push_cap = (p->gen_push_cap + 3u) & ~3u;
         p->gen_stride = p->gen_ids.empty() ? 0 : (pya_general_scratch_bytes(p->gen_n_cap, p->gen_push_cap) + 255) & ~(size_t)255;
@@ -1609,7 +1617,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->d_redo4.adopt(base + o_redo4, (size_t)p->n_fused_total + 64);
         p->d_ws_top.adopt(base + o_ws_top, n * 4);
         p->d_ws.adopt(base + o_ws, (size_t)sig_total);
-        p->d_rec.adopt(base + o_rec, (size_t)sig_total * PYA_REC_WORDS);
+        p->d_rec.adopt(base + o_rec, (size_t)sig_total * h->rec_words());
         if (flags & PYA_FLAG_KEEP) p->d_sorted.adopt(base + o_sorted, (size_t)sig_total);
         if (h2d_bytes <= kStageLimit) {
             /* small batch: HIP call overhead dominates, so gather on the host and copy once */
@@ -2450,7 +2458,7 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     if (per_type > PYA_MAX_FRAGMENTS_PER_TYPE)
         return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: %u fragments per ion type exceed %d", per_type, PYA_MAX_FRAGMENTS_PER_TYPE);
     /* (beyond a limit of the fast kernels: the caller takes the batch path, which has the general kernel) */
-    if (L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) return PYA_ERR_STATE;
+    if (h->n_top != PYA_NTOP || L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) return PYA_ERR_STATE;
     if (n_aux > PYA_ONE_MAX_AUX || (uint32_t)n_of_mod > 64u) return PYA_ERR_STATE;     /* (the caller takes the batch path) */
     if (out->max_k < (uint32_t)std::max(n_of_mod, 1)) return h->fail(PYA_ERR_ARG, -1, "results.max_k is smaller than n_of_mod");
     HIPCHK(h, hipSetDevice(h->device));
@@ -2571,9 +2579,10 @@ int pya_get_pep_scores_range(pya_handle *h, uint64_t psm_begin, uint64_t psm_end
     if (!sig_bits || !counts || !scores || !ws_out || !nfrag_out) return h->fail(PYA_ERR_ARG, -1, "NULL output array");
     HIPCHK(h, hipSetDevice(h->device));
     /* one copy per workspace array for the whole range, then the permutation on the host */
-    std::vector<uint32_t> rec((size_t)total * PYA_REC_WORDS), sorted(total);
+    const uint32_t RW = h->rec_words(), NT = h->n_top;
+    std::vector<uint32_t> rec((size_t)total * RW), sorted(total);
     std::vector<float> ws(total);
-    HIPCHK(h, hipMemcpy(rec.data(), p->d_rec.p + s_begin * PYA_REC_WORDS, rec.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(rec.data(), p->d_rec.p + s_begin * RW, rec.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(sorted.data(), p->d_sorted.p + s_begin, (size_t)total * 4, hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(ws.data(), p->d_ws.p + s_begin, (size_t)total * 4, hipMemcpyDeviceToHost));
     for (uint64_t psm = psm_begin; psm < psm_end; psm++) {
@@ -2583,16 +2592,16 @@ int pya_get_pep_scores_range(pya_handle *h, uint64_t psm_begin, uint64_t psm_end
         for (uint32_t r = 0; r < N; r++) {
             const uint32_t i = sorted[o + r];
             if (i >= N) return h->fail(PYA_ERR_HIP, (int64_t)psm, "corrupt sort permutation");
-            const uint32_t *w = &rec[(o + i) * PYA_REC_WORDS];
-            const uint32_t nf = w[5];
+            const uint32_t *w = &rec[(o + i) * RW];
+            const uint32_t nf = w[RW - 1];
             sig_bits[o + r] = order[i];
             ws_out[o + r] = ws[o + i];
             nfrag_out[o + r] = (int32_t)nf;
-            for (int d = 0; d < PYA_NTOP; d++) {
+            for (uint32_t d = 0; d < NT; d++) {
                 const uint32_t c = (w[d >> 1] >> ((d & 1) * 16)) & 0xffffu;
-                counts[(o + r) * PYA_NTOP + d] = (int32_t)c;
+                counts[(o + r) * NT + d] = (int32_t)c;
                 /* same table the kernels read (score_table.cpp) */
-                scores[(o + r) * PYA_NTOP + d] =
+                scores[(o + r) * NT + d] =
                     nf < h->lut_off.size() ? h->lut[h->lut_off[nf] + (uint32_t)d * (nf + 1) + c] : 0.f;
             }
         }
@@ -2620,9 +2629,9 @@ int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits, cons
     if (psm >= p->n_psm) return h->fail(PYA_ERR_ARG, -1, "PSM index out of range");
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t L = p->pep_off[psm + 1] - p->pep_off[psm];
-    if (L > PYA_FAST_PEPTIDE_LEN)
-        return h->fail(PYA_ERR_LIMIT, (int64_t)psm, "calculate_ambiguity: peptides of more than %d residues are scored by the general "
-                       "kernel only (their Ascores are in the results)", PYA_FAST_PEPTIDE_LEN);
+    if (L > PYA_FAST_PEPTIDE_LEN || h->n_top != PYA_NTOP)
+        return h->fail(PYA_ERR_LIMIT, (int64_t)psm, "calculate_ambiguity takes peptides of up to %d residues and n_top = %d (everything "
+                       "else is scored by the general kernel only: the Ascores are in the results)", PYA_FAST_PEPTIDE_LEN, PYA_NTOP);
     const uint32_t list_cap = next_pow2(std::max<uint32_t>(1, (uint32_t)(L - 1) * (uint32_t)p->max_charge[psm] *
                                                                   (uint32_t)h->cfg.n_uniq));
     float host_scores[2 * PYA_NTOP];

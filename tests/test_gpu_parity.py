@@ -720,6 +720,36 @@ def test_general_kernel_many_site_assignments_and_long_lists():
     _same_psm_by_psm(_gpu(st), _checker(st), lists)
 
 
+@pytest.mark.parametrize("n_top", [11, 12, 16])
+def test_n_top_above_ten(n_top):
+    """n_top > 10: the reference retains n_top peaks per window, counts and scores n_top depths, weights the first ten and
+    searches all of them for the depth of an Ascore (cpp/Spectra.cpp:24-41, cpp/Ascore.cpp:15-36, :123-139, :164-172).
+    Such a scorer sends every PSM through the general kernel; results, records (n_top wide) and the tie-heavy binning
+    equal the reference's.  Below 10 the reference reads past its scores: refused."""
+    from pyascore_amd import PyAscore
+    for cfg, n, over in (("cfg2", 24, {}), ("cfg3", 30, {}), ("cfg4", 4, {})):
+        batch, settings = synth.make_batch(cfg, n_psm=n, seed=900 + n_top, **over)
+        st = dict(settings, n_top=n_top)
+        gpu, chk = _gpu(st), _checker(st)
+        got = gpu.score_batch(batch)
+        want = chk.score_batch(batch, got["ascores"].shape[1])
+        for key in ("n_sig", "best_sig", "best_score", "alt_mask", "ascores"):
+            assert np.array_equal(got[key], want[key]), (cfg, key)
+        _same_psm_by_psm(gpu, chk, synth.slice_batch(batch, 0, 3))
+    # count-like intensities: ties at the top of the windows decide which n_top peaks stay
+    batch, settings = synth.make_batch("cfg2", n_psm=40, seed=77)
+    tied = dict(batch, intensity=np.floor(batch["intensity"] / np.median(batch["intensity"]) * 6.0) + 1.0)
+    st = dict(settings, n_top=n_top)
+    got = _gpu(st).score_batch(tied)
+    want = _checker(st).score_batch(tied, got["ascores"].shape[1])
+    for key in want:
+        assert np.array_equal(got[key], want[key]), ("tied", key)
+    with pytest.raises(ValueError, match="n_top"):
+        PyAscore(100.0, 9, "STY", 79.966331)
+    with pytest.raises(ValueError, match="n_top"):
+        PyAscore(100.0, 17, "STY", 79.966331)
+
+
 def test_retained_batch_invalidates_single_psm_state():
     """score() then score_batch(keep=True): the handle's retained records now belong to the batch, so
     the per-PSM properties go back to their initial state instead of mixing the two."""
