@@ -60,7 +60,8 @@ extern "C" {
 #define PYA_FAST_PEPTIDE_LEN 64
 #define PYA_FAST_SIGNATURES 15000
 #define PYA_FAST_FRAGMENTS_PER_TYPE 2048
-#define PYA_MAX_PEAKS 8192
+#define PYA_MAX_PEAKS 65535                /* peaks of one spectrum */
+#define PYA_FAST_PEAKS 8192
 #define PYA_MAX_FRAGMENT_TYPES 8
 #define PYA_MAX_NL_VALUES 4
 #define PYA_N_TOP 10                       /* the value everything is built for (the reference's command line passes 10) */

@@ -397,9 +397,23 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     return (b.debug & 64) ? 0 : (int)total;
 }
 
+/* lanes hand data to each other through the arrays of the general body: LDS, or (GLOBAL: spectra of more than 8 192
+ * peaks, pya_bin_global_kernel) a scratch area in the workspace */
+template <bool GLOBAL>
+DEV void bin_sync() {
+    if (GLOBAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        wave_lds_sync();
+    }
+}
+
 /* The general body (see above): any peak order, any number of windows, equal intensities resolved as
  * std::nth_element + std::sort resolve them.  LDS: inten f64[cap] | mzf f32[cap] | window u16[cap] | rank u8[cap]
  * (+ 192 bytes of window starts behind it). */
+template <bool GLOBAL>
 DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
                   const uint8_t **out_rank, int *status) {
     const int lane = lane_id();
@@ -522,7 +536,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
             for (int i = lane; i < P; i += 64) s_bin[i] = window_of(mz[i]);
         }
     }
-    wave_lds_sync();
+    bin_sync<GLOBAL>();
     STAMP_T(b, 2, -1);
 
     /* pass 3: intensity rank inside the window = number of window mates that are more intense
@@ -567,7 +581,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
                     if (lane == 0 && cnt <= 64) run_lo[cnt] = (uint16_t)P;   /* the last window ends with the spectrum */
                 }
                 if (cnt > 64) cnt = 64;
-                wave_lds_sync();
+                bin_sync<GLOBAL>();
                 if (lane < cnt) {
                     const int lo = run_lo[lane], len = (int)run_lo[lane + 1] - lo;
                     RunDirect r;
@@ -576,7 +590,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
                     for (int e = 0; e < len; e++) r.idx[e] = (uint16_t)e;
                     run_exact_ranks(r, len, s_rank + lo, ntop);
                 }
-                wave_lds_sync();
+                bin_sync<GLOBAL>();
             }
         } else {
             /* peaks out of m/z order: a window's peaks are scattered, every pair is compared */
@@ -615,7 +629,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
                     }
                 }
                 __threadfence();
-                wave_lds_sync();
+                bin_sync<GLOBAL>();
                 for (int base = 0; base < P; base += 64) {
                     const int q = base + lane;
                     const bool in = q < P;
@@ -645,7 +659,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
             }
         }
     }
-    wave_lds_sync();
+    bin_sync<GLOBAL>();
     STAMP_T(b, 3, -1);
 
     /* pass 4: retained peaks in ascending float m/z, written over the (no longer needed)
@@ -685,7 +699,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
             total += __popcll(__ballot(keep));
         }
     }
-    wave_lds_sync();
+    bin_sync<GLOBAL>();
     STAMP_T(b, 4, -1);
     *out_mz = o_mz;
     *out_rank = o_rank;
@@ -695,7 +709,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
 template <bool EXACT>
 DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
                  const uint8_t **out_rank, int *status) {
-    if (EXACT) return bin_exact(b, psm, lds, cap, out_mz, out_rank, status);
+    if (EXACT) return bin_exact<false>(b, psm, lds, cap, out_mz, out_rank, status);
     return bin_fast(b, psm, lds, cap, out_mz, out_rank, status);
 }
 

@@ -55,6 +55,30 @@ __global__ __launch_bounds__(64) void pya_bin_exact_kernel(BatchDev b, uint32_t 
     }
 }
 
+/* Spectra of more than 8 192 peaks (up to 65 535: 16-bit peak indices): the general body with its arrays in a scratch
+ * area of the workspace instead of LDS, one spectrum per wavefront.  Slow (every array access is a trip to memory)
+ * and rare; the PSMs behind such spectra are scored by the general kernel, which reads the retained table from the
+ * workspace like this kernel leaves it. */
+__global__ __launch_bounds__(64) void pya_bin_global_kernel(BatchDev b, const uint32_t *ids, uint32_t n_ids, unsigned char *scratch,
+                                                            uint64_t stride, uint32_t cap) {
+    if (blockIdx.x >= n_ids) return;
+    const uint32_t psm = ids[blockIdx.x];
+    const float *r_mz;
+    const uint8_t *r_rank;
+    int status;
+    const int R = bin_exact<true>(b, psm, scratch + (size_t)blockIdx.x * stride, cap, &r_mz, &r_rank, &status);
+    bin_store(b, psm, R, status, r_mz, r_rank);
+}
+
+extern "C" size_t pya_bin_global_scratch_bytes(uint32_t cap) { return (((size_t)cap * 15 + 63) & ~(size_t)63) + 256; }
+
+extern "C" int pya_launch_bin_global(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch,
+                                     uint64_t stride, uint32_t cap, hipStream_t stream) {
+    if (n_ids == 0) return 0;
+    hipLaunchKernelGGL(pya_bin_global_kernel, dim3(n_ids), dim3(64), 0, stream, *b, d_ids, n_ids, d_scratch, stride, cap);
+    return (int)hipGetLastError();
+}
+
 extern "C" size_t pya_bin_lds_bytes(uint32_t cap) { return PYA_BIN_WAVE_BYTES(cap); }
 
 extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,

@@ -83,6 +83,9 @@ size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
                      uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
                      uint32_t multi_z, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
+size_t pya_bin_global_scratch_bytes(uint32_t cap);
+int pya_launch_bin_global(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch, uint64_t stride,
+                          uint32_t cap, hipStream_t stream);
 size_t pya_general_lds_bytes(uint32_t l_cap, uint32_t list_cap);
 size_t pya_general_scratch_bytes(uint32_t n_cap, uint32_t push_cap);
 int pya_launch_general(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch, uint64_t scratch_stride,
@@ -467,6 +470,12 @@ struct pya_plan {
     DevBuf<unsigned char> d_gen_scratch;
     uint32_t gen_n_cap = 1, gen_push_cap = 1, gen_l_cap = 1, gen_list_cap = 1;
     size_t gen_stride = 0;
+    /* ... of them the spectra of more than 8 192 peaks: binned by pya_bin_global_kernel (arrays in the workspace) */
+    std::vector<uint32_t> bigbin_ids;
+    DevBuf<uint32_t> d_bigbin_ids;
+    DevBuf<unsigned char> d_bigbin_scratch;
+    uint32_t bigbin_cap = 32;
+    size_t bigbin_stride = 0;
     std::vector<uint8_t> big;           /* [n_psm] scored by score_big.hip (thousands of site assignments, plain settings) */
     DevBuf<uint32_t> d_big_ids;
     uint32_t big_pos_cap = 1;
@@ -1211,10 +1220,10 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->order_off[i] = ooff;
         p->sig_off[i] = sig_total;
         sig_total += (int64_t)N;
-        max_P = std::max<uint32_t>(max_P, (uint32_t)P);
+        if (P <= PYA_FAST_PEAKS) max_P = std::max<uint32_t>(max_P, (uint32_t)P);    /* (sizes the LDS of the fast kernels) */
         lut_need = std::max(lut_need, per_type * n_types);
         if ((uint32_t)k > max_k) max_k = (uint32_t)k;
-        if (L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE || h->n_top != PYA_NTOP) {
+        if (P > PYA_FAST_PEAKS || L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE || h->n_top != PYA_NTOP) {
             /* beyond a limit of the fast kernels (or n_top > 10): the general kernel takes the PSM whole */
             p->gen[i] = 1;
             p->gen_ids.push_back((uint32_t)i);
@@ -1222,6 +1231,10 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             p->gen_push_cap = std::max<uint32_t>(p->gen_push_cap, (uint32_t)k <= ns ? (uint32_t)k * (ns - (uint32_t)k) : 0u);
             p->gen_l_cap = std::max<uint32_t>(p->gen_l_cap, (uint32_t)L);
             p->gen_list_cap = std::max<uint32_t>(p->gen_list_cap, per_type);
+            if (P > PYA_FAST_PEAKS) {
+                p->bigbin_ids.push_back((uint32_t)i);
+                p->bigbin_cap = std::max<uint32_t>(p->bigbin_cap, ((uint32_t)P + 31u) & ~31u);
+            }
             continue;
         }
         int cls_of_i = 0;
@@ -1345,6 +1358,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
             std::vector<uint32_t> pk(n);
             for (uint64_t i = 0; i < n; i++)
                 pk[i] = p->pre_status[i] ? 1u : (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
+            for (uint32_t id : p->bigbin_ids) pk[id] = 1u;         /* (binned by their own kernel) */
             for (double q : {0.5, 0.9, 0.99}) {
                 const size_t at = (size_t)(q * (double)(n - 1));
                 std::nth_element(pk.begin(), pk.begin() + at, pk.end());
@@ -1362,6 +1376,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;                  /* set aside: neither binned nor scored */
             const uint32_t P = (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
+            if (P > PYA_FAST_PEAKS) continue;               /* (pya_bin_global_kernel; scored by the general kernel) */
             size_t c = 0;
             while (caps[c] < P) c++;
             pcls[i] = (uint8_t)c;
@@ -1395,6 +1410,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->score_ids.resize(n_score);
         for (uint64_t i = 0; i < n; i++) {
             if (p->pre_status[i]) continue;
+            if (p->peak_off[i + 1] - p->peak_off[i] > PYA_FAST_PEAKS) continue;
             {
                 pya_plan::IdList &bl = p->bin_lists[pcls[i]];
                 p->bin_ids[bl.off + bl.n++] = (uint32_t)i;
@@ -1541,6 +1557,7 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
                      o_big_ids = meta(p->big_ids.data(), p->big_ids.size() * 4);
         const size_t o_bigloc_ids = meta(p->bigloc.ids.data(), p->bigloc.ids.size() * 4);
         const size_t o_gen_ids = meta(p->gen_ids.data(), p->gen_ids.size() * 4);
+        const size_t o_bigbin_ids = meta(p->bigbin_ids.data(), p->bigbin_ids.size() * 4);
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
             o_bucket_ids[i] = meta(p->buckets[i].ids.data(), p->buckets[i].ids.size() * 4);
@@ -1567,6 +1584,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->gen_push_cap = (p->gen_push_cap + 3u) & ~3u;
         p->gen_stride = p->gen_ids.empty() ? 0 : (pya_general_scratch_bytes(p->gen_n_cap, p->gen_push_cap) + 255) & ~(size_t)255;
         const size_t o_gen_scratch = reserve(p->gen_ids.size() * p->gen_stride);
+        p->bigbin_stride = p->bigbin_ids.empty() ? 0 : (pya_bin_global_scratch_bytes(p->bigbin_cap) + 255) & ~(size_t)255;
+        const size_t o_bigbin_scratch = reserve(p->bigbin_ids.size() * p->bigbin_stride);
         if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
             HIPCHK(h, p->arena.alloc(total));
         unsigned char *base = p->arena.p;
@@ -1593,6 +1612,8 @@ static int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, c
         p->bigloc.d_ids.adopt(base + o_bigloc_ids, p->bigloc.ids.size());
         p->d_gen_ids.adopt(base + o_gen_ids, p->gen_ids.size());
         p->d_gen_scratch.adopt(base + o_gen_scratch, p->gen_ids.size() * p->gen_stride);
+        p->d_bigbin_ids.adopt(base + o_bigbin_ids, p->bigbin_ids.size());
+        p->d_bigbin_scratch.adopt(base + o_bigbin_scratch, p->bigbin_ids.size() * p->bigbin_stride);
         if (io) {
             if (own_spectra) {
                 p->d_mz.adopt(base + o_mz, (size_t)p->total_peaks);
@@ -1719,6 +1740,8 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     }
     e = pya_launch_bin_exact(&d, (uint32_t)p->n_psm, p->peak_cap, st);
     if (e) return h->hip_fail((hipError_t)e, "bin_spectra (exact) launch");
+    e = pya_launch_bin_global(&d, p->d_bigbin_ids.p, (uint32_t)p->bigbin_ids.size(), p->d_bigbin_scratch.p, p->bigbin_stride, p->bigbin_cap, st);
+    if (e) return h->hip_fail((hipError_t)e, "bin_spectra (global) launch");
     if (timing) HIPCHK(h, hipEventRecord(p->ev[1], st));
     for (const pya_plan::IdList &l : p->score_lists) {
         /* classes with C(n,k) > 64 share the walk over the first sites between signatures */
@@ -2255,9 +2278,9 @@ int pya_score_batch(pya_handle *h, const pya_batch *b, const double *mz, const d
 /* ------------------------------------------------------------------------------------------------------ */
 namespace {
 /* layout of the pinned block: [flag 64 B | status 64 B | best_score, n_sig, best_sig 64 B | ascores 64 x 4 |
- * alt masks 64 x 8 | m/z PYA_MAX_PEAKS x 8 | intensity PYA_MAX_PEAKS x 8] */
+ * alt masks 64 x 8 | m/z PYA_FAST_PEAKS x 8 | intensity PYA_FAST_PEAKS x 8] */
 const size_t kOneFlag = 0, kOneStatus = 64, kOneBest = 128, kOneAsc = 192, kOneAlt = 448, kOneMz = 1024,
-             kOneInt = kOneMz + (size_t)PYA_MAX_PEAKS * 8, kOneBytes = kOneInt + (size_t)PYA_MAX_PEAKS * 8;
+             kOneInt = kOneMz + (size_t)PYA_FAST_PEAKS * 8, kOneBytes = kOneInt + (size_t)PYA_FAST_PEAKS * 8;
 
 int one_prepare(pya_handle *h, uint32_t n_sig) {
     pya_handle::One &o = h->one;
@@ -2270,7 +2293,7 @@ int one_prepare(pya_handle *h, uint32_t n_sig) {
     if (!o.ws.p || o.sig_cap < n_sig) {
         /* device workspace of one PSM: small arrays, the retained table, grid, per-signature scores / records / order */
         const uint32_t cap = std::max<uint32_t>(1024, next_pow2(n_sig));
-        const size_t bytes = 4096 + ((size_t)PYA_MAX_PEAKS + 8) * sizeof(PeakEntry) + PYA_GRID_CELLS * 2 + 4096 +
+        const size_t bytes = 4096 + ((size_t)PYA_FAST_PEAKS + 8) * sizeof(PeakEntry) + PYA_GRID_CELLS * 2 + 4096 +
                              (size_t)cap * (4 + PYA_REC_WORDS * 4 + 4) + 1024;
         HIPCHK(h, hipStreamSynchronize(o.stream));
         /* the retained view (if any) points into the allocation that goes away */
@@ -2311,7 +2334,7 @@ int one_prepare(pya_handle *h, uint32_t n_sig) {
         d.redo4_count = redo + 68;
         d.redo4_ids = redo + 74;
         d.grid = (uint16_t *)take(PYA_GRID_CELLS * 2);
-        d.ret = (PeakEntry *)take(((size_t)PYA_MAX_PEAKS + 8) * sizeof(PeakEntry));
+        d.ret = (PeakEntry *)take(((size_t)PYA_FAST_PEAKS + 8) * sizeof(PeakEntry));
         d.ws = (float *)take((size_t)cap * 4);
         d.rec = (uint32_t *)take((size_t)cap * PYA_REC_WORDS * 4);
         d.sorted_idx = (uint32_t *)take((size_t)cap * 4);
@@ -2458,7 +2481,7 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     if (per_type > PYA_MAX_FRAGMENTS_PER_TYPE)
         return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: %u fragments per ion type exceed %d", per_type, PYA_MAX_FRAGMENTS_PER_TYPE);
     /* (beyond a limit of the fast kernels: the caller takes the batch path, which has the general kernel) */
-    if (h->n_top != PYA_NTOP || L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) return PYA_ERR_STATE;
+    if (h->n_top != PYA_NTOP || n_peaks > PYA_FAST_PEAKS || L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) return PYA_ERR_STATE;
     if (n_aux > PYA_ONE_MAX_AUX || (uint32_t)n_of_mod > 64u) return PYA_ERR_STATE;     /* (the caller takes the batch path) */
     if (out->max_k < (uint32_t)std::max(n_of_mod, 1)) return h->fail(PYA_ERR_ARG, -1, "results.max_k is smaller than n_of_mod");
     HIPCHK(h, hipSetDevice(h->device));

@@ -568,8 +568,8 @@ def test_largest_spectra_and_limits():
     want = _checker(settings).score_batch(batch, got["ascores"].shape[1])
     _same(got, want)
     s = PyAscore(100.0, 10, "STY", 79.966331)
-    with pytest.raises(ValueError, match="8192"):
-        s.score(np.sort(rng.uniform(100.0, 3000.0, 8193)), np.ones(8193), "ASTK", 1)
+    with pytest.raises(ValueError, match="65535"):
+        s.score(np.sort(rng.uniform(100.0, 3000.0, 65536)), np.ones(65536), "ASTK", 1)
     with pytest.raises(ValueError, match="length"):
         s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 256, 0)
     s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 65, 0)          # (the general kernel: 65 to 255 residues)
@@ -718,6 +718,41 @@ def test_general_kernel_many_site_assignments_and_long_lists():
     st = dict(settings, fragment_types="b", mz_error=0.02, neutral_losses=[["sty", 97.9769], ["ST", 18.01528]])
     lists, _ = synth.make_batch("cfg2", n_psm=4, seed=74, L=60, n_sites=5, n_mod=2, max_charge=8)
     _same_psm_by_psm(_gpu(st), _checker(st), lists)
+
+
+def test_spectra_of_more_than_8192_peaks():
+    """8 193 to 65 535 peaks: binned by pya_bin_global_kernel (the general binning body with its arrays in the workspace),
+    scored by the general kernel; sorted, unsorted and tie-heavy, next to ordinary PSMs in one batch."""
+    rng = np.random.default_rng(23)
+    small, settings = synth.make_batch("cfg2", n_psm=12, seed=81)
+    psms = []
+    for i in range(small["n_psm"]):
+        kw = synth.unpack_psm(small, i)
+        psms.append(dict(mz=kw["mz_arr"], intensity=kw["int_arr"], peptide=kw["peptide"], n_of_mod=kw["n_of_mod"], max_charge=1))
+    for j, (P, mode) in enumerate([(8193, "sorted"), (20000, "sorted"), (65535, "sorted"), (9000, "shuffled"), (12000, "counts")]):
+        base = psms[j]
+        mz = np.concatenate([base["mz"], rng.uniform(100.0, 2500.0, P - base["mz"].size)])
+        it = np.concatenate([base["intensity"], rng.lognormal(4.0, 1.0, P - base["intensity"].size)])
+        o = np.argsort(mz, kind="stable")
+        mz, it = mz[o], it[o]
+        if mode == "shuffled":
+            q = rng.permutation(P)
+            mz, it = mz[q], it[q]
+        if mode == "counts":
+            it = np.floor(it / np.median(it) * 5.0) + 1.0
+        psms.append(dict(base, mz=mz, intensity=it))
+    batch = synth.pack_batch(psms)
+    gpu, chk = _gpu(settings), _checker(settings)
+    got = gpu.score_batch(batch, skip_invalid=True)
+    assert not got["status"].any()
+    want = chk.score_batch(batch, got["ascores"].shape[1])
+    for key in want:
+        assert np.array_equal(got[key], want[key]), key
+    kw = synth.unpack_psm(batch, batch["n_psm"] - 4)           # 20 000 peaks through score()
+    gpu.score(**kw)
+    chk.score(**kw)
+    assert gpu.best_sequence == chk.best_sequence and np.float32(gpu.best_score) == np.float32(chk.best_score)
+    assert np.array_equal(gpu.ascores, chk.ascores)
 
 
 @pytest.mark.parametrize("n_top", [11, 12, 16])
