@@ -15,7 +15,7 @@
  * scored, the first ten weighted, all of them searched for the depth of an Ascore (Ascore.cpp:15-36, :123-139, :164-172);
  * a scorer created with n_top > 10 sends every PSM here.
  * Binning is not repeated: the PSM's spectrum goes through bin_spectra like every other one.  The host sends a PSM
- * here only when it exceeds a limit of the fast kernels (host.cpp: plan_create_impl); a batch of ordinary PSMs never
+ * here only when it exceeds a limit of the fast kernels (host_plan.cpp: plan_create_impl); a batch of ordinary PSMs never
  * launches this kernel.  Speed is not a goal: the lookups are binary searches in the workspace table, the lists are
  * ranked by counting, the walk is one lane's.
  */
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
     const int T = cfg->n_types, n_fwd = cfg->n_fwd;
     const uint64_t types64 = load_types64(cfg);
     const int ntop = cfg->n_top;                               /* 10..PYA_NTOP_MAX */
-    const uint32_t rec_words = (uint32_t)(ntop + 1) / 2u + 1u;    /* count record: ntop 16-bit counts + the fragment total (host.cpp: rec_words) */
+    const uint32_t rec_words = (uint32_t)(ntop + 1) / 2u + 1u;    /* count record: ntop 16-bit counts + the fragment total (host_internal.h: rec_words) */
 
     /* ---- residues (ModifiedPeptide.cpp:24-79) ---- */
     for (int i = lane; i < L; i += 64) {
