@@ -1,5 +1,6 @@
 /* host_one.cpp -- pya_score_one: one PSM per call through a pinned, device-mapped block (PyAscore.score). */
 #include "host_internal.h"
+#include <climits>
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* pya_score_one: one PSM per call, lowest latency (tiny_batch.hip: pya_one_kernel)                        */
@@ -122,6 +123,13 @@ int one_run(pya_handle *h, bool keep, uint32_t max_k) {
                           f_n_cap, f_stride, f_ent, f_push, z > 1) > kMaxLds)
         return h->fail(PYA_ERR_LIMIT, 0, "LDS budget exceeded for this PSM");
     volatile uint32_t *flag = (volatile uint32_t *)(o.host + kOneFlag);
+    /* belt and braces for the hand-over through host memory: the kernel echoes the sequence number next to the status
+     * before it publishes it, and n_sig starts from a value no result has -- the results are read only when all three
+     * say this call's kernel wrote them */
+    volatile int32_t *echo = (volatile int32_t *)(o.host + kOneStatus + 4);
+    volatile int32_t *n_sig_word = (volatile int32_t *)(o.host + kOneBest + 8);
+    const int32_t kUnset = INT32_MIN;
+    *n_sig_word = kUnset;
     int e = pya_launch_one(&d, &m, cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(),
                            bk.sb(), bk.gtp(), use_fused, f_n_cap, f_stride, f_ent, f_push, z > 1 ? 1u : 0u,
                            (int32_t *)(o.host_dev + kOneStatus), (uint32_t *)(o.host_dev + kOneFlag), o.stream);
@@ -129,11 +137,12 @@ int one_run(pya_handle *h, bool keep, uint32_t max_k) {
     /* the kernel's last store is the sequence number: poll it (a stream synchronisation costs several
      * microseconds more); give up after two seconds and ask the runtime what happened */
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint64_t spins = 0; *flag != m.seq; spins++) {
+    auto published = [&]() { return *flag == m.seq && (uint32_t)*echo == m.seq && *n_sig_word != kUnset; };
+    for (uint64_t spins = 0; !published(); spins++) {
         __builtin_ia32_pause();
         if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
             HIPCHK(h, hipStreamSynchronize(o.stream));
-            if (*flag != m.seq) return h->fail(PYA_ERR_HIP, 0, "the kernel finished without publishing its results");
+            if (!published()) return h->fail(PYA_ERR_HIP, 0, "the kernel finished without publishing its results");
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);

@@ -139,11 +139,14 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
         wave_lds_sync();
         localize_body<false>(b, 0, lds_raw, push_cap, pos_cap, pool_cap, sb, gtp);
     }
-    /* results are in host memory (the output arrays point there); the status, then the sequence number */
-    __threadfence();
+    /* results are in host memory (the output arrays point there), written by several lanes: every lane makes its own
+     * stores visible to the host (system scope), then lane 0 writes the status, an echo of the sequence number next
+     * to it and -- after another system fence -- the sequence number the host polls */
+    __threadfence_system();
     wave_lds_sync();
     if (lane == 0) {
-        *host_status = b.status[0];
+        host_status[0] = b.status[0];
+        host_status[1] = (int32_t)m.seq;
         __threadfence_system();
         __hip_atomic_store(host_flag, m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
