@@ -56,13 +56,14 @@ FAMILIES = {
 
 def valu_costs():
     """Measured cycles a SIMD spends per vector instruction of each kernel's own instruction mix
-    (profiles/r03_isa_mix.json = scripts/isa_hist.py over the kernels' inner loops, every class priced
+    (profiles/r0N_isa_mix.json = scripts/isa_hist.py over the kernels' inner loops, every class priced
     from profiles/r03_valu_ceiling.csv = scripts/valu_ceiling.hip on MI355X at 6 waves per SIMD), and
     the scalar unit's measured rate (one instruction per cycle per CU)."""
+    import glob
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_isa_mix.json")) as f:
+        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_isa_mix.json")))[-1]) as f:    # (the newest round's)
             mix = json.load(f)
-    except OSError:
+    except (OSError, IndexError):
         return {}, 3.7
     cost = {k: v.get("inner_loops_cycles_per_valu") or v.get("all_cycles_per_valu") for k, v in mix.items()}
     vals = [c for c in cost.values() if c]

@@ -166,7 +166,7 @@ def main():
     result = {}
     cost = load_costs(args.costs, args.waves) if args.costs else None
     with tempfile.TemporaryDirectory() as tmp:
-        for src in b.DEVICE_SRC:
+        for src in sorted(f for f in os.listdir(b.CSRC) if f.endswith(".hip")):
             s = os.path.join(tmp, src + ".s")
             subprocess.check_call([b.HIPCC] + b.DEVICE_FLAGS + ["-S", "--cuda-device-only", "-o", s, os.path.join(b.CSRC, src)],
                                   stderr=subprocess.DEVNULL)
