@@ -750,8 +750,11 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
                         const int q = i - 1 + uu;
                         ok[uu] = q >= 0 && q < Lm1;
                         const float o = ok[uu] ? other[q] : (q < 0 ? -__builtin_huge_valf() : __builtin_huge_valf());
-                        df[uu] = side ? (o - me) : (me - o);   /* always (winner's ion) - (competitor's ion) */
-                        sk[uu] = side ? (df[uu] <= -err) : (df[uu] >= err);
+                        /* (winner's ion) - (competitor's ion) is me - o on one side and o - me = -(me - o), exactly, on the
+                         * other, where the walk skips the other list's ion when that difference is <= -err: either way the
+                         * test is (me - o) >= err, and a partner is |me - o| < err */
+                        df[uu] = me - o;
+                        sk[uu] = df[uu] >= err;
                     }
                     const int w1 = (ok[1] && __builtin_fabsf(df[1]) < err) ? 1 : 0;
                     const int w2 = (ok[2] && __builtin_fabsf(df[2]) < err) ? 1 : 0;

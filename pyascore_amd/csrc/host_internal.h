@@ -76,10 +76,10 @@ int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_id
                          uint32_t inline_on, hipStream_t stream);
 size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc, uint32_t hs,
-                                   uint32_t pp, uint32_t tab_cap, uint32_t max_k, uint32_t n_nl);
+                                   uint32_t pp, uint32_t max_k, uint32_t n_nl);
 int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap, uint32_t n_cap,
                              uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t vc, uint32_t hs, uint32_t pp,
-                             uint32_t tab_cap, uint32_t n_nl, hipStream_t stream);
+                             uint32_t n_nl, hipStream_t stream);
 int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t push_cap,
                                 uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t *d_redo, hipStream_t stream);
 int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
@@ -383,9 +383,9 @@ struct Bucket {
      * pair_cap, for the tests of the hand-over; 6 instead of 7 measured 4 % slower on cfg4 at the same occupancy: where
      * the arrays behind the lists land in the LDS banks) */
     uint32_t hash_pp() const { return ((g_knob_hash_pp > 0 ? (uint32_t)g_knob_hash_pp : 1u + 2u * (sb() - 1u)) * pair_cap + 7u) & ~7u; }
-    bool hash_ok(uint32_t tab_cap, uint32_t max_k, uint32_t n_nl) const {
+    bool hash_ok(uint32_t max_k, uint32_t n_nl) const {
         return pos_cap <= 64u && hash_vc() <= 8192u &&
-               pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp(), tab_cap, max_k, n_nl) <= 64u * 1024u;
+               pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp(), max_k, n_nl) <= 64u * 1024u;
     }
     uint32_t push_max = 1;              /* largest k * (n_sites - k): single-move competitors of one PSM */
     uint32_t push_cap() const {

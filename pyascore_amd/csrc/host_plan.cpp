@@ -877,10 +877,9 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
                                 bk.gtp(), 1u, sort_room, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
         const uint32_t nnl = (uint32_t)h->cfg.n_nl;
-        const uint32_t tab_cap = 0u;
-        if (!h->kn.no_loc_hash && bk.hash_ok(tab_cap, p->max_k, nnl))
+        if (!h->kn.no_loc_hash && bk.hash_ok(p->max_k, nnl))
             e = pya_launch_localize_hash(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
-                                         bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), bk.hash_vc(), bk.hash_hs(), bk.hash_pp(), tab_cap,
+                                         bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), bk.hash_vc(), bk.hash_hs(), bk.hash_pp(),
                                          nnl, st);
         else
         e = pya_launch_localize(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,

@@ -7,7 +7,7 @@
 
 /* the hash route: same carve-up with the fragment pool and its keep flags replaced by loc_hash_words() words */
 static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                             uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k, uint32_t n_nl);
+                                             uint32_t hs, uint32_t pp, uint32_t max_k, uint32_t n_nl);
 static inline size_t localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap,
                                         uint32_t sb) {
     /* (the localize kernel looks peaks up in global memory: no peak table here) */
@@ -29,10 +29,9 @@ static inline __host__ __device__ uint32_t hash_res_cap(uint32_t pos_cap) {
     return v > 64u ? 64u : v;
 }
 static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                             uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k, uint32_t n_nl) {
+                                             uint32_t hs, uint32_t pp, uint32_t max_k, uint32_t n_nl) {
     const uint32_t site_cap = hash_site_cap(max_k), res_cap = hash_res_cap(pos_cap);
-    size_t fixed = 2 * (size_t)hash_nl_cap(n_nl) + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + (size_t)site_cap * 16 + 16 +
-                   (tab_cap ? PYA_GRID_CELLS * 2 + ((size_t)tab_cap + PYA_TABLE_PAD) * 8 : 0);
+    size_t fixed = 2 * (size_t)hash_nl_cap(n_nl) + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + (size_t)site_cap * 16 + 16;
     size_t srt = n_cap ? sort_lds_bytes(n_cap) + 64 : 64;
     /* (residue arrays by the launch, no span tables, 128 one-byte staging tags instead of 128 words) */
     size_t lst = pya_loc_lds_bytes(pos_cap, 0, sb) - (64 - res_cap) * 9 - (32 + 33) * 4 - (128 - 32) * 4 + 4 * loc_hash_words(vc, hs, pp, sb);
@@ -77,7 +76,7 @@ struct InlineSrc {
 template <bool PLAIN, bool HASH = false>
 DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t push_cap, uint32_t pos_cap,
                        uint32_t pool_cap, uint32_t sb, uint32_t gtp, bool sort_room = true, const InlineSrc *in = nullptr,
-                       uint32_t vc = 0, uint32_t hs = 0, uint32_t pp = 0, uint32_t tab_cap = 0) {
+                       uint32_t vc = 0, uint32_t hs = 0, uint32_t pp = 0) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const int k = b.n_of_mod[psm];
@@ -119,15 +118,14 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     STAMP_BEGIN();
     /* only a handful of ions are matched here, so the retained-peak table is not staged in LDS:
      * that keeps this kernel's LDS small (occupancy) and saves the staging + grid build */
-    /* (HASH with tab_cap: the hash route looks up ~1 300 ions per PSM on cfg4-like settings, so there the table
-     * and the grid are staged as in the score kernels) */
-    const bool staged_tab = HASH && tab_cap != 0;
+    /* (the hash route looks up ~1 300 ions per PSM on cfg4-like settings; staging the table for it was measured
+     * slower -- occupancy -- and is gone: DESIGN.md section 10) */
     const uint32_t site_cap = HASH ? hash_site_cap(max_k) : 64u, res_cap = HASH ? hash_res_cap(pos_cap) : 64u;
-    K3Lds lds = carve(lds_raw, tab_cap, staged_tab, push_cap, site_cap, HASH ? hash_nl_cap((uint32_t)cfg->n_nl) : 256u);
+    K3Lds lds = carve(lds_raw, 0, false, push_cap, site_cap, HASH ? hash_nl_cap((uint32_t)cfg->n_nl) : 256u);
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
-    stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, staged_tab);
+    stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, false);
     if (in) ctx.tab = in->tab;                               /* (the caller's table in LDS: lookups stay on chip) */
     const Residues res = load_residues(b, cfg, psm);
     const uint64_t site_mask_u = res.site_mask;

@@ -40,12 +40,12 @@ __global__ __launch_bounds__(64, PLAIN ? LOC_WAVES_PLAIN : LOC_WAVES) void pya_l
  * to the hand-over list and from there to the list-based general instantiation. */
 __global__ __launch_bounds__(64, LOC_WAVES_HASH) void pya_localize_hash_kernel(
     BatchDev b, const uint32_t *psm_ids, uint32_t n_ids, uint32_t push_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-    uint32_t hs, uint32_t pp, uint32_t tab_cap) {
+    uint32_t hs, uint32_t pp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
     const bool declined = localize_body<false, true>(b, psm, lds_raw, push_cap, pos_cap, (uint32_t)loc_hash_words(vc, hs, pp, sb), sb,
-                                                     0u, true, nullptr, vc, hs, pp, tab_cap);
+                                                     0u, true, nullptr, vc, hs, pp);
     if (declined && lane_id() == 0) b.redo3_ids[atomicAdd(b.redo3_count, 1u)] = psm;
 }
 
@@ -225,22 +225,22 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
 }
 
 extern "C" size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
-                                              uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t max_k, uint32_t n_nl) {
-    return localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, tab_cap, max_k, n_nl);
+                                              uint32_t hs, uint32_t pp, uint32_t max_k, uint32_t n_nl) {
+    return localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, max_k, n_nl);
 }
 
 /* general PSMs: the hash route first, then whatever it declined on the list-based instantiation */
 extern "C" int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t push_cap,
                                         uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
-                                        uint32_t vc, uint32_t hs, uint32_t pp, uint32_t tab_cap, uint32_t n_nl, hipStream_t stream) {
+                                        uint32_t vc, uint32_t hs, uint32_t pp, uint32_t n_nl, hipStream_t stream) {
     if (n_ids == 0) return 0;
     hipError_t e = hipMemsetAsync(b->redo3_count, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     e = PYA_ENSURE_MAX_LDS(pya_localize_hash_kernel);
     if (e != hipSuccess) return (int)e;
-    const size_t lds_hash = localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, tab_cap, b->max_k, n_nl);
+    const size_t lds_hash = localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, b->max_k, n_nl);
     hipLaunchKernelGGL(pya_localize_hash_kernel, dim3(n_ids), dim3(64), lds_hash, stream, *b, d_ids, n_ids, push_cap, pos_cap, sb,
-                       vc, hs, pp, tab_cap);
+                       vc, hs, pp);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     e = PYA_ENSURE_MAX_LDS(pya_localize_redo_kernel);
