@@ -166,9 +166,8 @@ DEV void run_exact_ranks(const R &r, int len, uint8_t *rank_out, int ntop) {
  *
  * Two bodies in two kernels, because the rare paths would otherwise double the registers of the common one:
  * bin_fast takes the common case -- peaks in m/z order, at most 64 windows, finite non-negative intensities, no
- * two intensities inside a window's top n_top that agree in their leading 20 mantissa bits -- and returns
- * PYA_BIN_REDO for everything else; bin_exact handles everything (any peak order, ties resolved as
- * std::nth_element + std::sort do). */
+ * two equal intensities inside a window's top n_top -- and returns PYA_BIN_REDO for everything else; bin_exact
+ * handles everything (any peak order, ties resolved as std::nth_element + std::sort do). */
 #define PYA_BIN_REDO (-2)
 #ifndef BIN_BLOCK
 #define BIN_BLOCK 6
@@ -215,8 +214,9 @@ DEV double first_lane_f64(double x) {
  * then the sign of a 32-bit difference: subtract, shift, add -- three instructions of the cheap class per mate
  * (profiles/r03_valu_ceiling.md) where a float64 compare with its masks took four of the expensive one.
  * Keys that are equal (intensities that agree in 20 mantissa bits, or lie 2^32 below the maximum) make the counts of a
- * window fall short of len (len - 1) / 2, which the deficit notices; only if such a peak ranks inside the top n_top
- * does it matter, and then the spectrum is handed over (as equal intensities at the top always were). */
+ * window fall short of len (len - 1) / 2, which the deficit notices; only for a peak that ranks inside the top n_top
+ * does it matter: those are then ordered by their whole intensities, and if these are equal too the spectrum is handed
+ * over (std::nth_element decides between equal intensities). */
 DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
                  const uint8_t **out_rank, int *status) {
     const int lane = lane_id();
@@ -235,12 +235,28 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     const double *inten = b.inten + p0;
     const float bin_size = b.cfg->bin_size;
     const int ntop = b.cfg->n_top;                           /* peaks retained per window */
-    const double bsd = (double)bin_size, inv_bs = 1. / bsd;
+    /* (an estimate of the reciprocal is enough: the quotients below are corrected with an exact remainder) */
+    const double bsd = (double)bin_size, inv_bs = __builtin_amdgcn_rcp(bsd);
     const double mn = mz[0], mx = mz[P - 1];                /* a sorted spectrum has its extremes at the ends */
     *status = PYA_ST_OK;
-    /* window bounds from the extremes (Spectra.cpp:46-48) */
-    const float min_mz = (float)(__builtin_floor(mn / 100.) * 100.);
-    const float max_mz = (float)(__builtin_ceil(mx / 100.) * 100.);
+    /* window bounds from the extremes (Spectra.cpp:46-48): floor(mn / 100.) and ceil(mx / 100.) as the reference's
+     * double divisions give them, without the divisions -- see window_of below: 100 k is exact in double for every
+     * integer k in reach, so the rounded quotient reaches k exactly when the true one does, and floor / ceil of the
+     * true quotient follow from an estimate and the exact remainder. */
+    auto div100 = [](double v, bool up) -> double {
+        double q = __builtin_floor(v * 0.01);
+        double r = __builtin_fma(-q, 100., v);
+        if (r >= 100.) {
+            q += 1.;
+            r -= 100.;
+        } else if (r < 0.) {
+            q -= 1.;
+            r += 100.;
+        }
+        return up && r > 0. ? q + 1. : q;
+    };
+    const float min_mz = (float)(div100(mn, false) * 100.);
+    const float max_mz = (float)(div100(mx, true) * 100.);
     const float nb_f = __builtin_ceilf((max_mz - min_mz) / bin_size);        /* float arithmetic, :48 */
     const bool ok = nb_f >= 1.f && nb_f <= 65535.f;
     const uint32_t n_bins = ok ? (uint32_t)nb_f : 1u;
@@ -373,22 +389,44 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
         total += (uint32_t)__popcll(m);
     }
     if (wave_sum_i32(deficit) != 0 && !(b.debug & 32)) {
-        /* equal keys somewhere: they matter only for a peak inside its window's top n_top */
-        bool hot = false;
+        /* Equal keys somewhere: the sweep once more, with the peaks that have such a mate and a count inside the top
+         * n_top ordered by their whole intensities (read again from memory: a few lanes, rarely).  Intensities that
+         * differ order the peaks strictly, whatever std::nth_element does; equal ones do not -- handed over. */
+        bool tie = false;
+        total = 0;
         for (uint32_t base = 0; base < P; base += 64) {
             const uint32_t i = base + (uint32_t)lane;
             const bool in = i < P;
             const uint32_t me = in ? ckey[i] : 0u;
-            const uint32_t *src = ckey + (in ? (uint32_t)w_first[s_win[i]] : 0u);
-            int cnt = 0, eq = 0;
+            const uint32_t w = in ? (uint32_t)s_win[i] : 0u;
+            const uint32_t lo = in ? (uint32_t)w_first[w] : 0u;
+            const uint32_t *src = ckey + lo;
+            uint32_t cnt = 0, eq = 0;
             for (uint32_t t = 0; t < trips; t++) {
                 const uint32_t o = src[t];
-                cnt += o > me ? 1 : 0;
-                eq += o == me ? 1 : 0;                       /* (the peak itself included) */
+                cnt += o > me ? 1u : 0u;
+                eq += o == me ? 1u : 0u;                     /* (the peak itself included) */
             }
-            hot = hot || (in && cnt < ntop && eq > 1);
+            if (in && eq > 1u && cnt < (uint32_t)ntop) {
+                const double mine = inten[i];
+                const uint32_t hi = (uint32_t)w_last[w];
+                for (uint32_t j = lo; j <= hi; j++) {
+                    if (j == i || ckey[j] != me) continue;
+                    const double o = inten[j];
+                    cnt += o > mine ? 1u : 0u;
+                    tie = tie || o == mine;
+                }
+            }
+            const bool keep = in && cnt < (uint32_t)ntop;
+            const uint64_t m = __ballot(keep);
+            if (keep && !(b.debug & 64)) {
+                const uint32_t pos = total + (uint32_t)__popcll(m & lanemask_lt());
+                s_mzf[pos] = (float)mz[i];                   /* (the first sweep has compacted over this array) */
+                o_rank[pos] = (uint8_t)cnt;
+            }
+            total += (uint32_t)__popcll(m);
         }
-        if (__any(hot)) return PYA_BIN_REDO;
+        if (__any(tie)) return PYA_BIN_REDO;
     }
     wave_lds_sync();
     STAMP_T(b, 4, -1);

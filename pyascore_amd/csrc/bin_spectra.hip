@@ -23,7 +23,9 @@
 __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDev b, const uint32_t *psm_ids,
                                                                          uint32_t n_ids, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
-    const uint32_t wave = threadIdx.x >> 6;
+    /* (the wavefront's number as a scalar: the spectrum's offsets, length and pointers then live in scalar registers and
+     * the tests on them are scalar branches) */
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t slot = xcd_slot(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
     if (slot >= n_ids) return;
     unsigned char *lds_raw = lds_all + (size_t)wave * PYA_BIN_WAVE_BYTES(cap);
