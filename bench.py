@@ -373,15 +373,22 @@ def main():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
+        plan.timings_sum()                                 # (forget the events of the warm-up / the block before)
+        n_ev = 0
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.step()
-            k_ms += np.asarray(plan.timings_ms())          # HIP events on the launch stream
+        for s_i in range(args.steps):
+            pipe.step()                                    # enqueued back to back: nothing waits for a step here
+            if (s_i + 1) % 96 == 0:                        # (the library keeps the events of 128 runs)
+                ms_, n_ = plan.timings_sum()
+                k_ms += np.asarray(ms_); n_ev += n_
         pipe.drain()                                       # every gather of the timed steps has landed
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         el = time.perf_counter() - t0
+        ms_, n_ = plan.timings_sum()                       # HIP events on the launch stream, read after the block
+        k_ms += np.asarray(ms_); n_ev += n_
+        assert n_ev == args.steps, (n_ev, args.steps)
         if use_dist:                                       # (the slowest rank's time, the same on every rank)
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -170,6 +170,10 @@ int pya_plan_run(pya_plan *plan, const double *d_mz, const double *d_intensity,
  * score_localize (the fused kernel, with the localize launch for what it hands over), localize;
  * synchronises */
 int pya_plan_timings(pya_plan *plan, float ms[4]);
+/* the same, summed over the runs since the last call of this function (the events live in a ring of 128 runs:
+ * of more runs than that only the latest 128 count); *n_runs = how many; synchronises with the latest run only,
+ * so a caller can enqueue run after run without waiting in between */
+int pya_plan_timings_sum(pya_plan *plan, double ms[4], uint32_t *n_runs);
 /* waits for the stream of the last run and reports the first PSM the kernels rejected */
 int pya_plan_check(pya_plan *plan);
 uint64_t pya_plan_workspace_bytes(const pya_plan *plan);

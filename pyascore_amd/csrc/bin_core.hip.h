@@ -196,15 +196,28 @@ DEV double first_lane_f64(double x) {
     return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32)));
 }
 
-/* LDS of one wavefront of the binning stage: 15 bytes per peak (cap a multiple of 32) and the window table */
-#define PYA_BIN_WAVE_BYTES(cap) ((((size_t)(cap) * 15 + 63) & ~(size_t)63) + 256)
+/* LDS of one wavefront of the binning stage: the general body's 15 bytes per peak (cap a multiple of 32) and its window
+ * starts; the common-case body needs 13 bytes per peak and its window table */
+#define PYA_BIN_WAVE_BYTES(cap) ((((size_t)(cap) * 15 + 63) & ~(size_t)63) + 320)
+#define PYA_BIN_FAST_BYTES(cap) ((((size_t)(cap) * 13 + 63) & ~(size_t)63) + 320)
 
-/* The common case.  LDS (PYA_BIN_WAVE_BYTES):
+/* number of set bits of m below this lane */
+DEV uint32_t lanes_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+/* next lane's value; lane 63 gets zeros (no copy of the old value, as lane_next_* need) */
+DEV double lane_next_f64_or_zero(double x) {
+    const uint64_t xb = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)xb, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(xb >> 32), 0x130, 0xf, 0xf, true);
+    return __longlong_as_double((long long)((uint64_t)lo | ((uint64_t)hi << 32)));
+}
+
+/* The common case.  LDS (PYA_BIN_FAST_BYTES):
  *   ckey u32[2 cap]  one composite key per peak, (63 - window) << 25 | intensity key, then zeros for the longest window
  *   mzf  f32[cap]    float m/z per peak; the retained m/z are compacted into it in place
- *   win  u16[cap]    window of the peak
  *   rank u8 [cap]    ranks of the retained peaks (output)
- *   wtab u16[2][64]  first and last peak of every window
+ *   wtab u16[65 + 64] last peak of every window (and a slot for "the window before the first"), first peak of every window
  * A sorted spectrum's windows are runs of consecutive peaks, so a peak's rank is the number of run mates that are more
  * intense.  The mates are read from the run's first peak on, straight through its end, for as many steps as the
  * longest run of the spectrum has peaks -- the same trip count for every lane, no per-lane bounds: what follows a run
@@ -222,10 +235,9 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     const int lane = lane_id();
     uint32_t *ckey = (uint32_t *)lds;
     float *s_mzf = (float *)(ckey + 2 * (size_t)cap);
-    uint16_t *s_win = (uint16_t *)(s_mzf + cap);
-    uint8_t *o_rank = (uint8_t *)(s_win + cap);
-    uint16_t *w_first = (uint16_t *)(lds + (((size_t)cap * 15 + 63) & ~(size_t)63));
-    uint16_t *w_last = w_first + PYA_BIN_FAST_WINDOWS;
+    uint8_t *o_rank = (uint8_t *)(s_mzf + cap);
+    uint16_t *w_last = (uint16_t *)(lds + (((size_t)cap * 13 + 63) & ~(size_t)63));   /* [64] + the slot of "window 64" */
+    uint16_t *w_first = w_last + PYA_BIN_FAST_WINDOWS + 1;
 
     STAMP_BEGIN();
     STAMP_T(b, 1, -1);
@@ -267,7 +279,7 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
      * reference's double division gives it, without the division: every multiple k * bin_size
      * (k < 2^16, bin_size a float) is exact in double, so the rounded quotient reaches k exactly when
      * the true one does and the floor equals the mathematical one -- which a reciprocal estimate plus
-     * an exact remainder (fma) pins down. */
+     * an exact remainder (fma) pins down.  (A NaN or a negative quotient converts to a window below 0: clamped too.) */
     auto window_of = [&](double v) -> uint32_t {
         const double x = v - (double)min_mz;
         const double q = __builtin_floor(x * inv_bs);
@@ -275,7 +287,9 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
         int qi = (int)q;
         qi += r >= bsd ? 1 : 0;
         qi -= r < 0. ? 1 : 0;
-        return (uint32_t)(qi > last_win ? last_win : qi);
+        int w;                                               /* (the clamp to [0, last_win] as one instruction) */
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(w) : "v"(qi), "s"(last_win));
+        return (uint32_t)w;
     };
     constexpr uint32_t U = BIN_BLOCK;
     constexpr uint32_t KMAX = (1u << PYA_BIN_KEY_BITS) - 1u;
@@ -292,9 +306,10 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     }
     /* m/z order: every peak against the next lane's below (one vector compare per 64 peaks), and the pairs that
      * straddle two chunks here: lane j looks at peaks 64 j + 63 and 64 j + 64 */
-    uint64_t uns = 0;                                        /* lanes that saw a larger m/z before a smaller one (scalar) */
-    for (uint32_t j = (uint32_t)lane; 64 * j + 64 < P; j += 64) uns |= __ballot(mz[64 * j + 63] > mz[64 * j + 64]);
-    uint32_t carry_w = 0x1ffffu, keybase = 0;
+    bool straddle = false;
+    for (uint32_t j = (uint32_t)lane; 64 * j + 64 < P; j += 64) straddle = straddle || mz[64 * j + 63] > mz[64 * j + 64];
+    uint64_t uns = __ballot(straddle);                       /* lanes that saw a larger m/z before a smaller one (scalar) */
+    uint32_t carry_w = PYA_BIN_FAST_WINDOWS, keybase = 0;    /* ("window 64" precedes the first peak: its slot takes the -1) */
     /* The sweep that bins the peaks, checks the order and builds the keys.  The spectrum comes in blocks of
      * 64 * BIN_BLOCK peaks whose loads are ALL issued before the first of them is used: a wavefront's time here is
      * HBM round trips, and a load-use-load-use loop makes one per 64 peaks instead of one per block. */
@@ -327,20 +342,20 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
                 const uint32_t i = cbase + (uint32_t)lane;
                 const bool in = i < P;
                 const double x = v[u];
-                uns |= __ballot(x > lane_next_f64(x, x));         /* (lane 63, and the last peak, against themselves) */
-                const uint32_t w = in ? window_of(x) : 0x10000u;
+                /* (lane 63 sees zeros and is left out: its pair is one of the straddling ones above; the lanes past the
+                 * end repeat the last peak) */
+                uns |= __ballot(x > lane_next_f64_or_zero(x)) & 0x7fffffffffffffffull;
+                const uint32_t w = window_of(x);
                 const uint32_t pw = lane_prev_u32(w, carry_w);
-                carry_w = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);
+                carry_w = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);    /* (ends as the window of the last peak) */
                 const uint32_t k = (hw[u] > keybase ? hw[u] : keybase) - keybase;
-                if (pw != w) {                                    /* a window starts here (or the spectrum has ended) */
-                    if (in) w_first[w] = (uint16_t)i;
-                    if (pw < 0x10000u) w_last[pw] = (uint16_t)(i - 1);
-                }
                 if (in) {
                     ckey[i] = ((63u - w) << PYA_BIN_KEY_BITS) | k;
                     s_mzf[i] = (float)x;
-                    s_win[i] = (uint16_t)w;
-                    if (i == P - 1) w_last[w] = (uint16_t)i;
+                    if (pw != w) {                                /* a window starts here, the one before has ended */
+                        w_last[pw] = (uint16_t)(i - 1u);
+                        w_first[w] = (uint16_t)i;
+                    }
                 }
             }
         }
@@ -351,12 +366,13 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
         return -1;
     }
     if (__any(bad) || n_bins > PYA_BIN_FAST_WINDOWS || (b.debug & 128)) return PYA_BIN_REDO;
+    if (lane == 0) w_last[carry_w] = (uint16_t)(P - 1u);
     wave_lds_sync();
     const uint32_t wf = w_first[lane], wl = w_last[lane];
     const uint32_t mylen = wf != 0xffffu ? wl - wf + 1u : 0u;
     const uint32_t maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(mylen));   /* (a scalar trip count) */
-    const uint32_t trips = (maxlen + 1u) & ~1u;               /* mates are read two at a time */
-    for (uint32_t q = (uint32_t)lane; q < trips; q += 64) ckey[P + q] = 0u;  /* (index < 2 cap: P + trips <= 2 P, and a single window stops at P) */
+    const uint32_t trips = (maxlen + 7u) & ~7u;               /* mates are read eight at a time */
+    for (uint32_t q = (uint32_t)lane; q < trips; q += 64) ckey[P + q] = 0u;  /* (index < 2 cap: trips <= cap, a multiple of 32) */
     wave_lds_sync();
     STAMP_T(b, 2, -1);
 
@@ -366,23 +382,28 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     for (uint32_t base = 0; base < P; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
         const bool in = i < P;
-        const uint32_t me = in ? ckey[i] : 0u;
-        const uint32_t lo = in ? (uint32_t)w_first[s_win[i]] : 0u;
-        const float mzf = in ? s_mzf[i] : 0.f;
+        const uint32_t ic = in ? i : P - 1u;                 /* (past the end: the last peak again, left out below) */
+        const uint32_t me = ckey[ic];
+        const uint32_t lo = (uint32_t)w_first[63u - (me >> PYA_BIN_KEY_BITS)];
+        const float mzf = s_mzf[ic];
         const uint32_t *src = ckey + lo;
-        uint32_t cnt = 0;
+        uint32_t c0 = 0, c1 = 0;
         if (!(b.debug & 32))
-#pragma unroll 4
-        for (uint32_t t = 0; t < trips; t += 2) {
-            const uint32_t o0 = src[t], o1 = src[t + 1];
-            cnt += (me - o0) >> 31;                          /* keys are below 2^31: the sign says "more intense" */
-            cnt += (me - o1) >> 31;
+#pragma unroll 1
+        for (uint32_t t = 0; t < trips; t += 8) {
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q += 2) {
+                const uint32_t o0 = src[t + q], o1 = src[t + q + 1];
+                c0 += (me - o0) >> 31;                       /* keys are below 2^31: the sign says "more intense" */
+                c1 += (me - o1) >> 31;
+            }
         }
+        const uint32_t cnt = c0 + c1;
         deficit += in ? (int)cnt - (int)(i - lo) : 0;        /* 0 over a window whose keys all differ */
         const bool keep = in && cnt < (uint32_t)ntop;
         const uint64_t m = __ballot(keep);
         if (keep && !(b.debug & 64)) {
-            const uint32_t pos = total + (uint32_t)__popcll(m & lanemask_lt());
+            const uint32_t pos = total + lanes_below(m);
             s_mzf[pos] = mzf;                                /* pos <= i: in place */
             o_rank[pos] = (uint8_t)cnt;
         }
@@ -398,7 +419,7 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             const uint32_t i = base + (uint32_t)lane;
             const bool in = i < P;
             const uint32_t me = in ? ckey[i] : 0u;
-            const uint32_t w = in ? (uint32_t)s_win[i] : 0u;
+            const uint32_t w = 63u - (me >> PYA_BIN_KEY_BITS);
             const uint32_t lo = in ? (uint32_t)w_first[w] : 0u;
             const uint32_t *src = ckey + lo;
             uint32_t cnt = 0, eq = 0;
@@ -420,7 +441,7 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             const bool keep = in && cnt < (uint32_t)ntop;
             const uint64_t m = __ballot(keep);
             if (keep && !(b.debug & 64)) {
-                const uint32_t pos = total + (uint32_t)__popcll(m & lanemask_lt());
+                const uint32_t pos = total + lanes_below(m);
                 s_mzf[pos] = (float)mz[i];                   /* (the first sweep has compacted over this array) */
                 o_rank[pos] = (uint8_t)cnt;
             }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDe
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t slot = xcd_slot(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
     if (slot >= n_ids) return;
-    unsigned char *lds_raw = lds_all + (size_t)wave * PYA_BIN_WAVE_BYTES(cap);
+    unsigned char *lds_raw = lds_all + (size_t)wave * PYA_BIN_FAST_BYTES(cap);
     const uint32_t psm = psm_ids[slot];
     const float *r_mz;
     const uint8_t *r_rank;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void pya_bin_global_kernel(BatchDev b, const ui
     bin_store(b, psm, R, status, r_mz, r_rank);
 }
 
-extern "C" size_t pya_bin_global_scratch_bytes(uint32_t cap) { return (((size_t)cap * 15 + 63) & ~(size_t)63) + 256; }
+extern "C" size_t pya_bin_global_scratch_bytes(uint32_t cap) { return PYA_BIN_WAVE_BYTES(cap); }
 
 extern "C" int pya_launch_bin_global(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch,
                                      uint64_t stride, uint32_t cap, hipStream_t stream) {
@@ -81,12 +81,12 @@ extern "C" int pya_launch_bin_global(const BatchDev *b, const uint32_t *d_ids, u
     return (int)hipGetLastError();
 }
 
-extern "C" size_t pya_bin_lds_bytes(uint32_t cap) { return PYA_BIN_WAVE_BYTES(cap); }
+extern "C" size_t pya_bin_lds_bytes(uint32_t cap) { return PYA_BIN_FAST_BYTES(cap); }
 
 extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                               hipStream_t stream) {
     if (n_ids == 0) return 0;
-    const size_t per_wave = PYA_BIN_WAVE_BYTES(cap);
+    const size_t per_wave = PYA_BIN_FAST_BYTES(cap);
     const uint32_t nw = per_wave * BIN_WAVES <= 64 * 1024 ? BIN_WAVES : 1;
     size_t lds = nw * per_wave;
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_bin_spectra_kernel);
@@ -100,7 +100,7 @@ extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t
  * zeroed before the first of them) */
 extern "C" int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream) {
     if (n_total == 0) return 0;
-    const size_t per_wave = (((size_t)cap * 15 + 63) & ~(size_t)63) + 192;      /* + the round's window starts */
+    const size_t per_wave = PYA_BIN_WAVE_BYTES(cap);
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_bin_exact_kernel);
     if (e != hipSuccess) return (int)e;
     const uint32_t grid = n_total < 16384u ? n_total : 16384u;   /* all spectra may need it (count-like intensities) */

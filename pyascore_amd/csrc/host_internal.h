@@ -81,7 +81,7 @@ int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids, uint32_t 
                              uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t vc, uint32_t hs, uint32_t pp,
                              uint32_t n_nl, hipStream_t stream);
 int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t push_cap,
-                                uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t *d_redo, hipStream_t stream);
+                                uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
 int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
                               uint32_t pos_cap, hipStream_t stream);
 uint32_t pya_big_inline_max(void);
@@ -484,13 +484,18 @@ struct pya_plan {
     size_t o_status = 0, d2h_bytes = 0, o_best_score = 0, o_best_sig = 0, o_n_sig_out = 0, o_ascores = 0, o_alt = 0;
     uint32_t io_max_k = 0;
     BatchDev dev;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    /* PYA_FLAG_TIMING: five events per run, in a ring so that a caller can enqueue run after run and read the
+     * timings of all of them afterwards (pya_plan_timings_sum) instead of waiting for every run */
+    static constexpr uint32_t kEvRing = 128;
+    std::vector<hipEvent_t> evring;      /* [kEvRing][5] */
+    uint64_t ev_runs = 0, ev_read = 0;   /* runs recorded, runs already summed */
+    hipEvent_t *ev_set(uint64_t run) { return evring.data() + 5 * (run % kEvRing); }
     hipStream_t last_stream = nullptr;
     bool ran = false;
     bool quiesced = false;               /* the owner has waited for everything that used the buffers */
 
     ~pya_plan() {
-        for (auto &e : ev)
+        for (auto &e : evring)
             if (e) (void)hipEventDestroy(e);
     }
     uint64_t workspace_bytes() const { return arena.bytes(); }

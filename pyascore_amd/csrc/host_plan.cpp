@@ -47,7 +47,7 @@ void fill_dev(pya_plan *p) {
     d.redo3_ids = p->d_redo3.p + 64;
     d.redo3b_count = p->d_redo3.p + 1;
     d.redo3b_ids = p->d_redo3.p + 64 + p->n_psm;
-    d.redo4_count = p->d_redo4.p;
+    d.redo4_count = p->d_redo.p + 1;          /* (the hand-over counts share the head of d_redo: one memset per run) */
     d.redo4_ids = p->d_redo4.p + 64;
     d.ws = p->d_ws.p;
     d.ws_top = p->d_ws_top.p;
@@ -722,8 +722,10 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
     if (n_skipped)      /* bin_spectra never touches these entries, so they keep their code for every run */
         HIPCHK(h, hipMemcpy(p->d_status.p, p->pre_status.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
     lap("arena+upload");
-    if (flags & PYA_FLAG_TIMING)
-        for (auto &e : p->ev) HIPCHK(h, hipEventCreate(&e));
+    if (flags & PYA_FLAG_TIMING) {
+        p->evring.assign(5 * pya_plan::kEvRing, nullptr);
+        for (auto &e : p->evring) HIPCHK(h, hipEventCreate(&e));
+    }
     fill_dev(p.get());
     *out = p.release();
     return PYA_OK;
@@ -798,8 +800,9 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         p->dev = d;
         return PYA_OK;
     }
-    if (timing) HIPCHK(h, hipEventRecord(p->ev[0], st));
-    HIPCHK(h, hipMemsetAsync(d.redo_count, 0, sizeof(uint32_t), st));
+    hipEvent_t *ev = timing ? p->ev_set(p->ev_runs) : nullptr;
+    if (timing) HIPCHK(h, hipEventRecord(ev[0], st));
+    HIPCHK(h, hipMemsetAsync(p->d_redo.p, 0, 3 * sizeof(uint32_t), st));     /* redo_count, redo4_count, the recount's */
     int e = 0;
     for (const pya_plan::IdList &l : p->bin_lists) {
         e = pya_launch_bin(&d, p->d_bin_ids.p + l.off, l.n, l.cap, st);
@@ -809,7 +812,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     if (e) return h->hip_fail((hipError_t)e, "bin_spectra (exact) launch");
     e = pya_launch_bin_global(&d, p->d_bigbin_ids.p, (uint32_t)p->bigbin_ids.size(), p->d_bigbin_scratch.p, p->bigbin_stride, p->bigbin_cap, st);
     if (e) return h->hip_fail((hipError_t)e, "bin_spectra (global) launch");
-    if (timing) HIPCHK(h, hipEventRecord(p->ev[1], st));
+    if (timing) HIPCHK(h, hipEventRecord(ev[1], st));
     for (const pya_plan::IdList &l : p->score_lists) {
         /* classes with C(n,k) > 64 share the walk over the first sites between signatures */
         const uint32_t prefix = (p->buckets[l.ncls].n_cap >= 128 && !h->kn.no_prefix) ? 1u : 0u;
@@ -839,11 +842,10 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         e = pya_launch_score_big(&d, p->d_big_ids.p + l.off, l.n, l.cap, p->big_pos_cap, p->big_inline ? 1u : 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "score_big launch");
     }
-    if (timing) HIPCHK(h, hipEventRecord(p->ev[2], st));
+    if (timing) HIPCHK(h, hipEventRecord(ev[2], st));
     if (p->n_fused_total) {
         /* few site assignments, plain settings: scored and localised in one pass (score_localize.hip), one PSM per
          * wavefront; what it hands over goes through the general localize instantiation */
-        HIPCHK(h, hipMemsetAsync(d.redo4_count, 0, sizeof(uint32_t), st));
         const Bucket &fb = p->fusedb;
         for (const pya_plan::FusedLaunch &l : p->fused_launches) {
             e = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, l.n_cap, l.stride, l.pos_cap, l.ent_cap, l.push_cap,
@@ -854,18 +856,17 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
                                      fb.pos_cap, fb.pool_cap(), fb.sb(), fb.gtp(), st);
         if (e) return h->hip_fail((hipError_t)e, "localize (hand-over) launch");
     }
-    if (timing) HIPCHK(h, hipEventRecord(p->ev[3], st));
+    if (timing) HIPCHK(h, hipEventRecord(ev[3], st));
     if (p->big_inline && !p->bigloc.ids.empty()) {
         /* what score_big scored in its summary mode: the lean body with recounted signatures and the winner score_big
          * named; what that declines is scored again with count records and goes to the general localize body */
         const Bucket &bl = p->bigloc;
-        HIPCHK(h, hipMemsetAsync(p->d_redo5.p, 0, sizeof(uint32_t), st));
         e = pya_launch_localize_recount(&d, bl.d_ids.p, (uint32_t)bl.ids.size(), 0u, bl.push_cap(), bl.pos_cap, bl.pool_cap(),
-                                        bl.sb(), bl.gtp(), p->d_redo5.p, st);
+                                        bl.sb(), bl.gtp(), p->d_redo.p + 2, p->d_redo5.p + 64, st);
         if (e) return h->hip_fail((hipError_t)e, "localize (recount) launch");
-        e = pya_launch_score_big_list(&d, p->d_redo5.p, p->d_redo5.p + 64, p->n_big_inline, p->peak_cap, p->big_pos_cap, st);
+        e = pya_launch_score_big_list(&d, p->d_redo.p + 2, p->d_redo5.p + 64, p->n_big_inline, p->peak_cap, p->big_pos_cap, st);
         if (e) return h->hip_fail((hipError_t)e, "score_big (hand-over) launch");
-        e = pya_launch_localize_redo(&d, p->d_redo5.p, p->d_redo5.p + 64, p->n_big_inline, bl.push_cap(), (uint32_t)pya_big_inline_max(),
+        e = pya_launch_localize_redo(&d, p->d_redo.p + 2, p->d_redo5.p + 64, p->n_big_inline, bl.push_cap(), (uint32_t)pya_big_inline_max(),
                                      bl.pos_cap, bl.pool_cap(), bl.sb(), bl.gtp(), st);
         if (e) return h->hip_fail((hipError_t)e, "localize (score_big hand-over) launch");
     }
@@ -891,7 +892,11 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
                                p->gen_push_cap, p->gen_l_cap, p->gen_list_cap, st);
         if (e) return h->hip_fail((hipError_t)e, "general kernel launch");
     }
-    if (timing) HIPCHK(h, hipEventRecord(p->ev[4], st));
+    if (timing) {
+        HIPCHK(h, hipEventRecord(ev[4], st));
+        p->ev_runs++;
+        if (p->ev_runs - p->ev_read > pya_plan::kEvRing) p->ev_read = p->ev_runs - pya_plan::kEvRing;   /* (overwritten) */
+    }
     p->last_stream = st;
     p->ran = true;
     p->dev = d;
@@ -901,9 +906,30 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
 int pya_plan_timings(pya_plan *p, float ms[4]) {
     if (!p || !ms) return PYA_ERR_ARG;
     pya_handle *h = p->h;
-    if (!(p->flags & PYA_FLAG_TIMING) || !p->ran) return h->fail(PYA_ERR_STATE, -1, "plan has no timing events");
-    HIPCHK(h, hipEventSynchronize(p->ev[4]));
-    for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
+    if (!(p->flags & PYA_FLAG_TIMING) || p->ev_runs == 0) return h->fail(PYA_ERR_STATE, -1, "plan has no timing events");
+    hipEvent_t *ev = p->ev_set(p->ev_runs - 1);
+    HIPCHK(h, hipEventSynchronize(ev[4]));
+    for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    return PYA_OK;
+}
+
+int pya_plan_timings_sum(pya_plan *p, double ms[4], uint32_t *n_runs) {
+    if (!p || !ms || !n_runs) return PYA_ERR_ARG;
+    pya_handle *h = p->h;
+    if (!(p->flags & PYA_FLAG_TIMING)) return h->fail(PYA_ERR_STATE, -1, "plan has no timing events");
+    for (int i = 0; i < 4; i++) ms[i] = 0.;
+    *n_runs = (uint32_t)(p->ev_runs - p->ev_read);
+    if (*n_runs == 0) return PYA_OK;
+    HIPCHK(h, hipEventSynchronize(p->ev_set(p->ev_runs - 1)[4]));
+    for (uint64_t r = p->ev_read; r < p->ev_runs; r++) {
+        hipEvent_t *ev = p->ev_set(r);
+        for (int i = 0; i < 4; i++) {
+            float t = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            ms[i] += (double)t;
+        }
+    }
+    p->ev_read = p->ev_runs;
     return PYA_OK;
 }
 
@@ -943,7 +969,7 @@ int pya_plan_check(pya_plan *p) {
     if (h->kn.host_timing) {                               /* diagnostics: how many PSMs the lean kernels handed over */
         uint32_t r3 = 0, r4 = 0;
         (void)hipMemcpy(&r3, p->d_redo3.p, 4, hipMemcpyDeviceToHost);
-        if (p->d_redo4.p) (void)hipMemcpy(&r4, p->d_redo4.p, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&r4, p->d_redo.p + 1, 4, hipMemcpyDeviceToHost);
         std::fprintf(stderr, "[pya plan] handed over: %u by the lean localize instantiation (last bucket), %u of %u by the fused kernel\n",
                      r3, r4, p->n_fused_total);
     }

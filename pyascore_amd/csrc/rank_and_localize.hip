@@ -259,13 +259,13 @@ extern "C" size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap
 
 extern "C" int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
                                            uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
-                                           uint32_t *d_redo, hipStream_t stream) {
+                                           uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream) {
     if (n_ids == 0) return 0;
     const size_t lds = pya_localize_recount_lds_bytes(cap, push_cap, pos_cap, pool_cap, sb);
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_localize_recount_kernel);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_localize_recount_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, cap, push_cap, pos_cap,
-                       pool_cap, sb, gtp, d_redo, d_redo + 64);
+                       pool_cap, sb, gtp, d_redo_count, d_redo_ids);
     return (int)hipGetLastError();
 }
 

@@ -100,6 +100,17 @@ class DevicePlan:
             self.scorer._raise(rc)
         return tuple(float(x) for x in ms)
 
+    def timings_sum(self):
+        """((bin_spectra, score_signatures, score_localize, localize) durations in ms summed over the runs since
+        the last call, number of runs).  The events sit in a ring of 128 runs; synchronises with the latest run
+        only, so runs can be enqueued back to back and read afterwards."""
+        ms = (C.c_double * 4)()
+        n = C.c_uint32(0)
+        rc = self._lib.pya_plan_timings_sum(self._plan, C.byref(ms), C.byref(n))
+        if rc:
+            self.scorer._raise(rc)
+        return tuple(float(x) for x in ms), int(n.value)
+
     def check(self):
         rc = self._lib.pya_plan_check(self._plan)
         if rc:
