@@ -488,8 +488,11 @@ struct pya_plan {
      * timings of all of them afterwards (pya_plan_timings_sum) instead of waiting for every run */
     static constexpr uint32_t kEvRing = 128;
     std::vector<hipEvent_t> evring;      /* [kEvRing][5] */
+    std::vector<uint8_t> evalias;        /* [kEvRing][5] the event that marks boundary i of the run: a family that launched
+                                          * nothing records no event of its own (a record costs microseconds of stream time) */
     uint64_t ev_runs = 0, ev_read = 0;   /* runs recorded, runs already summed */
     hipEvent_t *ev_set(uint64_t run) { return evring.data() + 5 * (run % kEvRing); }
+    uint8_t *ev_alias(uint64_t run) { return evalias.data() + 5 * (run % kEvRing); }
     hipStream_t last_stream = nullptr;
     bool ran = false;
     bool quiesced = false;               /* the owner has waited for everything that used the buffers */

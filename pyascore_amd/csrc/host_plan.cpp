@@ -724,7 +724,9 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
     lap("arena+upload");
     if (flags & PYA_FLAG_TIMING) {
         p->evring.assign(5 * pya_plan::kEvRing, nullptr);
-        for (auto &e : p->evring) HIPCHK(h, hipEventCreate(&e));
+        p->evalias.assign(5 * pya_plan::kEvRing, 0);
+        /* (timing only: nothing synchronises-with the work through these events, so no system-scope fence per record) */
+        for (auto &e : p->evring) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     }
     fill_dev(p.get());
     *out = p.release();
@@ -801,7 +803,18 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         return PYA_OK;
     }
     hipEvent_t *ev = timing ? p->ev_set(p->ev_runs) : nullptr;
-    if (timing) HIPCHK(h, hipEventRecord(ev[0], st));
+    uint8_t *alias = timing ? p->ev_alias(p->ev_runs) : nullptr;
+    /* boundary i of the run: a new event if the family before it launched anything, else the previous boundary's */
+    auto mark = [&](int i, bool launched) -> int {
+        if (!timing) return 0;
+        if (i > 0 && !launched) {
+            alias[i] = alias[i - 1];
+            return 0;
+        }
+        alias[i] = (uint8_t)i;
+        return (int)hipEventRecord(ev[i], st);
+    };
+    if (mark(0, true)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
     HIPCHK(h, hipMemsetAsync(p->d_redo.p, 0, 3 * sizeof(uint32_t), st));     /* redo_count, redo4_count, the recount's */
     int e = 0;
     for (const pya_plan::IdList &l : p->bin_lists) {
@@ -812,7 +825,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     if (e) return h->hip_fail((hipError_t)e, "bin_spectra (exact) launch");
     e = pya_launch_bin_global(&d, p->d_bigbin_ids.p, (uint32_t)p->bigbin_ids.size(), p->d_bigbin_scratch.p, p->bigbin_stride, p->bigbin_cap, st);
     if (e) return h->hip_fail((hipError_t)e, "bin_spectra (global) launch");
-    if (timing) HIPCHK(h, hipEventRecord(ev[1], st));
+    if (mark(1, true)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
     for (const pya_plan::IdList &l : p->score_lists) {
         /* classes with C(n,k) > 64 share the walk over the first sites between signatures */
         const uint32_t prefix = (p->buckets[l.ncls].n_cap >= 128 && !h->kn.no_prefix) ? 1u : 0u;
@@ -842,7 +855,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         e = pya_launch_score_big(&d, p->d_big_ids.p + l.off, l.n, l.cap, p->big_pos_cap, p->big_inline ? 1u : 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "score_big launch");
     }
-    if (timing) HIPCHK(h, hipEventRecord(ev[2], st));
+    if (mark(2, !p->score_lists.empty() || !p->big_lists.empty())) return h->hip_fail(hipGetLastError(), "hipEventRecord");
     if (p->n_fused_total) {
         /* few site assignments, plain settings: scored and localised in one pass (score_localize.hip), one PSM per
          * wavefront; what it hands over goes through the general localize instantiation */
@@ -856,7 +869,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
                                      fb.pos_cap, fb.pool_cap(), fb.sb(), fb.gtp(), st);
         if (e) return h->hip_fail((hipError_t)e, "localize (hand-over) launch");
     }
-    if (timing) HIPCHK(h, hipEventRecord(ev[3], st));
+    if (mark(3, p->n_fused_total != 0)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
     if (p->big_inline && !p->bigloc.ids.empty()) {
         /* what score_big scored in its summary mode: the lean body with recounted signatures and the winner score_big
          * named; what that declines is scored again with count records and goes to the general localize body */
@@ -893,7 +906,9 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "general kernel launch");
     }
     if (timing) {
-        HIPCHK(h, hipEventRecord(ev[4], st));
+        bool loc = (p->big_inline && !p->bigloc.ids.empty()) || !p->gen_ids.empty();
+        for (const Bucket &bk : p->buckets) loc = loc || !bk.ids.empty();
+        if (mark(4, loc)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
         p->ev_runs++;
         if (p->ev_runs - p->ev_read > pya_plan::kEvRing) p->ev_read = p->ev_runs - pya_plan::kEvRing;   /* (overwritten) */
     }
@@ -908,8 +923,12 @@ int pya_plan_timings(pya_plan *p, float ms[4]) {
     pya_handle *h = p->h;
     if (!(p->flags & PYA_FLAG_TIMING) || p->ev_runs == 0) return h->fail(PYA_ERR_STATE, -1, "plan has no timing events");
     hipEvent_t *ev = p->ev_set(p->ev_runs - 1);
-    HIPCHK(h, hipEventSynchronize(ev[4]));
-    for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    const uint8_t *al = p->ev_alias(p->ev_runs - 1);
+    HIPCHK(h, hipEventSynchronize(ev[al[4]]));
+    for (int i = 0; i < 4; i++) {
+        ms[i] = 0.f;
+        if (al[i] != al[i + 1]) HIPCHK(h, hipEventElapsedTime(&ms[i], ev[al[i]], ev[al[i + 1]]));
+    }
     return PYA_OK;
 }
 
@@ -920,12 +939,13 @@ int pya_plan_timings_sum(pya_plan *p, double ms[4], uint32_t *n_runs) {
     for (int i = 0; i < 4; i++) ms[i] = 0.;
     *n_runs = (uint32_t)(p->ev_runs - p->ev_read);
     if (*n_runs == 0) return PYA_OK;
-    HIPCHK(h, hipEventSynchronize(p->ev_set(p->ev_runs - 1)[4]));
+    HIPCHK(h, hipEventSynchronize(p->ev_set(p->ev_runs - 1)[p->ev_alias(p->ev_runs - 1)[4]]));
     for (uint64_t r = p->ev_read; r < p->ev_runs; r++) {
         hipEvent_t *ev = p->ev_set(r);
+        const uint8_t *al = p->ev_alias(r);
         for (int i = 0; i < 4; i++) {
             float t = 0.f;
-            HIPCHK(h, hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            if (al[i] != al[i + 1]) HIPCHK(h, hipEventElapsedTime(&t, ev[al[i]], ev[al[i + 1]]));
             ms[i] += (double)t;
         }
     }
