@@ -141,6 +141,9 @@ int pya_rescore_last_keep(pya_handle *h);
 /* Re-reads the PYA_* environment switches (routes, diagnostics) into the handle.  They are read once in
  * pya_create; this is the hook the tests use to flip a route on a live handle.  No reference counterpart. */
 int pya_reload_env(pya_handle *h);
+/* diagnostics: average microseconds per pya_score_one call since the last call of this function, by stage (checks
+ * and tables, spectrum into the pinned block, launch, wait for the kernel, results out); us[5] = calls averaged */
+int pya_one_times(pya_handle *h, double us[8]);
 
 const char *pya_last_error(const pya_handle *h);
 int64_t pya_error_index(const pya_handle *h);

@@ -229,7 +229,12 @@ DEV double lane_next_f64_or_zero(double x) {
  * Keys that are equal (intensities that agree in 20 mantissa bits, or lie 2^32 below the maximum) make the counts of a
  * window fall short of len (len - 1) / 2, which the deficit notices; only for a peak that ranks inside the top n_top
  * does it matter: those are then ordered by their whole intensities, and if these are equal too the spectrum is handed
- * over (std::nth_element decides between equal intensities). */
+ * over (std::nth_element decides between equal intensities).
+ *
+ * DIRECT: the retained peaks go straight to the workspace table as the sweep finds them (8 contiguous bytes per
+ * retained peak and lane) instead of being compacted in LDS for bin_store -- the batch kernel's way; the one-PSM
+ * kernels keep the LDS table for the stage that follows in the same wavefront. */
+template <bool DIRECT>
 DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
                  const uint8_t **out_rank, int *status) {
     const int lane = lane_id();
@@ -377,6 +382,7 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
     STAMP_T(b, 2, -1);
 
     /* ranks (Spectra.cpp:24-41) and, in the same sweep, the retained peaks in ascending m/z */
+    PeakEntry *dst = DIRECT ? b.ret + b.ret_off[psm] : nullptr;
     uint32_t total = 0;
     int deficit = 0;
     for (uint32_t base = 0; base < P; base += 64) {
@@ -404,8 +410,15 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
         const uint64_t m = __ballot(keep);
         if (keep && !(b.debug & 64)) {
             const uint32_t pos = total + lanes_below(m);
-            s_mzf[pos] = mzf;                                /* pos <= i: in place */
-            o_rank[pos] = (uint8_t)cnt;
+            if (DIRECT) {
+                PeakEntry e;
+                e.mz = mzf;
+                e.rank = cnt;
+                dst[pos] = e;
+            } else {
+                s_mzf[pos] = mzf;                            /* pos <= i: in place */
+                o_rank[pos] = (uint8_t)cnt;
+            }
         }
         total += (uint32_t)__popcll(m);
     }
@@ -442,12 +455,35 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
             const uint64_t m = __ballot(keep);
             if (keep && !(b.debug & 64)) {
                 const uint32_t pos = total + lanes_below(m);
-                s_mzf[pos] = (float)mz[i];                   /* (the first sweep has compacted over this array) */
-                o_rank[pos] = (uint8_t)cnt;
+                if (DIRECT) {
+                    PeakEntry e;
+                    e.mz = (float)mz[i];
+                    e.rank = cnt;
+                    dst[pos] = e;
+                } else {
+                    s_mzf[pos] = (float)mz[i];               /* (the first sweep has compacted over this array) */
+                    o_rank[pos] = (uint8_t)cnt;
+                }
             }
             total += (uint32_t)__popcll(m);
         }
         if (__any(tie)) return PYA_BIN_REDO;
+    }
+    if (DIRECT) {
+        /* what bin_store adds to the entries: the pad behind an odd count, the count, the status */
+        if (b.debug & 64) total = 0;
+        if (lane == 0) {
+            if (total & 1u) {
+                PeakEntry e;
+                e.mz = __builtin_huge_valf();
+                e.rank = (uint32_t)PYA_NO_MATCH;
+                dst[total] = e;
+            }
+            b.ret_n[psm] = total;
+            b.status[psm] = PYA_ST_OK;
+        }
+        STAMP_T(b, 4, -1);
+        return (int)total;
     }
     wave_lds_sync();
     STAMP_T(b, 4, -1);
@@ -769,7 +805,7 @@ template <bool EXACT>
 DEV int bin_core(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
                  const uint8_t **out_rank, int *status) {
     if (EXACT) return bin_exact<false>(b, psm, lds, cap, out_mz, out_rank, status);
-    return bin_fast(b, psm, lds, cap, out_mz, out_rank, status);
+    return bin_fast<false>(b, psm, lds, cap, out_mz, out_rank, status);
 }
 
 /* retained table of one spectrum (or its error status) to global memory */

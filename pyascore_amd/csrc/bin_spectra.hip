@@ -33,13 +33,13 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDe
     const float *r_mz;
     const uint8_t *r_rank;
     int status;
-    const int R = bin_core<false>(b, psm, lds_raw, cap, &r_mz, &r_rank, &status);
+    const int R = bin_fast<true>(b, psm, lds_raw, cap, &r_mz, &r_rank, &status);   /* (stores the table itself) */
     if (R == PYA_BIN_REDO) {
         /* peaks out of m/z order or equal intensities in a window: left to pya_bin_exact_kernel */
         if (lane_id() == 0) b.redo_ids[atomicAdd(b.redo_count, 1u)] = psm;
         return;
     }
-    bin_store(b, psm, R, status, r_mz, r_rank);
+    if (R < 0) bin_store(b, psm, R, status, r_mz, r_rank);                        /* (no windows: the status only) */
 }
 
 /* the spectra the kernel above declined, one per wavefront, a fixed grid striding over the list */

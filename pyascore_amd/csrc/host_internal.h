@@ -269,6 +269,8 @@ struct pya_handle {
         bool have_last = false, last_keep = false;
         uint32_t last_max_k = 1;
         pya_plan *view = nullptr;                  /* what pya_get_pep_scores / pya_calculate_ambiguity read */
+        double t_sum[5] = {0, 0, 0, 0, 0};         /* seconds in checks + tables, copy in, launch, wait, copy out (pya_one_times) */
+        uint64_t t_calls = 0;
     } one;
 
     std::string err;

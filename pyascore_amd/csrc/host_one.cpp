@@ -130,6 +130,7 @@ int one_run(pya_handle *h, bool keep, uint32_t max_k) {
     volatile int32_t *n_sig_word = (volatile int32_t *)(o.host + kOneBest + 8);
     const int32_t kUnset = INT32_MIN;
     *n_sig_word = kUnset;
+    const auto t_launch = std::chrono::steady_clock::now();
     int e = pya_launch_one(&d, &m, cap, prefix, h->cfg.n_nl != 0 ? 1u : 0u, compact, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(),
                            bk.sb(), bk.gtp(), use_fused, f_n_cap, f_stride, f_ent, f_push, z > 1 ? 1u : 0u,
                            (int32_t *)(o.host_dev + kOneStatus), (uint32_t *)(o.host_dev + kOneFlag), o.stream);
@@ -137,6 +138,7 @@ int one_run(pya_handle *h, bool keep, uint32_t max_k) {
     /* the kernel's last store is the sequence number: poll it (a stream synchronisation costs several
      * microseconds more); give up after two seconds and ask the runtime what happened */
     const auto t0 = std::chrono::steady_clock::now();
+    o.t_sum[2] += std::chrono::duration<double>(t0 - t_launch).count();
     auto published = [&]() { return *flag == m.seq && (uint32_t)*echo == m.seq && *n_sig_word != kUnset; };
     for (uint64_t spins = 0; !published(); spins++) {
         __builtin_ia32_pause();
@@ -146,6 +148,7 @@ int one_run(pya_handle *h, bool keep, uint32_t max_k) {
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    o.t_sum[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     o.last_keep = keep;
     o.last_max_k = max_k;
     /* a retained view for pya_get_pep_scores / pya_calculate_ambiguity */
@@ -182,6 +185,7 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
                              uint64_t L, int32_t n_of_mod, int32_t max_charge, const uint32_t *aux_pos, const float *aux_mass,
                              uint64_t n_aux, uint32_t flags, const pya_results *out) {
     if (!h || !out) return PYA_ERR_ARG;
+    const auto t_in = std::chrono::steady_clock::now();
     h->err.clear();
     h->err_index = -1;
     h->last_status.clear();
@@ -248,6 +252,7 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     if (rc) return rc;
     pya_handle::One &o = h->one;
     /* inputs: the spectrum into the pinned block, everything else into the kernel's arguments */
+    const auto t_copy = std::chrono::steady_clock::now();
     std::memcpy(o.host + kOneMz, mz, (size_t)n_peaks * 8);
     std::memcpy(o.host + kOneInt, inten, (size_t)n_peaks * 8);
     OneMeta &m = o.meta;
@@ -276,8 +281,12 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     o.have_last = true;
     const uint32_t mk = out->max_k;
     if (mk > 64) return PYA_ERR_STATE;
+    const auto t_run = std::chrono::steady_clock::now();
+    o.t_sum[0] += std::chrono::duration<double>(t_copy - t_in).count();
+    o.t_sum[1] += std::chrono::duration<double>(t_run - t_copy).count();
     rc = one_run(h, (flags & PYA_FLAG_KEEP) != 0, mk);
     if (rc) return rc;
+    const auto t_out = std::chrono::steady_clock::now();
     const int32_t st = *(const int32_t *)(o.host + kOneStatus);
     rc = check_status(h, &st, 1, false);
     if (rc) return rc;
@@ -286,6 +295,24 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     out->best_sig[0] = *(const uint64_t *)(o.host + kOneBest + 16);
     std::memcpy(out->ascores, o.host + kOneAsc, (size_t)mk * 4);
     std::memcpy(out->alt_mask, o.host + kOneAlt, (size_t)mk * 8);
+    o.t_sum[4] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count();
+    o.t_calls++;
+    return PYA_OK;
+}
+
+/* diagnostics: average microseconds per pya_score_one call since the last call of this function, by stage --
+ * checks and tables, copying the spectrum into the pinned block, the launch call (with the caps before it), waiting
+ * for the kernel's flag, copying the results out; us[5] = calls averaged */
+extern "C" int pya_one_times(pya_handle *h, double us[8]) {
+    if (!h || !us) return PYA_ERR_ARG;
+    pya_handle::One &o = h->one;
+    for (int i = 0; i < 8; i++) us[i] = 0.;
+    for (int i = 0; i < 5; i++) {
+        us[i] = o.t_calls ? 1e6 * o.t_sum[i] / (double)o.t_calls : 0.;
+        o.t_sum[i] = 0.;
+    }
+    us[5] = (double)o.t_calls;
+    o.t_calls = 0;
     return PYA_OK;
 }
 
