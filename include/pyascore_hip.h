@@ -142,8 +142,9 @@ int pya_rescore_last_keep(pya_handle *h);
  * pya_create; this is the hook the tests use to flip a route on a live handle.  No reference counterpart. */
 int pya_reload_env(pya_handle *h);
 /* diagnostics: average microseconds per pya_score_one call since the last call of this function, by stage (checks
- * and tables, spectrum into the pinned block, launch, wait for the kernel, results out); us[5] = calls averaged */
-int pya_one_times(pya_handle *h, double us[8]);
+ * and tables, spectrum into the pinned block, launch, wait for the kernel, results out); us[5] = calls averaged;
+ * us[6..9] = inside the kernel by its own clock (scalars into place, binning, scoring, the rest) */
+int pya_one_times(pya_handle *h, double us[12]);
 
 const char *pya_last_error(const pya_handle *h);
 int64_t pya_error_index(const pya_handle *h);

@@ -52,7 +52,7 @@ SYMBOLS = {
     "pya_plan_create": (C.c_int, [_vp, C.POINTER(Batch), C.c_uint32, C.POINTER(_vp)]),
     "pya_plan_run": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(Results)]),
     "pya_plan_timings": (C.c_int, [_vp, C.POINTER(C.c_float * 4)]),
-    "pya_one_times": (C.c_int, [_vp, C.POINTER(C.c_double * 8)]),
+    "pya_one_times": (C.c_int, [_vp, C.POINTER(C.c_double * 12)]),
     "pya_plan_timings_sum": (C.c_int, [_vp, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32)]),
     "pya_plan_check": (C.c_int, [_vp]),
     "pya_plan_workspace_bytes": (C.c_uint64, [_vp]),

@@ -47,6 +47,33 @@ def _check_typed(name, a, dtype, cname):
     return a
 
 
+try:                                  # the compiled way into pya_score_one (csrc/pyfast.c); ctypes without it
+    from . import _fast
+    _fast.setup(np.ndarray)
+except ImportError:                   # not built for this interpreter
+    _fast = None
+
+_NO_U32 = np.zeros(0, np.uint32)
+_NO_F32 = np.zeros(0, np.float32)
+
+
+class _Last(dict):
+    """What the last score() call left: the scalars as they came back, the arrays made from the raw bytes the first
+    time something reads them (a loop that only reads best_score never builds them)."""
+
+    def __missing__(self, key):
+        if key == "pep":
+            v = np.frombuffer(self["peptide"].encode("utf8"), dtype=np.uint8)
+        elif key == "ascores":
+            v = np.frombuffer(self["_asc"], dtype=np.float32)
+        elif key == "alt_mask":
+            v = np.frombuffer(self["_alt"], dtype=np.uint64)
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+
 class PyAscore:
     """Scores the localization of post translational modifications (Ascore.pyx:12-59).
 
@@ -86,6 +113,8 @@ class PyAscore:
         self._h = h if h.value else None
         if rc:
             self._raise(rc)
+        self._h_addr = int(h.value)
+        self._score_one_addr = C.cast(self._lib.pya_score_one, C.c_void_p).value
         self.device = int(device)
         self._n_top = int(n_top)
         self._last = None            # summary of the last score() call
@@ -99,6 +128,7 @@ class PyAscore:
         if h is not None and getattr(self, "_lib", None) is not None:
             self._lib.pya_destroy(h)
             self._h = None
+            self._h_addr = 0
 
     def _raise(self, rc):
         msg = self._lib.pya_last_error(self._h).decode("utf8", "replace") if self._h else "pya_create failed"
@@ -148,6 +178,19 @@ class PyAscore:
               aux_mod_mass=None):
         """Consume spectra and associated peptide information and score PTM localization
         (Ascore.pyx:103-152)."""
+        if _fast is not None:
+            # the compiled way: arguments as they are; None = something it does not take (types, layouts, lengths,
+            # negative numbers, more than 64 modifications): the checked way below raises what the reference raises
+            r = _fast.score_one(self._score_one_addr, self._h_addr, mz_arr, int_arr, peptide, n_of_mod, max_fragment_charge,
+                                aux_mod_pos, aux_mod_mass)
+            if r is not None and r[0] == 0:
+                have_aux = aux_mod_pos is not None and aux_mod_mass is not None
+                self._batch_n = None
+                self._last = _Last(peptide=peptide, k=r[6], aux_pos=aux_mod_pos.copy() if have_aux else _NO_U32,
+                                   aux_mass=aux_mod_mass.copy() if have_aux else _NO_F32, best_score=r[1], best_sig=r[2],
+                                   n_sig=r[3], _asc=r[4], _alt=r[5], lazy=True)
+                return
+            # (an error code, or PYA_ERR_STATE = "not for the one-PSM kernel": the way below handles both)
         mz_arr = _check_f64("mz_arr", mz_arr)
         int_arr = _check_f64("int_arr", int_arr)
         if not isinstance(peptide, str):

@@ -27,7 +27,9 @@ LIB = os.path.join(HERE, "libpyascore_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-SOURCE_EXT = (".hip", ".cpp", ".h")
+SOURCE_EXT = (".hip", ".cpp", ".h", ".c")
+FAST = os.path.join(HERE, "_fast.so")          # CPython extension behind PyAscore.score() (csrc/pyfast.c)
+FAST_SRC = "pyfast.c"
 VERSION_SRC = "version.cpp"          # compiled at every link with the tree digest as a macro
 
 DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
@@ -138,7 +140,24 @@ def build(force=False):
         relink = True
     if relink:
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + [vo])
+    build_fast(force)
     return LIB
+
+
+def build_fast(force=False):
+    """The CPython extension PyAscore.score() calls pya_score_one through (no ctypes on the per-PSM path).  Built
+    for the interpreter that runs this; pyascore_amd works without it (ascore.py falls back to ctypes)."""
+    import sysconfig
+    inc = sysconfig.get_paths()["include"]
+    if not os.path.exists(os.path.join(inc, "Python.h")):
+        print("no Python.h under %s: pyascore_amd/_fast.so not built (score() will go through ctypes)" % inc, flush=True)
+        return None
+    flags = ["-O2", "-fPIC", "-Wall", "-I" + inc]
+    src, obj = os.path.join(CSRC, FAST_SRC), os.path.join(CSRC, FAST_SRC + ".o")
+    if force or _stale(obj, flags) or not os.path.exists(FAST):
+        _compile(["gcc"], flags, src, obj)
+        _run(["gcc", "-shared", "-o", FAST, obj])
+    return FAST
 
 
 if __name__ == "__main__":

@@ -270,6 +270,7 @@ struct pya_handle {
         uint32_t last_max_k = 1;
         pya_plan *view = nullptr;                  /* what pya_get_pep_scores / pya_calculate_ambiguity read */
         double t_sum[5] = {0, 0, 0, 0, 0};         /* seconds in checks + tables, copy in, launch, wait, copy out (pya_one_times) */
+        double t_dev[4] = {0, 0, 0, 0};            /* seconds inside the kernel: scalars, binning, scoring, rest */
         uint64_t t_calls = 0;
     } one;
 

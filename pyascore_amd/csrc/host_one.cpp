@@ -296,20 +296,26 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     std::memcpy(out->ascores, o.host + kOneAsc, (size_t)mk * 4);
     std::memcpy(out->alt_mask, o.host + kOneAlt, (size_t)mk * 8);
     o.t_sum[4] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count();
+    for (int i = 0; i < 4; i++) o.t_dev[i] += 1e-8 * (double)*(const int32_t *)(o.host + kOneStatus + 8 + 4 * i);   /* 100 MHz ticks */
     o.t_calls++;
     return PYA_OK;
 }
 
 /* diagnostics: average microseconds per pya_score_one call since the last call of this function, by stage --
  * checks and tables, copying the spectrum into the pinned block, the launch call (with the caps before it), waiting
- * for the kernel's flag, copying the results out; us[5] = calls averaged */
-extern "C" int pya_one_times(pya_handle *h, double us[8]) {
+ * for the kernel's flag, copying the results out; us[5] = calls averaged; us[6..9] = inside the kernel (its own
+ * 100 MHz clock): scalars into place, binning, scoring (+ localisation on the fused route), the rest */
+extern "C" int pya_one_times(pya_handle *h, double us[12]) {
     if (!h || !us) return PYA_ERR_ARG;
     pya_handle::One &o = h->one;
-    for (int i = 0; i < 8; i++) us[i] = 0.;
+    for (int i = 0; i < 12; i++) us[i] = 0.;
     for (int i = 0; i < 5; i++) {
         us[i] = o.t_calls ? 1e6 * o.t_sum[i] / (double)o.t_calls : 0.;
         o.t_sum[i] = 0.;
+    }
+    for (int i = 0; i < 4; i++) {
+        us[6 + i] = o.t_calls ? 1e6 * o.t_dev[i] / (double)o.t_calls : 0.;
+        o.t_dev[i] = 0.;
     }
     us[5] = (double)o.t_calls;
     o.t_calls = 0;

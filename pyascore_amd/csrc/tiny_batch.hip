@@ -82,6 +82,8 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
                                                      int32_t *host_status, uint32_t *host_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
+    /* (the 100 MHz clock at the stage boundaries, handed to the host with the status: pya_one_times) */
+    const uint64_t tk0 = __builtin_amdgcn_s_memrealtime();
     /* the PSM's scalars into the batch arrays (all of them arrays of one PSM at offset 0) */
     if (lane == 0) {
         int64_t *w;
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
     }
     __threadfence();
     wave_lds_sync();
+    const uint64_t tk1 = __builtin_amdgcn_s_memrealtime();
     const float *r_mz;
     const uint8_t *r_rank;
     int bin_status;
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
         R = bin_core<true>(b, 0, lds_raw, cap, &r_mz, &r_rank, &bin_status);
     }
     bin_store(b, 0, R, bin_status, r_mz, r_rank);            /* (the general bodies and a retained PSM read it from the workspace) */
+    const uint64_t tk2 = __builtin_amdgcn_s_memrealtime();
     bool general = use_fused == 0;
     if (!general && R <= FUSED_LOCAL_CHUNKS * 64 - PYA_TABLE_PAD) {
         /* the fused body takes the table bin_core left in LDS: no round trip through the workspace */
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
             else score_body<false>(b, 0, lds_raw, cap, with_nl, 0u);
         }
     }
+    const uint64_t tk3 = __builtin_amdgcn_s_memrealtime();
     if (general) {
         __threadfence();
         wave_lds_sync();
@@ -147,6 +152,10 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
     if (lane == 0) {
         host_status[0] = b.status[0];
         host_status[1] = (int32_t)m.seq;
+        host_status[2] = (int32_t)(tk1 - tk0);
+        host_status[3] = (int32_t)(tk2 - tk1);
+        host_status[4] = (int32_t)(tk3 - tk2);
+        host_status[5] = (int32_t)(__builtin_amdgcn_s_memrealtime() - tk3);
         __threadfence_system();
         __hip_atomic_store(host_flag, m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

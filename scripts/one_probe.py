@@ -47,9 +47,10 @@ def direct2(i):
     f(h, a[0], a[1], a[2], a[3], a[4], a[5], a[6], apd, amd, 0, 0, Rb)
 print("... with the pointers prepared too median %.1f us (p10 %.1f, p90 %.1f)" % med_us(direct2, n_calls))
 print("pya_version() through ctypes   median %.2f us" % med_us(lambda i: lib.pya_version(), n_calls)[0])
-ms = (C.c_double * 8)()
+ms = (C.c_double * 12)()
 lib.pya_one_times(h, C.byref(ms))
 for i in range(n_calls):
     direct2(i)
 lib.pya_one_times(h, C.byref(ms))
 print("inside pya_score_one (us, averages of %d): checks+tables %.2f, copy in %.2f, launch %.2f, wait %.2f, copy out %.2f" % ((int(ms[5]),) + tuple(ms[:5])))
+print("inside the kernel (us): scalars into place %.2f, binning %.2f, scoring + localisation %.2f, rest %.2f" % tuple(ms[6:10]))
