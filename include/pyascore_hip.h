@@ -143,7 +143,8 @@ int pya_rescore_last_keep(pya_handle *h);
 int pya_reload_env(pya_handle *h);
 /* diagnostics: average microseconds per pya_score_one call since the last call of this function, by stage (checks
  * and tables, spectrum into the pinned block, launch, wait for the kernel, results out); us[5] = calls averaged;
- * us[6..9] = inside the kernel by its own clock (scalars into place, binning, scoring, the rest) */
+ * us[6..9] = inside the kernel by its own clock (scalars into place, binning, scoring, the rest), us[10] = the
+ * kernel's shader clock cycles */
 int pya_one_times(pya_handle *h, double us[12]);
 
 const char *pya_last_error(const pya_handle *h);

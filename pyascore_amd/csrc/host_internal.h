@@ -271,6 +271,7 @@ struct pya_handle {
         pya_plan *view = nullptr;                  /* what pya_get_pep_scores / pya_calculate_ambiguity read */
         double t_sum[5] = {0, 0, 0, 0, 0};         /* seconds in checks + tables, copy in, launch, wait, copy out (pya_one_times) */
         double t_dev[4] = {0, 0, 0, 0};            /* seconds inside the kernel: scalars, binning, scoring, rest */
+        double t_cycles = 0;                       /* its shader clock cycles */
         uint64_t t_calls = 0;
     } one;
 

@@ -297,6 +297,7 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     std::memcpy(out->alt_mask, o.host + kOneAlt, (size_t)mk * 8);
     o.t_sum[4] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count();
     for (int i = 0; i < 4; i++) o.t_dev[i] += 1e-8 * (double)*(const int32_t *)(o.host + kOneStatus + 8 + 4 * i);   /* 100 MHz ticks */
+    o.t_cycles += (double)*(const int32_t *)(o.host + kOneStatus + 24);
     o.t_calls++;
     return PYA_OK;
 }
@@ -304,7 +305,8 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
 /* diagnostics: average microseconds per pya_score_one call since the last call of this function, by stage --
  * checks and tables, copying the spectrum into the pinned block, the launch call (with the caps before it), waiting
  * for the kernel's flag, copying the results out; us[5] = calls averaged; us[6..9] = inside the kernel (its own
- * 100 MHz clock): scalars into place, binning, scoring (+ localisation on the fused route), the rest */
+ * 100 MHz clock): scalars into place, binning, scoring (+ localisation on the fused route), the rest; us[10] = shader
+ * clock cycles of the kernel (over the sum of 6..9: the clock it ran at) */
 extern "C" int pya_one_times(pya_handle *h, double us[12]) {
     if (!h || !us) return PYA_ERR_ARG;
     pya_handle::One &o = h->one;
@@ -318,6 +320,8 @@ extern "C" int pya_one_times(pya_handle *h, double us[12]) {
         o.t_dev[i] = 0.;
     }
     us[5] = (double)o.t_calls;
+    us[10] = o.t_calls ? o.t_cycles / (double)o.t_calls : 0.;       /* shader clock cycles per kernel */
+    o.t_cycles = 0.;
     o.t_calls = 0;
     return PYA_OK;
 }

@@ -69,13 +69,14 @@ struct InlineSrc {
     PeakTable tab;            /* staged table (tab.e, tab.cell set) */
     uint32_t *rec_batch;      /* [sb][PYA_REC_WORDS] */
     uint32_t *hist;           /* [sb][PYA_NTOP] */
+    bool valid;               /* false (the default): nothing handed in */
 };
 
 /* HASH (general instantiation only): the site-determining ions come from loc_site_ions_hash; pool_cap is then the
  * number of 4-byte words of its work area (loc_hash_words(vc, hs, pp)), and a PSM it declines returns true. */
 template <bool PLAIN, bool HASH = false>
 DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t push_cap, uint32_t pos_cap,
-                       uint32_t pool_cap, uint32_t sb, uint32_t gtp, bool sort_room = true, const InlineSrc *in = nullptr,
+                       uint32_t pool_cap, uint32_t sb, uint32_t gtp, bool sort_room = true, const InlineSrc in = InlineSrc(),
                        uint32_t vc = 0, uint32_t hs = 0, uint32_t pp = 0) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
@@ -101,7 +102,8 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     const int n_sites = (int)b.n_sites[psm];
     const uint64_t *order = b.order_tab + b.order_off[psm];
     const int64_t s0 = b.sig_off[psm];
-    const float *ws = in ? in->ws : b.ws + s0;
+    const bool use_in = in.valid;
+    const float *ws = use_in ? in.ws : b.ws + s0;
 
     /* Ascore::isUnambiguous, cpp/Ascore.cpp:38-51 */
     if (k >= n_sites) {
@@ -126,7 +128,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     ctx.b = &b;
     ctx.cfg = cfg;
     stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, false);
-    if (in) ctx.tab = in->tab;                               /* (the caller's table in LDS: lookups stay on chip) */
+    if (use_in) ctx.tab = in.tab;                               /* (the caller's table in LDS: lookups stay on chip) */
     const Residues res = load_residues(b, cfg, psm);
     const uint64_t site_mask_u = res.site_mask;
     /* positive residue masses make the float32 running sum, hence every m/z list, ascending */
@@ -151,10 +153,10 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     const float ws_lane = lane < N ? ws[lane] : 0.f;       /* the first 64 scores stay in a register */
     uint32_t kmax = 0, first_max = 0xffffffffu;
     int n_max = 0;
-    if (in) {                                               /* the caller knows the winner already */
-        kmax = in->kmax;
+    if (use_in) {                                           /* the caller knows the winner already */
+        kmax = in.kmax;
         n_max = 1;
-        first_max = in->best_i;
+        first_max = in.best_i;
     } else {
         const uint32_t *top = b.ws_top + (size_t)psm * 4;  /* score_signatures' summary (0 signatures = none) */
         kmax = top[0];
@@ -184,8 +186,8 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
      * what decides this kernel's occupancy -- and most PSMs have a unique best PepScore and never
      * sort.  Big-C(n,k) launches of the lean instantiation therefore run without that room and hand the
      * PSMs with a tie at the top to the general instantiation. */
-    if (PLAIN && !sort_room && !in && (n_max != 1 || (b.debug & 1024))) return true;
-    if (!in && (n_max != 1 || b.keep || (b.debug & 1024))) {
+    if (PLAIN && !sort_room && !use_in && (n_max != 1 || (b.debug & 1024))) return true;
+    if (!use_in && (n_max != 1 || b.keep || (b.debug & 1024))) {
         const SortLds srt = sort_carve(lds.scratch, N);
         /* (eight loads on their way before the first is stored: thousands of scores, and a wavefront
          * that makes one memory round trip per 64 of them spends its time waiting) */
@@ -224,8 +226,12 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
         }
     }
     STAMP_T(b, 22, false);
-    const float best_ws = __uint_as_float(kmax);
-    const uint64_t best_bits = order[best_i];
+    /* (wave-uniform values as scalars: they stay live across everything below, and a vector register holds 64 copies) */
+    best_i = (uint32_t)__builtin_amdgcn_readfirstlane((int)best_i);
+    const float best_ws = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)kmax));
+    const uint64_t best_bits_v = order[best_i];
+    const uint64_t best_bits = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)best_bits_v) |
+                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(best_bits_v >> 32)) << 32);
     wave_lds_sync();
 
     STAMP_T(b, 23, false);
@@ -292,7 +298,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
         }
         wave_lds_sync();
     }
-    const uint32_t n_pushed = *lds.n_pushed;
+    const uint32_t n_pushed = (uint32_t)__builtin_amdgcn_readfirstlane((int)*lds.n_pushed);
     int fail = 0;
     if (n_pushed > push_cap) fail = 2;                    /* cannot happen: push_cap >= k * (n_sites - k) */
     uint32_t np = n_pushed < push_cap ? n_pushed : push_cap;
@@ -325,7 +331,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     if (HASH) hl = hash_carve(w.pool, vc, hs, pp, sb);
     const bool declined = loc_ascore_all<PLAIN, HASH>(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
                    best_bits, best_ws, best_i, res.site_mask,
-                   &my_asc, &my_alt, &fail, in ? in->rec_batch : nullptr, in ? in->hist : nullptr, HASH ? &hl : nullptr);
+                   &my_asc, &my_alt, &fail, use_in ? in.rec_batch : nullptr, use_in ? in.hist : nullptr, HASH ? &hl : nullptr);
     if ((PLAIN || HASH) && declined) return true;
     STAMP_T(b, 36, false);
     if (lane < k && lds.site_tie[lane]) my_asc = 0.f < my_asc ? 0.f : my_asc;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64, LOC_WAVES_HASH) void pya_localize_hash_kernel(
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = psm_ids[xcd_slot(blockIdx.x, n_ids)];
     const bool declined = localize_body<false, true>(b, psm, lds_raw, push_cap, pos_cap, (uint32_t)loc_hash_words(vc, hs, pp, sb), sb,
-                                                     0u, true, nullptr, vc, hs, pp);
+                                                     0u, true, InlineSrc(), vc, hs, pp);
     if (declined && lane_id() == 0) b.redo3_ids[atomicAdd(b.redo3_count, 1u)] = psm;
 }
 
@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64, 2) void pya_localize_ties_kernel(BatchDev b, ui
  * PepScore has been resolved by score_big (the score summary names the winner), so there is no sort.  The
  * retained-peak table and the grid score_big left are staged in LDS: recount and site-determining-ion lookups
  * stay on chip.  What the body declines (or score_big could not resolve) goes to the hand-over list. */
-__global__ __launch_bounds__(64, LOC_WAVES_PLAIN) void pya_localize_recount_kernel(
+/* (its LDS allows four wavefronts per SIMD: 128 registers instead of the lean instantiation's 102 cost nothing) */
+__global__ __launch_bounds__(64, 4) void pya_localize_recount_kernel(
     BatchDev b, const uint32_t *psm_ids, uint32_t n_ids, uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap,
     uint32_t sb, uint32_t gtp, uint32_t *redo_count, uint32_t *redo_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(64, LOC_WAVES_PLAIN) void pya_localize_recount_kern
     in.best_i = top[2];
     in.rec_batch = rec_batch;
     in.hist = hist;
+    in.valid = ok;
+    in.tab = PeakTable();
     if (!ok || top[1] == 1u) {
         if (ok && !cap) {
             PeakTable tab;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(64, LOC_WAVES_PLAIN) void pya_localize_recount_kern
             if (tab.n > 0) grid_params(&tab, t_e[0].mz, t_e[tab.n - 1].mz);
             in.tab = tab;
         }
-        declined = localize_body<true>(b, psm, rest, push_cap, pos_cap, pool_cap, sb, gtp, true, ok ? &in : nullptr);
+        declined = localize_body<true>(b, psm, rest, push_cap, pos_cap, pool_cap, sb, gtp, true, in);
     }
     if (declined && lane == 0) redo_ids[atomicAdd(redo_count, 1u)] = psm;
 }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = lane_id();
     /* (the 100 MHz clock at the stage boundaries, handed to the host with the status: pya_one_times) */
-    const uint64_t tk0 = __builtin_amdgcn_s_memrealtime();
+    const uint64_t tk0 = __builtin_amdgcn_s_memrealtime(), cy0 = __builtin_amdgcn_s_memtime();
     /* the PSM's scalars into the batch arrays (all of them arrays of one PSM at offset 0) */
     if (lane == 0) {
         int64_t *w;
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
         host_status[3] = (int32_t)(tk2 - tk1);
         host_status[4] = (int32_t)(tk3 - tk2);
         host_status[5] = (int32_t)(__builtin_amdgcn_s_memrealtime() - tk3);
+        host_status[6] = (int32_t)(__builtin_amdgcn_s_memtime() - cy0);       /* shader clock cycles of the whole kernel */
         __threadfence_system();
         __hip_atomic_store(host_flag, m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

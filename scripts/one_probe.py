@@ -54,3 +54,4 @@ for i in range(n_calls):
 lib.pya_one_times(h, C.byref(ms))
 print("inside pya_score_one (us, averages of %d): checks+tables %.2f, copy in %.2f, launch %.2f, wait %.2f, copy out %.2f" % ((int(ms[5]),) + tuple(ms[:5])))
 print("inside the kernel (us): scalars into place %.2f, binning %.2f, scoring + localisation %.2f, rest %.2f" % tuple(ms[6:10]))
+print("shader clock during the kernel: %.0f cycles / %.2f us = %.2f GHz" % (ms[10], sum(ms[6:10]), ms[10] / max(sum(ms[6:10]), 1e-9) / 1e3))
