@@ -233,10 +233,34 @@ DEV double lane_next_f64_or_zero(double x) {
  *
  * DIRECT: the retained peaks go straight to the workspace table as the sweep finds them (8 contiguous bytes per
  * retained peak and lane) instead of being compacted in LDS for bin_store -- the batch kernel's way; the one-PSM
- * kernels keep the LDS table for the stage that follows in the same wavefront. */
-template <bool DIRECT>
+ * kernels keep the LDS table for the stage that follows in the same wavefront.
+ *
+ * PRE: the caller has the first block of the spectrum in registers already (the one-PSM kernel issues these loads
+ * before anything else: its spectrum sits in host memory, a round trip of microseconds) and knows the peak count;
+ * the spectrum starts at offset 0 of b.mz / b.inten then. */
+struct BinPre {
+    uint32_t P;                 /* peaks */
+    double v[BIN_BLOCK];        /* m/z of peak u * 64 + lane (past the end: the last peak's) */
+    uint32_t hw[BIN_BLOCK];     /* high word of its intensity */
+    double mx;                  /* m/z of the last peak */
+};
+/* the loads behind a BinPre (all issued, none waited for) */
+DEV void bin_preload(const double *mz, const double *inten, uint32_t P, BinPre *pre) {
+    const uint32_t *inten_hi = (const uint32_t *)inten + 1;
+    pre->P = P;
+#pragma unroll
+    for (uint32_t u = 0; u < BIN_BLOCK; u++) {
+        const uint32_t i = u * 64 + (uint32_t)lane_id();
+        const uint32_t ic = i < P ? i : P - 1;
+        pre->v[u] = mz[ic];
+        pre->hw[u] = inten_hi[2 * ic];
+    }
+    pre->mx = mz[P - 1];
+}
+
+template <bool DIRECT, bool PRE = false>
 DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t cap, const float **out_mz,
-                 const uint8_t **out_rank, int *status) {
+                 const uint8_t **out_rank, int *status, const BinPre *pre = nullptr) {
     const int lane = lane_id();
     uint32_t *ckey = (uint32_t *)lds;
     float *s_mzf = (float *)(ckey + 2 * (size_t)cap);
@@ -246,15 +270,16 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
 
     STAMP_BEGIN();
     STAMP_T(b, 1, -1);
-    const int64_t p0 = b.peak_off[psm];
-    const uint32_t P = (uint32_t)(b.peak_off[psm + 1] - p0);
+    const int64_t p0 = PRE ? 0 : b.peak_off[psm];
+    const uint32_t P = PRE ? pre->P : (uint32_t)(b.peak_off[psm + 1] - p0);
     const double *mz = b.mz + p0;
     const double *inten = b.inten + p0;
     const float bin_size = b.cfg->bin_size;
     const int ntop = b.cfg->n_top;                           /* peaks retained per window */
     /* (an estimate of the reciprocal is enough: the quotients below are corrected with an exact remainder) */
     const double bsd = (double)bin_size, inv_bs = __builtin_amdgcn_rcp(bsd);
-    const double mn = mz[0], mx = mz[P - 1];                /* a sorted spectrum has its extremes at the ends */
+    /* a sorted spectrum has its extremes at the ends */
+    const double mn = PRE ? first_lane_f64(pre->v[0]) : mz[0], mx = PRE ? first_lane_f64(pre->mx) : mz[P - 1];
     *status = PYA_ST_OK;
     /* window bounds from the extremes (Spectra.cpp:46-48): floor(mn / 100.) and ceil(mx / 100.) as the reference's
      * double divisions give them, without the divisions -- see window_of below: 100 k is exact in double for every
@@ -325,8 +350,13 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t i = base + u * 64 + (uint32_t)lane;       /* (past the end: the last peak again) */
             const uint32_t ic = i < P ? i : P - 1;
-            v[u] = mz[ic];
-            hw[u] = inten_hi[2 * ic];
+            if (PRE && base == 0) {
+                v[u] = pre->v[u];
+                hw[u] = pre->hw[u];
+            } else {
+                v[u] = mz[ic];
+                hw[u] = inten_hi[2 * ic];
+            }
         }
         if (base == 0) {
             uint32_t m = maxhw;

@@ -84,6 +84,10 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
     const int lane = lane_id();
     /* (the 100 MHz clock at the stage boundaries, handed to the host with the status: pya_one_times) */
     const uint64_t tk0 = __builtin_amdgcn_s_memrealtime(), cy0 = __builtin_amdgcn_s_memtime();
+    /* the spectrum sits in host memory: the loads of its first 384 peaks go out before anything else and travel while
+     * the scalars below are put into place (the peak count is a kernel argument, the spectrum starts at offset 0) */
+    BinPre pre;
+    bin_preload(b.mz, b.inten, m.n_peaks, &pre);
     /* the PSM's scalars into the batch arrays (all of them arrays of one PSM at offset 0) */
     if (lane == 0) {
         int64_t *w;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(64) void pya_one_kernel(BatchDev b, OneMeta m, uint
     const float *r_mz;
     const uint8_t *r_rank;
     int bin_status;
-    int R = bin_core<false>(b, 0, lds_raw, cap, &r_mz, &r_rank, &bin_status);
+    int R = bin_fast<false, true>(b, 0, lds_raw, cap, &r_mz, &r_rank, &bin_status, &pre);
     if (R == PYA_BIN_REDO) {
         wave_lds_sync();
         R = bin_core<true>(b, 0, lds_raw, cap, &r_mz, &r_rank, &bin_status);

@@ -254,6 +254,11 @@ def test_binning_keys_and_their_hand_overs(monkeypatch):
         g.reload_env()
         for key in got:
             assert np.array_equal(got[key], forced[key]), (name, "forced", key)
+        # the same spectra one PSM per call: PyAscore.score() bins with the four wavefronts of its own kernel
+        # (bin_core.hip.h: bin_fast_mw), which has its own sweeps, hand-overs and second sweep for equal keys
+        few = synth.slice_batch(b2, 0, min(6, int(b2["n_psm"])))
+        diff = harness.compare(harness.collect(g, few, synth.unpack_psm), harness.collect(c, few, synth.unpack_psm), exact_float=True)
+        assert not diff, (name, "score()", diff)
 
     for name, inten in cases.items():
         both(dict(batch, intensity=inten), name)
