@@ -265,6 +265,9 @@ class PyAscore:
         last = self._last
         if last is not None and last.get("lazy"):
             rc = self._lib.pya_rescore_last_keep(self._h)
+            if rc == _lib.PYA_ERR_STATE and not self._lib.pya_last_error(self._h):
+                raise RuntimeError("the records of this PSM do not fit the one-PSM kernel; score it with "
+                                   "score_batch(keep=True) to read pep_scores")
             if rc:
                 self._raise(rc)
             last["lazy"] = False

@@ -27,6 +27,9 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDe
      * the tests on them are scalar branches) */
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t slot = xcd_slot(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
+    /* the plan's runs alternate between two sets of hand-over counts: this run zeroes the next one's (nothing of this
+     * run touches them, everything of the run before has finished) -- no memset between the runs */
+    if (blockIdx.x == 0 && threadIdx.x < 3 && b.zero_next) b.zero_next[threadIdx.x] = 0u;
     if (slot >= n_ids) return;
     unsigned char *lds_raw = lds_all + (size_t)wave * PYA_BIN_FAST_BYTES(cap);
     const uint32_t psm = psm_ids[slot];

@@ -85,6 +85,7 @@ struct BatchDev {
     const int64_t *ret_off;         /* [n_psm] even; room for the PSM's raw peak count rounded up to even           */
     uint32_t *ret_n;                /* [n_psm]                                              */
     uint16_t *grid;                 /* [n_psm][PYA_GRID_CELLS] m/z grid over the retained peaks (score_signatures) */
+    uint32_t *zero_next;            /* [3] or NULL: the hand-over counts of the plan's NEXT run, zeroed by this run's binning kernel */
     uint32_t *redo_count;           /* spectra bin_spectra hands to its exact variant (peaks out of */
     uint32_t *redo_ids;             /* [n_psm] m/z order, or equal intensities inside a window)     */
     uint32_t *redo3_count;          /* PSMs the lean localize instantiation hands to the general one */

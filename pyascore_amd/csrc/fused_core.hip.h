@@ -323,7 +323,7 @@ DEV int partners_in_run(const float *run, int n, int p2, float me, int side, flo
 /* ZM: fragment charges above 1 possible (otherwise the charge loops compile away). */
 /* The retained table as bin_core has just left it in this wavefront's LDS (float m/z array, byte rank array):
  * a caller that binned the spectrum itself passes it instead of having it read back from the workspace
- * (score_localize.hip: pya_bin_score_localize_kernel).  Up to FUSED_LOCAL_CHUNKS x 64 retained peaks. */
+ * (tiny_batch.hip: pya_one_kernel).  Up to FUSED_LOCAL_CHUNKS x 64 retained peaks. */
 #define FUSED_LOCAL_CHUNKS 8
 struct LocalTable {
     const float *mz;

@@ -498,6 +498,7 @@ struct pya_plan {
     hipEvent_t *ev_set(uint64_t run) { return evring.data() + 5 * (run % kEvRing); }
     uint8_t *ev_alias(uint64_t run) { return evalias.data() + 5 * (run % kEvRing); }
     hipStream_t last_stream = nullptr;
+    uint64_t n_runs = 0;                 /* pya_plan_run calls so far (which set of hand-over counts is in use) */
     bool ran = false;
     bool quiesced = false;               /* the owner has waited for everything that used the buffers */
 

@@ -121,7 +121,7 @@ int one_run(pya_handle *h, bool keep, uint32_t max_k) {
     }
     if (pya_one_lds_bytes(cap, prefix, h->cfg.n_nl != 0, compact, bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb(), use_fused,
                           f_n_cap, f_stride, f_ent, f_push, z > 1) > kMaxLds)
-        return h->fail(PYA_ERR_LIMIT, 0, "LDS budget exceeded for this PSM");
+        return PYA_ERR_STATE;        /* no room in one workgroup's LDS: declined, the caller takes the batch path (per-stage kernels) */
     volatile uint32_t *flag = (volatile uint32_t *)(o.host + kOneFlag);
     /* belt and braces for the hand-over through host memory: the kernel echoes the sequence number next to the status
      * before it publishes it, and n_sig starts from a value no result has -- the results are read only when all three

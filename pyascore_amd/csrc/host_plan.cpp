@@ -815,7 +815,15 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         return (int)hipEventRecord(ev[i], st);
     };
     if (mark(0, true)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
-    HIPCHK(h, hipMemsetAsync(p->d_redo.p, 0, 3 * sizeof(uint32_t), st));     /* redo_count, redo4_count, the recount's */
+    /* hand-over counts (bin_spectra's, the fused kernel's, the recount's): two sets at the head of d_redo, taken in turn;
+     * the binning kernel of a run zeroes the set of the next (bin_spectra.hip), so only a plan without such a launch --
+     * and the first run -- needs a memset */
+    uint32_t *cnt = p->d_redo.p + 8 * (p->n_runs & 1u);
+    d.redo_count = cnt;
+    d.redo4_count = cnt + 1;
+    d.zero_next = p->d_redo.p + 8 * ((p->n_runs + 1u) & 1u);
+    if (p->n_runs == 0 || p->bin_lists.empty()) HIPCHK(h, hipMemsetAsync(p->d_redo.p, 0, 16 * sizeof(uint32_t), st));
+    p->n_runs++;
     int e = 0;
     for (const pya_plan::IdList &l : p->bin_lists) {
         e = pya_launch_bin(&d, p->d_bin_ids.p + l.off, l.n, l.cap, st);
@@ -855,7 +863,12 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         e = pya_launch_score_big(&d, p->d_big_ids.p + l.off, l.n, l.cap, p->big_pos_cap, p->big_inline ? 1u : 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "score_big launch");
     }
-    if (mark(2, !p->score_lists.empty() || !p->big_lists.empty())) return h->hip_fail(hipGetLastError(), "hipEventRecord");
+    {
+        bool any = false;                                    /* (lists exist per class even when no PSM is in them) */
+        for (const pya_plan::IdList &l : p->score_lists) any = any || l.n != 0;
+        for (const pya_plan::IdList &l : p->big_lists) any = any || l.n != 0;
+        if (mark(2, any)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
+    }
     if (p->n_fused_total) {
         /* few site assignments, plain settings: scored and localised in one pass (score_localize.hip), one PSM per
          * wavefront; what it hands over goes through the general localize instantiation */
@@ -875,11 +888,11 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
          * named; what that declines is scored again with count records and goes to the general localize body */
         const Bucket &bl = p->bigloc;
         e = pya_launch_localize_recount(&d, bl.d_ids.p, (uint32_t)bl.ids.size(), 0u, bl.push_cap(), bl.pos_cap, bl.pool_cap(),
-                                        bl.sb(), bl.gtp(), p->d_redo.p + 2, p->d_redo5.p + 64, st);
+                                        bl.sb(), bl.gtp(), cnt + 2, p->d_redo5.p + 64, st);
         if (e) return h->hip_fail((hipError_t)e, "localize (recount) launch");
-        e = pya_launch_score_big_list(&d, p->d_redo.p + 2, p->d_redo5.p + 64, p->n_big_inline, p->peak_cap, p->big_pos_cap, st);
+        e = pya_launch_score_big_list(&d, cnt + 2, p->d_redo5.p + 64, p->n_big_inline, p->peak_cap, p->big_pos_cap, st);
         if (e) return h->hip_fail((hipError_t)e, "score_big (hand-over) launch");
-        e = pya_launch_localize_redo(&d, p->d_redo.p + 2, p->d_redo5.p + 64, p->n_big_inline, bl.push_cap(), (uint32_t)pya_big_inline_max(),
+        e = pya_launch_localize_redo(&d, cnt + 2, p->d_redo5.p + 64, p->n_big_inline, bl.push_cap(), (uint32_t)pya_big_inline_max(),
                                      bl.pos_cap, bl.pool_cap(), bl.sb(), bl.gtp(), st);
         if (e) return h->hip_fail((hipError_t)e, "localize (score_big hand-over) launch");
     }
@@ -989,7 +1002,7 @@ int pya_plan_check(pya_plan *p) {
     if (h->kn.host_timing) {                               /* diagnostics: how many PSMs the lean kernels handed over */
         uint32_t r3 = 0, r4 = 0;
         (void)hipMemcpy(&r3, p->d_redo3.p, 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(&r4, p->d_redo.p + 1, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&r4, p->d_redo.p + 8 * ((p->n_runs + 1u) & 1u) + 1, 4, hipMemcpyDeviceToHost);   /* (the last run's set) */
         std::fprintf(stderr, "[pya plan] handed over: %u by the lean localize instantiation (last bucket), %u of %u by the fused kernel\n",
                      r3, r4, p->n_fused_total);
     }

@@ -613,6 +613,78 @@ def test_rccl_gather_path_single_rank():
         dist.destroy_process_group()
 
 
+def test_score_of_a_psm_too_big_for_one_workgroup_takes_the_batch_path():
+    """C(26,4) = 14 950 site assignments (inside the fast kernels' limit of 15 000): the one-PSM kernel has no room
+    for its sort area in one workgroup's LDS and declines (r03 advisor: it raised "LDS budget exceeded"); score()
+    then goes through the plan machinery and answers like the reference."""
+    rng = np.random.default_rng(12)
+    pep = list("AKLGEDNVQR" * 4)
+    for p in rng.permutation(40)[:26]:
+        pep[p] = "STY"[p % 3]
+    pep = "".join(pep)
+    mz = np.sort(rng.uniform(150.0, 4200.0, 900))
+    it = rng.lognormal(5, 1, 900)
+    settings = dict(bin_size=100.0, n_top=10, mod_group="STY", mod_mass=79.966331, mz_error=0.05, fragment_types="by",
+                    neutral_losses=[])
+    g, c = _gpu(settings), _checker(settings)
+    for s in (g, c):
+        s.score(mz, it, pep, 4, 1)
+    assert g.best_score == c.best_score and g.best_sequence == c.best_sequence
+    assert np.array_equal(g.ascores, c.ascores)
+    assert [a.tolist() for a in g.alt_sites] == [a.tolist() for a in c.alt_sites]
+    assert len(g.pep_scores) == 14950
+
+
+def test_timing_events_of_runs_enqueued_back_to_back():
+    """PYA_FLAG_TIMING keeps the events of the last 128 runs: pya_plan_timings_sum answers for every run since it was
+    last asked (bench.py enqueues a block of steps and reads afterwards), a kernel family that launched nothing costs
+    no event and reads 0, and the results of such a plan are the plain ones."""
+    import torch
+    from pyascore_amd.device import DevicePlan, unpack_summary
+    batch, settings = synth.make_batch("cfg2", n_psm=3000, seed=77)
+    gpu = _gpu(settings)
+    dev = torch.device("cuda", 0)
+    mz, it = torch.from_numpy(batch["mz"]).to(dev), torch.from_numpy(batch["intensity"]).to(dev)
+    plan = DevicePlan(gpu, batch, timing=True)
+    ms, n = plan.timings_sum()
+    assert n == 0 and ms == (0.0, 0.0, 0.0, 0.0)
+    for _ in range(7):
+        plan.run(mz, it)
+    ms, n = plan.timings_sum()
+    assert n == 7
+    assert ms[0] > 0 and ms[2] > 0                  # binning, the fused kernel
+    assert ms[1] == 0 and ms[3] == 0                # nothing of cfg2 goes through the other two families
+    last = plan.timings_ms()
+    assert last[0] > 0 and last[2] > 0 and last[1] == 0 and last[3] == 0
+    assert plan.timings_sum()[1] == 0
+    for _ in range(150):                            # more runs than the ring holds: the latest 128 count
+        plan.run(mz, it)
+    ms, n = plan.timings_sum()
+    assert n == 128 and ms[0] > 0
+    got = unpack_summary(plan.packed_summary().cpu().numpy(), plan.max_k)
+    plan.check()
+    _same(got, gpu.score_batch(batch))
+    plan.close()
+
+
+def test_one_psm_stage_clocks():
+    """pya_one_times: per-stage averages of the pya_score_one calls since it was last asked, on the host and inside
+    the kernel (diagnostics behind scripts/one_probe.py)."""
+    import ctypes as C
+    batch, settings = synth.make_batch("cfg2", n_psm=12, seed=3)
+    gpu = _gpu(settings)
+    us = (C.c_double * 12)()
+    gpu._lib.pya_one_times(gpu._h, C.byref(us))
+    for i in range(12):
+        gpu.score(**synth.unpack_psm(batch, i))
+    assert gpu._lib.pya_one_times(gpu._h, C.byref(us)) == 0
+    assert us[5] == 12
+    assert all(us[i] > 0 for i in (2, 3, 6, 7, 8, 10)), list(us)
+    assert 0.5e3 < us[10] / sum(us[6:10]) < 3.5e3       # cycles per microsecond: a shader clock between 0.5 and 3.5 GHz
+    gpu._lib.pya_one_times(gpu._h, C.byref(us))
+    assert us[5] == 0
+
+
 def test_skip_invalid_sets_psms_aside():
     """PYA_FLAG_SKIP_INVALID: PSMs the library cannot take (a limit the reference does not have, an
     unknown residue, an empty spectrum, a spectrum without m/z windows) get a status code and
