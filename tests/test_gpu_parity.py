@@ -635,6 +635,47 @@ def test_score_of_a_psm_too_big_for_one_workgroup_takes_the_batch_path():
     assert len(g.pep_scores) == 14950
 
 
+@pytest.mark.parametrize("mz_error", [0.05, 0.02, 0.004, 0.3])
+def test_peaks_at_the_window_edges(mz_error):
+    """Spectra whose peaks sit AT the window edges of the fragments -- the theoretical ions of random site assignments
+    (float32 running sums as the scorer makes them) shifted by the tolerance plus or minus anything from one float32
+    ulp to 0.05 -- must score exactly as the reference does: the window test is `f32(f - err) < peak < f32(f + err)` on
+    each walker's own running sum, and a shortcut that decides a fragment for several site assignments at once (r04
+    tried one: DESIGN.md section 10) has to get exactly these spectra right."""
+    settings = dict(bin_size=100.0, n_top=10, mod_group="STY", mod_mass=79.966331, mz_error=mz_error, fragment_types="by",
+                    neutral_losses=[])
+    batch, _ = synth.make_batch("cfg2", n_psm=400, seed=31)
+    rng = np.random.default_rng(17)
+    res = synth.RESIDUE_MASS
+    mzs, its, offs = [], [], [0]
+    for i in range(batch["n_psm"]):
+        pep = bytes(batch["pep"][batch["pep_off"][i]:batch["pep_off"][i + 1]]).decode()
+        sites = [p for p, ch in enumerate(pep) if ch in "STY"]
+        ions = []
+        for _ in range(6):                                   # fragments of random site assignments, float32 sums as the scorer makes them
+            mod = set(rng.choice(sites, size=int(batch["n_of_mod"][i]), replace=False).tolist()) if sites else set()
+            for order, a_off in ((range(len(pep) - 1), 0.0), (range(len(pep) - 1, 0, -1), 18.010565)):
+                run = np.float32(0.0)
+                for p in order:
+                    run = np.float32(run + np.float32(np.float32(res[pep[p]]) + (np.float32(79.966331) if p in mod else np.float32(0.0))))
+                    ions.append(float(np.float32(float(run) + a_off + 1.007825)))
+        ions = np.asarray(ions)
+        side = rng.choice([-1.0, 1.0], ions.size)
+        ulp = np.spacing(ions.astype(np.float32)).astype(np.float64)
+        off = np.where(rng.random(ions.size) < 0.5, ulp * rng.integers(-40, 41, ions.size), rng.uniform(-0.05, 0.05, ions.size))
+        m = np.concatenate([ions + side * mz_error + off, batch["mz"][batch["peak_off"][i]:batch["peak_off"][i + 1]][::3]])
+        m = np.sort(m[m > 50.0])
+        mzs.append(m)
+        its.append(rng.lognormal(5.0, 1.0, m.size))
+        offs.append(offs[-1] + m.size)
+    b2 = dict(batch, mz=np.concatenate(mzs), intensity=np.concatenate(its), peak_off=np.asarray(offs, np.int64))
+    gpu, chk = _gpu(settings), _checker(settings)
+    want = chk.score_batch(b2, int(b2["n_of_mod"].max()))
+    got = gpu.score_batch(b2)
+    for key in want:
+        assert np.array_equal(got[key], want[key]), (mz_error, key)
+
+
 def test_timing_events_of_runs_enqueued_back_to_back():
     """PYA_FLAG_TIMING keeps the events of the last 128 runs: pya_plan_timings_sum answers for every run since it was
     last asked (bench.py enqueues a block of steps and reads afterwards), a kernel family that launched nothing costs
