@@ -175,30 +175,7 @@ DEV FusedLds fused_carve(unsigned char *raw, uint32_t cap, uint32_t n_cap, uint3
     return f;
 }
 
-/* Cumulative counts (Ascore.cpp:115-118: counts[d] = fragments matched at rank <= d) are kept in three registers per
- * walker, a byte per depth (a PSM of this kernel has at most 255 fragments per site assignment): a fragment that
- * matched rank r adds 1 to the bytes d >= r, which is one 16-byte LDS read of the entry below and three adds of the
- * cheap class -- where bumping a histogram column in LDS took four instructions of the expensive class and an LDS
- * atomic, and the scores then had to sum the histogram up.  Entry 15 (no match) is all zeros. */
-DEV uint4 fused_cum_entry(uint32_t r) {
-    const uint32_t full = 0x01010101u;
-    uint4 e;
-    e.x = r < 4u ? full << (8u * r) : 0u;
-    e.y = r <= 4u ? full : (r < 8u ? full << (8u * (r - 4u)) : 0u);
-    e.z = r <= 8u ? 0x0101u : (r == 9u ? 0x0100u : 0u);
-    e.w = 0u;
-    if (r >= (uint32_t)PYA_NTOP) e.x = e.y = e.z = 0u;
-    return e;
-}
-struct CumCounts {
-    uint32_t a, b, c;        /* depths 0-3 | 4-7 | 8-9 */
-    DEV void add(const uint4 &e) {
-        a += e.x;
-        b += e.y;
-        c += e.z;
-    }
-    DEV uint32_t at(int d) const { return ((d < 4 ? a : (d < 8 ? b : c)) >> ((d & 3) * 8)) & 0xffu; }
-};
+/* (CumCounts and fused_cum_entry: walk_core.hip.h) */
 
 /* the straight-line walker of walk_core.hip.h that also records the rank every fragment matched in
  * column `w` of rkl (entry step * zmax + z - 1); A, B: the ion-type offsets of the lane's direction.

@@ -39,19 +39,26 @@
 /* (the level-2 table is indexed by the 10-site pattern itself; a dense table -- 638 instead of 1024
  * entries per direction for k = 5, 4 instead of 3 workgroups per CU -- was measured and lost to its
  * index arithmetic: 6.05 vs 5.66 ms on 50 000 PSMs of 3003 signatures) */
+/* (r04: the walkers keep their rank counts in registers -- walk_core.hip.h: CumCounts -- so the eight histograms, 10 KB,
+ * are gone: 40 KB per workgroup on cfg5's shape, a fourth workgroup per CU) */
 static inline size_t score_big_lds_bytes(uint32_t cap, uint32_t pos_cap) {
     return PYA_GRID_CELLS * 2 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8 + 2 * 64 * sizeof(PrefixCompact) +
-           2 * 1024 * sizeof(PrefixCompact) + (size_t)BIG_WAVES * (PYA_NTOP / 2 * 64 * 4) + BIG_WAVES * 16 +
+           2 * 1024 * sizeof(PrefixCompact) + 16 * sizeof(uint4) + BIG_WAVES * 16 +
            (size_t)PYA_NTOP * (2 * pos_cap + 1) * 4 + 64;             /* + the score-table row of the PSM */
 }
 
-/* rank counts of column `lane` of a wave's histogram, packed in 8-bit fields (<= 63 per direction) */
-DEV void pack_counts(const uint32_t *cnt, int lane, uint64_t *lo, uint32_t *hi) {
-    uint64_t l = 0ull;
-#pragma unroll
-    for (int d = 0; d < 8; d++) l |= (uint64_t)hist_count(cnt, lane, d) << (d * 8);
-    *lo = l;
-    *hi = hist_count(cnt, lane, 8) | (hist_count(cnt, lane, 9) << 8);
+/* a table entry's counts: the CUMULATIVE counts of depths 0..7 in lo, 8..9 in hi, a byte each (they add without
+ * unpacking: at most 126 fragments per site assignment here) */
+DEV CumCounts entry_counts(const PrefixCompact &p) {
+    CumCounts c = {(uint32_t)p.lo, (uint32_t)(p.lo >> 32), p.hi};
+    return c;
+}
+DEV PrefixCompact make_entry(float running, const CumCounts &c) {
+    PrefixCompact p;
+    p.running = running;
+    p.lo = (uint64_t)c.a | ((uint64_t)c.b << 32);
+    p.hi = c.c;
+    return p;
 }
 
 
@@ -177,7 +184,7 @@ DEV uint32_t wg_spine_front(const BigSortLds &s, int N, uint32_t kmax, bool *out
 }
 
 __host__ __device__ static inline uint32_t pya_big_inline_max_dev() {
-    const size_t dead = 2 * 64 * sizeof(PrefixCompact) + 2 * 1024 * sizeof(PrefixCompact) + (size_t)BIG_WAVES * (PYA_NTOP / 2 * 64 * 4);
+    const size_t dead = 2 * 64 * sizeof(PrefixCompact) + 2 * 1024 * sizeof(PrefixCompact) + 16 * sizeof(uint4);
     const size_t n = (dead - BIG_INLINE_AUX) / 10;
     return (uint32_t)(n < 4096 ? n : 4096);                  /* (chunk masks and counts: 64 chunks of 64 positions) */
 }
@@ -203,9 +210,8 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     unsigned char *tail = lds_raw + PYA_GRID_CELLS * 2 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8;
     PrefixCompact *l1 = (PrefixCompact *)tail;                   /* [2][64]   */
     PrefixCompact *l2 = l1 + 2 * 64;                             /* [2][1024] indexed by the 10-site pattern */
-    uint32_t *cnt_all = (uint32_t *)(l2 + 2 * 1024);             /* [BIG_WAVES][5][64] */
-    uint32_t *tops = cnt_all + BIG_WAVES * (PYA_NTOP / 2 * 64);  /* [BIG_WAVES][4] */
-    uint32_t *cnt = cnt_all + wave * (PYA_NTOP / 2 * 64);
+    uint4 *cum_lut = (uint4 *)(l2 + 2 * 1024);                   /* [16] rank -> increments of the cumulative counts */
+    uint32_t *tops = (uint32_t *)(cum_lut + 16);                 /* [BIG_WAVES][4] */
     float *lutl = (float *)(tops + BIG_WAVES * 4);               /* [10][nfrag + 1] */
 
     if (b.status[psm] != PYA_ST_OK) return;                      /* (uniform over the workgroup) */
@@ -231,14 +237,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         tab.half_check = false;                                  /* (the host sends mz_error > 0.49 elsewhere) */
     }
     if (wave == 0) stage_residues(res, resd, nullptr);
-    {
-        /* the one row of the score table every signature of this PSM reads: 10 x (nfrag + 1) floats */
-        const uint32_t nf = 2u * (uint32_t)(L - 1);
-        if (nf <= b.lut_n_max) {
-            const float *src = b.lut + lut_row(nf);
-            for (uint32_t i = (uint32_t)tid; i < PYA_NTOP * (nf + 1); i += 64 * BIG_WAVES) lutl[i] = src[i];
-        }
-    }
+    if (tid < 16) cum_lut[tid] = fused_cum_entry((uint32_t)tid);
     __syncthreads();
     /* the grid: cell geometry in every wavefront's registers, cells written by wavefront 0 */
     if (wave == 0) {
@@ -258,7 +257,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     env.nl_uniq = nullptr;
     env.resd = resd;
     env.resn = nullptr;
-    env.cnt = cnt;
+    env.cnt = nullptr;                                           /* (no histogram: register counts) */
     env.L = L;
     env.zmax = 1;
     const int n_sites = __popcll(res.site_mask);
@@ -278,40 +277,69 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     if (wave < 2) {
         const int dir = wave;
         const uint64_t pbits = dir == 0 ? (uint64_t)lane : (__brevll((uint64_t)lane) >> (64 - n_sites));
-        WalkState st = {0.f, 0u};
-        hist_clear(env);
-        walk_simple_range(env, tab, deposit_sites(pbits, res.site_mask), dir, true, 0, stop1[dir], st);
-        wave_lds_sync();
-        PrefixCompact pc;
-        pc.running = st.running;
-        pack_counts(cnt, lane, &pc.lo, &pc.hi);
-        l1[dir * 64 + lane] = pc;
+        float run = 0.f;
+        CumCounts cum = {0u, 0u, 0u};
+        walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, 0, stop1[dir], run, cum);
+        l1[dir * 64 + lane] = make_entry(run, cum);
     }
     __syncthreads();
     STAMP_BEGIN();
     STAMP_T(b, 9, );
     /* ---- level 2: the patterns of the first 10 sites that a signature can have (at most k modified,
-     * enough sites left for the rest), resumed from level 1 ---- */
-    for (int base = 0; base < 2 * 1024; base += 64 * BIG_WAVES) {
-        const int item = base + tid;                             /* direction * 1024 + pattern */
-        const int dir = item >> 10;                              /* (uniform within a wavefront: 64 | 1024) */
-        const uint32_t c = (uint32_t)item & 1023u;
+     * enough sites left for the rest), resumed from level 1.  Which patterns those are depends on their number of
+     * modified sites only (638 of the 1024 for 5 of 15): they are listed first -- in the LDS the score-table row
+     * will take afterwards -- so that the wavefronts walk full rounds of them, not rounds with a third of the lanes
+     * idle.  (No room for the list -- short peptides: the patterns in their natural order, as before.) ---- */
+    uint16_t *vlist = (uint16_t *)lutl;
+    const bool listed = (size_t)PYA_NTOP * (2 * (size_t)(L - 1) + 1) * 4 >= 1024 * sizeof(uint16_t);
+    uint32_t nv = 1024u;
+    if (listed) {
+        uint32_t before = 0;                                     /* valid patterns below this thread's, round by round */
+        for (int r = 0; r < 1024 / BIG_T; r++) {
+            const uint32_t c = (uint32_t)(r * BIG_T + tid);
+            const int m = __popc(c);
+            const bool valid = m <= k && k - m <= n_sites - BIG_SITES2;
+            const uint64_t vm = __ballot(valid);
+            if (lane == 0) tops[wave] = (uint32_t)__popcll(vm);
+            __syncthreads();
+            uint32_t off = before, tot = 0;
+            for (int wv = 0; wv < BIG_WAVES; wv++) {
+                const uint32_t n_w = tops[wv];
+                off += wv < wave ? n_w : 0u;
+                tot += n_w;
+            }
+            if (valid) vlist[off + (uint32_t)__popcll(vm & lanemask_lt())] = (uint16_t)c;
+            before += tot;
+            __syncthreads();
+        }
+        nv = before;
+    }
+    const uint32_t nv64 = (nv + 63u) & ~63u;                     /* a wavefront's 64 items share their direction */
+    for (uint32_t base = 0; base < 2u * nv64; base += 64 * BIG_WAVES) {
+        const uint32_t it2 = base + (uint32_t)tid;
+        const int dir = it2 >= nv64 ? 1 : 0;                     /* (uniform within a wavefront) */
+        const uint32_t q = it2 - (dir ? nv64 : 0u);
+        const bool listed_on = q < nv && it2 < 2u * nv64;
+        const uint32_t c = listed ? (listed_on ? (uint32_t)vlist[q] : 0u) : q;
+        const int item = dir * 1024 + (int)c;                    /* direction * 1024 + pattern */
         const int m = __popc(c);
-        const bool valid = m <= k && k - m <= n_sites - BIG_SITES2;
+        const bool valid = listed_on && m <= k && k - m <= n_sites - BIG_SITES2;
         if (!__any(valid)) continue;                             /* (no __syncthreads inside this loop) */
         const uint64_t pbits = dir == 0 ? (uint64_t)c : (__brevll((uint64_t)c) >> (64 - n_sites));
         const PrefixCompact par = l1[dir * 64 + (c & 63u)];
-        WalkState st = {par.running, 0u};
-        hist_clear(env);
-        walk_simple_range(env, tab, deposit_sites(pbits, res.site_mask), dir, valid, stop1[dir], stop2[dir], st);
-        wave_lds_sync();
-        PrefixCompact pc;
-        pc.running = st.running;
-        pack_counts(cnt, lane, &pc.lo, &pc.hi);
-        pc.lo += par.lo;                                         /* fields stay below 256: <= 63 per direction */
-        pc.hi += par.hi;
-        if (valid) l2[item] = pc;
-        wave_lds_sync();
+        float run = par.running;
+        CumCounts cum = entry_counts(par);                       /* (the walk adds to the parent's counts) */
+        walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, stop1[dir], stop2[dir], run, cum);
+        if (valid) l2[item] = make_entry(run, cum);
+    }
+    __syncthreads();
+    {
+        /* the one row of the score table every signature of this PSM reads: 10 x (nfrag + 1) floats (over the list) */
+        const uint32_t nf = 2u * (uint32_t)(L - 1);
+        if (nf <= b.lut_n_max) {
+            const float *src = b.lut + lut_row(nf);
+            for (uint32_t i = (uint32_t)tid; i < PYA_NTOP * (nf + 1); i += 64 * BIG_WAVES) lutl[i] = src[i];
+        }
     }
     __syncthreads();
     STAMP_T(b, 10, );
@@ -326,21 +354,15 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         const uint64_t resmask = deposit_sites(bits, res.site_mask);
         const PrefixCompact p0 = l2[(uint32_t)(bits & 1023ull)];
         const PrefixCompact p1 = l2[1024u + (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 1023ull)];
-        WalkState st0 = {p0.running, 0u}, st1 = {p1.running, 0u};
-        const uint64_t p8lo = p0.lo + p1.lo;
-        const uint32_t p8hi = p0.hi + p1.hi;
-        hist_clear(env);
-        walk_simple_both(env, tab, resmask, active, stop2[0], L - 1, st0, stop2[1], L - 1, st1);
-        wave_lds_sync();
+        float run0 = p0.running, run1 = p1.running;
+        CumCounts cc = entry_counts(p0);                         /* both directions' prefixes, then the rest of the walk */
+        cc.add(make_uint4((uint32_t)p1.lo, (uint32_t)(p1.lo >> 32), p1.hi, 0u));
+        walk_cum_both(env, tab, cum_lut, resmask, stop2[0], L - 1, run0, stop2[1], L - 1, run1, cc);
         if (active) {
             /* cumulative counts over rank (Ascore.cpp:115-118) and scores (Ascore.cpp:123-139) */
             uint32_t cum[PYA_NTOP];
-            uint32_t acc = 0;
 #pragma unroll
-            for (int d = 0; d < PYA_NTOP; d++) {
-                acc += hist_count(cnt, lane, d) + (d < 8 ? (uint32_t)(p8lo >> (d * 8)) & 0xffu : (p8hi >> ((d - 8) * 8)) & 0xffu);
-                cum[d] = acc;
-            }
+            for (int d = 0; d < PYA_NTOP; d++) cum[d] = cc.at(d);
             float ws = -1.f;
             if (nfrag <= b.lut_n_max) {
                 double sum = 0.;
@@ -370,7 +392,6 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
                 rec[5] = nfrag;
             }
         }
-        wave_lds_sync();
     }
     STAMP_T(b, 11, );
     /* (the PepScores are read back below by other wavefronts of this workgroup: the barriers' workgroup-scope
@@ -422,7 +443,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     if (n_max == 1 && !(b.debug & 1024u)) return;                /* a unique best PepScore: nothing to resolve */
     /* a tie for the best PepScore: the front of std::sort decides (cpp/Ascore.cpp:141-146) */
     BigSortLds srt;
-    srt.key = (float *)l1;                                       /* l1 | l2 | cnt_all: nothing reads them any more */
+    srt.key = (float *)l1;                                       /* l1 | l2 | cum_lut: nothing reads them any more */
     srt.idx = (uint16_t *)(srt.key + N);
     srt.lq = srt.idx + N;
     srt.rq = srt.lq + N;

@@ -42,6 +42,31 @@ DEV uint32_t hist_count(const uint32_t *cnt, int lane, int d) {
     return (cnt[(d >> 1) * 64 + lane] >> ((d & 1) * 16)) & 0xffffu;
 }
 
+/* Cumulative counts (Ascore.cpp:115-118: counts[d] = fragments matched at rank <= d) are kept in three registers per
+ * walker, a byte per depth (a PSM of this kernel has at most 255 fragments per site assignment): a fragment that
+ * matched rank r adds 1 to the bytes d >= r, which is one 16-byte LDS read of the entry below and three adds of the
+ * cheap class -- where bumping a histogram column in LDS took four instructions of the expensive class and an LDS
+ * atomic, and the scores then had to sum the histogram up.  Entry 15 (no match) is all zeros. */
+DEV uint4 fused_cum_entry(uint32_t r) {
+    const uint32_t full = 0x01010101u;
+    uint4 e;
+    e.x = r < 4u ? full << (8u * r) : 0u;
+    e.y = r <= 4u ? full : (r < 8u ? full << (8u * (r - 4u)) : 0u);
+    e.z = r <= 8u ? 0x0101u : (r == 9u ? 0x0100u : 0u);
+    e.w = 0u;
+    if (r >= (uint32_t)PYA_NTOP) e.x = e.y = e.z = 0u;
+    return e;
+}
+struct CumCounts {
+    uint32_t a, b, c;        /* depths 0-3 | 4-7 | 8-9 */
+    DEV void add(const uint4 &e) {
+        a += e.x;
+        b += e.y;
+        c += e.z;
+    }
+    DEV uint32_t at(int d) const { return ((d < 4 ? a : (d < 8 ? b : c)) >> ((d & 3) * 8)) & 0xffu; }
+};
+
 /* stages resd / resn from the one-residue-per-lane registers (caller syncs afterwards) */
 DEV void stage_residues(const Residues &res, float2 *resd, uint8_t *resn) {
     const int i = lane_id();
@@ -239,6 +264,110 @@ DEV void walk_simple_both(const WalkEnv &e, const PeakTable &tab, uint64_t resma
     }
     st0.running = run0;
     st1.running = run1;
+}
+
+/* The simple walkers once more for charge 1 and at most 255 fragments per site assignment, with the cumulative rank
+ * counts in three registers per lane (CumCounts: one 16-byte read of `lut` and three adds per fragment) instead of a
+ * histogram column in LDS bumped with an atomic -- score_big's way since r04: no histogram to clear, to sum up, or to
+ * make room for (10 KB of its workgroup's LDS).  Lanes without work run along; nobody reads their counts. */
+DEV void walk_cum_range(const WalkEnv &e, const PeakTable &tab, const uint4 *lut, uint64_t resmask, int dir, int step_begin,
+                        int step_end, float &running_io, CumCounts &cum) {
+    const DevConfig *cfg = e.cfg;
+    const int L = e.L;
+    double Af = 0., Bf = 0., Ab = 0., Bb = 0.;
+    if (cfg->n_fwd > 0) type_constants(cfg->types[0], &Af, &Bf);
+    if (cfg->n_fwd < cfg->n_types) type_constants(cfg->types[cfg->n_fwd], &Ab, &Bb);
+    const double A = dir ? Ab : Af, B = dir ? Bb : Bf;
+    const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
+    const uint32_t tlo = (uint32_t)tmask, thi = (uint32_t)(tmask >> 32);
+    const float2 *rp = e.resd + (dir ? L - 1 - step_begin : step_begin);
+    const int stride = dir ? -1 : 1;
+    float running = running_io;
+    for (int step = step_begin; step < step_end; step++, rp += stride) {
+        const float2 mm = *rp;
+        const uint32_t word = step < 32 ? tlo : thi;
+        const bool mod = (word >> (step & 31)) & 1u;
+        running = (mod ? mm.y : mm.x) + running;           /* ModifiedPeptide.cpp:385-389 */
+        const double m = ((double)running + A) - B;
+        const Look k = look4(tab, (float)(m + 1.007825));
+        int rk = k.best;
+        if (k.more()) rk = look_rest(tab, k);
+        cum.add(lut[rk]);
+    }
+    running_io = running;
+}
+template <bool BY>
+DEV void walk_cum_both_steps(const PeakTable &tab, const uint4 *lut, CumCounts &cum, const float2 *&rp0, const float2 *&rp1,
+                             StepBits &b0, StepBits &b1, float &run0, float &run1, double A0, double B0, double A1, double B1,
+                             int count) {
+    for (int i = 0; i < count; i++, rp0++, rp1--) {
+        const float2 m0 = *rp0, m1 = *rp1;
+        const float r0 = b0.next() ? m0.y : m0.x, r1 = b1.next() ? m1.y : m1.x;
+        run0 = r0 + run0;                                    /* ModifiedPeptide.cpp:385-389 */
+        run1 = r1 + run1;
+        float f0, f1;
+        if (BY) {
+            f0 = (float)((double)run0 + 1.007825);
+            f1 = (float)(((double)run1 + A1) + 1.007825);
+        } else {
+            f0 = (float)((((double)run0 + A0) - B0) + 1.007825);
+            f1 = (float)((((double)run1 + A1) - B1) + 1.007825);
+        }
+        const Look k0 = look4(tab, f0), k1 = look4(tab, f1);
+        int rk0 = k0.best, rk1 = k1.best;
+        if (k0.more()) rk0 = look_rest(tab, k0);
+        if (k1.more()) rk1 = look_rest(tab, k1);
+        cum.add(lut[rk0]);
+        cum.add(lut[rk1]);
+    }
+}
+template <bool BY>
+DEV void walk_cum_one_steps(const PeakTable &tab, const uint4 *lut, CumCounts &cum, const float2 *&rp, int stride, StepBits &bits,
+                            float &run, double A, double B, int count) {
+    for (int i = 0; i < count; i++, rp += stride) {
+        const float2 mm = *rp;
+        const float r = bits.next() ? mm.y : mm.x;
+        run = r + run;
+        const float f = BY ? (float)(((double)run + A) + 1.007825) : (float)((((double)run + A) - B) + 1.007825);
+        const Look k = look4(tab, f);
+        int rk = k.best;
+        if (k.more()) rk = look_rest(tab, k);
+        cum.add(lut[rk]);
+    }
+}
+/* walk_simple_both with register counts: steps [begin_d, end_d) of direction d, running sums in and out */
+DEV void walk_cum_both(const WalkEnv &e, const PeakTable &tab, const uint4 *lut, uint64_t resmask, int begin0, int end0, float &run0_io,
+                       int begin1, int end1, float &run1_io, CumCounts &cum) {
+    const DevConfig *cfg = e.cfg;
+    const int L = e.L;
+    double A0 = 0., B0 = 0., A1 = 0., B1 = 0.;
+    type_constants(cfg->types[0], &A0, &B0);
+    type_constants(cfg->types[cfg->n_fwd], &A1, &B1);
+    const bool by = A0 == 0. && B0 == 0. && B1 == 0.;
+    const uint64_t M0 = msb_first_from(resmask, begin0), M1 = msb_first_from(__brevll(resmask) >> (64 - L), begin1);
+    const float2 *rp0 = e.resd + begin0, *rp1 = e.resd + (L - 1 - begin1);
+    float run0 = run0_io, run1 = run1_io;
+    const int n0 = end0 - begin0, n1 = end1 - begin1, both = n0 < n1 ? n0 : n1;
+    for (int seg = 0; seg < 2; seg++) {
+        StepBits b0 = {seg ? (uint32_t)M0 : (uint32_t)(M0 >> 32)}, b1 = {seg ? (uint32_t)M1 : (uint32_t)(M1 >> 32)};
+        const int lo = seg * 32, hi = lo + 32;
+        int c = (both < hi ? both : hi) - lo;
+        if (c < 0) c = 0;
+        if (by) walk_cum_both_steps<true>(tab, lut, cum, rp0, rp1, b0, b1, run0, run1, A0, B0, A1, B1, c);
+        else walk_cum_both_steps<false>(tab, lut, cum, rp0, rp1, b0, b1, run0, run1, A0, B0, A1, B1, c);
+        const int from = lo + c;
+        int t0 = (n0 < hi ? n0 : hi) - from, t1 = (n1 < hi ? n1 : hi) - from;
+        if (t0 > 0) {
+            if (by) walk_cum_one_steps<true>(tab, lut, cum, rp0, 1, b0, run0, A0, B0, t0);
+            else walk_cum_one_steps<false>(tab, lut, cum, rp0, 1, b0, run0, A0, B0, t0);
+        }
+        if (t1 > 0) {
+            if (by) walk_cum_one_steps<true>(tab, lut, cum, rp1, -1, b1, run1, A1, B1, t1);
+            else walk_cum_one_steps<false>(tab, lut, cum, rp1, -1, b1, run1, A1, B1, t1);
+        }
+    }
+    run0_io = run0;
+    run1_io = run1;
 }
 
 DEV bool walk_is_simple(const WalkEnv &e) {
