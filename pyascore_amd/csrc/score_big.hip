@@ -41,10 +41,17 @@
  * index arithmetic: 6.05 vs 5.66 ms on 50 000 PSMs of 3003 signatures) */
 /* (r04: the walkers keep their rank counts in registers -- walk_core.hip.h: CumCounts -- so the eight histograms, 10 KB,
  * are gone: 40 KB per workgroup on cfg5's shape, a fourth workgroup per CU) */
+/* layout: grid | residues [pos_cap + 1] | peak table | level-2 table | count table | summary words | a region that holds
+ * the level-1 table and the list of valid level-2 patterns while the tables are built, then the score-table row of the
+ * PSM (38.1 KB + 8 B per retained peak for a 30-mer: four workgroups per CU up to 358 retained peaks) */
+__host__ __device__ static inline size_t score_big_resd_bytes(uint32_t pos_cap) { return (((size_t)pos_cap + 1) * 8 + 15) & ~(size_t)15; }
+static inline size_t score_big_tail_bytes(uint32_t pos_cap) {
+    const size_t build = 2 * 64 * sizeof(PrefixCompact) + 1024 * sizeof(uint16_t), row = (size_t)PYA_NTOP * (2 * pos_cap + 1) * 4;
+    return (build > row ? build : row) + 64;
+}
 static inline size_t score_big_lds_bytes(uint32_t cap, uint32_t pos_cap) {
-    return PYA_GRID_CELLS * 2 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8 + 2 * 64 * sizeof(PrefixCompact) +
-           2 * 1024 * sizeof(PrefixCompact) + 16 * sizeof(uint4) + BIG_WAVES * 16 +
-           (size_t)PYA_NTOP * (2 * pos_cap + 1) * 4 + 64;             /* + the score-table row of the PSM */
+    return PYA_GRID_CELLS * 2 + score_big_resd_bytes(pos_cap) + ((size_t)cap + PYA_TABLE_PAD) * 8 +
+           2 * 1024 * sizeof(PrefixCompact) + 16 * sizeof(uint4) + BIG_WAVES * 16 + score_big_tail_bytes(pos_cap);
 }
 
 /* a table entry's counts: the CUMULATIVE counts of depths 0..7 in lo, 8..9 in hi, a byte each (they add without
@@ -184,7 +191,7 @@ DEV uint32_t wg_spine_front(const BigSortLds &s, int N, uint32_t kmax, bool *out
 }
 
 __host__ __device__ static inline uint32_t pya_big_inline_max_dev() {
-    const size_t dead = 2 * 64 * sizeof(PrefixCompact) + 2 * 1024 * sizeof(PrefixCompact) + 16 * sizeof(uint4);
+    const size_t dead = 2 * 1024 * sizeof(PrefixCompact) + 16 * sizeof(uint4);     /* level-2 table | count table */
     const size_t n = (dead - BIG_INLINE_AUX) / 10;
     return (uint32_t)(n < 4096 ? n : 4096);                  /* (chunk masks and counts: 64 chunks of 64 positions) */
 }
@@ -198,21 +205,22 @@ struct BigLoc {
 };
 
 /* one PSM, one workgroup (uniform control flow: it contains workgroup barriers) */
-DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, const BigLoc &loc) {
+DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t pos_cap, const BigLoc &loc) {
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const int tid = (int)threadIdx.x;
     const DevConfig *cfg = b.cfg;
 
     uint16_t *grid = (uint16_t *)lds_raw;                        /* [PYA_GRID_CELLS] */
-    float2 *resd = (float2 *)(lds_raw + PYA_GRID_CELLS * 2);     /* [64] */
-    PeakEntry *t_e = (PeakEntry *)(lds_raw + PYA_GRID_CELLS * 2 + 64 * 8);
-    unsigned char *tail = lds_raw + PYA_GRID_CELLS * 2 + 64 * 8 + ((size_t)cap + PYA_TABLE_PAD) * 8;
-    PrefixCompact *l1 = (PrefixCompact *)tail;                   /* [2][64]   */
-    PrefixCompact *l2 = l1 + 2 * 64;                             /* [2][1024] indexed by the 10-site pattern */
+    float2 *resd = (float2 *)(lds_raw + PYA_GRID_CELLS * 2);     /* [pos_cap + 1] */
+    PeakEntry *t_e = (PeakEntry *)(lds_raw + PYA_GRID_CELLS * 2 + score_big_resd_bytes(pos_cap));
+    unsigned char *tail = (unsigned char *)t_e + ((size_t)cap + PYA_TABLE_PAD) * 8;
+    PrefixCompact *l2 = (PrefixCompact *)tail;                   /* [2][1024] indexed by the 10-site pattern */
     uint4 *cum_lut = (uint4 *)(l2 + 2 * 1024);                   /* [16] rank -> increments of the cumulative counts */
     uint32_t *tops = (uint32_t *)(cum_lut + 16);                 /* [BIG_WAVES][4] */
-    float *lutl = (float *)(tops + BIG_WAVES * 4);               /* [10][nfrag + 1] */
+    float *lutl = (float *)(tops + BIG_WAVES * 4);               /* [10][nfrag + 1], once the tables are built; until then: */
+    PrefixCompact *l1 = (PrefixCompact *)lutl;                   /* [2][64]   */
+    uint16_t *vlist = (uint16_t *)(l1 + 2 * 64);                 /* [1024] the level-2 patterns a signature can have */
 
     if (b.status[psm] != PYA_ST_OK) return;                      /* (uniform over the workgroup) */
     const uint32_t N = b.n_sig[psm];
@@ -289,11 +297,10 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
      * enough sites left for the rest), resumed from level 1.  Which patterns those are depends on their number of
      * modified sites only (638 of the 1024 for 5 of 15): they are listed first -- in the LDS the score-table row
      * will take afterwards -- so that the wavefronts walk full rounds of them, not rounds with a third of the lanes
-     * idle.  (No room for the list -- short peptides: the patterns in their natural order, as before.) ---- */
-    uint16_t *vlist = (uint16_t *)lutl;
-    const bool listed = (size_t)PYA_NTOP * (2 * (size_t)(L - 1) + 1) * 4 >= 1024 * sizeof(uint16_t);
+     * idle. ---- */
+    const bool listed = true;
     uint32_t nv = 1024u;
-    if (listed) {
+    {
         uint32_t before = 0;                                     /* valid patterns below this thread's, round by round */
         for (int r = 0; r < 1024 / BIG_T; r++) {
             const uint32_t c = (uint32_t)(r * BIG_T + tid);
@@ -443,7 +450,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     if (n_max == 1 && !(b.debug & 1024u)) return;                /* a unique best PepScore: nothing to resolve */
     /* a tie for the best PepScore: the front of std::sort decides (cpp/Ascore.cpp:141-146) */
     BigSortLds srt;
-    srt.key = (float *)l1;                                       /* l1 | l2 | cum_lut: nothing reads them any more */
+    srt.key = (float *)l2;                                       /* l2 | cum_lut: nothing reads them any more */
     srt.idx = (uint16_t *)(srt.key + N);
     srt.lq = srt.idx + N;
     srt.rq = srt.lq + N;
@@ -472,21 +479,21 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
 }
 
 __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchDev b, const uint32_t *psm_ids, uint32_t n_ids,
-                                                                       uint32_t cap, BigLoc loc) {
+                                                                       uint32_t cap, uint32_t pos_cap, BigLoc loc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
-    big_body(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, loc);
+    big_body(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, pos_cap, loc);
 }
 
 /* the PSMs the in-kernel localisation declined, scored again with count records for the general localize body:
  * a small grid strides over the list */
 __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_list_kernel(BatchDev b, const uint32_t *count, const uint32_t *ids,
-                                                                            uint32_t cap) {
+                                                                            uint32_t cap, uint32_t pos_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t n = *count;
     BigLoc loc = {};
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        big_body(b, ids[k], lds_raw, cap, loc);
+        big_body(b, ids[k], lds_raw, cap, pos_cap, loc);
         __syncthreads();
     }
 }
@@ -503,7 +510,7 @@ extern "C" int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, ui
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_score_big_kernel);
     if (e != hipSuccess) return (int)e;
     BigLoc loc = {inline_on};
-    hipLaunchKernelGGL(pya_score_big_kernel, dim3(n_ids), dim3(64 * BIG_WAVES), lds, stream, *b, d_ids, n_ids, cap, loc);
+    hipLaunchKernelGGL(pya_score_big_kernel, dim3(n_ids), dim3(64 * BIG_WAVES), lds, stream, *b, d_ids, n_ids, cap, pos_cap, loc);
     return (int)hipGetLastError();
 }
 
@@ -514,6 +521,6 @@ extern "C" int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_co
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_score_big_list_kernel);
     if (e != hipSuccess) return (int)e;
     const uint32_t grid = n_max < 2048u ? n_max : 2048u;
-    hipLaunchKernelGGL(pya_score_big_list_kernel, dim3(grid), dim3(64 * BIG_WAVES), lds, stream, *b, d_count, d_ids, cap);
+    hipLaunchKernelGGL(pya_score_big_list_kernel, dim3(grid), dim3(64 * BIG_WAVES), lds, stream, *b, d_count, d_ids, cap, pos_cap);
     return (int)hipGetLastError();
 }
