@@ -708,6 +708,35 @@ def test_timing_events_of_runs_enqueued_back_to_back():
     plan.close()
 
 
+def test_hand_over_counts_between_the_runs_of_a_plan(monkeypatch):
+    """A plan's runs alternate between two sets of hand-over counters, and the binning kernel of a run zeroes the set
+    of the next (host_plan.cpp, bin_spectra.hip) -- no memset in between.  Ten runs of one plan whose every spectrum
+    goes to the exact binning kernel (equal intensities everywhere) and whose every PSM is handed over by the fused
+    kernel (PYA_DEBUG=512) must give the same, right results every time: counters that were not zeroed would grow
+    past their lists."""
+    import torch
+    from pyascore_amd.device import DevicePlan, unpack_summary
+    batch, settings = synth.make_batch("cfg2", n_psm=1500, seed=91)
+    batch = dict(batch, intensity=np.round(batch["intensity"] / 50.0) * 50.0 + 50.0)      # count-like: ties in every window
+    monkeypatch.setenv("PYA_DEBUG", "512")
+    monkeypatch.setenv("PYA_NO_TINY", "1")
+    gpu = _gpu(settings)
+    want = _checker(settings).score_batch(batch, int(batch["n_of_mod"].max()))
+    dev = torch.device("cuda", 0)
+    mz, it = torch.from_numpy(batch["mz"]).to(dev), torch.from_numpy(batch["intensity"]).to(dev)
+    plan = DevicePlan(gpu, batch)
+    for run in range(10):
+        plan.run(mz, it)
+        if run in (0, 1, 2, 9):
+            got = unpack_summary(plan.packed_summary().cpu().numpy(), plan.max_k)
+            plan.check()
+            for key in ("n_sig", "best_sig", "best_score", "ascores", "alt_mask"):
+                assert np.array_equal(got[key], want[key]), (run, key)
+    plan.close()
+    monkeypatch.delenv("PYA_DEBUG", raising=False)
+    gpu.reload_env()
+
+
 def test_one_psm_stage_clocks():
     """pya_one_times: per-stage averages of the pya_score_one calls since it was last asked, on the host and inside
     the kernel (diagnostics behind scripts/one_probe.py)."""
