@@ -1,0 +1,89 @@
+"""The bench line the round commits (profiles/*_bench_cfg2.json, written by bench.py on the GPU box) keeps the driver's
+contract and is consistent with itself and with the counters it names -- checked on the CPU, so that a hand-edited or
+stale record fails here: every contract key; value = PSMs / step time; roofline.achieved = algorithmic bytes of the
+workload (recomputed from the synthetic batch) / the dominant kernel family's duration; frac = achieved /
+peak; traffic = the named profile's own counters for that kernel; the CPU baseline's fields."""
+import csv
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _newest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        pytest.skip("no committed bench record")
+    return files[-1]
+
+
+@pytest.fixture(scope="module")
+def line():
+    with open(_newest("*_bench_cfg2.json")) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_contract_keys_and_types(line):
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[key], typ), key
+    assert "vs_baseline" in line and line["vs_baseline"] is None          # BASELINE.md has no number for this metric
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert line["unit"] == "PSMs/s" and "synthetic" in line["data"]
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["config"]["workload"].startswith("cfg2")
+    r = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    c = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "PSMs/s"
+
+
+def test_value_and_roofline_follow_from_the_measured_times(line):
+    from pyascore_amd import synth
+    import bench
+    psms = line["config"]["psms_total"]
+    assert line["value"] == pytest.approx(psms / (line["ms_per_step"] * 1e-3), rel=1e-6)
+    blocks = line["blocks"]["ms_per_step"]
+    assert len(blocks) >= 5 and sorted(blocks)[len(blocks) // 2] == pytest.approx(line["ms_per_step"], rel=1e-9)
+    r = line["roofline"]
+    kern = r["kernel_ms"]
+    dom = max(kern, key=kern.get)
+    assert r["kernel"] == dom
+    assert sum(kern.values()) <= line["ms_per_step"] * 1.001               # the families are inside the step
+    # the algorithmic bytes of the workload, from the same seeded generator bench.py uses
+    desc = synth.describe("cfg2", seed=1000)
+    batch = synth.make_slice(desc)
+    assert batch["n_psm"] == psms
+    alg = bench.algorithmic_bytes(batch, int(np.max(batch["n_of_mod"])))
+    assert r["algorithmic_bytes_per_launch"] == alg
+    assert r["achieved"] == pytest.approx(alg / (kern[dom] * 1e-3) / 1e9, rel=1e-9)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-12)
+    assert 0.0 < r["frac"] < 1.0 and r["achieved"] < r["peak"]
+
+
+def test_traffic_is_the_named_profiles_counter(line):
+    r = line["roofline"]
+    src = r.get("traffic_source")
+    if not src:
+        pytest.skip("the record names no counters")
+    path = os.path.join(ROOT, src)
+    assert os.path.exists(path), "the record names counters that are not committed: %s" % src
+    fetch = write = 0.0
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["kernel"].strip('"').startswith(r["kernel"]):
+                v = float(row.get("per_step") or row["mean_value"])
+                fetch += v if row["counter"] == "FETCH_SIZE" else 0.0
+                write += v if row["counter"] == "WRITE_SIZE" else 0.0
+    assert r["traffic"] == pytest.approx((2.0 * fetch + write) * 1024.0, rel=1e-6)
+    # wasted re-reads would show here first: the whole path moves less than twice its algorithmic bytes on cfg2
+    assert r["traffic_over_algorithmic"] < 2.0
