@@ -432,12 +432,12 @@ DEV int bin_fast(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t c
         const float mzf = s_mzf[ic];
         const uint32_t *src = ckey + lo;
         uint32_t c0 = 0, c1 = 0;
-        const uint32_t tc = per_chunk ? (((uint32_t)__builtin_amdgcn_readfirstlane((int)cmax[base >> 6]) + 7u) & ~7u) : trips;
+        const uint32_t tc = per_chunk ? (((uint32_t)__builtin_amdgcn_readfirstlane((int)cmax[base >> 6]) + 3u) & ~3u) : trips;
         if (!(b.debug & 32))
-#pragma unroll 1
-        for (uint32_t t = 0; t < tc; t += 8) {
+#pragma unroll 2
+        for (uint32_t t = 0; t < tc; t += 4) {                /* (trips is a multiple of 8, a chunk's own count of 4) */
 #pragma unroll
-            for (uint32_t q = 0; q < 8; q += 2) {
+            for (uint32_t q = 0; q < 4; q += 2) {
                 const uint32_t o0 = src[t + q], o1 = src[t + q + 1];
                 c0 += (me - o0) >> 31;                       /* keys are below 2^31: the sign says "more intense" */
                 c1 += (me - o1) >> 31;
