@@ -100,13 +100,19 @@ def profiled_counters(cfg, kern_ms, names, default_size):
                 per_kernel.setdefault(row["kernel"], {})[row["counter"]] = float(row.get("per_step") or row["mean_value"])
     except OSError:
         return None, None
-    # the profiled run's own kernel durations (rocprofv3 --kernel-trace --stats of the same command: scripts/profile.sh
-    # runs 10 steps + 2 warm-up steps)
+    # the profiled run's own kernel durations per step (rocprofv3 --kernel-trace --stats of the same command); the
+    # number of steps that run made is written next to it by scripts/profile.sh (records older than that file: 10 + 2)
+    stats_steps = 12.0
+    try:
+        with open(os.path.join(dirs[-1], "profile_steps.json")) as f:
+            stats_steps = float(json.load(f)["stats_steps"])
+    except (OSError, KeyError, ValueError):
+        pass
     prof_ns = {}
     try:
         with open(os.path.join(dirs[-1], "kernel_stats.csv"), newline="") as f:
             for row in csv.DictReader(f):
-                prof_ns[row["Name"].split("(")[0].replace("void ", "").strip()] = float(row["TotalDurationNs"]) / 12.0
+                prof_ns[row["Name"].split("(")[0].replace("void ", "").strip()] = float(row["TotalDurationNs"]) / stats_steps
     except (OSError, KeyError, ValueError):
         prof_ns = {}
     cost, cost_default = valu_costs()
@@ -264,6 +270,158 @@ def cpu_baseline(batch, settings, target_seconds=12.0):
             "efficiency": rate_all / (len(slices) * rate1)}
 
 
+def timed_blocks(torch, dist, dev, pipe, plan, steps, n_blocks):
+    """`n_blocks` timed blocks of EXACTLY `steps` steps, each between barrier + synchronize on both sides, the steps
+    enqueued back to back.  Per block: (wall seconds = the slowest rank's, own wall seconds, mean HIP-event ms of the
+    four kernel families per step, seconds spent waiting for gathers).  `dist` is None without a process group."""
+    blocks = []
+    for _ in range(max(1, n_blocks)):
+        pipe.reset_stats()
+        k_ms = np.zeros(4)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        plan.timings_sum()                                 # (forget the events of the warm-up / the block before)
+        n_ev = 0
+        t0 = time.perf_counter()
+        for s_i in range(steps):
+            pipe.step()                                    # enqueued back to back: nothing waits for a step here
+            if (s_i + 1) % 96 == 0:                        # (the library keeps the events of 128 runs)
+                ms_, n_ = plan.timings_sum()
+                k_ms += np.asarray(ms_); n_ev += n_
+        pipe.drain()                                       # every gather of the timed steps has landed
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        ms_, n_ = plan.timings_sum()                       # HIP events on the launch stream, read after the block
+        k_ms += np.asarray(ms_); n_ev += n_
+        assert n_ev == steps, (n_ev, steps)
+        if dist is not None:                               # (the slowest rank's time, the same on every rank)
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_own, el = el, float(t.item())
+        else:
+            el_own = el
+        blocks.append((el, el_own, k_ms / max(steps, 1), pipe.gather_wait_s))
+    return blocks
+
+
+FAMILY_NAMES = ["pya_bin_spectra_kernel", "pya_score_signatures_kernel", "pya_score_localize_kernel", "pya_localize_kernel"]
+
+
+def other_config_leg(torch, dev, local_rank, cfg, steps, warmup, n_blocks):
+    """One of BASELINE's other single-GPU workloads at its full size, timed exactly like the headline (spectra resident,
+    plan pre-built, `n_blocks` blocks of `steps` steps, the median block): value, ms per step, the kernel families'
+    HIP-event times, the dominant family and its algorithmic GB/s against the HBM peak.  cfg3 is quoted on 8 GPUs:
+    its per-GPU share (125 000 PSMs) is what one GPU scores here."""
+    from pyascore_amd import PyAscore, shard, synth
+    from pyascore_amd.device import DevicePlan
+    n = synth.CONFIGS[cfg]["n_psm"] // (8 if cfg == "cfg3" else 1)
+    t_gen = time.perf_counter()
+    desc = synth.describe(cfg, n_psm=n, seed=1000)
+    batch = synth.make_slice(desc, 0, n)
+    t_gen = time.perf_counter() - t_gen
+    st = desc["settings"]
+    scorer = PyAscore(st["bin_size"], st["n_top"], st["mod_group"], st["mod_mass"], st["mz_error"], st["fragment_types"],
+                      device=local_rank)
+    for g, m in st["neutral_losses"]:
+        scorer.add_neutral_loss(g, m)
+    d_mz = torch.from_numpy(batch["mz"]).to(dev)
+    d_int = torch.from_numpy(batch["intensity"]).to(dev)
+    plan = DevicePlan(scorer, batch, timing=True)
+    pipe = shard.StepPipeline(lambda: plan.run(d_mz, d_int), None, n, n, shard.record_width(plan.max_k), dev, enabled=False)
+    for _ in range(warmup):
+        pipe.step()
+    plan.check()
+    blocks = timed_blocks(torch, None, dev, pipe, plan, steps, n_blocks)
+    plan.check()
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    elapsed, _, kern_ms, _ = blocks[order[len(order) // 2]]
+    dom = int(np.argmax(kern_ms))
+    alg = algorithmic_bytes(batch, plan.max_k)
+    achieved = alg / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
+    out = {"workload": "%s: %d PSMs on 1 GPU" % (cfg, n), "value": n * steps / elapsed, "unit": "PSMs/s",
+           "ms_per_step": 1e3 * elapsed / max(steps, 1), "steps": steps, "warmup": warmup,
+           "blocks_ms_per_step": [1e3 * b[0] / max(steps, 1) for b in blocks],
+           "kernel_ms": {k: float(m) for k, m in zip(FAMILY_NAMES, kern_ms)}, "kernel": FAMILY_NAMES[dom],
+           "algorithmic_bytes_per_launch": alg, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+           "signatures_total": plan.total_signatures, "mz_error": st["mz_error"], "fragment_types": st["fragment_types"],
+           "max_fragment_charge": int(batch["max_charge"].max()), "neutral_losses": st["neutral_losses"],
+           "generate_s": t_gen}
+    plan.close()
+    del plan, d_mz, d_int, scorer
+    torch.cuda.empty_cache()
+    return out
+
+
+def self_launch(n, argv):
+    """Starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv>` as a child process
+    on a free port of 127.0.0.1 and returns its exit code (stdout and stderr are inherited: rank 0's JSON line is
+    the only thing on stdout)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_dry_run(args, rank, world):
+    """PYA_BENCH_BACKEND=gloo: NO scoring and NO measurement -- the launch, the rendezvous, the job's partition, the
+    step loop's gathers (shard.StepPipeline over gloo, CPU tensors filled with the rank's PSM indices instead of
+    results) and the shape of the line, so that the N > 1 plumbing can be run where there is no GPU
+    (tests/test_bench_launch.py).  `value` is null and `data` says so: nothing here is a number."""
+    import torch
+    import torch.distributed as dist
+    from pyascore_amd import shard, synth
+    n_per_gpu = args.psms or 1000
+    total = world * n_per_gpu if args.scaling == "weak" else (args.total or world * n_per_gpu)
+    desc = synth.describe(args.config, n_psm=total, seed=1000)
+    weights = shard.work_estimate_shapes(desc["n_sites"], desc["n_mod"], desc["L"], desc["max_charge"],
+                                         n_types=len(desc["settings"]["fragment_types"]))
+    ranges = shard.partition(weights, world)
+    lo, hi = ranges[rank]
+    job_max_k = max(1, int(desc["n_mod"].max()))
+    width = shard.record_width(job_max_k)
+    longest = max(h - l for l, h in ranges)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    sys.stdout.flush()
+    real_stdout = os.dup(1)                                 # (the backend's banners go to stderr: one line on stdout)
+    os.dup2(2, 1)
+    dist.init_process_group(os.environ["PYA_BENCH_BACKEND"], rank=rank, world_size=world)
+    ids = torch.arange(lo, hi, dtype=torch.int32).unsqueeze(1).expand(hi - lo, width)
+    pipe = shard.StepPipeline(lambda: None, lambda out: out.copy_(ids), hi - lo, longest, width, torch.device("cpu"))
+    for _ in range(args.warmup + args.steps):
+        pipe.step()
+    pipe.drain()
+    dist.barrier()
+    ok = None
+    if rank == 0:
+        got = pipe.gathered(ranges)
+        ok = bool(got.shape == (total, width) and torch.equal(got[:, 0], torch.arange(total, dtype=torch.int32)))
+        os.write(real_stdout, (json.dumps({"metric": METRIC, "value": None, "unit": "PSMs/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
+                          "vs_baseline": None, "dtype": "none", "data": "DRY RUN of the launcher and the gather: nothing scored",
+                          "config": {"workload": "%s: %d PSMs over %d rank(s)" % (args.config, total, world),
+                                     "shard_sizes": [h - l for l, h in ranges]},
+                          "multi_gpu": {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                                        "gathered_in_input_order": ok, "steps_gathered": pipe.steps}}) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
+    return 0 if ok in (None, True) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,15 +439,26 @@ def main():
                     help="timed blocks of --steps steps each (every block bracketed by barrier + synchronize); the line "
                          "reports the MEDIAN block, and every block's ms per step beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default cfg2 run only: leave out the short timed legs of BASELINE's other configs "
+                         "(`other_configs` in the line)")
+    ap.add_argument("--other-blocks", type=int, default=2, help="timed blocks per config of `other_configs`")
     ap.add_argument("--no-host-api", action="store_true",
                     help="skip the host-array legs (profiling runs: only the timed device-resident steps launch kernels)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as written: this process becomes the launcher.  The ranks are CHILDREN
+        # (one per GPU under torch.distributed.run), started before anything here touched the GPU; their one
+        # JSON line passes through this process's stdout and their exit code is this one's.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if os.environ.get("PYA_BENCH_BACKEND", "nccl") != "nccl":
+        return launcher_dry_run(args, rank, world)
 
     # ---- CPU only up to the marked line: the job, this rank's shard, and the CPU baseline's worker
     # processes all come before the first call that initialises the GPU ----
@@ -366,36 +535,7 @@ def main():
     # A timed block = EXACTLY --steps steps between barrier + synchronize on both sides.  One block of a 0.6 ms step is
     # 30 ms of wall time, which a clock ramp or a noisy neighbour can move by 10 %: several blocks are timed, the
     # median one is the line's value, all of them are listed.
-    blocks = []
-    for _ in range(max(1, args.blocks)):
-        pipe.reset_stats()
-        k_ms = np.zeros(4)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        plan.timings_sum()                                 # (forget the events of the warm-up / the block before)
-        n_ev = 0
-        t0 = time.perf_counter()
-        for s_i in range(args.steps):
-            pipe.step()                                    # enqueued back to back: nothing waits for a step here
-            if (s_i + 1) % 96 == 0:                        # (the library keeps the events of 128 runs)
-                ms_, n_ = plan.timings_sum()
-                k_ms += np.asarray(ms_); n_ev += n_
-        pipe.drain()                                       # every gather of the timed steps has landed
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        el = time.perf_counter() - t0
-        ms_, n_ = plan.timings_sum()                       # HIP events on the launch stream, read after the block
-        k_ms += np.asarray(ms_); n_ev += n_
-        assert n_ev == args.steps, (n_ev, args.steps)
-        if use_dist:                                       # (the slowest rank's time, the same on every rank)
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el_own, el = el, float(t.item())
-        else:
-            el_own = el
-        blocks.append((el, el_own, k_ms / max(args.steps, 1), pipe.gather_wait_s))
+    blocks = timed_blocks(torch, dist if use_dist else None, dev, pipe, plan, args.steps, args.blocks)
     plan.check()
     order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
     elapsed, elapsed_own, kern_ms, gather_wait_s = blocks[order[len(order) // 2]]
@@ -412,7 +552,7 @@ def main():
         per_rank = [[float(x) for x in r.tolist()] for r in allr]
 
     if rank == 0:
-        names = ["pya_bin_spectra_kernel", "pya_score_signatures_kernel", "pya_score_localize_kernel", "pya_localize_kernel"]
+        names = FAMILY_NAMES
         dom = int(np.argmax(kern_ms))
         alg = algorithmic_bytes(batch, plan.max_k)
         achieved = alg / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
@@ -500,6 +640,16 @@ def main():
                                          "sum of the work estimate the partition balanced"}
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if world == 1 and default_size and args.config == "cfg2" and not args.no_other_configs:
+            # BASELINE's other workloads on this GPU in the same run, so that the driver's record carries every config
+            # (short legs: a step of the slowest is 14 ms).  The headline fields above are cfg2's and only cfg2's.
+            others = {}
+            for cfg in ("cfg3", "cfg4", "cfg5"):
+                try:
+                    others[cfg] = other_config_leg(torch, dev, local_rank, cfg, args.steps, args.warmup, args.other_blocks)
+                except Exception as e:                       # (never lose the headline line to an extra)
+                    others[cfg] = {"error": "%s: %s" % (type(e).__name__, e)}
+            line["other_configs"] = others
         if real_stdout is not None:
             os.write(real_stdout, (json.dumps(line) + "\n").encode())
         else:

@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 for c in ${1:-cfg2}; do
   for rep in 1 2; do
     for lib in ${AB_LIBS:-libbase.so libpyascore_hip.so}; do
-      PYA_LIB=$PWD/pyascore_amd/$lib python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > /tmp/ab.json
+      PYA_LIB=$PWD/pyascore_amd/$lib python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs 2>&1 | tail -1 > /tmp/ab.json
       python - <<PY
 import json
 d = json.load(open("/tmp/ab.json"))

@@ -7,7 +7,7 @@ CFGS=${1:-cfg2}
 shift
 timeout 1200 python -m pytest tests -m gpu -x -q "$@" 2>&1 > gpurun_out/gpu_tests.log; grep -E "passed|failed|error" gpurun_out/gpu_tests.log | tail -5
 for c in $CFGS; do
-  timeout 600 python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_$c.json
+  timeout 600 python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs 2>&1 | tail -1 > gpurun_out/bench_$c.json
   python - <<PY
 import json
 d = json.load(open("gpurun_out/bench_$c.json"))

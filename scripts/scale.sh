@@ -10,10 +10,6 @@ cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 CFG=${1:-cfg2}; MODE=${2:-weak}; NS=${3:-"1 2 4 8"}; shift; shift; shift
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 for N in $NS; do
-  if [ "$N" = "1" ]; then
-    python3 bench.py --gpus 1 --config $CFG --scaling $MODE --no-cpu-baseline "$@" | tail -1
-  else
-    python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
-      bench.py --gpus $N --config $CFG --scaling $MODE --no-cpu-baseline "$@" | tail -1
-  fi
+  # bench.py launches its own ranks for N > 1 (one child process per GPU under torch.distributed.run)
+  python3 bench.py --gpus $N --config $CFG --scaling $MODE --no-cpu-baseline --no-other-configs "$@" | tail -1
 done

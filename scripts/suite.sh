@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 TAG=${1:-r04x}; CFGS=${2:-"cfg2"}
 timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_tests.log 2>&1; grep -E "passed|failed|error" gpurun_out/${TAG}_gpu_tests.log | tail -3; grep -E "^(FAILED|ERROR)|Error|assert" gpurun_out/${TAG}_gpu_tests.log | head -20
 for c in $CFGS; do
-  timeout 900 python bench.py --config $c --no-cpu-baseline 2>gpurun_out/${TAG}_bench_$c.err | tail -1 > gpurun_out/${TAG}_bench_$c.json
+  timeout 900 python bench.py --config $c --no-cpu-baseline --no-other-configs 2>gpurun_out/${TAG}_bench_$c.err | tail -1 > gpurun_out/${TAG}_bench_$c.json
   python - <<PY
 import json
 d = json.load(open("gpurun_out/${TAG}_bench_$c.json"))
