@@ -439,6 +439,9 @@ def main():
                     help="timed blocks of --steps steps each (every block bracketed by barrier + synchronize); the line "
                          "reports the MEDIAN block, and every block's ms per step beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B experiments: a debug switch of the scorer (include/pyascore_debug.h), e.g. --debug PYA_NO_FUSED=1; "
+                         "the line then carries `debug_switches` and is not the headline")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1, default cfg2 run only: leave out the short timed legs of BASELINE's other configs "
                          "(`other_configs` in the line)")
@@ -514,6 +517,8 @@ def main():
                       settings["mz_error"], settings["fragment_types"], device=local_rank)
     for g, m in settings["neutral_losses"]:
         scorer.add_neutral_loss(g, m)
+    for kv in args.debug:
+        scorer.set_debug(*kv.split("=", 1))
 
     d_mz = torch.from_numpy(batch["mz"]).to(dev)
     d_int = torch.from_numpy(batch["intensity"]).to(dev)
@@ -587,7 +592,7 @@ def main():
                             "with planning, kernels and result copies); pcie_only = the same bytes copied up "
                             "and back with nothing else"}
         copy_gbs = achievable_hbm_gbs(torch, dev)
-        default_size = args.psms is None and args.max_charge is None and args.scaling == "weak"
+        default_size = args.psms is None and args.max_charge is None and args.scaling == "weak" and not args.debug
         counters, fams = profiled_counters(args.config, kern_ms, names, default_size)
         dom_c = (fams or {}).get(names[dom], {})
         traffic_path = counters["whole_path_traffic"] if counters else None
@@ -638,6 +643,8 @@ def main():
                                  "note": "per rank: mean HIP-event ms of each kernel family per step, ms per step spent "
                                          "waiting for the previous step's gather, own wall ms per step, shard size, "
                                          "sum of the work estimate the partition balanced"}
+        if args.debug:
+            line["debug_switches"] = list(args.debug)
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if world == 1 and default_size and args.config == "cfg2" and not args.no_other_configs:

@@ -138,8 +138,10 @@ int pya_score_one(pya_handle *h, const double *mz, const double *intensity, uint
                   const float *aux_mass, uint64_t n_aux, uint32_t flags, const pya_results *out);
 int pya_rescore_last_keep(pya_handle *h);
 
-/* Re-reads the PYA_* environment switches (routes, diagnostics) into the handle.  They are read once in
- * pya_create; this is the hook the tests use to flip a route on a live handle.  No reference counterpart. */
+/* The environment reaches a handle through four variables, read once in pya_create: PYA_WORKSPACE_MB and
+ * PYA_CHUNK_MB (sizes of pya_score_batch's device budget and chunks), PYA_HOST_TIMING and PYA_STAMPS (diagnostics that
+ * change no result and no route).  This re-reads them and puts every debug switch (include/pyascore_debug.h) back to
+ * its production default.  No reference counterpart. */
 int pya_reload_env(pya_handle *h);
 /* diagnostics: average microseconds per pya_score_one call since the last call of this function, by stage (checks
  * and tables, spectrum into the pinned block, launch, wait for the kernel, results out); us[5] = calls averaged;
@@ -198,6 +200,11 @@ int pya_get_pep_scores_range(pya_handle *h, uint64_t psm_begin, uint64_t psm_end
                              int64_t *rec_off, uint64_t *sig_bits, int32_t *counts /* cap x n_top */,
                              float *scores /* cap x n_top */, float *weighted_score,
                              int32_t *total_fragments);
+/* PyAscore.calculate_ambiguity (Ascore.pyx:208-230 -> Ascore::calculateAmbiguity, cpp/Ascore.cpp:157-210) for PSM `psm`
+ * of the retained batch: the caller's two score containers as (signature bits over the modifiable residues, n_top depth
+ * scores, weighted score).  Any PSM the library scores: peptides of up to 64 residues with ten depths and a spectrum of
+ * up to PYA_FAST_PEAKS peaks on the fast kernel, everything else (long peptides, n_top 11..16, big spectra) on the
+ * general kernel's Ascore code. */
 int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits,
                             const float *ref_scores, float ref_weighted, uint64_t other_bits,
                             const float *other_scores, float other_weighted, float *out);

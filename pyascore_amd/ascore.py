@@ -148,10 +148,20 @@ class PyAscore:
             self._raise(rc)
 
     def reload_env(self):
-        """Re-reads the PYA_* environment switches (kernel routes, diagnostics).  The library reads them once,
-        when the scorer is created; tests that flip a route on a live scorer call this afterwards."""
+        """Re-reads the four environment variables the library knows (PYA_WORKSPACE_MB, PYA_CHUNK_MB, PYA_HOST_TIMING,
+        PYA_STAMPS: sizes and diagnostics, read once when the scorer is created) and puts every debug switch back to
+        its production default."""
         self._ensure_kept()
         rc = self._lib.pya_reload_env(self._h)
+        if rc:
+            self._raise(rc)
+
+    def set_debug(self, key, value=None):
+        """TEST-ONLY (include/pyascore_debug.h): one debug switch of this scorer -- force a kernel route, make a kernel
+        decline its work, resize a table.  ``value=None`` restores the production default.  Nothing in the
+        environment selects a route; the parity suite sets the switches through this call."""
+        self._ensure_kept()
+        rc = self._lib.pya_set_debug(self._h, key.encode("ascii"), None if value is None else str(value).encode("ascii"))
         if rc:
             self._raise(rc)
 
@@ -542,8 +552,8 @@ class PyAscore:
         from_sig = lambda s: sum(1 << j for j, v in enumerate(s) if int(v))  # noqa: E731
         rs = np.ascontiguousarray(ref_score["scores"], np.float32)
         os_ = np.ascontiguousarray(other_score["scores"], np.float32)
-        if rs.size != 10 or os_.size != 10:
-            raise ValueError("score containers must hold 10 depth scores")
+        if rs.size != self._n_top or os_.size != self._n_top:
+            raise ValueError("score containers must hold %d depth scores (n_top)" % self._n_top)
         out = C.c_float()
         rc = self._lib.pya_calculate_ambiguity(
             self._h, 0, from_sig(ref_score["signature"]), _as_ptr(rs), float(ref_score["weighted_score"]),

@@ -159,6 +159,136 @@ DEV void gen_rank_sort(const float *in, float *out, int n) {
     }
 }
 
+/* residues, fixed modifications, neutral-loss classes, the list of modifiable residues (ModifiedPeptide.cpp:24-79);
+ * zeroes the per-site work areas.  Returns the number of modifiable residues. */
+DEV int gen_setup_residues(const BatchDev &b, const DevConfig *cfg, const GenLds &g, uint32_t psm, int64_t pep0, int L) {
+    const int lane = lane_id();
+    for (int i = lane; i < L; i += 64) {
+        const uint32_t li = ((uint32_t)b.pep[pep0 + i] - 'A') & 31u;
+        const float m0 = cfg->res_mass[li];
+        const bool modifiable = cfg->res_modifiable[li] || (cfg->allow_n && i == 0) || (cfg->allow_c && i == L - 1);
+        g.m0[i] = m0;
+        g.m1[i] = m0 + cfg->mod_mass;
+        g.nl0[i] = cfg->nl_upper[li];
+        g.nl1[i] = modifiable ? cfg->nl_lower[li] : 0;
+        g.sor[i] = modifiable ? 0 : 255;
+    }
+    for (int i = lane; i < 256; i += 64) g.present[i] = cfg->present[i];
+    if (lane < PYA_MAX_UNIQ) g.uniq[lane] = cfg->uniq[lane];
+    if (lane < GEN_MAX_SITES) {
+        g.site_max[lane] = 0;
+        g.site_tie[lane] = 0;
+        g.site_alt[lane] = 0ull;
+        g.site_asc[lane] = __builtin_huge_valf();
+    }
+    if (lane < 16) g.misc[lane] = 0;
+    gen_sync();
+    if (lane == 0) {
+        for (int64_t a = b.aux_off[psm]; a < b.aux_off[psm + 1]; a++) {       /* fixed modifications, in their order */
+            const uint32_t pos = b.aux_pos[a];
+            const float am = b.aux_mass[a];
+            const int idx = pos > 0 ? (int)pos - 1 : 0;
+            if (idx < L) {
+                const uint32_t li = ((uint32_t)b.pep[pep0 + idx] - 'A') & 31u;
+                g.m0[idx] += am;
+                g.m1[idx] += am;
+                if (cfg->nl_lower[li]) g.nl0[idx] = cfg->nl_lower[li];
+            }
+        }
+        int j = 0;
+        for (int i = 0; i < L; i++)
+            if (g.sor[i] != 255) {
+                if (j < GEN_MAX_SITES) g.site_pos[j] = (uint8_t)i;
+                g.sor[i] = (uint8_t)j;
+                j++;
+            }
+        g.misc[0] = (uint32_t)j;
+    }
+    gen_sync();
+    return (int)g.misc[0];
+}
+
+/* Ascore of `ref` against `oth` at `depth` (Ascore.cpp:177-209): per ion type both fragment lists, sorted, the greedy
+ * walk for the site-determining ions (ModifiedPeptide.cpp:259-320), their matches of rank <= depth, the two binomial
+ * scores from the table.  The value is lane 0's; returns non-zero (wave-uniform) when a list or a trial count is
+ * beyond what the launch / the score table was sized for. */
+DEV int gen_ascore_pair(const BatchDev &b, const DevConfig *cfg, const GenLds &g, uint64_t ref_bits, uint64_t oth_bits, int depth,
+                        int L, int zmax, uint32_t lc, uint32_t list_cap, const PeakEntry *tab, int R, float *asc_out) {
+    const int lane = lane_id();
+    const float err = cfg->mz_error;
+    const bool half_check = err > 0.49f;
+    const int T = cfg->n_types, n_fwd = cfg->n_fwd;
+    const uint64_t types64 = load_types64(cfg);
+    int fail = 0;
+    uint32_t tr0 = 0, tr1 = 0, c0 = 0, c1 = 0;              /* (lane 0 keeps the tallies) */
+    int tables_dir = -1;
+    uint32_t npairs_a = 0, npairs_b = 0;
+    for (int t = 0; t < T; t++) {
+        const int dir = t < n_fwd ? 0 : 1;
+        if (dir != tables_dir) {
+            gen_sync();
+            uint32_t n = 0;
+            if (lane < 2) n = gen_prefix_table(g, cfg, lane ? oth_bits : ref_bits, L, dir, lane, lc);
+            npairs_a = (uint32_t)__shfl((int)n, 0, 64);
+            npairs_b = (uint32_t)__shfl((int)n, 1, 64);
+            tables_dir = dir;
+            gen_sync();
+        }
+        const int na = (int)npairs_a * zmax, nb = (int)npairs_b * zmax;
+        if ((uint32_t)na > list_cap || (uint32_t)nb > list_cap) {
+            fail = 1;                                       /* (the host sized list_cap for the longest list: not reached) */
+            break;
+        }
+        double A, B;
+        type_constants(type_at(types64, t), &A, &B);
+        gen_fill_list(g, cfg, L, zmax, 0, lc, A, B, g.la);
+        gen_fill_list(g, cfg, L, zmax, 1, lc, A, B, g.lb);
+        gen_sync();
+        gen_rank_sort(g.la, g.sa, na);
+        gen_rank_sort(g.lb, g.sb, nb);
+        gen_sync();
+        for (int i = lane; i < na; i += 64) g.ha[i] = gen_match_rank(tab, R, g.sa[i], err, half_check) <= depth ? 1 : 0;
+        for (int i = lane; i < nb; i += 64) g.hb[i] = gen_match_rank(tab, R, g.sb[i], err, half_check) <= depth ? 1 : 0;
+        gen_sync();
+        if (lane == 0) {                                    /* the greedy walk (ModifiedPeptide.cpp:291-316) */
+            int ia = 0, ib = 0;
+            while (ia < na || ib < nb) {
+                if (ib == nb) {
+                    tr0++;
+                    c0 += g.ha[ia++];
+                } else if (ia == na) {
+                    tr1++;
+                    c1 += g.hb[ib++];
+                } else {
+                    const float xa = g.sa[ia], xb = g.sb[ib];
+                    if (__builtin_fabsf(xa - xb) < err) {
+                        ia++;
+                        ib++;
+                    } else if (xa < xb) {
+                        tr0++;
+                        c0 += g.ha[ia++];
+                    } else {
+                        tr1++;
+                        c1 += g.hb[ib++];
+                    }
+                }
+            }
+        }
+        gen_sync();
+    }
+    if (lane == 0 && !fail) {
+        if (tr0 > b.lut_n_max || tr1 > b.lut_n_max) {
+            fail = 1;
+        } else {
+            const float sc0 = b.lut[b.lut_off[tr0] + (uint32_t)depth * (tr0 + 1) + c0];
+            const float sc1 = b.lut[b.lut_off[tr1] + (uint32_t)depth * (tr1 + 1) + c1];
+            *asc_out = sc0 - sc1;
+        }
+    }
+    gen_sync();
+    return __any(fail) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const uint32_t *ids, uint32_t n_ids, unsigned char *scratch,
                                                               uint64_t scratch_stride, uint32_t n_cap, uint32_t push_cap,
                                                               uint32_t l_cap, uint32_t list_cap) {
@@ -204,51 +334,7 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
     const int ntop = cfg->n_top;                               /* 10..PYA_NTOP_MAX */
     const uint32_t rec_words = (uint32_t)(ntop + 1) / 2u + 1u;    /* count record: ntop 16-bit counts + the fragment total (host_internal.h: rec_words) */
 
-    /* ---- residues (ModifiedPeptide.cpp:24-79) ---- */
-    for (int i = lane; i < L; i += 64) {
-        const uint32_t li = ((uint32_t)b.pep[pep0 + i] - 'A') & 31u;
-        const float m0 = cfg->res_mass[li];
-        const bool modifiable = cfg->res_modifiable[li] || (cfg->allow_n && i == 0) || (cfg->allow_c && i == L - 1);
-        g.m0[i] = m0;
-        g.m1[i] = m0 + cfg->mod_mass;
-        g.nl0[i] = cfg->nl_upper[li];
-        g.nl1[i] = modifiable ? cfg->nl_lower[li] : 0;
-        g.sor[i] = modifiable ? 0 : 255;
-    }
-    for (int i = lane; i < 256; i += 64) g.present[i] = cfg->present[i];
-    if (lane < PYA_MAX_UNIQ) g.uniq[lane] = cfg->uniq[lane];
-    if (lane < GEN_MAX_SITES) {
-        g.site_max[lane] = 0;
-        g.site_tie[lane] = 0;
-        g.site_alt[lane] = 0ull;
-        g.site_asc[lane] = __builtin_huge_valf();
-    }
-    if (lane < 16) g.misc[lane] = 0;
-    gen_sync();
-    int n_sites = 0;
-    if (lane == 0) {
-        for (int64_t a = b.aux_off[psm]; a < b.aux_off[psm + 1]; a++) {       /* fixed modifications, in their order */
-            const uint32_t pos = b.aux_pos[a];
-            const float am = b.aux_mass[a];
-            const int idx = pos > 0 ? (int)pos - 1 : 0;
-            if (idx < L) {
-                const uint32_t li = ((uint32_t)b.pep[pep0 + idx] - 'A') & 31u;
-                g.m0[idx] += am;
-                g.m1[idx] += am;
-                if (cfg->nl_lower[li]) g.nl0[idx] = cfg->nl_lower[li];
-            }
-        }
-        int j = 0;
-        for (int i = 0; i < L; i++)
-            if (g.sor[i] != 255) {
-                if (j < GEN_MAX_SITES) g.site_pos[j] = (uint8_t)i;
-                g.sor[i] = (uint8_t)j;
-                j++;
-            }
-        g.misc[0] = (uint32_t)j;
-    }
-    gen_sync();
-    n_sites = (int)g.misc[0];
+    const int n_sites = gen_setup_residues(b, cfg, g, psm, pep0, L);
 
     /* ---- counts and PepScores, one site assignment per lane and trip (Ascore.cpp:53-139) ---- */
     int fail = 0;
@@ -450,72 +536,9 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
                 }
             }
         }
-        uint32_t tr0 = 0, tr1 = 0, c0 = 0, c1 = 0;              /* (lane 0 keeps the tallies) */
-        int tables_dir = -1;
-        uint32_t npairs_a = 0, npairs_b = 0;
-        for (int t = 0; t < T; t++) {
-            const int dir = t < n_fwd ? 0 : 1;
-            if (dir != tables_dir) {
-                gen_sync();
-                uint32_t n = 0;
-                if (lane < 2) n = gen_prefix_table(g, cfg, lane ? pe.bits : best_bits, L, dir, lane, lc);
-                npairs_a = (uint32_t)__shfl((int)n, 0, 64);
-                npairs_b = (uint32_t)__shfl((int)n, 1, 64);
-                tables_dir = dir;
-                gen_sync();
-            }
-            const int na = (int)npairs_a * zmax, nb = (int)npairs_b * zmax;
-            if ((uint32_t)na > list_cap || (uint32_t)nb > list_cap) {
-                fail = 1;                                       /* (the host sized list_cap for the longest list: not reached) */
-                break;
-            }
-            double A, B;
-            type_constants(type_at(types64, t), &A, &B);
-            gen_fill_list(g, cfg, L, zmax, 0, lc, A, B, g.la);
-            gen_fill_list(g, cfg, L, zmax, 1, lc, A, B, g.lb);
-            gen_sync();
-            gen_rank_sort(g.la, g.sa, na);
-            gen_rank_sort(g.lb, g.sb, nb);
-            gen_sync();
-            for (int i = lane; i < na; i += 64) g.ha[i] = gen_match_rank(tab, R, g.sa[i], err, half_check) <= depth ? 1 : 0;
-            for (int i = lane; i < nb; i += 64) g.hb[i] = gen_match_rank(tab, R, g.sb[i], err, half_check) <= depth ? 1 : 0;
-            gen_sync();
-            if (lane == 0) {                                    /* the greedy walk (ModifiedPeptide.cpp:291-316) */
-                int ia = 0, ib = 0;
-                while (ia < na || ib < nb) {
-                    if (ib == nb) {
-                        tr0++;
-                        c0 += g.ha[ia++];
-                    } else if (ia == na) {
-                        tr1++;
-                        c1 += g.hb[ib++];
-                    } else {
-                        const float xa = g.sa[ia], xb = g.sb[ib];
-                        if (__builtin_fabsf(xa - xb) < err) {
-                            ia++;
-                            ib++;
-                        } else if (xa < xb) {
-                            tr0++;
-                            c0 += g.ha[ia++];
-                        } else {
-                            tr1++;
-                            c1 += g.hb[ib++];
-                        }
-                    }
-                }
-            }
-            gen_sync();
-        }
-        if (lane == 0 && !fail) {
-            if (tr0 > b.lut_n_max || tr1 > b.lut_n_max) {
-                fail = 1;
-            } else {
-                const float sc0 = b.lut[b.lut_off[tr0] + (uint32_t)depth * (tr0 + 1) + c0];
-                const float sc1 = b.lut[b.lut_off[tr1] + (uint32_t)depth * (tr1 + 1) + c1];
-                const float asc = sc0 - sc1;
-                g.site_asc[a] = asc < g.site_asc[a] ? asc : g.site_asc[a];
-            }
-        }
+        float asc = 0.f;
+        if (gen_ascore_pair(b, cfg, g, best_bits, pe.bits, depth, L, zmax, lc, list_cap, tab, R, &asc)) fail = 1;
+        else if (lane == 0) g.site_asc[a] = asc < g.site_asc[a] ? asc : g.site_asc[a];
         gen_sync();
     }
     if (lane < k && lane < GEN_MAX_SITES) {
@@ -535,6 +558,49 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
     }
 }
 
+/* PyAscore.calculate_ambiguity (Ascore.pyx:208-230, Ascore.cpp:157-210) for PSM `psm` of a retained batch with the
+ * caller's two score containers, without the fast kernels' limits: any peptide the general kernel takes, n_top up to
+ * PYA_NTOP_MAX (`scores` = n_scores depth scores of the reference container, then n_scores of the other), a retained
+ * table of any size (looked up where it lies in the workspace).  out[0] = the value, out[1] != 0: a list or a trial
+ * count beyond the launch / the score table. */
+__global__ __launch_bounds__(64) void pya_general_ambiguity_kernel(BatchDev b, uint32_t psm, uint32_t l_cap, uint32_t list_cap,
+                                                                    uint64_t ref_bits, uint64_t oth_bits, const float *scores,
+                                                                    uint32_t n_scores, float ref_ws, float oth_ws, float *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const DevConfig *cfg = b.cfg;
+    const GenLds g = gen_carve(lds_raw, l_cap, list_cap);
+    const uint32_t lc = (l_cap + 3u) & ~3u;
+    if ((double)__builtin_fabsf(ref_ws - oth_ws) < 1e-6) {          /* Ascore.cpp:159-161 */
+        if (lane == 0) {
+            out[0] = 0.f;
+            out[1] = 0.f;
+        }
+        return;
+    }
+    const int64_t pep0 = b.pep_off[psm];
+    const int L = (int)(b.pep_off[psm + 1] - pep0);
+    (void)gen_setup_residues(b, cfg, g, psm, pep0, L);
+    int depth = 0;
+    {
+        float bestd = 0.f;                                          /* Ascore.cpp:164-172 */
+        for (int d = 0; d < (int)n_scores; d++) {
+            const float diff = scores[d] - scores[n_scores + d];
+            if (diff > bestd) {
+                bestd = diff;
+                depth = d;
+            }
+        }
+    }
+    float asc = 0.f;
+    const int fail = gen_ascore_pair(b, cfg, g, ref_bits, oth_bits, depth, L, b.max_charge[psm], lc, list_cap,
+                                     b.ret + b.ret_off[psm], (int)b.ret_n[psm], &asc);
+    if (lane == 0) {
+        out[0] = asc;
+        out[1] = fail ? 1.f : 0.f;
+    }
+}
+
 extern "C" size_t pya_general_lds_bytes(uint32_t l_cap, uint32_t list_cap) { return gen_lds_bytes(l_cap, list_cap); }
 extern "C" size_t pya_general_scratch_bytes(uint32_t n_cap, uint32_t push_cap) {
     return ((sort_global_bytes(n_cap) + 15) & ~(size_t)15) + (size_t)push_cap * sizeof(PushedEntry) + 64;
@@ -549,5 +615,16 @@ extern "C" int pya_launch_general(const BatchDev *b, const uint32_t *d_ids, uint
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_general_psm_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, d_scratch, scratch_stride,
                        n_cap, push_cap, l_cap, list_cap);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pya_launch_general_ambiguity(const BatchDev *b, uint32_t psm, uint32_t l_cap, uint32_t list_cap, uint64_t ref_bits,
+                                            uint64_t oth_bits, const float *d_scores, uint32_t n_scores, float ref_ws, float oth_ws,
+                                            float *d_out, hipStream_t stream) {
+    const size_t lds = gen_lds_bytes(l_cap, list_cap);
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_general_ambiguity_kernel);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pya_general_ambiguity_kernel, dim3(1), dim3(64), lds, stream, *b, psm, l_cap, list_cap, ref_bits, oth_bits,
+                       d_scores, n_scores, ref_ws, oth_ws, d_out);
     return (int)hipGetLastError();
 }

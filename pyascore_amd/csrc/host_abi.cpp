@@ -1,6 +1,7 @@
 /* host_abi.cpp -- the C ABI of include/pyascore_hip.h that is not a plan, a batch call or the one-PSM path: handles, settings,
  * strings, retained records, ambiguity. */
 #include "host_internal.h"
+#include "../../include/pyascore_debug.h"
 
 extern "C" {
 
@@ -67,6 +68,13 @@ void pya_destroy(pya_handle *h) {
 int pya_reload_env(pya_handle *h) {
     if (!h) return PYA_ERR_ARG;
     read_knobs(h->kn);
+    h->one.have_last = false;        /* (a replay of the last pya_score_one PSM would run under other switches) */
+    return PYA_OK;
+}
+
+int pya_set_debug(pya_handle *h, const char *key, const char *value) {
+    if (!h || !key) return PYA_ERR_ARG;
+    if (!set_knob(h->kn, key, value)) return h->fail(PYA_ERR_ARG, -1, "pya_set_debug: \"%s\" is not a debug switch", key);
     h->one.have_last = false;        /* (a replay of the last pya_score_one PSM would run under other switches) */
     return PYA_OK;
 }
@@ -286,20 +294,31 @@ int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits, cons
     if (psm >= p->n_psm) return h->fail(PYA_ERR_ARG, -1, "PSM index out of range");
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t L = p->pep_off[psm + 1] - p->pep_off[psm];
-    if (L > PYA_FAST_PEPTIDE_LEN || h->n_top != PYA_NTOP)
-        return h->fail(PYA_ERR_LIMIT, (int64_t)psm, "calculate_ambiguity takes peptides of up to %d residues and n_top = %d (everything "
-                       "else is scored by the general kernel only: the Ascores are in the results)", PYA_FAST_PEPTIDE_LEN, PYA_NTOP);
-    const uint32_t list_cap = next_pow2(std::max<uint32_t>(1, (uint32_t)(L - 1) * (uint32_t)p->max_charge[psm] *
-                                                                  (uint32_t)h->cfg.n_uniq));
-    float host_scores[2 * PYA_NTOP];
-    std::memcpy(host_scores, ref_scores, PYA_NTOP * sizeof(float));
-    std::memcpy(host_scores + PYA_NTOP, other_scores, PYA_NTOP * sizeof(float));
+    const int64_t P = p->peak_off[psm + 1] - p->peak_off[psm];
+    const uint32_t NT = h->n_top;                                  /* depth scores per container (Ascore.pyx:196-201) */
+    const uint32_t per_type = (uint32_t)std::max<int64_t>(L - 1, 1) * (uint32_t)p->max_charge[psm] * (uint32_t)h->cfg.n_uniq;
+    std::vector<float> host_scores(2 * (size_t)NT);
+    std::memcpy(host_scores.data(), ref_scores, NT * sizeof(float));
+    std::memcpy(host_scores.data() + NT, other_scores, NT * sizeof(float));
     DevBuf<float> d_scores, d_out;
     refresh_shared(p);
-    HIPCHK(h, d_scores.upload(host_scores, 2 * PYA_NTOP));
+    HIPCHK(h, d_scores.upload(host_scores.data(), host_scores.size()));
     HIPCHK(h, d_out.alloc(2));
-    int e = pya_launch_ambiguity(&p->dev, (uint32_t)psm, p->peak_cap, list_cap, ref_bits, other_bits, d_scores.p,
+    int e;
+    /* The fast kernel stages the PSM's retained table in LDS sized by the plan's peak_cap, which covers the spectra of
+     * up to PYA_FAST_PEAKS peaks only; it takes peptides of up to 64 residues and ten depths.  Everything else -- a long
+     * peptide, n_top 11..16, a spectrum binned by the global kernel -- goes through the general kernel's own Ascore
+     * code (general_psm.hip), which reads the retained table where it lies. */
+    if (L > PYA_FAST_PEPTIDE_LEN || NT != PYA_NTOP || P > PYA_FAST_PEAKS || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) {
+        if (pya_general_lds_bytes((uint32_t)L, per_type) > kMaxLds)
+            return h->fail(PYA_ERR_LIMIT, (int64_t)psm, "calculate_ambiguity: %u fragments per ion type exceed the general kernel's room", per_type);
+        e = pya_launch_general_ambiguity(&p->dev, (uint32_t)psm, (uint32_t)L, per_type, ref_bits, other_bits, d_scores.p, NT,
+                                         ref_ws, other_ws, d_out.p, nullptr);
+    } else {
+        const uint32_t list_cap = next_pow2(std::max<uint32_t>(1, per_type));
+        e = pya_launch_ambiguity(&p->dev, (uint32_t)psm, p->peak_cap, list_cap, ref_bits, other_bits, d_scores.p,
                                  ref_ws, other_ws, d_out.p, nullptr);
+    }
     if (e) return h->hip_fail((hipError_t)e, "ambiguity launch");
     float res[2];
     HIPCHK(h, hipMemcpy(res, d_out.p, sizeof res, hipMemcpyDeviceToHost));

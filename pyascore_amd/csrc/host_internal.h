@@ -97,6 +97,9 @@ size_t pya_general_lds_bytes(uint32_t l_cap, uint32_t list_cap);
 size_t pya_general_scratch_bytes(uint32_t n_cap, uint32_t push_cap);
 int pya_launch_general(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch, uint64_t scratch_stride,
                        uint32_t n_cap, uint32_t push_cap, uint32_t l_cap, uint32_t list_cap, hipStream_t stream);
+int pya_launch_general_ambiguity(const BatchDev *b, uint32_t psm, uint32_t l_cap, uint32_t list_cap, uint64_t ref_bits,
+                                 uint64_t oth_bits, const float *d_scores, uint32_t n_scores, float ref_ws, float oth_ws,
+                                 float *d_out, hipStream_t stream);
 int pya_launch_localize_redo(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max,
                              uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
                              uint32_t gtp, hipStream_t stream);
@@ -199,10 +202,10 @@ inline float std_residue_mass(char c) {                       /* Types.h:7-30 */
 }
 
 
-/* The PYA_* environment switches (route selection for the tests, diagnostics, A/B experiments).  They are
- * read ONCE per handle, in pya_create -- a variable set in a user's shell afterwards changes nothing, and no
- * call pays for getenv -- and again only when pya_reload_env asks for it (the tests flip routes on a live
- * handle that way).  Defaults are the production behaviour. */
+/* Debug switches (route selection for the tests, diagnostics, A/B experiments): per handle, set through
+ * pya_set_debug (include/pyascore_debug.h) -- NOT from the environment, which reaches the library through four
+ * variables only (host_tables.cpp:read_env: PYA_WORKSPACE_MB, PYA_CHUNK_MB, PYA_HOST_TIMING, PYA_STAMPS; read in
+ * pya_create, re-read by pya_reload_env).  Defaults are the production behaviour. */
 struct Knobs {
     bool no_plain = false, no_fused = false, no_big = false, no_tiny = false, no_prefix = false, no_chunks = false;
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
@@ -211,7 +214,7 @@ struct Knobs {
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64;
     uint32_t sort_room_max = 1024;
-    int sb = -1, gtp = -1;                      /* < 0: the built-in rule */
+    int sb = -1, gtp = -1, hash_pp = -1;        /* < 0: the built-in rule */
     int node_cap = -1;                          /* >= 0: room for that many shared nodes per direction (tests: small values force the walkers) */
     double chunk_mb = 0.;                       /* 0: the default chunk size */
     int64_t workspace_mb = 0;                   /* 0: the default budget */
@@ -219,6 +222,7 @@ struct Knobs {
 extern int g_knob_sb, g_knob_gtp, g_knob_hash_pp;     /* (Bucket has no handle: the two A/B overrides are process-wide) */
 
 void read_knobs(Knobs &k);
+bool set_knob(Knobs &k, const char *key, const char *value);
 
 struct pya_handle {
     Knobs kn;

@@ -3,39 +3,67 @@
 
 int g_knob_sb = -1, g_knob_gtp = -1, g_knob_hash_pp = -1;     /* (Bucket has no handle: the A/B overrides are process-wide) */
 
-void read_knobs(Knobs &k) {
+/* The environment reaches the library through FOUR variables, read once per handle (pya_create) and again only when
+ * pya_reload_env asks: two sizes a deployment may want to set without touching code, two diagnostics that change no
+ * result and no route.  Everything that selects a kernel route or makes a kernel decline work is a DEBUG SWITCH: set
+ * per handle through pya_set_debug (include/pyascore_debug.h, test-only), never by a user's shell. */
+static void read_env(Knobs &k) {
     auto flag = [](const char *n) { return std::getenv(n) != nullptr; };
-    auto num = [](const char *n, int64_t dflt) { const char *v = std::getenv(n); return v ? (int64_t)std::atoll(v) : dflt; };
-    k = Knobs();
-    k.no_plain = flag("PYA_NO_PLAIN");
-    k.no_fused = flag("PYA_NO_FUSED");
-    k.no_big = flag("PYA_NO_BIG");
-    k.no_tiny = flag("PYA_NO_TINY");
-    k.no_prefix = flag("PYA_NO_PREFIX");
-    k.no_chunks = flag("PYA_NO_CHUNKS");
-    k.no_upload_thread = flag("PYA_NO_UPLOAD_THREAD");
-    k.one_peak_class = flag("PYA_ONE_PEAK_CLASS");
-    k.peak_classes = flag("PYA_PEAK_CLASSES");
-    k.one_lds_class = flag("PYA_ONE_LDS_CLASS");
     k.host_timing = flag("PYA_HOST_TIMING");
     k.stamps = flag("PYA_STAMPS");
-    k.sort_room = flag("PYA_SORT_ROOM");
-    k.no_big_inline = flag("PYA_NO_BIG_INLINE");
-    k.no_loc_hash = flag("PYA_NO_LOC_HASH");
-    k.no_nodes = flag("PYA_NO_NODES");
-    k.node_cap = (int)num("PYA_NODE_CAP", -1);
-    if (const char *d = std::getenv("PYA_DEBUG")) k.debug = (uint32_t)std::strtoul(d, nullptr, 0);
-    k.plain_min = num("PYA_PLAIN_MIN", 512);
-    k.big_min_n = num("PYA_BIG_MIN_N", 1024);
-    k.tiny_max = num("PYA_TINY_MAX", 64);
-    k.sort_room_max = (uint32_t)num("PYA_SORT_ROOM_MAX", 1024);
-    k.sb = (int)num("PYA_SB", -1);
-    k.gtp = (int)num("PYA_GTP", -1);
+    k.chunk_mb = 0.;
     if (const char *e = std::getenv("PYA_CHUNK_MB")) k.chunk_mb = std::max(1.0, std::atof(e));
-    k.workspace_mb = num("PYA_WORKSPACE_MB", 0);
+    const char *w = std::getenv("PYA_WORKSPACE_MB");
+    k.workspace_mb = w ? (int64_t)std::atoll(w) : 0;
+}
+
+static void publish_process_wide(const Knobs &k) {
     g_knob_sb = k.sb;
     g_knob_gtp = k.gtp;
-    g_knob_hash_pp = (int)num("PYA_HASH_PP", -1);
+    g_knob_hash_pp = k.hash_pp;
+}
+
+void read_knobs(Knobs &k) {
+    k = Knobs();                 /* every debug switch back to the production default */
+    read_env(k);
+    publish_process_wide(k);
+}
+
+/* One debug switch by name (the names the tests have always used); value == nullptr restores its default.
+ * Returns false for a name that is not a switch. */
+bool set_knob(Knobs &k, const char *key, const char *value) {
+    const Knobs dflt;
+    const std::string name(key ? key : "");
+    const bool on = value != nullptr;
+    auto num = [&](int64_t d) { return on ? (int64_t)std::strtoll(value, nullptr, 0) : d; };
+    struct { const char *n; bool Knobs::*m; } flags[] = {
+        {"PYA_NO_PLAIN", &Knobs::no_plain}, {"PYA_NO_FUSED", &Knobs::no_fused}, {"PYA_NO_BIG", &Knobs::no_big},
+        {"PYA_NO_TINY", &Knobs::no_tiny}, {"PYA_NO_PREFIX", &Knobs::no_prefix}, {"PYA_NO_CHUNKS", &Knobs::no_chunks},
+        {"PYA_NO_UPLOAD_THREAD", &Knobs::no_upload_thread}, {"PYA_ONE_PEAK_CLASS", &Knobs::one_peak_class},
+        {"PYA_PEAK_CLASSES", &Knobs::peak_classes}, {"PYA_ONE_LDS_CLASS", &Knobs::one_lds_class},
+        {"PYA_SORT_ROOM", &Knobs::sort_room}, {"PYA_NO_BIG_INLINE", &Knobs::no_big_inline},
+        {"PYA_NO_LOC_HASH", &Knobs::no_loc_hash}, {"PYA_NO_NODES", &Knobs::no_nodes},
+        {"PYA_HOST_TIMING", &Knobs::host_timing}, {"PYA_STAMPS", &Knobs::stamps},
+    };
+    bool known = false;
+    for (auto &f : flags)
+        if (name == f.n) {
+            k.*(f.m) = on;
+            known = true;
+        }
+    if (name == "PYA_DEBUG") k.debug = (uint32_t)num(0), known = true;
+    else if (name == "PYA_PLAIN_MIN") k.plain_min = num(dflt.plain_min), known = true;
+    else if (name == "PYA_BIG_MIN_N") k.big_min_n = num(dflt.big_min_n), known = true;
+    else if (name == "PYA_TINY_MAX") k.tiny_max = num(dflt.tiny_max), known = true;
+    else if (name == "PYA_SORT_ROOM_MAX") k.sort_room_max = (uint32_t)num(dflt.sort_room_max), known = true;
+    else if (name == "PYA_SB") k.sb = (int)num(-1), known = true;
+    else if (name == "PYA_GTP") k.gtp = (int)num(-1), known = true;
+    else if (name == "PYA_HASH_PP") k.hash_pp = (int)num(-1), known = true;
+    else if (name == "PYA_NODE_CAP") k.node_cap = (int)num(-1), known = true;
+    else if (name == "PYA_CHUNK_MB") k.chunk_mb = on ? std::max(1.0, std::atof(value)) : 0., known = true;
+    else if (name == "PYA_WORKSPACE_MB") k.workspace_mb = num(0), known = true;
+    if (known) publish_process_wide(k);
+    return known;
 }
 
 

@@ -6,6 +6,7 @@ os.environ.setdefault("PYA_NO_TINY", "1")
 os.environ.setdefault("PYA_PLAIN_MIN", "0")
 from oracle import harness, orc
 from pyascore_amd import PyAscore, synth
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import switches; switches.install()   # route switches named in os.environ reach the scorers (tests/switches.py)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 21
 bad_total = 0

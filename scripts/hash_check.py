@@ -11,6 +11,7 @@ os.environ["PYA_NO_PLAIN"] = "1"
 os.environ["PYA_NO_FUSED"] = "1"
 from oracle import harness, orc
 from pyascore_amd import PyAscore, synth
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import switches; switches.install()   # route switches named in os.environ reach the scorers (tests/switches.py)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 31
 cases = [("cfg4", n, {}),

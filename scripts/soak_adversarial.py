@@ -10,6 +10,7 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "t
 import numpy as np
 from oracle import harness, orc
 from pyascore_amd import PyAscore, synth
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import switches; switches.install()   # route switches named in os.environ reach the scorers (tests/switches.py)
 masses = dict(G=57.02146, S=87.03203, T=101.04768, Y=163.06333, N=114.04293, A=71.03711, K=128.09496, R=156.10111)
 peps = ["SGSGTGYGK", "GSGGSGGTK", "NGSGNGTGYR", "AGSTGGYGSGK", "SGGGSAGTGNK", "GGSGGSGGTGGYK", "TGSGNR", "SGTK", "SGSGTGYGKASGTGNGSGTK"]
 bad = 0

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PYA_DEBUG"] = sys.argv[2] if len(sys.argv) > 2 else "0"
 import torch
 from pyascore_amd import PyAscore, synth
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); import switches; switches.install()   # route switches named in os.environ reach the scorers (tests/switches.py)
 from pyascore_amd.device import DevicePlan
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"

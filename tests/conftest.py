@@ -22,6 +22,14 @@ def _build_oracle():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"])
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _debug_switches():
+    """Scorers created by the tests take the route switches the tests name in the environment (tests/switches.py);
+    the library itself reads no route from the environment."""
+    import switches
+    switches.install()
+
+
 def checker_kind():
     """Which CPU checker the parity tests compare the HIP path with.  "ref" = the reference's own
     C++ core (oracle/_ref/libascore_ref.so: built here from /root/reference, prebuilt on the GPU

@@ -9,7 +9,7 @@ import pytest
 
 from conftest import ROOT
 
-HEADERS = [os.path.join(ROOT, "include", "pyascore_hip.h"), os.path.join(ROOT, "include", "pyascore_aux.h")]
+HEADERS = [os.path.join(ROOT, "include", n) for n in ("pyascore_hip.h", "pyascore_aux.h", "pyascore_debug.h")]
 
 
 @pytest.fixture(scope="module")
@@ -37,6 +37,25 @@ def test_header_symbols_are_exported(lib):
     assert not missing, "declared but not exported: %s" % missing
     for n in names:
         assert getattr(lib, n) is not None
+
+
+def test_the_environment_reaches_the_library_through_four_variables():
+    """Route and debug switches are per-handle calls (include/pyascore_debug.h: pya_set_debug); the only getenv
+    calls of the library are the two sizes and the two diagnostics host_tables.cpp:read_env names."""
+    names = set()
+    csrc = os.path.join(ROOT, "pyascore_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".cpp", ".hip", ".h", ".c")):
+            text = open(os.path.join(csrc, f), errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            for m in re.finditer(r"getenv\(\s*(\w+|\"[A-Z_0-9]+\")", text):
+                names.add((f, m.group(1)))
+    assert {f for f, _ in names} <= {"host_tables.cpp"}, names
+    text = open(os.path.join(csrc, "host_tables.cpp")).read()
+    body = text[text.index("static void read_env"): text.index("static void publish_process_wide")]
+    env = set(re.findall(r'"(PYA_[A-Z_]+)"', body))
+    assert env == {"PYA_WORKSPACE_MB", "PYA_CHUNK_MB", "PYA_HOST_TIMING", "PYA_STAMPS"}
+    assert len(re.findall(r"getenv", text)) - len(re.findall(r"getenv", body)) == 0
 
 
 def test_version_string(lib):

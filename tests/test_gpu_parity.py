@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+import switches
+
 from conftest import GOLDEN, golden_cases, checker_kind
 from oracle import harness, orc
 from pyascore_amd import synth
@@ -173,16 +175,16 @@ def test_equal_intensities_follow_nth_element(monkeypatch):
     for name, inten in cases.items():
         tied = dict(batch, intensity=inten)
         monkeypatch.delenv("PYA_DEBUG", raising=False)
-        gpu.reload_env()                                  # (the switches are read once per scorer)
+        switches.from_env(gpu)                                  # (the switches are read once per scorer)
         got = gpu.score_batch(tied)
         want = chk.score_batch(tied, got["ascores"].shape[1])
         for key in want:
             assert np.array_equal(got[key], want[key]), (name, key)
         monkeypatch.setenv("PYA_DEBUG", "128")
-        gpu.reload_env()
+        switches.from_env(gpu)
         forced = gpu.score_batch(tied)
         monkeypatch.delenv("PYA_DEBUG", raising=False)
-        gpu.reload_env()
+        switches.from_env(gpu)
         for key in got:
             assert np.array_equal(got[key], forced[key]), (name, key)
     # peaks out of m/z order AND equal intensities: the windows' input order decides
@@ -199,10 +201,10 @@ def test_equal_intensities_follow_nth_element(monkeypatch):
         assert np.array_equal(got[key], want[key]), ("shuffled", key)
     # no ties at all: the forced route must still agree with the fast one
     monkeypatch.setenv("PYA_DEBUG", "128")
-    gpu.reload_env()
+    switches.from_env(gpu)
     forced = gpu.score_batch(batch)
     monkeypatch.delenv("PYA_DEBUG", raising=False)
-    gpu.reload_env()
+    switches.from_env(gpu)
     plain = gpu.score_batch(batch)
     for key in plain:
         assert np.array_equal(plain[key], forced[key]), key
@@ -242,16 +244,16 @@ def test_binning_keys_and_their_hand_overs(monkeypatch):
 
     def both(b2, name, g=gpu, c=chk):
         monkeypatch.delenv("PYA_DEBUG", raising=False)
-        g.reload_env()
+        switches.from_env(g)
         got = g.score_batch(b2)
         want = c.score_batch(b2, got["ascores"].shape[1])
         for key in want:
             assert np.array_equal(got[key], want[key]), (name, key)
         monkeypatch.setenv("PYA_DEBUG", "128")
-        g.reload_env()
+        switches.from_env(g)
         forced = g.score_batch(b2)
         monkeypatch.delenv("PYA_DEBUG", raising=False)
-        g.reload_env()
+        switches.from_env(g)
         for key in got:
             assert np.array_equal(got[key], forced[key]), (name, "forced", key)
         # the same spectra one PSM per call: PyAscore.score() bins with the four wavefronts of its own kernel
@@ -734,7 +736,7 @@ def test_hand_over_counts_between_the_runs_of_a_plan(monkeypatch):
                 assert np.array_equal(got[key], want[key]), (run, key)
     plan.close()
     monkeypatch.delenv("PYA_DEBUG", raising=False)
-    gpu.reload_env()
+    switches.from_env(gpu)
 
 
 def test_one_psm_stage_clocks():
@@ -865,6 +867,62 @@ def test_general_kernel_many_site_assignments_and_long_lists():
     st = dict(settings, fragment_types="b", mz_error=0.02, neutral_losses=[["sty", 97.9769], ["ST", 18.01528]])
     lists, _ = synth.make_batch("cfg2", n_psm=4, seed=74, L=60, n_sites=5, n_mod=2, max_charge=8)
     _same_psm_by_psm(_gpu(st), _checker(st), lists)
+
+
+def _ambiguity_agrees(gpu, chk, kw, picks=(1, 2, -1)):
+    """calculate_ambiguity of the last scored PSM for a few record pairs, both ways round, against the checker."""
+    gpu.score(**kw)
+    chk.score(**kw)
+    ps, cps = gpu.pep_scores, chk.pep_scores
+    assert len(ps) == len(cps) and len(ps) > 1
+    assert gpu.calculate_ambiguity(ps[0], ps[0]) == 0.0
+    seen = 0
+    for j in picks:
+        j = j % len(ps)
+        if j == 0:
+            continue
+        assert np.array_equal(ps[j]["signature"], cps[j]["signature"])
+        assert gpu.calculate_ambiguity(ps[0], ps[j]) == chk.calculate_ambiguity(cps[0], cps[j]), j
+        assert gpu.calculate_ambiguity(ps[j], ps[0]) == chk.calculate_ambiguity(cps[j], cps[0]), j
+        seen += 1
+    assert seen
+    # the value for the runner-up of a site is that site's Ascore (Ascore.cpp:239-251)
+    assert np.any(np.isclose(gpu.calculate_ambiguity(ps[0], ps[1]), gpu.ascores)) or len(ps) > 2
+
+
+def test_calculate_ambiguity_beyond_the_fast_kernel():
+    """PyAscore.calculate_ambiguity (Ascore.pyx:208-230, cpp/Ascore.cpp:157-210) wherever the reference computes it: after
+    score() of a spectrum of more than 8 192 peaks (its retained table is larger than the LDS the fast kernel is launched
+    with: r04 advisor finding), of a peptide of more than 64 residues, with n_top 11 / 16 (n_top depth scores per
+    container, all of them searched for the depth), and with neutral losses + several charges on a long peptide."""
+    rng = np.random.default_rng(5)
+    small, settings = synth.make_batch("cfg2", n_psm=4, seed=91)
+    gpu, chk = _gpu(settings), _checker(settings)
+    for j, P in enumerate((8193, 20000, 65535)):                       # big spectra
+        kw = synth.unpack_psm(small, j)
+        mz = np.concatenate([kw["mz_arr"], rng.uniform(100.0, 2500.0, P - kw["mz_arr"].size)])
+        it = np.concatenate([kw["int_arr"], rng.lognormal(4.0, 1.0, P - kw["int_arr"].size)])
+        o = np.argsort(mz, kind="stable")
+        _ambiguity_agrees(gpu, chk, dict(kw, mz_arr=mz[o], int_arr=it[o]))
+    _ambiguity_agrees(gpu, chk, synth.unpack_psm(small, 3))          # (an ordinary PSM afterwards: the fast kernel again)
+    for L, n_sites, n_mod, over in ((65, 4, 2, {}), (130, 6, 3, dict(max_charge=2)), (255, 5, 2, {}),
+                                    (70, 4, 2, dict(fragment_types="bycz", max_charge=2, mz_error=0.02,
+                                                    neutral_loss=("sty", 97.9769)))):
+        batch, st = _long_batch(L, n_sites, n_mod, 2, 2000 + L, **over)
+        g2, c2 = _gpu(st), _checker(st)
+        for i in range(batch["n_psm"]):
+            _ambiguity_agrees(g2, c2, synth.unpack_psm(batch, i))
+    for n_top in (11, 16):
+        for cfg in ("cfg2", "cfg4"):
+            batch, st = synth.make_batch(cfg, n_psm=3, seed=950 + n_top)
+            st = dict(st, n_top=n_top)
+            g2, c2 = _gpu(st), _checker(st)
+            for i in range(batch["n_psm"]):
+                _ambiguity_agrees(g2, c2, synth.unpack_psm(batch, i))
+            ps = g2.pep_scores
+            assert ps[0]["scores"].shape == (n_top,)
+            with pytest.raises(ValueError, match="depth scores"):
+                g2.calculate_ambiguity(dict(ps[0], scores=ps[0]["scores"][:10]), ps[1])
 
 
 def test_spectra_of_more_than_8192_peaks():
@@ -1054,18 +1112,18 @@ def test_chunked_calls_equal_one_plan(monkeypatch):
     settings = synth.describe("cfg3", 1, seed=17)["settings"]
     gpu = _gpu(settings)
     monkeypatch.setenv("PYA_NO_CHUNKS", "1")
-    gpu.reload_env()                                   # (the switches are read once per scorer)
+    switches.from_env(gpu)                                   # (the switches are read once per scorer)
     one = gpu.score_batch(batch)
     monkeypatch.delenv("PYA_NO_CHUNKS")
-    gpu.reload_env()
+    switches.from_env(gpu)
     _same(gpu.score_batch(batch), one)                 # default: ~96 MB of spectra per chunk
     gpu.set_workspace_budget(48 << 20)                 # tight budget: dozens of chunks
     _same(gpu.score_batch(batch), one)
     monkeypatch.setenv("PYA_CHUNK_MB", "3")            # ... and ~100 chunks of 3 MB
-    gpu.reload_env()
+    switches.from_env(gpu)
     _same(gpu.score_batch(batch), one)
     monkeypatch.delenv("PYA_CHUNK_MB")
-    gpu.reload_env()
+    switches.from_env(gpu)
     gpu.set_workspace_budget(0)
     with pytest.raises(ValueError):
         gpu.set_workspace_budget(1000)
