@@ -294,7 +294,8 @@ int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits, cons
     if (psm >= p->n_psm) return h->fail(PYA_ERR_ARG, -1, "PSM index out of range");
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t L = p->pep_off[psm + 1] - p->pep_off[psm];
-    const int64_t P = p->peak_off[psm + 1] - p->peak_off[psm];
+    /* (the one-PSM kernel's retained view carries no peak offsets: its spectra are staged in LDS, never big) */
+    const int64_t P = p->peak_off.size() > psm + 1 ? p->peak_off[psm + 1] - p->peak_off[psm] : 0;
     const uint32_t NT = h->n_top;                                  /* depth scores per container (Ascore.pyx:196-201) */
     const uint32_t per_type = (uint32_t)std::max<int64_t>(L - 1, 1) * (uint32_t)p->max_charge[psm] * (uint32_t)h->cfg.n_uniq;
     std::vector<float> host_scores(2 * (size_t)NT);
