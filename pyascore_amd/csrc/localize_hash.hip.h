@@ -102,7 +102,9 @@ DEV void lh_insert(const HashLds &h, int cell, int id, int hshift) {
     for (;;) {
         uint32_t *wp = h.tab + (s >> 1);
         const uint32_t sh = (s & 1u) * 16u;
-        const uint32_t old = *(volatile uint32_t *)wp;
+        /* (an atomic load, not a volatile one: a volatile access through this pointer is compiled as a FLAT load with
+         * system scope, which also waits for every global load in flight) */
+        const uint32_t old = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         if ((old >> sh) & 0xffffu) {
             s = (s + 1u) & hmask;
             continue;
@@ -464,6 +466,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
             if (lh_build_lists(c, h, S, d, tau, nn)) return true;
             lists_dir = d;
             wave_lds_sync();
+            STAMP_T(*c.b, 60, false);
         }
         double A, B;
         type_constants(type_at(types64, t), &A, &B);
@@ -503,6 +506,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                 }
             }
             wave_lds_sync();
+            STAMP_T(*c.b, 61, false);
             for (int i = lane; i < nW + nB; i += 64) lh_insert(h, lh_cell(h.val[i], inv_cw), i, hshift);
             wave_lds_sync();
             STAMP_T(*c.b, 31, false);
