@@ -117,8 +117,9 @@ struct BatchDev {
      * 4096 the list-based general localize instantiation replays a task with a doubly partnered ion serially
      * instead of walking its clusters in parallel, 8192 the hash route of the general localize declines every
      * PSM (hand-over list, list-based kernel), 16384 it sends every in-span ion through the exact run walk,
-     * 256 score_signatures walks every signature under general settings (no shared tree nodes), 0x8000 the
-     * packed fused kernel passes every slot on.  Ablation: 2 the hash route looks no surviving ion up.
+     * 256 score_signatures walks every signature under general settings (no shared tree nodes), 0x8000 no
+     * count-node table (walk_core.hip.h: every walker looks every fragment up itself), 0x40000000 every node of that
+     * table marked (the table is read, then every walker looks up itself).  Ablation: 2 the hash route looks no surviving ion up.
      * Bits 16..31: truncation point of the diagnostic build (device_common.hip.h, STAMP_T). */
     uint32_t debug;
     unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */

@@ -71,8 +71,8 @@ int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uin
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
 int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream);
-size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap);
-int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap,
+size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap, uint32_t kc);
+int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap, uint32_t kc,
                          uint32_t inline_on, hipStream_t stream);
 size_t pya_localize_recount_lds_bytes(uint32_t cap, uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc, uint32_t hs,
@@ -83,7 +83,7 @@ int pya_launch_localize_hash(const BatchDev *b, const uint32_t *d_ids, uint32_t 
 int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t push_cap,
                                 uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
 int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max, uint32_t cap,
-                              uint32_t pos_cap, hipStream_t stream);
+                              uint32_t pos_cap, uint32_t kc, hipStream_t stream);
 uint32_t pya_big_inline_max(void);
 size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap,
                            uint32_t both, uint32_t multi_z);
@@ -460,7 +460,12 @@ struct pya_plan {
     size_t bigbin_stride = 0;
     std::vector<uint8_t> big;           /* [n_psm] scored by score_big.hip (thousands of site assignments, plain settings) */
     DevBuf<uint32_t> d_big_ids;
-    uint32_t big_pos_cap = 1;
+    uint32_t big_pos_cap = 1, big_k_max = 1;
+    uint32_t big_kc() const {            /* row length of score_big's count-node table: a power of two >= 8, > the most modifications */
+        uint32_t v = 8u;
+        while (v < big_k_max + 1u) v <<= 1;
+        return v;
+    }
     /* score_big's own localisation (summary mode, plain settings, C(n,k) <= pya_big_inline_max()): those PSMs are
      * in no localize list; `bigloc` carries the lean localize body's caps for them, d_redo5 the ones it declines */
     bool big_inline = false;

@@ -316,6 +316,7 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
             if (big_on && z == 1 && N > big_min_n && ns >= 11) { /* (its second level shares ten sites: at least eleven) */
                 p->big[i] = 1;
                 p->big_pos_cap = std::max(p->big_pos_cap, (uint32_t)(L - 1));
+                p->big_k_max = std::max(p->big_k_max, (uint32_t)k);
                 inl = big_inline_ok && N <= big_inline_max;
             }
             Bucket &bk = to_fused ? p->fusedb : (inl ? p->bigloc : p->buckets[bi]);
@@ -860,7 +861,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "score_signatures launch");
     }
     for (const pya_plan::IdList &l : p->big_lists) {
-        e = pya_launch_score_big(&d, p->d_big_ids.p + l.off, l.n, l.cap, p->big_pos_cap, p->big_inline ? 1u : 0u, st);
+        e = pya_launch_score_big(&d, p->d_big_ids.p + l.off, l.n, l.cap, p->big_pos_cap, p->big_kc(), p->big_inline ? 1u : 0u, st);
         if (e) return h->hip_fail((hipError_t)e, "score_big launch");
     }
     {
@@ -890,7 +891,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         e = pya_launch_localize_recount(&d, bl.d_ids.p, (uint32_t)bl.ids.size(), 0u, bl.push_cap(), bl.pos_cap, bl.pool_cap(),
                                         bl.sb(), bl.gtp(), cnt + 2, p->d_redo5.p + 64, st);
         if (e) return h->hip_fail((hipError_t)e, "localize (recount) launch");
-        e = pya_launch_score_big_list(&d, cnt + 2, p->d_redo5.p + 64, p->n_big_inline, p->peak_cap, p->big_pos_cap, st);
+        e = pya_launch_score_big_list(&d, cnt + 2, p->d_redo5.p + 64, p->n_big_inline, p->peak_cap, p->big_pos_cap, p->big_kc(), st);
         if (e) return h->hip_fail((hipError_t)e, "score_big (hand-over) launch");
         e = pya_launch_localize_redo(&d, cnt + 2, p->d_redo5.p + 64, p->n_big_inline, bl.push_cap(), (uint32_t)pya_big_inline_max(),
                                      bl.pos_cap, bl.pool_cap(), bl.sb(), bl.gtp(), st);

@@ -49,9 +49,12 @@ static inline size_t score_big_tail_bytes(uint32_t pos_cap) {
     const size_t build = 2 * 64 * sizeof(PrefixCompact) + 1024 * sizeof(uint16_t), row = (size_t)PYA_NTOP * (2 * pos_cap + 1) * 4;
     return (build > row ? build : row) + 64;
 }
-static inline size_t score_big_lds_bytes(uint32_t cap, uint32_t pos_cap) {
+/* the count-node table (walk_core.hip.h): one byte per (direction, step, modified residues so far) */
+__host__ __device__ static inline size_t score_big_cnt_bytes(uint32_t pos_cap, uint32_t kc) { return ((size_t)2 * pos_cap * kc + 15) & ~(size_t)15; }
+static inline size_t score_big_lds_bytes(uint32_t cap, uint32_t pos_cap, uint32_t kc) {
     return PYA_GRID_CELLS * 2 + score_big_resd_bytes(pos_cap) + ((size_t)cap + PYA_TABLE_PAD) * 8 +
-           2 * 1024 * sizeof(PrefixCompact) + 16 * sizeof(uint4) + BIG_WAVES * 16 + score_big_tail_bytes(pos_cap);
+           2 * 1024 * sizeof(PrefixCompact) + 16 * sizeof(uint4) + BIG_WAVES * 16 + score_big_cnt_bytes(pos_cap, kc) +
+           score_big_tail_bytes(pos_cap);
 }
 
 /* a table entry's counts: the CUMULATIVE counts of depths 0..7 in lo, 8..9 in hi, a byte each (they add without
@@ -205,7 +208,7 @@ struct BigLoc {
 };
 
 /* one PSM, one workgroup (uniform control flow: it contains workgroup barriers) */
-DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t pos_cap, const BigLoc &loc) {
+DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t pos_cap, uint32_t kc, const BigLoc &loc) {
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const int tid = (int)threadIdx.x;
@@ -218,7 +221,8 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     PrefixCompact *l2 = (PrefixCompact *)tail;                   /* [2][1024] indexed by the 10-site pattern */
     uint4 *cum_lut = (uint4 *)(l2 + 2 * 1024);                   /* [16] rank -> increments of the cumulative counts */
     uint32_t *tops = (uint32_t *)(cum_lut + 16);                 /* [BIG_WAVES][4] */
-    float *lutl = (float *)(tops + BIG_WAVES * 4);               /* [10][nfrag + 1], once the tables are built; until then: */
+    uint8_t *cnt_t = (uint8_t *)(tops + BIG_WAVES * 4);          /* [2][pos_cap][kc] the count-node table */
+    float *lutl = (float *)(cnt_t + score_big_cnt_bytes(pos_cap, kc));   /* [10][nfrag + 1], once the tables are built; until then: */
     PrefixCompact *l1 = (PrefixCompact *)lutl;                   /* [2][64]   */
     uint16_t *vlist = (uint16_t *)(l1 + 2 * 64);                 /* [1024] the level-2 patterns a signature can have */
 
@@ -258,6 +262,49 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     __syncthreads();
     if (wave == 0) ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)grid)[lane];
 
+    /* ---- the count-node table (walk_core.hip.h): one lookup per (direction, step, modified residues so far) ----
+     * The representative of (d, s, j) is the chain with the FIRST j modifiable residues of direction d modified: one chain
+     * per (d, j) gives the nodes of every step (a node it does not reach with j modified -- fewer than j sites in the
+     * fragment -- is reached by no site assignment).  The chains' running sums go through the level-2 table's LDS,
+     * which is not in use yet; then every thread looks up a share of the nodes. */
+    const int k = b.n_of_mod[psm];
+    const int n_sites = __popcll(res.site_mask);
+    const bool use_cnt = !(b.debug & 0x8000u) && (uint32_t)k + 1u <= kc && kc >= 8u;
+    if (use_cnt) {
+        float *rep = (float *)l2;                                /* [2][k + 1][pos_cap] */
+        for (uint32_t i = (uint32_t)tid; i < (uint32_t)score_big_cnt_bytes(pos_cap, kc) / 4u; i += BIG_T) ((uint32_t *)cnt_t)[i] = 0x0f0f0f0fu;
+        if (tid < 2 * (k + 1)) {
+            const int d = tid / (k + 1), j = tid - d * (k + 1);
+            const uint64_t first_j = j >= 64 ? ~0ull : ((1ull << j) - 1ull);
+            const uint64_t pbits = d == 0 ? first_j : (first_j << (n_sites - j));
+            const uint64_t resmask = deposit_sites(pbits, res.site_mask);
+            const uint64_t tmask = d ? (__brevll(resmask) >> (64 - L)) : resmask;
+            float *out = rep + (size_t)(d * (k + 1) + j) * pos_cap;
+            float running = 0.f;
+            for (int step = 0; step + 1 < L; step++) {
+                const float2 mm = resd[d ? L - 1 - step : step];
+                running = (((tmask >> step) & 1ull) ? mm.y : mm.x) + running;
+                out[step] = running;
+            }
+        }
+        __syncthreads();
+        double A0 = 0., B0 = 0., A1 = 0., B1 = 0.;
+        type_constants(cfg->types[0], &A0, &B0);
+        type_constants(cfg->types[cfg->n_fwd], &A1, &B1);
+        const double off0 = A0 - B0, off1 = A1 - B1;
+        const double D = cnt_table_bound(res, k, __builtin_fabs(off0) > __builtin_fabs(off1) ? off0 : off1);
+        const uint32_t per_dir = (uint32_t)(k + 1) * (uint32_t)(L - 1);
+        for (uint32_t i = (uint32_t)tid; i < 2u * per_dir; i += BIG_T) {
+            const uint32_t d = i >= per_dir ? 1u : 0u, r = i - d * per_dir, j = r / (uint32_t)(L - 1), st = r - j * (uint32_t)(L - 1);
+            const float running = rep[(size_t)(d * (uint32_t)(k + 1) + j) * pos_cap + st];
+            const double m = ((double)running + (d ? A1 : A0)) - (d ? B1 : B0);
+            uint32_t ent = cnt_table_entry(tab, (float)(m + 1.007825), D);
+            if (b.debug & 0x40000000u) ent |= CNT_MARK;                  /* (every walker looks every fragment up itself: must agree) */
+            cnt_t[((size_t)d * pos_cap + st) * kc + j] = (uint8_t)ent;
+        }
+        __syncthreads();
+    }
+
     WalkEnv env;
     env.cfg = cfg;
     env.n_nl = 0;
@@ -268,7 +315,6 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     env.cnt = nullptr;                                           /* (no histogram: register counts) */
     env.L = L;
     env.zmax = 1;
-    const int n_sites = __popcll(res.site_mask);
     /* steps [0, stop1) of a direction cover exactly its first 6 sites, [0, stop2) its first 10 */
     int stop1[2], stop2[2];
     stop1[0] = nth_set_bit(res.site_mask, BIG_SITES1);
@@ -279,7 +325,6 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         if (stop1[d] > L - 1) stop1[d] = L - 1;
         if (stop2[d] > L - 1) stop2[d] = L - 1;
     }
-    const int k = b.n_of_mod[psm];
 
     /* ---- level 1: wavefront d walks the 64 patterns of the first 6 sites of direction d ---- */
     if (wave < 2) {
@@ -287,7 +332,9 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         const uint64_t pbits = dir == 0 ? (uint64_t)lane : (__brevll((uint64_t)lane) >> (64 - n_sites));
         float run = 0.f;
         CumCounts cum = {0u, 0u, 0u};
-        walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, 0, stop1[dir], run, cum);
+        uint32_t j = 0;
+        if (use_cnt) walk_cnt_range(env, tab, cum_lut, cnt_t + (size_t)dir * pos_cap * kc, kc, deposit_sites(pbits, res.site_mask), dir, 0, stop1[dir], run, j, cum);
+        else walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, 0, stop1[dir], run, cum);
         l1[dir * 64 + lane] = make_entry(run, cum);
     }
     __syncthreads();
@@ -336,7 +383,9 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         const PrefixCompact par = l1[dir * 64 + (c & 63u)];
         float run = par.running;
         CumCounts cum = entry_counts(par);                       /* (the walk adds to the parent's counts) */
-        walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, stop1[dir], stop2[dir], run, cum);
+        uint32_t j = (uint32_t)__popc(c & 63u);                  /* modified among the first six sites */
+        if (use_cnt) walk_cnt_range(env, tab, cum_lut, cnt_t + ((size_t)dir * pos_cap + (size_t)stop1[dir]) * kc, kc, deposit_sites(pbits, res.site_mask), dir, stop1[dir], stop2[dir], run, j, cum);
+        else walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, stop1[dir], stop2[dir], run, cum);
         if (valid) l2[item] = make_entry(run, cum);
     }
     __syncthreads();
@@ -364,7 +413,13 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         float run0 = p0.running, run1 = p1.running;
         CumCounts cc = entry_counts(p0);                         /* both directions' prefixes, then the rest of the walk */
         cc.add(make_uint4((uint32_t)p1.lo, (uint32_t)(p1.lo >> 32), p1.hi, 0u));
-        walk_cum_both(env, tab, cum_lut, resmask, stop2[0], L - 1, run0, stop2[1], L - 1, run1, cc);
+        if (use_cnt) {
+            const uint32_t rev = (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 1023ull);
+            walk_cnt_both(env, tab, cum_lut, cnt_t, pos_cap, kc, resmask, stop2[0], L - 1, run0, (uint32_t)__popc((uint32_t)(bits & 1023ull)),
+                          stop2[1], L - 1, run1, (uint32_t)__popc(rev), cc);
+        } else {
+            walk_cum_both(env, tab, cum_lut, resmask, stop2[0], L - 1, run0, stop2[1], L - 1, run1, cc);
+        }
         if (active) {
             /* cumulative counts over rank (Ascore.cpp:115-118) and scores (Ascore.cpp:123-139) */
             uint32_t cum[PYA_NTOP];
@@ -479,48 +534,49 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
 }
 
 __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_kernel(BatchDev b, const uint32_t *psm_ids, uint32_t n_ids,
-                                                                       uint32_t cap, uint32_t pos_cap, BigLoc loc) {
+                                                                       uint32_t cap, uint32_t pos_cap, uint32_t kc, BigLoc loc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
-    big_body(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, pos_cap, loc);
+    big_body(b, psm_ids[xcd_slot(blockIdx.x, n_ids)], lds_raw, cap, pos_cap, kc, loc);
 }
 
 /* the PSMs the in-kernel localisation declined, scored again with count records for the general localize body:
  * a small grid strides over the list */
 __global__ __launch_bounds__(64 * BIG_WAVES, 6) void pya_score_big_list_kernel(BatchDev b, const uint32_t *count, const uint32_t *ids,
-                                                                            uint32_t cap, uint32_t pos_cap) {
+                                                                            uint32_t cap, uint32_t pos_cap, uint32_t kc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t n = *count;
     BigLoc loc = {};
     for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        big_body(b, ids[k], lds_raw, cap, pos_cap, loc);
+        big_body(b, ids[k], lds_raw, cap, pos_cap, kc, loc);
         __syncthreads();
     }
 }
 
-extern "C" size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap) { return score_big_lds_bytes(cap, pos_cap); }
+extern "C" size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap, uint32_t kc) { return score_big_lds_bytes(cap, pos_cap, kc); }
 
 /* pos_cap: the largest L - 1 of the launch (sizes the score-table row kept in LDS).  inline_on: summary mode --
  * for PSMs of up to pya_big_inline_max() signatures no count records are written and a tie for the best score is
  * resolved in the kernel (pya_launch_localize_recount finishes them). */
+/* kc: a power of two >= 8 and > the launch's largest number of modifications (the row length of the count-node table) */
 extern "C" int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap,
-                                    uint32_t pos_cap, uint32_t inline_on, hipStream_t stream) {
+                                    uint32_t pos_cap, uint32_t kc, uint32_t inline_on, hipStream_t stream) {
     if (n_ids == 0) return 0;
-    const size_t lds = score_big_lds_bytes(cap, pos_cap);
+    const size_t lds = score_big_lds_bytes(cap, pos_cap, kc);
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_score_big_kernel);
     if (e != hipSuccess) return (int)e;
     BigLoc loc = {inline_on};
-    hipLaunchKernelGGL(pya_score_big_kernel, dim3(n_ids), dim3(64 * BIG_WAVES), lds, stream, *b, d_ids, n_ids, cap, pos_cap, loc);
+    hipLaunchKernelGGL(pya_score_big_kernel, dim3(n_ids), dim3(64 * BIG_WAVES), lds, stream, *b, d_ids, n_ids, cap, pos_cap, kc, loc);
     return (int)hipGetLastError();
 }
 
 extern "C" int pya_launch_score_big_list(const BatchDev *b, const uint32_t *d_count, const uint32_t *d_ids, uint32_t n_max,
-                                         uint32_t cap, uint32_t pos_cap, hipStream_t stream) {
+                                         uint32_t cap, uint32_t pos_cap, uint32_t kc, hipStream_t stream) {
     if (n_max == 0) return 0;
-    const size_t lds = score_big_lds_bytes(cap, pos_cap);
+    const size_t lds = score_big_lds_bytes(cap, pos_cap, kc);
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_score_big_list_kernel);
     if (e != hipSuccess) return (int)e;
     const uint32_t grid = n_max < 2048u ? n_max : 2048u;
-    hipLaunchKernelGGL(pya_score_big_list_kernel, dim3(grid), dim3(64 * BIG_WAVES), lds, stream, *b, d_count, d_ids, cap, pos_cap);
+    hipLaunchKernelGGL(pya_score_big_list_kernel, dim3(grid), dim3(64 * BIG_WAVES), lds, stream, *b, d_count, d_ids, cap, pos_cap, kc);
     return (int)hipGetLastError();
 }

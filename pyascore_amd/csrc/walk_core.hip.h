@@ -370,6 +370,178 @@ DEV void walk_cum_both(const WalkEnv &e, const PeakTable &tab, const uint4 *lut,
     run1_io = run1;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * The count-node table (plain settings: no neutral losses, fragment charge 1, one ion type per direction).
+ *
+ * A fragment's m/z depends on the site assignment only through HOW MANY of the residues it contains are modified --
+ * up to rounding: the walkers' float32 running sums add the same masses in the same order except that different
+ * residues carry the modification, so two site assignments with j modified residues among the first s + 1 (in travel
+ * order) reach step s with sums that differ by the roundings of at most s additions each and by the differences
+ * between the residues' own (modified - unmodified) float32 gaps.  With D a bound on that difference (cnt_table_bound)
+ * ONE lookup per (direction, step, j) -- of a representative chain, with the window test done on the window shrunk by
+ * D and on the window widened by D -- decides the fragment for EVERY walker through the node:
+ *   a peak inside the shrunk window matches for every walker, a peak outside the widened window for none;
+ *   the node's rank is the lowest rank of the former; a peak in the band between the two with a LOWER rank than
+ *   that could change some walker's answer: the node is then MARKED and every walker through it does its own lookup
+ *   (the reference's test on the walker's own m/z: exact by construction).
+ * Entry: rank (0 .. 9, PYA_NO_MATCH = 15) | 0x80 when marked.  C(15,5) = 3003 site assignments x 58 fragments read
+ * 2 x 29 x 6 = 348 node lookups instead of making 64 000 of their own (score_big's two-level prefix tree included).
+ * Table layout: entry of (direction d, step s, j modified so far) at t[((d * pos_cap + s) * kc) + j], kc a power of
+ * two > the largest j a walker of the launch can reach.  PYA_DEBUG 0x8000: no table (every walker looks every fragment
+ * up itself); 0x40000000: every node marked (the table is read, then every walker looks up itself): the two must agree. */
+#define CNT_MARK 0x80u
+
+/* D of the note above, for one PSM (every wavefront computes it for itself from the residues in its registers):
+ *   |run_a - run_b| <= (L - 1) u  (at most L - 1 additions per chain, each rounded by <= u / 2, u = ulp32 of a bound on
+ *                                   every running sum and every m/z of the PSM)
+ *                    + k Dlt      (Dlt = largest - smallest (modified - unmodified) gap over the modifiable residues)
+ *   the narrowing of the m/z to float32: u / 2 each; the window ends f32(f - err), f32(f + err): u / 2 each. */
+DEV double cnt_table_bound(const Residues &res, int k, double type_off) {
+    const int lane = lane_id();
+    const bool in = lane < res.L;
+    const float big = in ? __builtin_fmaxf(__builtin_fabsf(res.m0), __builtin_fabsf(res.m1)) : 0.f;
+    float tot = big;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    const float rtop = tot * 1.001f + (float)__builtin_fabs(type_off) + 64.f;     /* >= every |running sum| and every m/z */
+    const float u = __uint_as_float((__float_as_uint(rtop) & 0x7f800000u) - (23u << 23));
+    const bool site = in && ((res.site_mask >> lane) & 1ull);
+    const double gap = (double)res.m1 - (double)res.m0;
+    const double gmax = wave_max_f64(site ? gap : -1e300), gmin = wave_min_f64(site ? gap : 1e300);
+    const double dlt = gmax > gmin ? gmax - gmin : 0.;
+    return (double)(res.L + 2) * (double)u + (double)(k + 1) * dlt + 1e-6;
+}
+
+/* One node: the representative's m/z `c` against the staged peak table.  (charge 1, mz_error <= 0.49) */
+DEV uint32_t cnt_table_entry(const PeakTable &t, float c, double D) {
+    const double err = (double)t.err;
+    const double lo_out = (double)c - err - D, hi_out = (double)c + err + D, lo_in = (double)c - err + D, hi_in = (double)c + err - D;
+    float lo_f = (float)lo_out;
+    if ((double)lo_f > lo_out) lo_f = __uint_as_float(__float_as_uint(lo_f) - 1u);   /* (m/z are positive: one ulp down) */
+    int in_best = PYA_NO_MATCH, band_best = PYA_NO_MATCH;
+    for (int idx = (int)t.cell[grid_cell(t, lo_f)];; idx++) {     /* every peak > lo_f has index >= that (the sentinels end the scan) */
+        const PeakEntry x = t.e[idx];
+        const double p = (double)x.mz;
+        if (!(p < hi_out)) break;
+        if (p > lo_out) {
+            const int r = (int)x.rank;
+            if (p > lo_in && p < hi_in) in_best = r < in_best ? r : in_best;
+            else band_best = r < band_best ? r : band_best;
+        }
+    }
+    return (uint32_t)in_best | (band_best < in_best ? CNT_MARK : 0u);
+}
+
+template <bool BY>
+DEV void walk_cnt_both_steps(const PeakTable &tab, const uint4 *lut, CumCounts &cum, const float2 *&rp0, const float2 *&rp1,
+                             StepBits &b0, StepBits &b1, float &run0, float &run1, double A0, double B0, double A1, double B1,
+                             const uint8_t *&row0, const uint8_t *&row1, uint32_t kc, uint32_t &j0, uint32_t &j1, int count) {
+    for (int i = 0; i < count; i++, rp0++, rp1--, row0 += kc, row1 += kc) {
+        const float2 m0 = *rp0, m1 = *rp1;
+        const bool d0 = b0.next(), d1 = b1.next();
+        run0 = (d0 ? m0.y : m0.x) + run0;                    /* ModifiedPeptide.cpp:385-389 */
+        run1 = (d1 ? m1.y : m1.x) + run1;
+        j0 += d0 ? 1u : 0u;
+        j1 += d1 ? 1u : 0u;
+        const uint32_t e0 = row0[j0], e1 = row1[j1];
+        int rk0 = (int)(e0 & 15u), rk1 = (int)(e1 & 15u);
+        if ((e0 | e1) & CNT_MARK) {
+            if (e0 & CNT_MARK) {
+                const float f0 = BY ? (float)((double)run0 + 1.007825) : (float)((((double)run0 + A0) - B0) + 1.007825);
+                const Look k0 = look4(tab, f0);
+                rk0 = k0.best;
+                if (k0.more()) rk0 = look_rest(tab, k0);
+            }
+            if (e1 & CNT_MARK) {
+                const float f1 = BY ? (float)(((double)run1 + A1) + 1.007825) : (float)((((double)run1 + A1) - B1) + 1.007825);
+                const Look k1 = look4(tab, f1);
+                rk1 = k1.best;
+                if (k1.more()) rk1 = look_rest(tab, k1);
+            }
+        }
+        cum.add(lut[rk0]);
+        cum.add(lut[rk1]);
+    }
+}
+template <bool BY>
+DEV void walk_cnt_one_steps(const PeakTable &tab, const uint4 *lut, CumCounts &cum, const float2 *&rp, int stride, StepBits &bits,
+                            float &run, double A, double B, const uint8_t *&row, uint32_t kc, uint32_t &j, int count) {
+    for (int i = 0; i < count; i++, rp += stride, row += kc) {
+        const float2 mm = *rp;
+        const bool d = bits.next();
+        run = (d ? mm.y : mm.x) + run;
+        j += d ? 1u : 0u;
+        const uint32_t ent = row[j];
+        int rk = (int)(ent & 15u);
+        if (ent & CNT_MARK) {
+            const float f = BY ? (float)(((double)run + A) + 1.007825) : (float)((((double)run + A) - B) + 1.007825);
+            const Look k = look4(tab, f);
+            rk = k.best;
+            if (k.more()) rk = look_rest(tab, k);
+        }
+        cum.add(lut[rk]);
+    }
+}
+/* walk_cum_range reading the count-node table: `row` = the table row of (dir, step_begin), `j` = modified residues
+ * before step_begin (both advance) */
+DEV void walk_cnt_range(const WalkEnv &e, const PeakTable &tab, const uint4 *lut, const uint8_t *row, uint32_t kc, uint64_t resmask,
+                        int dir, int step_begin, int step_end, float &running_io, uint32_t &j_io, CumCounts &cum) {
+    const DevConfig *cfg = e.cfg;
+    const int L = e.L;
+    double Af = 0., Bf = 0., Ab = 0., Bb = 0.;
+    if (cfg->n_fwd > 0) type_constants(cfg->types[0], &Af, &Bf);
+    if (cfg->n_fwd < cfg->n_types) type_constants(cfg->types[cfg->n_fwd], &Ab, &Bb);
+    const double A = dir ? Ab : Af, B = dir ? Bb : Bf;
+    const uint64_t tmask = dir ? (__brevll(resmask) >> (64 - L)) : resmask;
+    const uint64_t M = msb_first_from(tmask, step_begin);
+    const float2 *rp = e.resd + (dir ? L - 1 - step_begin : step_begin);
+    const int stride = dir ? -1 : 1;
+    const int n = step_end - step_begin;
+    for (int seg = 0; seg < 2; seg++) {                      /* the mask words change after 32 steps */
+        StepBits bits = {seg ? (uint32_t)M : (uint32_t)(M >> 32)};
+        int c = (n < seg * 32 + 32 ? n : seg * 32 + 32) - seg * 32;
+        if (c < 0) c = 0;
+        walk_cnt_one_steps<false>(tab, lut, cum, rp, stride, bits, running_io, A, B, row, kc, j_io, c);
+    }
+}
+/* walk_cum_both reading the count-node table: t = the table, rows of direction d start at t + d * pos_cap * kc;
+ * j0 / j1 = modified residues before begin0 / begin1 in the respective travel order */
+DEV void walk_cnt_both(const WalkEnv &e, const PeakTable &tab, const uint4 *lut, const uint8_t *t, uint32_t pos_cap, uint32_t kc,
+                       uint64_t resmask, int begin0, int end0, float &run0_io, uint32_t j0, int begin1, int end1, float &run1_io,
+                       uint32_t j1, CumCounts &cum) {
+    const DevConfig *cfg = e.cfg;
+    const int L = e.L;
+    double A0 = 0., B0 = 0., A1 = 0., B1 = 0.;
+    type_constants(cfg->types[0], &A0, &B0);
+    type_constants(cfg->types[cfg->n_fwd], &A1, &B1);
+    const bool by = A0 == 0. && B0 == 0. && B1 == 0.;
+    const uint64_t M0 = msb_first_from(resmask, begin0), M1 = msb_first_from(__brevll(resmask) >> (64 - L), begin1);
+    const float2 *rp0 = e.resd + begin0, *rp1 = e.resd + (L - 1 - begin1);
+    const uint8_t *row0 = t + (size_t)begin0 * kc, *row1 = t + ((size_t)pos_cap + (size_t)begin1) * kc;
+    float run0 = run0_io, run1 = run1_io;
+    const int n0 = end0 - begin0, n1 = end1 - begin1, both = n0 < n1 ? n0 : n1;
+    for (int seg = 0; seg < 2; seg++) {
+        StepBits b0 = {seg ? (uint32_t)M0 : (uint32_t)(M0 >> 32)}, b1 = {seg ? (uint32_t)M1 : (uint32_t)(M1 >> 32)};
+        const int lo = seg * 32, hi = lo + 32;
+        int c = (both < hi ? both : hi) - lo;
+        if (c < 0) c = 0;
+        if (by) walk_cnt_both_steps<true>(tab, lut, cum, rp0, rp1, b0, b1, run0, run1, A0, B0, A1, B1, row0, row1, kc, j0, j1, c);
+        else walk_cnt_both_steps<false>(tab, lut, cum, rp0, rp1, b0, b1, run0, run1, A0, B0, A1, B1, row0, row1, kc, j0, j1, c);
+        const int from = lo + c;
+        int t0 = (n0 < hi ? n0 : hi) - from, t1 = (n1 < hi ? n1 : hi) - from;
+        if (t0 > 0) {
+            if (by) walk_cnt_one_steps<true>(tab, lut, cum, rp0, 1, b0, run0, A0, B0, row0, kc, j0, t0);
+            else walk_cnt_one_steps<false>(tab, lut, cum, rp0, 1, b0, run0, A0, B0, row0, kc, j0, t0);
+        }
+        if (t1 > 0) {
+            if (by) walk_cnt_one_steps<true>(tab, lut, cum, rp1, -1, b1, run1, A1, B1, row1, kc, j1, t1);
+            else walk_cnt_one_steps<false>(tab, lut, cum, rp1, -1, b1, run1, A1, B1, row1, kc, j1, t1);
+        }
+    }
+    run0_io = run0;
+    run1_io = run1;
+}
+
 DEV bool walk_is_simple(const WalkEnv &e) {
     const int n_f = e.cfg->n_fwd, n_b = e.cfg->n_types - e.cfg->n_fwd;
     return e.n_nl == 0 && n_f <= 1 && n_b <= 1;
