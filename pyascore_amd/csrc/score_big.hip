@@ -262,46 +262,32 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     __syncthreads();
     if (wave == 0) ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)grid)[lane];
 
-    /* ---- the count-node table (walk_core.hip.h): one lookup per (direction, step, modified residues so far) ----
-     * The representative of (d, s, j) is the chain with the FIRST j modifiable residues of direction d modified: one chain
-     * per (d, j) gives the nodes of every step (a node it does not reach with j modified -- fewer than j sites in the
-     * fragment -- is reached by no site assignment).  The chains' running sums go through the level-2 table's LDS,
-     * which is not in use yet; then every thread looks up a share of the nodes. */
+    /* ---- the count-node table (walk_core.hip.h): one lookup per (direction, step, modified residues so far), then the
+     * prefix sums over the steps.  The envelopes and the prefix sums go through the level-2 table's LDS, which this route
+     * does not use (it needs neither prefix level): P at l2, the envelopes 16 KB behind it. ---- */
     const int k = b.n_of_mod[psm];
     const int n_sites = __popcll(res.site_mask);
-    const bool use_cnt = !(b.debug & 0x8000u) && (uint32_t)k + 1u <= kc && kc >= 8u;
+    uint4 *cntP = (uint4 *)l2;                                  /* [2][k + 1][L] */
+    const bool use_cnt = !(b.debug & 0x8000u) && (uint32_t)k + 1u <= kc && k + 1 <= 32 && (size_t)2 * (k + 1) * L * sizeof(uint4) <= 16384 &&
+                         (size_t)2 * (k + 1) * pos_cap * sizeof(float2) <= 16384;
     if (use_cnt) {
-        float *rep = (float *)l2;                                /* [2][k + 1][pos_cap] */
+        float2 *envl = (float2 *)((unsigned char *)l2 + 16384);  /* [2][k + 1][pos_cap] */
+        if (wave == 0) cnt_envelopes(resd, res.site_mask, L, k, pos_cap, envl);
         for (uint32_t i = (uint32_t)tid; i < (uint32_t)score_big_cnt_bytes(pos_cap, kc) / 4u; i += BIG_T) ((uint32_t *)cnt_t)[i] = 0x0f0f0f0fu;
-        if (tid < 2 * (k + 1)) {
-            const int d = tid / (k + 1), j = tid - d * (k + 1);
-            const uint64_t first_j = j >= 64 ? ~0ull : ((1ull << j) - 1ull);
-            const uint64_t pbits = d == 0 ? first_j : (first_j << (n_sites - j));
-            const uint64_t resmask = deposit_sites(pbits, res.site_mask);
-            const uint64_t tmask = d ? (__brevll(resmask) >> (64 - L)) : resmask;
-            float *out = rep + (size_t)(d * (k + 1) + j) * pos_cap;
-            float running = 0.f;
-            for (int step = 0; step + 1 < L; step++) {
-                const float2 mm = resd[d ? L - 1 - step : step];
-                running = (((tmask >> step) & 1ull) ? mm.y : mm.x) + running;
-                out[step] = running;
-            }
-        }
         __syncthreads();
         double A0 = 0., B0 = 0., A1 = 0., B1 = 0.;
         type_constants(cfg->types[0], &A0, &B0);
         type_constants(cfg->types[cfg->n_fwd], &A1, &B1);
-        const double off0 = A0 - B0, off1 = A1 - B1;
-        const double D = cnt_table_bound(res, k, __builtin_fabs(off0) > __builtin_fabs(off1) ? off0 : off1);
         const uint32_t per_dir = (uint32_t)(k + 1) * (uint32_t)(L - 1);
         for (uint32_t i = (uint32_t)tid; i < 2u * per_dir; i += BIG_T) {
             const uint32_t d = i >= per_dir ? 1u : 0u, r = i - d * per_dir, j = r / (uint32_t)(L - 1), st = r - j * (uint32_t)(L - 1);
-            const float running = rep[(size_t)(d * (uint32_t)(k + 1) + j) * pos_cap + st];
-            const double m = ((double)running + (d ? A1 : A0)) - (d ? B1 : B0);
-            uint32_t ent = cnt_table_entry(tab, (float)(m + 1.007825), D);
-            if (b.debug & 0x40000000u) ent |= CNT_MARK;                  /* (every walker looks every fragment up itself: must agree) */
+            const float2 lh = envl[(size_t)(d * (uint32_t)(k + 1) + j) * pos_cap + st];
+            uint32_t ent = cnt_table_entry(tab, lh.x, lh.y, d ? A1 : A0, d ? B1 : B0);
+            if ((b.debug & 0x40000000u) && lh.x <= lh.y) ent |= CNT_MARK;      /* (every walker looks every fragment up itself: must agree) */
             cnt_t[((size_t)d * pos_cap + st) * kc + j] = (uint8_t)ent;
         }
+        __syncthreads();
+        cnt_prefix_sums(cnt_t, cum_lut, pos_cap, kc, L, k, cntP, tid);
         __syncthreads();
     }
 
@@ -327,14 +313,12 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     }
 
     /* ---- level 1: wavefront d walks the 64 patterns of the first 6 sites of direction d ---- */
-    if (wave < 2) {
+    if (wave < 2 && !use_cnt) {
         const int dir = wave;
         const uint64_t pbits = dir == 0 ? (uint64_t)lane : (__brevll((uint64_t)lane) >> (64 - n_sites));
         float run = 0.f;
         CumCounts cum = {0u, 0u, 0u};
-        uint32_t j = 0;
-        if (use_cnt) walk_cnt_range(env, tab, cum_lut, cnt_t + (size_t)dir * pos_cap * kc, kc, deposit_sites(pbits, res.site_mask), dir, 0, stop1[dir], run, j, cum);
-        else walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, 0, stop1[dir], run, cum);
+        walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, 0, stop1[dir], run, cum);
         l1[dir * 64 + lane] = make_entry(run, cum);
     }
     __syncthreads();
@@ -347,7 +331,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
      * idle. ---- */
     const bool listed = true;
     uint32_t nv = 1024u;
-    {
+    if (!use_cnt) {
         uint32_t before = 0;                                     /* valid patterns below this thread's, round by round */
         for (int r = 0; r < 1024 / BIG_T; r++) {
             const uint32_t c = (uint32_t)(r * BIG_T + tid);
@@ -369,7 +353,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         nv = before;
     }
     const uint32_t nv64 = (nv + 63u) & ~63u;                     /* a wavefront's 64 items share their direction */
-    for (uint32_t base = 0; base < 2u * nv64; base += 64 * BIG_WAVES) {
+    for (uint32_t base = 0; !use_cnt && base < 2u * nv64; base += 64 * BIG_WAVES) {
         const uint32_t it2 = base + (uint32_t)tid;
         const int dir = it2 >= nv64 ? 1 : 0;                     /* (uniform within a wavefront) */
         const uint32_t q = it2 - (dir ? nv64 : 0u);
@@ -383,9 +367,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         const PrefixCompact par = l1[dir * 64 + (c & 63u)];
         float run = par.running;
         CumCounts cum = entry_counts(par);                       /* (the walk adds to the parent's counts) */
-        uint32_t j = (uint32_t)__popc(c & 63u);                  /* modified among the first six sites */
-        if (use_cnt) walk_cnt_range(env, tab, cum_lut, cnt_t + ((size_t)dir * pos_cap + (size_t)stop1[dir]) * kc, kc, deposit_sites(pbits, res.site_mask), dir, stop1[dir], stop2[dir], run, j, cum);
-        else walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, stop1[dir], stop2[dir], run, cum);
+        walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, stop1[dir], stop2[dir], run, cum);
         if (valid) l2[item] = make_entry(run, cum);
     }
     __syncthreads();
@@ -408,16 +390,24 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         const bool active = s < N;
         const uint64_t bits = active ? order[s] : 0ull;
         const uint64_t resmask = deposit_sites(bits, res.site_mask);
-        const PrefixCompact p0 = l2[(uint32_t)(bits & 1023ull)];
-        const PrefixCompact p1 = l2[1024u + (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 1023ull)];
-        float run0 = p0.running, run1 = p1.running;
-        CumCounts cc = entry_counts(p0);                         /* both directions' prefixes, then the rest of the walk */
-        cc.add(make_uint4((uint32_t)p1.lo, (uint32_t)(p1.lo >> 32), p1.hi, 0u));
+        CumCounts cc = {0u, 0u, 0u};
         if (use_cnt) {
-            const uint32_t rev = (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 1023ull);
-            walk_cnt_both(env, tab, cum_lut, cnt_t, pos_cap, kc, resmask, stop2[0], L - 1, run0, (uint32_t)__popc((uint32_t)(bits & 1023ull)),
-                          stop2[1], L - 1, run1, (uint32_t)__popc(rev), cc);
+            /* the counts from the prefix sums: k + 1 differences per direction; a site assignment whose path crosses a
+             * marked node is walked, looking its fragments at the marked nodes up itself */
+            uint32_t marked = 0;
+            if (active) cc = cnt_eval(cntP, resmask, L, k, &marked);
+            if (__any(marked != 0)) {
+                float run0 = 0.f, run1 = 0.f;
+                CumCounts cw = {0u, 0u, 0u};
+                walk_cnt_both(env, tab, cum_lut, cnt_t, pos_cap, kc, resmask, 0, L - 1, run0, 0u, 0, L - 1, run1, 0u, cw);
+                if (marked != 0) cc = cw;
+            }
         } else {
+            const PrefixCompact p0 = l2[(uint32_t)(bits & 1023ull)];
+            const PrefixCompact p1 = l2[1024u + (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 1023ull)];
+            float run0 = p0.running, run1 = p1.running;
+            cc = entry_counts(p0);                               /* both directions' prefixes, then the rest of the walk */
+            cc.add(make_uint4((uint32_t)p1.lo, (uint32_t)(p1.lo >> 32), p1.hi, 0u));
             walk_cum_both(env, tab, cum_lut, resmask, stop2[0], L - 1, run0, stop2[1], L - 1, run1, cc);
         }
         if (active) {

@@ -374,62 +374,157 @@ DEV void walk_cum_both(const WalkEnv &e, const PeakTable &tab, const uint4 *lut,
  * The count-node table (plain settings: no neutral losses, fragment charge 1, one ion type per direction).
  *
  * A fragment's m/z depends on the site assignment only through HOW MANY of the residues it contains are modified --
- * up to rounding: the walkers' float32 running sums add the same masses in the same order except that different
- * residues carry the modification, so two site assignments with j modified residues among the first s + 1 (in travel
- * order) reach step s with sums that differ by the roundings of at most s additions each and by the differences
- * between the residues' own (modified - unmodified) float32 gaps.  With D a bound on that difference (cnt_table_bound)
- * ONE lookup per (direction, step, j) -- of a representative chain, with the window test done on the window shrunk by
- * D and on the window widened by D -- decides the fragment for EVERY walker through the node:
- *   a peak inside the shrunk window matches for every walker, a peak outside the widened window for none;
- *   the node's rank is the lowest rank of the former; a peak in the band between the two with a LOWER rank than
- *   that could change some walker's answer: the node is then MARKED and every walker through it does its own lookup
- *   (the reference's test on the walker's own m/z: exact by construction).
+ * up to rounding: the walkers' float32 running sums add the same masses in the same order, except that different
+ * residues carry the modification.  The set of running sums that the site assignments with j modified residues among
+ * the first s + 1 (in travel order) can have at step s is enclosed EXACTLY by a recurrence over (s, j): float32
+ * addition is monotone (x <= y implies fl(r + x) <= fl(r + y)), so
+ *     lo(s, j) = min( fl(m0_s + lo(s-1, j)),  fl(m1_s + lo(s-1, j-1)) if residue s is modifiable ),   hi(s, j) alike with max,
+ * lo(-1, 0) = hi(-1, 0) = 0, are the smallest and the largest sum any chain through the node has (cnt_envelopes; the
+ * interval is a few float32 ulps wide).  The m/z and the window ends are monotone functions of the sum as well
+ * (double additions of constants, a narrowing, a float32 subtraction / addition of the tolerance), so with
+ *     a0 = f32(f(lo) - err), a = f32(f(hi) - err), b0 = f32(f(lo) + err), b1 = f32(f(hi) + err)
+ * every walker through the node has its window's lower end in [a0, a] and its upper end in [b0, b1], and ONE scan of
+ * the peak table decides the fragment for all of them (the reference's test is lower < peak < upper, strict,
+ * cpp/ModifiedPeptide.cpp:133-135):
+ *     a peak with a < p < b0 matches for every walker, a peak with p <= a0 or p >= b1 for none;
+ *     the node's rank is the lowest rank among the former; a peak in between -- within a few ulps of a window end --
+ *     with a LOWER rank could change some walker's answer: the node is then MARKED and a walker through it looks its
+ *     fragment up itself, with its own sum (exact by construction).
  * Entry: rank (0 .. 9, PYA_NO_MATCH = 15) | 0x80 when marked.  C(15,5) = 3003 site assignments x 58 fragments read
  * 2 x 29 x 6 = 348 node lookups instead of making 64 000 of their own (score_big's two-level prefix tree included).
- * Table layout: entry of (direction d, step s, j modified so far) at t[((d * pos_cap + s) * kc) + j], kc a power of
- * two > the largest j a walker of the launch can reach.  PYA_DEBUG 0x8000: no table (every walker looks every fragment
- * up itself); 0x40000000: every node marked (the table is read, then every walker looks up itself): the two must agree. */
+ * Table layout: entry of (direction d, step s, j modified so far) at t[((d * pos_cap + s) * kc) + j].
+ *
+ * The counts of a site assignment are then a sum over the nodes on its path, and j is constant between two of its
+ * modified residues: with P(d, j, s) = the sum of the nodes' increments over the steps below s (cnt_prefix_sums:
+ * cumulative counts as packed bytes, marked nodes counted in a fourth word) a direction's counts are k + 1 differences
+ * P(d, i, e_{i+1}) - P(d, i, e_i) over the steps e_i at which its modified residues enter the fragment -- O(k) table
+ * reads per site assignment instead of a walk over L - 1 residues (cnt_eval).  A site assignment whose path crosses a
+ * marked node (the fourth word says so) is walked (walk_cnt_both).
+ * PYA_DEBUG 0x8000: no table (every walker looks every fragment up itself); 0x40000000: every node marked (the table is
+ * read, then every walker looks up itself): the three must agree. */
 #define CNT_MARK 0x80u
 
-/* D of the note above, for one PSM (every wavefront computes it for itself from the residues in its registers):
- *   |run_a - run_b| <= (L - 1) u  (at most L - 1 additions per chain, each rounded by <= u / 2, u = ulp32 of a bound on
- *                                   every running sum and every m/z of the PSM)
- *                    + k Dlt      (Dlt = largest - smallest (modified - unmodified) gap over the modifiable residues)
- *   the narrowing of the m/z to float32: u / 2 each; the window ends f32(f - err), f32(f + err): u / 2 each. */
-DEV double cnt_table_bound(const Residues &res, int k, double type_off) {
+/* lo / hi of every node (see above), by wavefront 0: lane = d * 32 + j (k + 1 <= 32), written to env[(d * (k + 1) + j) * pos_cap + s]
+ * as float2 {lo, hi}; an unreachable node gets lo > hi. */
+DEV void cnt_envelopes(const float2 *resd, uint64_t site_mask, int L, int k, uint32_t pos_cap, float2 *env) {
     const int lane = lane_id();
-    const bool in = lane < res.L;
-    const float big = in ? __builtin_fmaxf(__builtin_fabsf(res.m0), __builtin_fabsf(res.m1)) : 0.f;
-    float tot = big;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-    const float rtop = tot * 1.001f + (float)__builtin_fabs(type_off) + 64.f;     /* >= every |running sum| and every m/z */
-    const float u = __uint_as_float((__float_as_uint(rtop) & 0x7f800000u) - (23u << 23));
-    const bool site = in && ((res.site_mask >> lane) & 1ull);
-    const double gap = (double)res.m1 - (double)res.m0;
-    const double gmax = wave_max_f64(site ? gap : -1e300), gmin = wave_min_f64(site ? gap : 1e300);
-    const double dlt = gmax > gmin ? gmax - gmin : 0.;
-    return (double)(res.L + 2) * (double)u + (double)(k + 1) * dlt + 1e-6;
+    const int d = lane >> 5, j = lane & 31;
+    const float inf = __builtin_huge_valf();
+    float lo = 0.f, hi = 0.f;
+    bool valid = j == 0;
+    for (int s = 0; s + 1 < L; s++) {
+        const int ri = d ? L - 1 - s : s;
+        const float2 mm = resd[ri];
+        const bool site = (site_mask >> ri) & 1ull;
+        const float lo_m = __shfl_up(lo, 1, 64), hi_m = __shfl_up(hi, 1, 64);
+        const bool v_m = __shfl_up((int)valid, 1, 64) != 0 && j >= 1;
+        float nlo = inf, nhi = -inf;
+        if (valid) {                                        /* the residue enters unmodified */
+            nlo = mm.x + lo;
+            nhi = mm.x + hi;
+        }
+        if (site && v_m) {                                  /* ... or modified, from the node with one modification fewer */
+            const float x = mm.y + lo_m, y = mm.y + hi_m;
+            nlo = x < nlo ? x : nlo;
+            nhi = y > nhi ? y : nhi;
+        }
+        valid = valid || (site && v_m);
+        lo = nlo;
+        hi = nhi;
+        if (j <= k) env[(size_t)(d * (k + 1) + j) * pos_cap + s] = make_float2(lo, hi);
+    }
 }
 
-/* One node: the representative's m/z `c` against the staged peak table.  (charge 1, mz_error <= 0.49) */
-DEV uint32_t cnt_table_entry(const PeakTable &t, float c, double D) {
-    const double err = (double)t.err;
-    const double lo_out = (double)c - err - D, hi_out = (double)c + err + D, lo_in = (double)c - err + D, hi_in = (double)c + err - D;
-    float lo_f = (float)lo_out;
-    if ((double)lo_f > lo_out) lo_f = __uint_as_float(__float_as_uint(lo_f) - 1u);   /* (m/z are positive: one ulp down) */
+/* One node: the envelope [lo, hi] of its running sums against the staged peak table (A, B: the ion type's offsets).
+ * (charge 1, mz_error <= 0.49) */
+DEV uint32_t cnt_table_entry(const PeakTable &t, float lo, float hi, double A, double B) {
+    if (!(lo <= hi)) return (uint32_t)PYA_NO_MATCH;           /* unreachable: never read */
+    const float f_lo = (float)((((double)lo + A) - B) + 1.007825), f_hi = (float)((((double)hi + A) - B) + 1.007825);
+    const float a0 = f_lo - t.err, a = f_hi - t.err, b0 = f_lo + t.err, b1 = f_hi + t.err;
     int in_best = PYA_NO_MATCH, band_best = PYA_NO_MATCH;
-    for (int idx = (int)t.cell[grid_cell(t, lo_f)];; idx++) {     /* every peak > lo_f has index >= that (the sentinels end the scan) */
+    for (int idx = (int)t.cell[grid_cell(t, a0)];; idx++) {      /* every peak > a0 has index >= that; the sentinels end the scan */
         const PeakEntry x = t.e[idx];
-        const double p = (double)x.mz;
-        if (!(p < hi_out)) break;
-        if (p > lo_out) {
+        if (!(x.mz < b1)) break;
+        if (x.mz > a0) {
             const int r = (int)x.rank;
-            if (p > lo_in && p < hi_in) in_best = r < in_best ? r : in_best;
+            if (x.mz > a && x.mz < b0) in_best = r < in_best ? r : in_best;
             else band_best = r < band_best ? r : band_best;
         }
     }
     return (uint32_t)in_best | (band_best < in_best ? CNT_MARK : 0u);
+}
+
+/* P(d, j, s) for s = 0 .. L - 1 at P[(d * (k + 1) + j) * L + s]: x, y, z = the packed cumulative-count increments of the
+ * nodes (d, j, t < s) summed (bytes: at most L - 1 per field), w = how many of them are marked.  One lane per (d, j). */
+DEV void cnt_prefix_sums(const uint8_t *t, const uint4 *lut, uint32_t pos_cap, uint32_t kc, int L, int k, uint4 *P, int tid) {
+    if (tid >= 2 * (k + 1)) return;
+    const int d = tid / (k + 1), j = tid - d * (k + 1);
+    uint4 *out = P + (size_t)tid * L;
+    const uint8_t *col = t + (size_t)d * pos_cap * kc + j;
+    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+    out[0] = acc;
+    for (int s = 0; s + 1 < L; s++, col += kc) {
+        const uint32_t ent = *col;
+        const uint4 inc = lut[ent & 15u];
+        acc.x += inc.x;
+        acc.y += inc.y;
+        acc.z += inc.z;
+        acc.w += ent >> 7;
+        out[s + 1] = acc;
+    }
+}
+
+/* The counts of one site assignment (residue mask `resmask`, k modified residues) from the prefix sums: both directions.
+ * Returns the packed cumulative counts; *marked = nodes on its two paths that are marked. */
+DEV CumCounts cnt_eval(const uint4 *P, uint64_t resmask, int L, int k, uint32_t *marked) {
+    uint32_t ax = 0, ay = 0, az = 0, aw = 0;
+    const int Lm1 = L - 1;
+    {
+        const uint4 *row = P;                               /* direction 0, j = 0 */
+        uint64_t m = resmask;
+        int start = 0;
+        for (int i = 0; i < k; i++, row += L) {
+            const int p = __builtin_ctzll(m);
+            m &= m - 1;
+            const int end = p < Lm1 ? p : Lm1;
+            const uint4 hi = row[end], lo = row[start];
+            ax += hi.x - lo.x;
+            ay += hi.y - lo.y;
+            az += hi.z - lo.z;
+            aw += hi.w - lo.w;
+            start = end;
+        }
+        const uint4 hi = row[Lm1], lo = row[start];
+        ax += hi.x - lo.x;
+        ay += hi.y - lo.y;
+        az += hi.z - lo.z;
+        aw += hi.w - lo.w;
+    }
+    {
+        const uint4 *row = P + (size_t)(k + 1) * L;         /* direction 1: travel step of residue p is L - 1 - p */
+        uint64_t m = resmask;
+        int start = 0;
+        for (int i = 0; i < k; i++, row += L) {
+            const int p = 63 - __builtin_clzll(m);
+            m &= ~(1ull << p);
+            const int q = Lm1 - p;
+            const int end = q < Lm1 ? q : Lm1;
+            const uint4 hi = row[end], lo = row[start];
+            ax += hi.x - lo.x;
+            ay += hi.y - lo.y;
+            az += hi.z - lo.z;
+            aw += hi.w - lo.w;
+            start = end;
+        }
+        const uint4 hi = row[Lm1], lo = row[start];
+        ax += hi.x - lo.x;
+        ay += hi.y - lo.y;
+        az += hi.z - lo.z;
+        aw += hi.w - lo.w;
+    }
+    *marked = aw;
+    CumCounts c = {ax, ay, az};
+    return c;
 }
 
 template <bool BY>
