@@ -267,8 +267,10 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
      * does not use (it needs neither prefix level): P at l2, the envelopes 16 KB behind it. ---- */
     const int k = b.n_of_mod[psm];
     const int n_sites = __popcll(res.site_mask);
-    uint4 *cntP = (uint4 *)l2;                                  /* [2][k + 1][L] */
-    const bool use_cnt = !(b.debug & 0x8000u) && (uint32_t)k + 1u <= kc && k + 1 <= 32 && (size_t)2 * (k + 1) * L * sizeof(uint4) <= 16384 &&
+    uint4 *cntP = (uint4 *)l2;                                  /* [2][k + 1][L] prefix sums; behind them [k * n_sites + 1] the per-site table */
+    uint4 *cntG = cntP + (size_t)2 * (k + 1) * L;
+    const bool use_cnt = !(b.debug & 0x8000u) && (uint32_t)k + 1u <= kc && k + 1 <= 32 && n_sites <= 32 &&
+                         ((size_t)2 * (k + 1) * L + (size_t)k * n_sites + 1) * sizeof(uint4) <= 16384 &&
                          (size_t)2 * (k + 1) * pos_cap * sizeof(float2) <= 16384;
     if (use_cnt) {
         float2 *envl = (float2 *)((unsigned char *)l2 + 16384);  /* [2][k + 1][pos_cap] */
@@ -285,9 +287,19 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
             uint32_t ent = cnt_table_entry(tab, lh.x, lh.y, d ? A1 : A0, d ? B1 : B0);
             if ((b.debug & 0x40000000u) && lh.x <= lh.y) ent |= CNT_MARK;      /* (every walker looks every fragment up itself: must agree) */
             cnt_t[((size_t)d * pos_cap + st) * kc + j] = (uint8_t)ent;
+#ifdef PYA_STAMPS                                              /* diagnostic build: nodes looked up / marked (slots 50, 51) */
+            if (b.stamps) {
+                atomicAdd(&b.stamps[50], 1ull);
+                if (ent & CNT_MARK) atomicAdd(&b.stamps[51], 1ull);
+            }
+#endif
         }
         __syncthreads();
         cnt_prefix_sums(cnt_t, cum_lut, pos_cap, kc, L, k, cntP, tid);
+        if (wave == 1 && ((res.site_mask >> lane) & 1ull))       /* residue of the j-th modifiable one (first bytes of the envelopes' room) */
+            ((uint8_t *)envl)[__popcll(res.site_mask & lanemask_lt())] = (uint8_t)lane;
+        __syncthreads();
+        cnt_site_table(cntP, (const uint8_t *)envl, L, k, n_sites, cntG, tid, BIG_T);
         __syncthreads();
     }
 
@@ -395,7 +407,15 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
             /* the counts from the prefix sums: k + 1 differences per direction; a site assignment whose path crosses a
              * marked node is walked, looking its fragments at the marked nodes up itself */
             uint32_t marked = 0;
-            if (active) cc = cnt_eval(cntP, resmask, L, k, &marked);
+            if (active) cc = cnt_eval_sites(cntG, (uint32_t)bits, k, n_sites, &marked);
+#ifdef PYA_STAMPS                                              /* ... site assignments / those with a marked node / wave rounds that walk (52-54) */
+            if (b.stamps) {
+                if (active) atomicAdd(&b.stamps[52], 1ull);
+                if (marked != 0) atomicAdd(&b.stamps[53], 1ull);
+                if (lane == 0 && __any(marked != 0)) atomicAdd(&b.stamps[54], 1ull);
+                if (lane == 0) atomicAdd(&b.stamps[55], 1ull);
+            }
+#endif
             if (__any(marked != 0)) {
                 float run0 = 0.f, run1 = 0.f;
                 CumCounts cw = {0u, 0u, 0u};

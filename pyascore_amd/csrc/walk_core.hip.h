@@ -474,56 +474,53 @@ DEV void cnt_prefix_sums(const uint8_t *t, const uint4 *lut, uint32_t pos_cap, u
     }
 }
 
-/* The counts of one site assignment (residue mask `resmask`, k modified residues) from the prefix sums: both directions.
- * Returns the packed cumulative counts; *marked = nodes on its two paths that are marked. */
-DEV CumCounts cnt_eval(const uint4 *P, uint64_t resmask, int L, int k, uint32_t *marked) {
-    uint32_t ax = 0, ay = 0, az = 0, aw = 0;
+/* The counts of a site assignment from the prefix sums.  Direction d, modified residues entering at travel steps
+ * e_1 < ... < e_k (e_0 = 0, e_{k+1} = L - 1):  sum_i P(d, i, e_{i+1}) - P(d, i, e_i)  =  P(d, k, L - 1) + sum_{i=1..k} Q(d, i, e_i),
+ * Q(d, i, s) = P(d, i - 1, s) - P(d, i, s)  (P(d, 0, 0) = 0).  The words are added and subtracted as integers mod 2^32: a
+ * byte field of a Q may be "negative" and borrow from its neighbour, but the final fields are true counts below 256, so
+ * the final word is their packed form whatever happened in between.  The t-th modified SITE of a site assignment (sites
+ * in N -> C order, t = 1 .. k) is the t-th modification of the forward direction and the (k + 1 - t)-th of the backward
+ * one, and a site's residue fixes both steps, so one table serves both directions:
+ *     G(t, site) = Q(0, t, min(pos, L - 1)) + Q(1, k + 1 - t, min(L - 1 - pos, L - 1)),     pos = the site's residue,
+ *     counts = C + sum_t G(t, site_t),   C = P(0, k, L - 1) + P(1, k, L - 1)
+ * -- k reads of 16 bytes per site assignment.  (A modified last residue enters no fragment: its step is capped at
+ * L - 1, where P is the total.)  The fourth word counts the marked nodes on the two paths.
+ * cnt_site_table: G[(t - 1) * n_sites + site] for t = 1 .. k, then C at G[k * n_sites]; one thread per entry. */
+DEV void cnt_site_table(const uint4 *P, const uint8_t *site_pos, int L, int k, int n_sites, uint4 *G, int tid, int nthreads) {
     const int Lm1 = L - 1;
-    {
-        const uint4 *row = P;                               /* direction 0, j = 0 */
-        uint64_t m = resmask;
-        int start = 0;
-        for (int i = 0; i < k; i++, row += L) {
-            const int p = __builtin_ctzll(m);
-            m &= m - 1;
-            const int end = p < Lm1 ? p : Lm1;
-            const uint4 hi = row[end], lo = row[start];
-            ax += hi.x - lo.x;
-            ay += hi.y - lo.y;
-            az += hi.z - lo.z;
-            aw += hi.w - lo.w;
-            start = end;
+    for (int i = tid; i <= k * n_sites; i += nthreads) {
+        uint4 g;
+        if (i == k * n_sites) {
+            const uint4 a = P[(size_t)k * L + Lm1], c = P[(size_t)(k + 1 + k) * L + Lm1];
+            g = make_uint4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+        } else {
+            const int t = i / n_sites + 1, site = i - (t - 1) * n_sites;
+            const int pos = (int)site_pos[site];
+            const int ef = pos < Lm1 ? pos : Lm1, qb = Lm1 - pos, eb = qb < Lm1 ? qb : Lm1;
+            const int tb = k + 1 - t;
+            const uint4 f0 = P[(size_t)(t - 1) * L + ef], f1 = P[(size_t)t * L + ef];
+            const uint4 b0 = P[(size_t)(k + 1 + tb - 1) * L + eb], b1 = P[(size_t)(k + 1 + tb) * L + eb];
+            g = make_uint4((f0.x - f1.x) + (b0.x - b1.x), (f0.y - f1.y) + (b0.y - b1.y), (f0.z - f1.z) + (b0.z - b1.z),
+                           (f0.w - f1.w) + (b0.w - b1.w));
         }
-        const uint4 hi = row[Lm1], lo = row[start];
-        ax += hi.x - lo.x;
-        ay += hi.y - lo.y;
-        az += hi.z - lo.z;
-        aw += hi.w - lo.w;
+        G[i] = g;
     }
-    {
-        const uint4 *row = P + (size_t)(k + 1) * L;         /* direction 1: travel step of residue p is L - 1 - p */
-        uint64_t m = resmask;
-        int start = 0;
-        for (int i = 0; i < k; i++, row += L) {
-            const int p = 63 - __builtin_clzll(m);
-            m &= ~(1ull << p);
-            const int q = Lm1 - p;
-            const int end = q < Lm1 ? q : Lm1;
-            const uint4 hi = row[end], lo = row[start];
-            ax += hi.x - lo.x;
-            ay += hi.y - lo.y;
-            az += hi.z - lo.z;
-            aw += hi.w - lo.w;
-            start = end;
-        }
-        const uint4 hi = row[Lm1], lo = row[start];
-        ax += hi.x - lo.x;
-        ay += hi.y - lo.y;
-        az += hi.z - lo.z;
-        aw += hi.w - lo.w;
+}
+/* the counts of the site assignment `bits` (bit = site, k bits set); *marked = marked nodes on its two paths */
+DEV CumCounts cnt_eval_sites(const uint4 *G, uint32_t bits, int k, int n_sites, uint32_t *marked) {
+    uint4 acc = G[k * n_sites];
+    const uint4 *row = G;
+    for (int t = 0; t < k; t++, row += n_sites) {
+        const int site = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        const uint4 g = row[site];
+        acc.x += g.x;
+        acc.y += g.y;
+        acc.z += g.z;
+        acc.w += g.w;
     }
-    *marked = aw;
-    CumCounts c = {ax, ay, az};
+    *marked = acc.w;
+    CumCounts c = {acc.x, acc.y, acc.z};
     return c;
 }
 
