@@ -226,6 +226,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     PrefixCompact *l1 = (PrefixCompact *)lutl;                   /* [2][64]   */
     uint16_t *vlist = (uint16_t *)(l1 + 2 * 64);                 /* [1024] the level-2 patterns a signature can have */
 
+    STAMP_BEGIN();
     if (b.status[psm] != PYA_ST_OK) return;                      /* (uniform over the workgroup) */
     const uint32_t N = b.n_sig[psm];
     if (N == 0) return;
@@ -251,6 +252,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     if (wave == 0) stage_residues(res, resd, nullptr);
     if (tid < 16) cum_lut[tid] = fused_cum_entry((uint32_t)tid);
     __syncthreads();
+    STAMP_T(b, 13, );
     /* the grid: cell geometry in every wavefront's registers, cells written by wavefront 0 */
     if (wave == 0) {
         grid_build(&tab, grid);
@@ -261,6 +263,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     }
     __syncthreads();
     if (wave == 0) ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)grid)[lane];
+    STAMP_T(b, 14, );
 
     /* ---- the count-node table (walk_core.hip.h): one lookup per (direction, step, modified residues so far), then the
      * prefix sums over the steps.  The envelopes and the prefix sums go through the level-2 table's LDS, which this route
@@ -274,9 +277,10 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
                          (size_t)2 * (k + 1) * pos_cap * sizeof(float2) <= 16384;
     if (use_cnt) {
         float2 *envl = (float2 *)((unsigned char *)l2 + 16384);  /* [2][k + 1][pos_cap] */
-        if (wave == 0) cnt_envelopes(resd, res.site_mask, L, k, pos_cap, envl);
+        if (wave == 0) cnt_envelopes(res, k, pos_cap, envl);
         for (uint32_t i = (uint32_t)tid; i < (uint32_t)score_big_cnt_bytes(pos_cap, kc) / 4u; i += BIG_T) ((uint32_t *)cnt_t)[i] = 0x0f0f0f0fu;
         __syncthreads();
+        STAMP_T(b, 15, );
         double A0 = 0., B0 = 0., A1 = 0., B1 = 0.;
         type_constants(cfg->types[0], &A0, &B0);
         type_constants(cfg->types[cfg->n_fwd], &A1, &B1);
@@ -295,7 +299,8 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
 #endif
         }
         __syncthreads();
-        cnt_prefix_sums(cnt_t, cum_lut, pos_cap, kc, L, k, cntP, tid);
+        STAMP_T(b, 16, );
+        cnt_prefix_sums(cnt_t, cum_lut, pos_cap, kc, L, k, cntP, wave, BIG_WAVES);
         if (wave == 1 && ((res.site_mask >> lane) & 1ull))       /* residue of the j-th modifiable one (first bytes of the envelopes' room) */
             ((uint8_t *)envl)[__popcll(res.site_mask & lanemask_lt())] = (uint8_t)lane;
         __syncthreads();
@@ -334,7 +339,6 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         l1[dir * 64 + lane] = make_entry(run, cum);
     }
     __syncthreads();
-    STAMP_BEGIN();
     STAMP_T(b, 9, );
     /* ---- level 2: the patterns of the first 10 sites that a signature can have (at most k modified,
      * enough sites left for the rest), resumed from level 1.  Which patterns those are depends on their number of

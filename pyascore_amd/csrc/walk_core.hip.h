@@ -404,34 +404,44 @@ DEV void walk_cum_both(const WalkEnv &e, const PeakTable &tab, const uint4 *lut,
  * read, then every walker looks up itself): the three must agree. */
 #define CNT_MARK 0x80u
 
-/* lo / hi of every node (see above), by wavefront 0: lane = d * 32 + j (k + 1 <= 32), written to env[(d * (k + 1) + j) * pos_cap + s]
- * as float2 {lo, hi}; an unreachable node gets lo > hi. */
-DEV void cnt_envelopes(const float2 *resd, uint64_t site_mask, int L, int k, uint32_t pos_cap, float2 *env) {
+/* lo / hi of every node (see above), by one wavefront: lane = d * 32 + j (k + 1 <= 32), written to
+ * env[(d * (k + 1) + j) * pos_cap + s] as float2 {lo, hi}; an unreachable node gets lo > hi.  The residues come from the
+ * wavefront's registers (one residue per lane: a v_readlane per step, the step being wave-uniform) and the neighbour's
+ * state by a whole-wave DPP shift -- the chain of L - 1 dependent steps makes no LDS round trip. */
+DEV float cnt_lane_prev_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+DEV void cnt_envelopes(const Residues &res, int k, uint32_t pos_cap, float2 *env) {
     const int lane = lane_id();
-    const int d = lane >> 5, j = lane & 31;
+    const int d = lane >> 5, j = lane & 31, L = res.L;
     const float inf = __builtin_huge_valf();
-    float lo = 0.f, hi = 0.f;
-    bool valid = j == 0;
+    float lo = 0.f, hi = 0.f, validf = j == 0 ? 1.f : 0.f;
+    float2 *out = env + (size_t)(d * (k + 1) + j) * pos_cap;
     for (int s = 0; s + 1 < L; s++) {
-        const int ri = d ? L - 1 - s : s;
-        const float2 mm = resd[ri];
-        const bool site = (site_mask >> ri) & 1ull;
-        const float lo_m = __shfl_up(lo, 1, 64), hi_m = __shfl_up(hi, 1, 64);
-        const bool v_m = __shfl_up((int)valid, 1, 64) != 0 && j >= 1;
+        const int rf = s, rb = L - 1 - s;
+        const float m0f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), rf));
+        const float m1f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), rf));
+        const float m0b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), rb));
+        const float m1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), rb));
+        const bool site_f = (res.site_mask >> rf) & 1ull, site_b = (res.site_mask >> rb) & 1ull;
+        const float m0 = d ? m0b : m0f, m1 = d ? m1b : m1f;
+        const bool site = d ? site_b : site_f;
+        const float lo_m = cnt_lane_prev_f32(lo), hi_m = cnt_lane_prev_f32(hi);
+        const bool v_m = cnt_lane_prev_f32(validf) != 0.f && j >= 1, valid = validf != 0.f;
         float nlo = inf, nhi = -inf;
         if (valid) {                                        /* the residue enters unmodified */
-            nlo = mm.x + lo;
-            nhi = mm.x + hi;
+            nlo = m0 + lo;
+            nhi = m0 + hi;
         }
         if (site && v_m) {                                  /* ... or modified, from the node with one modification fewer */
-            const float x = mm.y + lo_m, y = mm.y + hi_m;
+            const float x = m1 + lo_m, y = m1 + hi_m;
             nlo = x < nlo ? x : nlo;
             nhi = y > nhi ? y : nhi;
         }
-        valid = valid || (site && v_m);
+        validf = (valid || (site && v_m)) ? 1.f : 0.f;
         lo = nlo;
         hi = nhi;
-        if (j <= k) env[(size_t)(d * (k + 1) + j) * pos_cap + s] = make_float2(lo, hi);
+        if (j <= k) out[s] = make_float2(lo, hi);
     }
 }
 
@@ -455,22 +465,32 @@ DEV uint32_t cnt_table_entry(const PeakTable &t, float lo, float hi, double A, d
 }
 
 /* P(d, j, s) for s = 0 .. L - 1 at P[(d * (k + 1) + j) * L + s]: x, y, z = the packed cumulative-count increments of the
- * nodes (d, j, t < s) summed (bytes: at most L - 1 per field), w = how many of them are marked.  One lane per (d, j). */
-DEV void cnt_prefix_sums(const uint8_t *t, const uint4 *lut, uint32_t pos_cap, uint32_t kc, int L, int k, uint4 *P, int tid) {
-    if (tid >= 2 * (k + 1)) return;
-    const int d = tid / (k + 1), j = tid - d * (k + 1);
-    uint4 *out = P + (size_t)tid * L;
-    const uint8_t *col = t + (size_t)d * pos_cap * kc + j;
-    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
-    out[0] = acc;
-    for (int s = 0; s + 1 < L; s++, col += kc) {
-        const uint32_t ent = *col;
-        const uint4 inc = lut[ent & 15u];
-        acc.x += inc.x;
-        acc.y += inc.y;
-        acc.z += inc.z;
-        acc.w += ent >> 7;
-        out[s + 1] = acc;
+ * nodes (d, j, t < s) summed (bytes: at most L - 1 per field), w = how many of them are marked.  One wavefront per row
+ * (d, j) at a time, one step per lane (L - 1 <= 63), an inclusive scan over the lanes. */
+DEV void cnt_prefix_sums(const uint8_t *t, const uint4 *lut, uint32_t pos_cap, uint32_t kc, int L, int k, uint4 *P, int wave, int n_waves) {
+    const int lane = lane_id();
+    for (int row = wave; row < 2 * (k + 1); row += n_waves) {
+        const int d = row / (k + 1), j = row - d * (k + 1);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (lane + 1 < L) {
+            const uint32_t ent = t[((size_t)d * pos_cap + lane) * kc + j];
+            v = lut[ent & 15u];
+            v.w = ent >> 7;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t x = (uint32_t)__shfl_up((int)v.x, o, 64), y = (uint32_t)__shfl_up((int)v.y, o, 64);
+            const uint32_t z = (uint32_t)__shfl_up((int)v.z, o, 64), w = (uint32_t)__shfl_up((int)v.w, o, 64);
+            if (lane >= o) {
+                v.x += x;
+                v.y += y;
+                v.z += z;
+                v.w += w;
+            }
+        }
+        uint4 *out = P + (size_t)row * L;
+        if (lane == 0) out[0] = make_uint4(0u, 0u, 0u, 0u);
+        if (lane + 1 < L) out[lane + 1] = v;
     }
 }
 
