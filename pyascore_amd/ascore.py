@@ -176,13 +176,17 @@ class PyAscore:
 
     def _retained_bytes(self, arrs):
         """Device bytes a retained (keep=True) plan of this batch holds, per PSM: 16 per raw peak (spectra) + 8 per
-        peak (retained table) + 32 per site assignment (score, count record, order) + grid, descriptor, results."""
+        peak (retained table) + per site assignment the score, the order and the count record (4 + 4 + 4 x its words:
+        32 bytes for n_top = 10, 44 for 16; with n_top > 10 also the general kernel's sort area, 8 more) + grid,
+        descriptor, results."""
         from .shard import comb_table, count_sites
         n_sites = np.clip(count_sites(arrs, self._mod_group), 0, 64)
         k = arrs["n_of_mod"].astype(np.int64)
         sigs = np.where((k >= 0) & (k <= n_sites), comb_table()[n_sites, np.clip(k, 0, 64)], 0.0)
         peaks = np.diff(arrs["peak_off"]).astype(np.float64)
-        return 24.0 * peaks + 32.0 * sigs + 1024.0
+        rec_words = (self._n_top + 1) // 2 + 1
+        per_sig = 8.0 + 4.0 * rec_words + (8.5 if self._n_top != 10 else 0.0)
+        return 24.0 * peaks + per_sig * sigs + 1024.0
 
     def score(self, mz_arr, int_arr, peptide, n_of_mod, max_fragment_charge=1, aux_mod_pos=None,
               aux_mod_mass=None):

@@ -134,12 +134,22 @@ def build(force=False):
     digest = tree_digest()
     vflags = HOST_FLAGS + ['-DPYA_TREE_DIGEST="%s"' % digest]
     vs, vo = os.path.join(CSRC, VERSION_SRC), os.path.join(CSRC, VERSION_SRC + ".o")
-    relink = force or bool(jobs) or not os.path.exists(LIB)
+    # relink when anything was compiled, the library is missing, or it is OLDER than one of its objects (a link that failed
+    # after the compiles of an earlier call leaves fresh objects beside a stale library)
+    relink = force or bool(jobs) or not os.path.exists(LIB) or \
+        any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs if os.path.exists(o))
     if relink or _stale(vo, vflags):
         _compile(["g++"], vflags, vs, vo)
         relink = True
     if relink:
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + [vo])
+        try:
+            _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + [vo])
+        except BaseException:
+            # the version object names a tree no library was linked from: the next call must link again
+            for stale in (vo, vo + ".flags"):
+                if os.path.exists(stale):
+                    os.remove(stale)
+            raise
     build_fast(force)
     return LIB
 

@@ -289,9 +289,11 @@ DEV int gen_ascore_pair(const BatchDev &b, const DevConfig *cfg, const GenLds &g
     return __any(fail) ? 1 : 0;
 }
 
+/* scratch_off[i]: where the i-th PSM of the list has its slice of `scratch` -- sized for ITS OWN number of site assignments
+ * and competitors (pya_general_scratch_bytes), not for the launch's largest (r04 advisor finding: one PSM with millions
+ * of site assignments made every general PSM of the batch reserve as much) */
 __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const uint32_t *ids, uint32_t n_ids, unsigned char *scratch,
-                                                              uint64_t scratch_stride, uint32_t n_cap, uint32_t push_cap,
-                                                              uint32_t l_cap, uint32_t list_cap) {
+                                                              const uint64_t *scratch_off, uint32_t l_cap, uint32_t list_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (blockIdx.x >= n_ids) return;
     const uint32_t psm = ids[blockIdx.x];
@@ -299,8 +301,7 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
     const DevConfig *cfg = b.cfg;
     const GenLds g = gen_carve(lds_raw, l_cap, list_cap);
     const uint32_t lc = (l_cap + 3u) & ~3u;
-    unsigned char *my = scratch + (size_t)blockIdx.x * scratch_stride;
-    PushedEntry *pushed = (PushedEntry *)(my + sort_global_bytes(n_cap));
+    unsigned char *my = scratch + scratch_off[blockIdx.x];
 
     const uint32_t max_k = b.max_k;
     float *out_asc = b.ascores + (size_t)psm * max_k;
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
     const int k = b.n_of_mod[psm];
     const int zmax = b.max_charge[psm];
     const int N = (int)b.n_sig[psm];
+    PushedEntry *pushed = (PushedEntry *)(my + ((sort_global_bytes((size_t)N) + 15) & ~(size_t)15));
     const uint64_t *order = b.order_tab + b.order_off[psm];
     const uint32_t *inv = b.inv_tab + b.order_off[psm];
     const int64_t s0 = b.sig_off[psm];
@@ -335,6 +337,8 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
     const uint32_t rec_words = (uint32_t)(ntop + 1) / 2u + 1u;    /* count record: ntop 16-bit counts + the fragment total (host_internal.h: rec_words) */
 
     const int n_sites = gen_setup_residues(b, cfg, g, psm, pep0, L);
+    /* (its own competitors: k (n - k) single moves -- what the host sized the slice for) */
+    const uint32_t push_cap = k >= 0 && k <= n_sites ? (((uint32_t)k * (uint32_t)(n_sites - k)) + 3u) & ~3u : 0u;
 
     /* ---- counts and PepScores, one site assignment per lane and trip (Ascore.cpp:53-139) ---- */
     int fail = 0;
@@ -606,15 +610,16 @@ extern "C" size_t pya_general_scratch_bytes(uint32_t n_cap, uint32_t push_cap) {
     return ((sort_global_bytes(n_cap) + 15) & ~(size_t)15) + (size_t)push_cap * sizeof(PushedEntry) + 64;
 }
 
+/* d_scratch_off[n_ids]: the PSMs' slices of d_scratch, each pya_general_scratch_bytes(its site assignments, its k (n - k)
+ * rounded up to a multiple of 4) long */
 extern "C" int pya_launch_general(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch,
-                                  uint64_t scratch_stride, uint32_t n_cap, uint32_t push_cap, uint32_t l_cap, uint32_t list_cap,
-                                  hipStream_t stream) {
+                                  const uint64_t *d_scratch_off, uint32_t l_cap, uint32_t list_cap, hipStream_t stream) {
     if (n_ids == 0) return 0;
     const size_t lds = gen_lds_bytes(l_cap, list_cap);
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_general_psm_kernel);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pya_general_psm_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, d_scratch, scratch_stride,
-                       n_cap, push_cap, l_cap, list_cap);
+    hipLaunchKernelGGL(pya_general_psm_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, d_scratch, d_scratch_off,
+                       l_cap, list_cap);
     return (int)hipGetLastError();
 }
 

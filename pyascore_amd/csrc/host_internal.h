@@ -95,8 +95,8 @@ int pya_launch_bin_global(const BatchDev *b, const uint32_t *d_ids, uint32_t n_i
                           uint32_t cap, hipStream_t stream);
 size_t pya_general_lds_bytes(uint32_t l_cap, uint32_t list_cap);
 size_t pya_general_scratch_bytes(uint32_t n_cap, uint32_t push_cap);
-int pya_launch_general(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch, uint64_t scratch_stride,
-                       uint32_t n_cap, uint32_t push_cap, uint32_t l_cap, uint32_t list_cap, hipStream_t stream);
+int pya_launch_general(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch, const uint64_t *d_scratch_off,
+                       uint32_t l_cap, uint32_t list_cap, hipStream_t stream);
 int pya_launch_general_ambiguity(const BatchDev *b, uint32_t psm, uint32_t l_cap, uint32_t list_cap, uint64_t ref_bits,
                                  uint64_t oth_bits, const float *d_scores, uint32_t n_scores, float ref_ws, float oth_ws,
                                  float *d_out, hipStream_t stream);
@@ -450,8 +450,9 @@ struct pya_plan {
     std::vector<uint32_t> gen_ids;
     DevBuf<uint32_t> d_gen_ids;
     DevBuf<unsigned char> d_gen_scratch;
-    uint32_t gen_n_cap = 1, gen_push_cap = 1, gen_l_cap = 1, gen_list_cap = 1;
-    size_t gen_stride = 0;
+    uint32_t gen_l_cap = 1, gen_list_cap = 1;
+    std::vector<uint64_t> gen_off;      /* [gen_ids.size() + 1] every general PSM's own slice of the scratch */
+    DevBuf<uint64_t> d_gen_off;
     /* ... of them the spectra of more than 8 192 peaks: binned by pya_bin_global_kernel (arrays in the workspace) */
     std::vector<uint32_t> bigbin_ids;
     DevBuf<uint32_t> d_bigbin_ids;

@@ -294,8 +294,12 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
             /* beyond a limit of the fast kernels (or n_top > 10): the general kernel takes the PSM whole */
             p->gen[i] = 1;
             p->gen_ids.push_back((uint32_t)i);
-            p->gen_n_cap = std::max<uint32_t>(p->gen_n_cap, (uint32_t)N);
-            p->gen_push_cap = std::max<uint32_t>(p->gen_push_cap, (uint32_t)k <= ns ? (uint32_t)k * (ns - (uint32_t)k) : 0u);
+            {
+                /* its own slice of the general kernel's scratch: sort area for ITS site assignments, room for ITS competitors */
+                const uint32_t push = ((uint32_t)k <= ns ? (uint32_t)k * (ns - (uint32_t)k) : 0u);
+                if (p->gen_off.empty()) p->gen_off.push_back(0);
+                p->gen_off.push_back(p->gen_off.back() + ((pya_general_scratch_bytes((uint32_t)N, (push + 3u) & ~3u) + 255) & ~(size_t)255));
+            }
             p->gen_l_cap = std::max<uint32_t>(p->gen_l_cap, (uint32_t)L);
             p->gen_list_cap = std::max<uint32_t>(p->gen_list_cap, per_type);
             if (P > PYA_FAST_PEAKS) {
@@ -625,6 +629,7 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
                      o_big_ids = meta(p->big_ids.data(), p->big_ids.size() * 4);
         const size_t o_bigloc_ids = meta(p->bigloc.ids.data(), p->bigloc.ids.size() * 4);
         const size_t o_gen_ids = meta(p->gen_ids.data(), p->gen_ids.size() * 4);
+        const size_t o_gen_off = meta(p->gen_off.data(), p->gen_off.size() * 8);
         const size_t o_bigbin_ids = meta(p->bigbin_ids.data(), p->bigbin_ids.size() * 4);
         size_t o_bucket_ids[kNumBuckets];
         for (int i = 0; i < kNumBuckets; i++)
@@ -649,9 +654,8 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
                      o_grid = reserve(n * PYA_GRID_CELLS * 2), o_redo = reserve((n + 64) * 4), o_redo3 = reserve((2 * n + 64) * 4), o_redo4 = reserve(((size_t)p->n_fused_total + 64) * 4), o_redo5 = reserve(((size_t)p->n_big_inline + 64) * 4), o_ws_top = reserve(n * 16),
                      o_ws = reserve((size_t)sig_total * 4), o_rec = reserve((size_t)sig_total * h->rec_words() * 4),
                      o_sorted = reserve((flags & PYA_FLAG_KEEP) ? (size_t)sig_total * 4 : 0);
-        p->gen_push_cap = (p->gen_push_cap + 3u) & ~3u;
-        p->gen_stride = p->gen_ids.empty() ? 0 : (pya_general_scratch_bytes(p->gen_n_cap, p->gen_push_cap) + 255) & ~(size_t)255;
-        const size_t o_gen_scratch = reserve(p->gen_ids.size() * p->gen_stride);
+        const size_t gen_scratch_bytes = p->gen_off.empty() ? 0 : (size_t)p->gen_off.back();
+        const size_t o_gen_scratch = reserve(gen_scratch_bytes);
         p->bigbin_stride = p->bigbin_ids.empty() ? 0 : (pya_bin_global_scratch_bytes(p->bigbin_cap) + 255) & ~(size_t)255;
         const size_t o_bigbin_scratch = reserve(p->bigbin_ids.size() * p->bigbin_stride);
         if (!p->arena.take_if_fits(h->spare_arena, total) && !p->arena.take_if_fits(h->spare_arena2, total))
@@ -679,7 +683,8 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
             p->buckets[i].d_ids.adopt(base + o_bucket_ids[i], p->buckets[i].ids.size());
         p->bigloc.d_ids.adopt(base + o_bigloc_ids, p->bigloc.ids.size());
         p->d_gen_ids.adopt(base + o_gen_ids, p->gen_ids.size());
-        p->d_gen_scratch.adopt(base + o_gen_scratch, p->gen_ids.size() * p->gen_stride);
+        p->d_gen_scratch.adopt(base + o_gen_scratch, gen_scratch_bytes);
+        p->d_gen_off.adopt(base + o_gen_off, p->gen_off.size());
         p->d_bigbin_ids.adopt(base + o_bigbin_ids, p->bigbin_ids.size());
         p->d_bigbin_scratch.adopt(base + o_bigbin_scratch, p->bigbin_ids.size() * p->bigbin_stride);
         if (io) {
@@ -823,7 +828,11 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     d.redo_count = cnt;
     d.redo4_count = cnt + 1;
     d.zero_next = p->d_redo.p + 8 * ((p->n_runs + 1u) & 1u);
-    if (p->n_runs == 0 || p->bin_lists.empty()) HIPCHK(h, hipMemsetAsync(p->d_redo.p, 0, 16 * sizeof(uint32_t), st));
+    /* (the binning kernel zeroes the next run's set only when it is launched: a plan whose lists are all empty -- every
+     * spectrum binned by the global kernel, or set aside -- has nobody to do it) */
+    bool any_bin = false;
+    for (const pya_plan::IdList &l : p->bin_lists) any_bin = any_bin || l.n != 0;
+    if (p->n_runs == 0 || !any_bin) HIPCHK(h, hipMemsetAsync(p->d_redo.p, 0, 16 * sizeof(uint32_t), st));
     p->n_runs++;
     int e = 0;
     for (const pya_plan::IdList &l : p->bin_lists) {
@@ -915,8 +924,8 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
     }
     if (!p->gen_ids.empty()) {
-        e = pya_launch_general(&d, p->d_gen_ids.p, (uint32_t)p->gen_ids.size(), p->d_gen_scratch.p, p->gen_stride, p->gen_n_cap,
-                               p->gen_push_cap, p->gen_l_cap, p->gen_list_cap, st);
+        e = pya_launch_general(&d, p->d_gen_ids.p, (uint32_t)p->gen_ids.size(), p->d_gen_scratch.p, p->d_gen_off.p, p->gen_l_cap,
+                               p->gen_list_cap, st);
         if (e) return h->hip_fail((hipError_t)e, "general kernel launch");
     }
     if (timing) {

@@ -925,6 +925,34 @@ def test_calculate_ambiguity_beyond_the_fast_kernel():
                 g2.calculate_ambiguity(dict(ps[0], scores=ps[0]["scores"][:10]), ps[1])
 
 
+def test_one_huge_psm_does_not_size_everybody_elses_scratch():
+    """The general kernel's scratch (sort area of the std::sort emulation, competitor list) is a slice per PSM, sized for
+    that PSM: a batch of a thousand small PSMs and ONE with C(20,10) = 184 756 site assignments on a scorer with n_top = 12
+    (every PSM through the general kernel) needs megabytes, not a thousand times the big one's room (r04 advisor
+    finding: it was sized by the largest), and pya_score_batch's chunking accounts for it."""
+    from pyascore_amd import PyAscore
+    from pyascore_amd.device import DevicePlan
+    small, settings = synth.make_batch("cfg2", n_psm=1000, seed=61)
+    big, _ = _long_batch(30, 20, 10, 1, 62)
+    st = dict(settings, n_top=12)
+    psms = []
+    for bt in (small, big):
+        for i in range(bt["n_psm"]):
+            kw = synth.unpack_psm(bt, i)
+            psms.append(dict(mz=kw["mz_arr"], intensity=kw["int_arr"], peptide=kw["peptide"], n_of_mod=kw["n_of_mod"],
+                             max_charge=kw["max_fragment_charge"]))
+    batch = synth.pack_batch(psms)
+    gpu, chk = _gpu(st), _checker(st)
+    plan = DevicePlan(gpu, batch)
+    assert plan.workspace_bytes < 64 << 20, plan.workspace_bytes          # (sized by the largest: 1001 x 1.5 MB)
+    plan.close()
+    got = gpu.score_batch(batch)
+    want = chk.score_batch(batch, got["ascores"].shape[1])
+    for key in ("n_sig", "best_sig", "best_score", "alt_mask", "ascores"):
+        assert np.array_equal(got[key], want[key]), key
+    assert int(got["n_sig"][-1]) == 184756
+
+
 def test_spectra_of_more_than_8192_peaks():
     """8 193 to 65 535 peaks: binned by pya_bin_global_kernel (the general binning body with its arrays in the workspace),
     scored by the general kernel; sorted, unsorted and tie-heavy, next to ordinary PSMs in one batch."""
