@@ -176,6 +176,23 @@ DEV uint64_t load_types64(const DevConfig *cfg) {
 }
 DEV uint8_t type_at(uint64_t types64, int t) { return (uint8_t)(types64 >> (8 * t)); }
 
+/* e / d for e*d < 2^32 with a precomputed multiplier (integer division is ~40 instructions) */
+struct FastDiv {
+    uint32_t d, m;
+};
+DEV FastDiv fastdiv_make(uint32_t d) {
+    FastDiv f;
+    f.d = d ? d : 1u;
+    f.m = (uint32_t)__builtin_ceil(4294967296.0 / (double)f.d);
+    return f;
+}
+DEV uint32_t fastdiv(uint32_t e, const FastDiv &f) {
+    if (f.d == 1u) return e;                             /* 2^32 / 1 does not fit the multiplier */
+    uint32_t q = __umulhi(e, f.m);
+    return q * f.d > e ? q - 1u : q;                     /* the multiplier can be one too large */
+}
+
+
 DEV float charge_mz(double m, int z) {
     if (z == 1) return (float)(m + 1.007825);             /* (m + 1*P)/1 is exact in both steps */
     /* dividing by a power of two is a multiplication by its (exact) reciprocal: same bits as the IEEE

@@ -90,6 +90,9 @@ size_t pya_fused_lds_bytes(uint32_t cap, uint32_t n_cap, uint32_t stride, uint32
 int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t n_cap,
                      uint32_t stride, uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, uint32_t both,
                      uint32_t multi_z, uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream);
+size_t pya_score_cnt_lds_bytes(uint32_t cap, uint32_t pos_cap, uint32_t kc, uint32_t k_cap, uint32_t n_cap);
+int pya_launch_score_cnt(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap, uint32_t kc, uint32_t k_cap,
+                         uint32_t n_cap, hipStream_t stream);
 size_t pya_bin_global_scratch_bytes(uint32_t cap);
 int pya_launch_bin_global(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch, uint64_t stride,
                           uint32_t cap, hipStream_t stream);
@@ -210,7 +213,7 @@ struct Knobs {
     bool no_plain = false, no_fused = false, no_big = false, no_tiny = false, no_prefix = false, no_chunks = false;
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
     bool host_timing = false, stamps = false, sort_room = false, no_big_inline = false;
-    bool no_loc_hash = false, no_nodes = false;
+    bool no_loc_hash = false, no_nodes = false, no_cnt = false;
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64;
     uint32_t sort_room_max = 1024;
@@ -372,6 +375,7 @@ struct Bucket {
         return 2u * per_sig > want ? 2u * per_sig : want;
     }
     uint32_t n_types = 1, k_max = 1;
+    uint32_t ns_max = 1;                /* most modifiable residues of one PSM */
     uint32_t z_max = 1;                 /* largest fragment charge in the bucket */
     uint32_t list_max = 1;              /* longest fragment list of one (signature, ion type) */
     uint32_t pair_cap = 1;              /* largest (L - 1) * loss variants: (prefix, variant) pairs of one fragment list */

@@ -340,6 +340,7 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
             bk.pos_cap = std::max<uint32_t>(bk.pos_cap, (uint32_t)std::max<int64_t>(L - 1, 1));
             bk.n_types = n_types;
             bk.k_max = std::max<uint32_t>(bk.k_max, (uint32_t)k);
+            bk.ns_max = std::max<uint32_t>(bk.ns_max, ns);
             bk.push_max = std::max<uint32_t>(bk.push_max, (uint32_t)k * (ns - (uint32_t)k));
             bk.z_max = std::max<uint32_t>(bk.z_max, (uint32_t)z);
             bk.pair_cap = std::max<uint32_t>(bk.pair_cap, (uint32_t)(L - 1) * n_uniq);
@@ -372,6 +373,7 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
                 bk.pos_cap = std::max(bk.pos_cap, bl.pos_cap);
                 bk.n_types = bl.n_types;
                 bk.k_max = std::max(bk.k_max, bl.k_max);
+                bk.ns_max = std::max(bk.ns_max, bl.ns_max);
                 bk.push_max = std::max(bk.push_max, bl.push_max);
                 bk.z_max = std::max(bk.z_max, bl.z_max);
             }
@@ -409,6 +411,7 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
             b0.pos_cap = std::max(b0.pos_cap, fb.pos_cap);
             b0.n_types = std::max(b0.n_types, fb.n_types);
             b0.k_max = std::max(b0.k_max, fb.k_max);
+            b0.ns_max = std::max(b0.ns_max, fb.ns_max);
             b0.push_max = std::max(b0.push_max, fb.push_max);
             b0.z_max = std::max(b0.z_max, fb.z_max);
             fb.ids.clear();
@@ -854,6 +857,18 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
          * the assignment tree instead of one per signature (score_core.hip.h: score_nodes_dir) */
         const Bucket &sbk = p->buckets[l.ncls];
         const bool general = h->cfg.n_nl != 0 || h->cfg.n_fwd > 1 || h->cfg.n_types - h->cfg.n_fwd > 1;
+        /* many site assignments (classes above 64) under the plain settings with both directions, charge 1: the count-node
+         * table decides the fragments (score_cnt.hip) */
+        if (l.ncls >= 1 && !general && h->cfg.n_fwd == 1 && h->cfg.n_types == 2 && sbk.z_max == 1 && h->mz_error <= 0.49f &&
+            sbk.k_max + 1u <= 31u && sbk.ns_max <= 32u && !h->kn.no_cnt && !(h->kn.debug & 0x8000u)) {
+            uint32_t kc = 8u;
+            while (kc < sbk.k_max + 1u) kc <<= 1;
+            if (pya_score_cnt_lds_bytes(l.cap, sbk.pos_cap, kc, sbk.k_max, sbk.ns_max) <= 64u * 1024u) {
+                e = pya_launch_score_cnt(&d, p->d_score_ids.p + l.off, l.n, l.cap, sbk.pos_cap, kc, sbk.k_max, sbk.ns_max, st);
+                if (e) return h->hip_fail((hipError_t)e, "score_cnt launch");
+                continue;
+            }
+        }
         uint32_t node_cap = 0, node_cols = std::max<uint32_t>(8u, (sbk.node_cols + 7u) & ~7u);
         /* (the node kernel's LDS decides its occupancy: residue and loss-state tables by the launch, room for 320 nodes
          * per direction -- cfg4's shape needs 186 on average, 328 at most; a direction with more is walked) */

@@ -42,7 +42,7 @@ bool set_knob(Knobs &k, const char *key, const char *value) {
         {"PYA_NO_UPLOAD_THREAD", &Knobs::no_upload_thread}, {"PYA_ONE_PEAK_CLASS", &Knobs::one_peak_class},
         {"PYA_PEAK_CLASSES", &Knobs::peak_classes}, {"PYA_ONE_LDS_CLASS", &Knobs::one_lds_class},
         {"PYA_SORT_ROOM", &Knobs::sort_room}, {"PYA_NO_BIG_INLINE", &Knobs::no_big_inline},
-        {"PYA_NO_LOC_HASH", &Knobs::no_loc_hash}, {"PYA_NO_NODES", &Knobs::no_nodes},
+        {"PYA_NO_LOC_HASH", &Knobs::no_loc_hash}, {"PYA_NO_CNT", &Knobs::no_cnt}, {"PYA_NO_NODES", &Knobs::no_nodes},
         {"PYA_HOST_TIMING", &Knobs::host_timing}, {"PYA_STAMPS", &Knobs::stamps},
     };
     bool known = false;

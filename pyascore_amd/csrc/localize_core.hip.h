@@ -725,22 +725,6 @@ DEV int ilog2_ceil(int v) {                     /* smallest g with (1 << g) >= v
     return g;
 }
 
-/* e / d for e*d < 2^32 with a precomputed multiplier (integer division is ~40 instructions) */
-struct FastDiv {
-    uint32_t d, m;
-};
-DEV FastDiv fastdiv_make(uint32_t d) {
-    FastDiv f;
-    f.d = d ? d : 1u;
-    f.m = (uint32_t)__builtin_ceil(4294967296.0 / (double)f.d);
-    return f;
-}
-DEV uint32_t fastdiv(uint32_t e, const FastDiv &f) {
-    if (f.d == 1u) return e;                             /* 2^32 / 1 does not fit the multiplier */
-    uint32_t q = __umulhi(e, f.m);
-    return q * f.d > e ? q - 1u : q;                     /* the multiplier can be one too large */
-}
-
 #define LOC_STAGE 128          /* surviving ions collected before they are looked up together */
 
 /* Surviving ions are few and scattered: they are collected into a dense staging buffer and looked
