@@ -66,12 +66,18 @@ DEV CntLds cnt_carve(unsigned char *raw, uint32_t cap, uint32_t pos_cap, uint32_
 DEV void site_prefix_sums(const CntLds &c, uint32_t pos_cap, uint32_t kc, int L, int k, int n_sites) {
     const int lane = lane_id();
     const int Lm1 = L - 1;
-    const int pos = lane < n_sites ? (int)c.site_pos[lane] : 0;
-    for (int row = 0; row < 2 * (k + 1); row++) {
-        const int d = row / (k + 1), j = row - d * (k + 1);
+    /* peptides of up to 33 residues (most): two rows at a time, one per half of the wavefront */
+    const bool two = Lm1 <= 32 && n_sites <= 32;
+    const int half = two ? lane >> 5 : 0, sl = two ? lane & 31 : lane, base = two ? (lane & 32) : 0;
+    const int pos = sl < n_sites ? (int)c.site_pos[sl] : 0;
+    const int rows = 2 * (k + 1);
+    for (int r0 = 0; r0 < rows; r0 += two ? 2 : 1) {
+        const int row = r0 + half;
+        const bool row_on = row < rows;
+        const int d = row_on ? row / (k + 1) : 0, j = row_on ? row - d * (k + 1) : 0;
         uint32_t x = 0, y = 0, z = 0;
-        if (lane < Lm1) {
-            const uint32_t ent = c.T[((size_t)d * pos_cap + lane) * kc + j];
+        if (sl < Lm1 && row_on) {
+            const uint32_t ent = c.T[((size_t)d * pos_cap + sl) * kc + j];
             const uint4 inc = c.cum_lut[ent & 15u];
             x = inc.x;
             y = inc.y;
@@ -79,24 +85,26 @@ DEV void site_prefix_sums(const CntLds &c, uint32_t pos_cap, uint32_t kc, int L,
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
+            if (two && o >= 32) break;
             const uint32_t ux = (uint32_t)__shfl_up((int)x, o, 64), uy = (uint32_t)__shfl_up((int)y, o, 64), uz = (uint32_t)__shfl_up((int)z, o, 64);
-            if (lane >= o) {
+            if (sl >= o) {
                 x += ux;
                 y += uy;
                 z += uz;
             }
         }
-        /* lane i: the sum over the steps below e = min(step of site i, L - 1) = the inclusive value of lane e - 1 */
+        /* lane i of the row's half: the sum over the steps below e = min(step of site i, L - 1) = the inclusive value of step e - 1 */
         const int st = d ? Lm1 - pos : pos;
         const int e = st < Lm1 ? st : Lm1;
-        const int src = e > 0 ? e - 1 : 0;
+        const int src = base + (e > 0 ? e - 1 : 0), last = base + (Lm1 > 0 ? Lm1 - 1 : 0);
         uint32_t px = (uint32_t)__shfl((int)x, src, 64), py = (uint32_t)__shfl((int)y, src, 64), pz = (uint32_t)__shfl((int)z, src, 64);
         if (e == 0) px = py = pz = 0u;
-        const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)x, Lm1 > 0 ? Lm1 - 1 : 0), ty = (uint32_t)__builtin_amdgcn_readlane((int)y, Lm1 > 0 ? Lm1 - 1 : 0),
-                       tz = (uint32_t)__builtin_amdgcn_readlane((int)z, Lm1 > 0 ? Lm1 - 1 : 0);
-        uint4 *out = c.psite + (size_t)row * (n_sites + 1);
-        if (lane < n_sites) out[lane] = make_uint4(px, py, pz, 0u);
-        if (lane == 0) out[n_sites] = make_uint4(tx, ty, tz, 0u);
+        const uint32_t tx = (uint32_t)__shfl((int)x, last, 64), ty = (uint32_t)__shfl((int)y, last, 64), tz = (uint32_t)__shfl((int)z, last, 64);
+        if (row_on) {
+            uint4 *out = c.psite + (size_t)row * (n_sites + 1);
+            if (sl < n_sites) out[sl] = make_uint4(px, py, pz, 0u);
+            if (sl == 0) out[n_sites] = make_uint4(tx, ty, tz, 0u);
+        }
     }
 }
 

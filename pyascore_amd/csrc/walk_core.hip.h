@@ -415,33 +415,31 @@ DEV void cnt_envelopes(const Residues &res, int k, uint32_t pos_cap, float2 *env
     const int lane = lane_id();
     const int d = lane >> 5, j = lane & 31, L = res.L;
     const float inf = __builtin_huge_valf();
-    float lo = 0.f, hi = 0.f, validf = j == 0 ? 1.f : 0.f;
+    /* an unreachable node is lo = +inf, hi = -inf: the additions keep it so (the masses are finite), so no flag travels.
+     * Lane j = 0 of either half has no neighbour below: the DPP shift hands it +inf / -inf (lanes 31 and 63 hold j = 31, never
+     * reachable: k + 1 <= 31). */
+    float lo = j == 0 ? 0.f : inf, hi = j == 0 ? 0.f : -inf;
     float2 *out = env + (size_t)(d * (k + 1) + j) * pos_cap;
+    const bool keep = j <= k;
     for (int s = 0; s + 1 < L; s++) {
         const int rf = s, rb = L - 1 - s;
         const float m0f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), rf));
         const float m1f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), rf));
         const float m0b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m0), rb));
         const float m1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(res.m1), rb));
+        /* a residue that cannot be modified offers no second way in: its "modified mass" is +inf for lo, -inf for hi */
         const bool site_f = (res.site_mask >> rf) & 1ull, site_b = (res.site_mask >> rb) & 1ull;
-        const float m0 = d ? m0b : m0f, m1 = d ? m1b : m1f;
-        const bool site = d ? site_b : site_f;
-        const float lo_m = cnt_lane_prev_f32(lo), hi_m = cnt_lane_prev_f32(hi);
-        const bool v_m = cnt_lane_prev_f32(validf) != 0.f && j >= 1, valid = validf != 0.f;
-        float nlo = inf, nhi = -inf;
-        if (valid) {                                        /* the residue enters unmodified */
-            nlo = m0 + lo;
-            nhi = m0 + hi;
+        const float m1lf = site_f ? m1f : inf, m1hf = site_f ? m1f : -inf, m1lb = site_b ? m1b : inf, m1hb = site_b ? m1b : -inf;   /* (scalar selects) */
+        const float m0 = d ? m0b : m0f, m1l = d ? m1lb : m1lf, m1h = d ? m1hb : m1hf;
+        float lo_m = cnt_lane_prev_f32(lo), hi_m = cnt_lane_prev_f32(hi);
+        if (j == 0) {
+            lo_m = inf;
+            hi_m = -inf;
         }
-        if (site && v_m) {                                  /* ... or modified, from the node with one modification fewer */
-            const float x = m1 + lo_m, y = m1 + hi_m;
-            nlo = x < nlo ? x : nlo;
-            nhi = y > nhi ? y : nhi;
-        }
-        validf = (valid || (site && v_m)) ? 1.f : 0.f;
-        lo = nlo;
-        hi = nhi;
-        if (j <= k) out[s] = make_float2(lo, hi);
+        const float a = m0 + lo, c = m1l + lo_m, e = m0 + hi, g = m1h + hi_m;
+        lo = a < c ? a : c;
+        hi = e > g ? e : g;
+        if (keep) out[s] = make_float2(lo, hi);
     }
 }
 

@@ -53,9 +53,14 @@ def _edge_spectra(batch, settings, rng, frac_ulp):
     return dict(batch, mz=np.concatenate(mzs), intensity=np.concatenate(its), peak_off=np.asarray(offs, np.int64))
 
 
+# thousands of site assignments (score_big.hip: one PSM per 8-wavefront workgroup) ...
 CASES = [({}, {}), (dict(L=24, n_sites=14, n_mod=6), {}), (dict(L=40, n_sites=12, n_mod=4), dict(mz_error=0.2)),
          (dict(L=18, n_sites=13, n_mod=7), dict(mz_error=0.01)), ({}, dict(fragment_types="cz")),
-         (dict(L=35, n_sites=16, n_mod=3), dict(fragment_types="zb", mz_error=0.45))]
+         (dict(L=35, n_sites=16, n_mod=3), dict(fragment_types="zb", mz_error=0.45)),
+         # ... and 65 to 1024 (score_cnt.hip: one PSM per wavefront): C(12,4) = 495, C(9,4) = 126, C(11,2) = 55 < 65 (walkers), C(13,2) = 78,
+         # a 64-residue peptide, the N-terminus and a lysine as sites
+         (dict(L=40, n_sites=12, n_mod=4), {}), (dict(L=12, n_sites=9, n_mod=4), dict(mz_error=0.3)), (dict(L=30, n_sites=11, n_mod=2), {}),
+         (dict(L=20, n_sites=13, n_mod=2), dict(fragment_types="zc", mz_error=0.02)), (dict(L=64, n_sites=10, n_mod=5), dict(mz_error=0.1))]
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
