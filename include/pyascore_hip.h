@@ -63,6 +63,7 @@ extern "C" {
 #define PYA_MAX_PEAKS 65535                /* peaks of one spectrum */
 #define PYA_FAST_PEAKS 8192
 #define PYA_MAX_FRAGMENT_TYPES 8
+#define PYA_MAX_CHARGE 255                 /* max_fragment_charge (the fragments per ion type above bound it long before) */
 #define PYA_MAX_NL_VALUES 4
 #define PYA_N_TOP 10                       /* the value everything is built for (the reference's command line passes 10) */
 #define PYA_MAX_N_TOP 16                   /* 11..16: every PSM of the scorer goes through the general kernel            */

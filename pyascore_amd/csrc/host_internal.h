@@ -349,12 +349,13 @@ struct Bucket {
      * localize, the number of batches its instruction count. */
     uint32_t sb() const {
         if (g_knob_sb >= 0) return (uint32_t)g_knob_sb;                            /* A/B experiments (PYA_SB) */
-        /* one batch should hold the winner and one competitor per modified site; long peptides
-         * have large per-signature tables, so they get fewer (measured: profiles/r01_c) */
+        /* one batch holds the winner and one competitor per modified site.  (r01 gave long peptides -- large per-signature
+         * tables -- two fewer to keep the LDS, hence the occupancy, up; r05 measured the opposite on cfg3, whose 40-mers then
+         * needed two or three batches where one does: 0.465 -> 0.431 ms with the full batch.  These kernels are bound by the
+         * instructions they issue, not by residency: DESIGN.md section 6.) */
         uint32_t v = k_max + 1;
         if (v < 2) v = 2;
         if (v > PYA_LOC_SB_MAX) v = PYA_LOC_SB_MAX;
-        if (pos_cap > 32 && v > 3) v = v - 2 < 3 ? 3 : v - 2;
         return v;
     }
     /* Ion types localised per pass (log2): as many as keep one signature's lists <= 256 floats,

@@ -200,7 +200,8 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     if (L < 1 || L > PYA_MAX_PEPTIDE_LEN)
         return h->fail(L < 1 ? PYA_ERR_PSM : PYA_ERR_LIMIT, 0, "PSM 0: peptide length %lld outside 1..%d", (long long)L, PYA_MAX_PEPTIDE_LEN);
     if (n_of_mod < 0) return h->fail(PYA_ERR_PSM, 0, "PSM 0: negative n_of_mod");
-    if (max_charge < 1 || max_charge > 16) return h->fail(PYA_ERR_PSM, 0, "PSM 0: max_fragment_charge %d outside 1..16", max_charge);
+    if (max_charge < 1 || max_charge > PYA_MAX_CHARGE)
+        return h->fail(max_charge < 1 ? PYA_ERR_PSM : PYA_ERR_LIMIT, 0, "PSM 0: max_fragment_charge %d outside 1..%d", max_charge, PYA_MAX_CHARGE);
     uint32_t ns = 0;
     for (uint64_t j = 0; j < L; j++) {
         if (!h->is_residue[pep[j]])

@@ -157,7 +157,7 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
                 const int64_t P = p->peak_off[i + 1] - p->peak_off[i];
                 const int64_t L = p->pep_off[i + 1] - p->pep_off[i];
                 const int32_t k = p->n_of_mod[i], z = p->max_charge[i];
-                bool ok = P > 0 && P <= PYA_MAX_PEAKS && L >= 1 && L <= PYA_MAX_PEPTIDE_LEN && k >= 0 && z >= 1 && z <= 16 &&
+                bool ok = P > 0 && P <= PYA_MAX_PEAKS && L >= 1 && L <= PYA_MAX_PEPTIDE_LEN && k >= 0 && z >= 1 && z <= PYA_MAX_CHARGE &&
                           p->aux_off[i + 1] >= p->aux_off[i];
                 uint32_t ns = 0;
                 if (ok) {
@@ -222,8 +222,8 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
                 rc2 = reject(L < 1 ? PYA_ERR_PSM : PYA_ERR_LIMIT, i, "PSM %llu: peptide length %lld outside 1..%d",
                              (unsigned long long)iu, (long long)L, PYA_MAX_PEPTIDE_LEN);
             else if (k < 0) rc2 = reject(PYA_ERR_PSM, i, "PSM %llu: negative n_of_mod", (unsigned long long)iu);
-            else if (z < 1 || z > 16)
-                rc2 = reject(PYA_ERR_PSM, i, "PSM %llu: max_fragment_charge %d outside 1..16", (unsigned long long)iu, z);
+            else if (z < 1 || z > PYA_MAX_CHARGE)
+                rc2 = reject(z < 1 ? PYA_ERR_PSM : PYA_ERR_LIMIT, i, "PSM %llu: max_fragment_charge %d outside 1..%d", (unsigned long long)iu, z, PYA_MAX_CHARGE);
             else if (p->aux_off[i + 1] < p->aux_off[i])
                 rc2 = reject(PYA_ERR_ARG, i, "PSM %llu: aux_off is not monotone", (unsigned long long)iu);
             else {

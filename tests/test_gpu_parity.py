@@ -953,6 +953,23 @@ def test_one_huge_psm_does_not_size_everybody_elses_scratch():
     assert int(got["n_sig"][-1]) == 184756
 
 
+def test_fragment_charges_above_sixteen():
+    """max_fragment_charge 17 ... 40 (the reference takes any charge, cpp/ModifiedPeptide.cpp:81-97; r04 refused above 16):
+    short peptides on the fast kernels while their fragment lists fit, the general kernel beyond."""
+    for L, n_sites, n_mod, z, over in ((9, 4, 2, 17, {}), (12, 5, 2, 24, {}), (8, 3, 1, 40, dict(fragment_types="bycz", mz_error=0.02)),
+                                       (30, 6, 3, 20, {})):
+        batch, settings = synth.make_batch("cfg2", n_psm=8, seed=300 + z, L=L, n_sites=n_sites, n_mod=n_mod, max_charge=z, **over)
+        gpu, chk = _gpu(settings), _checker(settings)
+        got = gpu.score_batch(batch)
+        want = chk.score_batch(batch, got["ascores"].shape[1])
+        for key in ("n_sig", "best_sig", "best_score", "alt_mask", "ascores"):
+            assert np.array_equal(got[key], want[key]), (z, key)
+        _same_psm_by_psm(gpu, chk, synth.slice_batch(batch, 0, 2))
+    kw = synth.unpack_psm(batch, 0)
+    with pytest.raises(ValueError, match="max_fragment_charge"):
+        gpu.score(**dict(kw, max_fragment_charge=256))
+
+
 def test_spectra_of_more_than_8192_peaks():
     """8 193 to 65 535 peaks: binned by pya_bin_global_kernel (the general binning body with its arrays in the workspace),
     scored by the general kernel; sorted, unsorted and tie-heavy, next to ordinary PSMs in one batch."""
