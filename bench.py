@@ -46,7 +46,7 @@ def algorithmic_bytes(batch, max_k):
 # the kernels between two of the plan's timing events = one family of the bench line
 FAMILIES = {
     "pya_bin_spectra_kernel": ("pya_bin_spectra_kernel", "pya_bin_exact_kernel"),
-    "pya_score_signatures_kernel": ("pya_score_signatures_kernel", "pya_score_nodes_kernel", "pya_score_big_kernel", "pya_score_cnt_kernel"),
+    "pya_score_signatures_kernel": ("pya_score_signatures_kernel", "pya_score_nodes_kernel", "pya_score_big_kernel", "pya_score_cnt_kernel", "pya_score_cntg_kernel"),
     "pya_score_localize_kernel": ("pya_score_localize_kernel", "pya_score_localize_pack_kernel", "pya_score_localize_list_kernel",
                                   "pya_bin_score_localize_kernel"),
     "pya_localize_kernel": ("pya_localize_kernel", "pya_localize_hash_kernel", "pya_localize_ties_kernel", "pya_localize_redo_kernel",

@@ -93,6 +93,9 @@ int pya_launch_fused(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, u
 size_t pya_score_cnt_lds_bytes(uint32_t cap, uint32_t pos_cap, uint32_t kc, uint32_t k_cap, uint32_t n_cap);
 int pya_launch_score_cnt(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap, uint32_t kc, uint32_t k_cap,
                          uint32_t n_cap, hipStream_t stream);
+size_t pya_score_cntg_lds_bytes(uint32_t cap, uint32_t pos_cap, uint32_t k_cap, uint32_t n_cap, uint32_t nl_cap);
+int pya_launch_score_cntg(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap, uint32_t k_cap, uint32_t n_cap,
+                          uint32_t nl_cap, hipStream_t stream);
 size_t pya_bin_global_scratch_bytes(uint32_t cap);
 int pya_launch_bin_global(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, unsigned char *d_scratch, uint64_t stride,
                           uint32_t cap, hipStream_t stream);

@@ -869,6 +869,16 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
                 continue;
             }
         }
+        /* general settings: the count nodes carry over when the loss variants depend on the count too (score_cntg.hip; the
+         * kernel checks that per peptide and walks what does not qualify) */
+        if (general && h->mz_error <= 0.49f && sbk.k_max + 1u <= 31u && sbk.ns_max <= 32u && !h->kn.no_cnt && !(h->kn.debug & 0x8000u)) {
+            const uint32_t nnl_g = (uint32_t)h->cfg.n_nl, nl_cap_g = nnl_g >= 4u ? 256u : (nnl_g == 0u ? 4u : 1u << (2u * nnl_g));
+            if (pya_score_cntg_lds_bytes(l.cap, sbk.pos_cap, sbk.k_max, sbk.ns_max, nl_cap_g) <= 64u * 1024u) {
+                e = pya_launch_score_cntg(&d, p->d_score_ids.p + l.off, l.n, l.cap, sbk.pos_cap, sbk.k_max, sbk.ns_max, nl_cap_g, st);
+                if (e) return h->hip_fail((hipError_t)e, "score_cntg launch");
+                continue;
+            }
+        }
         uint32_t node_cap = 0, node_cols = std::max<uint32_t>(8u, (sbk.node_cols + 7u) & ~7u);
         /* (the node kernel's LDS decides its occupancy: residue and loss-state tables by the launch, room for 320 nodes
          * per direction -- cfg4's shape needs 186 on average, 328 at most; a direction with more is walked) */

@@ -443,11 +443,10 @@ DEV void cnt_envelopes(const Residues &res, int k, uint32_t pos_cap, float2 *env
     }
 }
 
-/* One node: the envelope [lo, hi] of its running sums against the staged peak table (A, B: the ion type's offsets).
- * (charge 1, mz_error <= 0.49) */
-DEV uint32_t cnt_table_entry(const PeakTable &t, float lo, float hi, double A, double B) {
-    if (!(lo <= hi)) return (uint32_t)PYA_NO_MATCH;           /* unreachable: never read */
-    const float f_lo = (float)((((double)lo + A) - B) + 1.007825), f_hi = (float)((((double)hi + A) - B) + 1.007825);
+/* One fragment ion of a node: its smallest and largest m/z over the chains through the node (f_lo <= f_hi) against the
+ * staged peak table: the rank every walker finds, | CNT_MARK when a peak between the windows could make walkers differ.
+ * (mz_error <= 0.49: no half check) */
+DEV uint32_t cnt_entry_f(const PeakTable &t, float f_lo, float f_hi) {
     const float a0 = f_lo - t.err, a = f_hi - t.err, b0 = f_lo + t.err, b1 = f_hi + t.err;
     int in_best = PYA_NO_MATCH, band_best = PYA_NO_MATCH;
     for (int idx = (int)t.cell[grid_cell(t, a0)];; idx++) {      /* every peak > a0 has index >= that; the sentinels end the scan */
@@ -460,6 +459,11 @@ DEV uint32_t cnt_table_entry(const PeakTable &t, float lo, float hi, double A, d
         }
     }
     return (uint32_t)in_best | (band_best < in_best ? CNT_MARK : 0u);
+}
+/* One node of the plain settings (one ion: charge 1): the envelope [lo, hi] of its running sums (A, B: the ion type's offsets) */
+DEV uint32_t cnt_table_entry(const PeakTable &t, float lo, float hi, double A, double B) {
+    if (!(lo <= hi)) return (uint32_t)PYA_NO_MATCH;           /* unreachable: never read */
+    return cnt_entry_f(t, (float)((((double)lo + A) - B) + 1.007825), (float)((((double)hi + A) - B) + 1.007825));
 }
 
 /* P(d, j, s) for s = 0 .. L - 1 at P[(d * (k + 1) + j) * L + s]: x, y, z = the packed cumulative-count increments of the

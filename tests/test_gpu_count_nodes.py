@@ -97,3 +97,50 @@ def test_records_with_the_table_without_it_and_with_every_node_marked(case, monk
         bits = (raw["signature"].astype(np.uint64) << np.arange(raw["signature"].shape[1], dtype=np.uint64)).sum(axis=1)
         assert np.array_equal(recs["table"]["sig_bits"][a:e], bits.astype(np.uint64)), label
         assert np.array_equal(recs["table"]["counts"][a:e], raw["counts"]) and np.array_equal(recs["table"]["weighted_score"][a:e], raw["weighted_score"]), label
+
+
+# General settings (score_cntg.hip): neutral losses, charges, several ion types per direction.  The count nodes apply when
+# every modifiable residue has the same pair of loss classes; the kernel walks the rest.
+GENERAL = [
+    ("cfg4", {}, {}),                                                                                # b/y/c/z, charge <= 4, loss on modified s/t/y
+    ("cfg2", dict(fragment_types="yb", max_charge=2), {}),                                           # charges only
+    ("cfg2", dict(fragment_types="Zc", max_charge=3, neutral_loss=("STY", 18.01528)), {}),           # loss on the UNMODIFIED sites
+    ("cfg3", dict(max_charge=2, neutral_loss=("sty", 97.9769)), dict(mz_error=0.3)),                  # up to 495 site assignments
+    ("cfg2", dict(max_charge=2, neutral_loss=("st", 97.9769)), {}),                                   # Y sites without the loss: classes differ -> walked
+    ("cfg2", dict(fragment_types="bycz", max_charge=2, neutral_loss=("sty", 97.9769)), dict(mod_group="nSTY")),   # the N-terminus as a site
+    ("cfg4", {}, dict(neutral_losses=[["sty", 97.9769], ["ST", 18.01528], ["m", 63.998]])),          # three loss masses
+    ("cfg2", dict(L=30, n_sites=10, n_mod=4, max_charge=3, neutral_loss=("sty", 97.9769)), dict(mz_error=0.01)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(GENERAL)))
+def test_general_settings_records(case, monkeypatch):
+    from pyascore_amd import PyAscore
+    cfg, over, st_over = GENERAL[case]
+    monkeypatch.setenv("PYA_NO_TINY", "1")
+    monkeypatch.setenv("PYA_PLAIN_MIN", "0")
+    batch, settings = synth.make_batch(cfg, n_psm=24, seed=70 + case, **over)
+    settings = dict(settings, **st_over)
+    chk = harness.make_scorer(orc.OracleAscore, settings, kind=checker_kind())
+    want = chk.score_batch(batch, int(batch["n_of_mod"].max()))
+    recs = {}
+    for mode, dbg in (("table", None), ("no_table", str(0x8000)), ("all_walked", str(0x40000000))):
+        if dbg is None:
+            monkeypatch.delenv("PYA_DEBUG", raising=False)
+        else:
+            monkeypatch.setenv("PYA_DEBUG", dbg)
+        gpu = harness.make_scorer(PyAscore, settings)
+        got = gpu.score_batch(batch)
+        for key in want:
+            assert np.array_equal(got[key], want[key]), (mode, key)
+        gpu.score_batch(batch, keep=True)
+        recs[mode] = gpu.batch_pep_scores()
+    for mode in ("table", "all_walked"):
+        for key in ("rec_off", "sig_bits", "counts", "weighted_score", "total_fragments"):
+            assert np.array_equal(recs[mode][key], recs["no_table"][key]), (mode, key)
+    for i in range(3):
+        chk.score(**synth.unpack_psm(batch, i))
+        raw = chk.raw_pep_scores()
+        a, e = recs["table"]["rec_off"][i], recs["table"]["rec_off"][i + 1]
+        assert np.array_equal(recs["table"]["counts"][a:e], raw["counts"]) and np.array_equal(recs["table"]["weighted_score"][a:e], raw["weighted_score"]), i
+        assert np.array_equal(recs["table"]["total_fragments"][a:e], raw["total_fragments"]), i
