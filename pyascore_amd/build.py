@@ -28,7 +28,10 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 SOURCE_EXT = (".hip", ".cpp", ".h", ".c")
-FAST = os.path.join(HERE, "_fast.so")          # CPython extension behind PyAscore.score() (csrc/pyfast.c)
+import sysconfig  # noqa: E402
+# CPython extension behind PyAscore.score() (csrc/pyfast.c), named with the interpreter's ABI tag
+# (_fast.cpython-310-x86_64-linux-gnu.so): another interpreter does not pick it up
+FAST = os.path.join(HERE, "_fast" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 FAST_SRC = "pyfast.c"
 VERSION_SRC = "version.cpp"          # compiled at every link with the tree digest as a macro
 
@@ -167,6 +170,9 @@ def build_fast(force=False):
     if force or _stale(obj, flags) or not os.path.exists(FAST):
         _compile(["gcc"], flags, src, obj)
         _run(["gcc", "-shared", "-o", FAST, obj])
+        untagged = os.path.join(HERE, "_fast.so")           # (builds before r05 left the untagged name)
+        if untagged != FAST and os.path.exists(untagged):
+            os.remove(untagged)
     return FAST
 
 
