@@ -308,7 +308,9 @@ struct LocalTable {
     int R, status;
 };
 
-template <bool BOTH, bool ZM>
+/* WIDE (BOTH only): the launch holds PSMs of 33 .. 64 site assignments, which walk their two directions one after the other,
+ * a lane per site assignment (an instantiation of its own: the walk of the others -- cfg2's -- stays as it was) */
+template <bool BOTH, bool ZM, bool WIDE = false>
 DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t n_cap, uint32_t stride,
                     uint32_t pos_cap, uint32_t ent_cap, uint32_t push_cap, const LocalTable *local = nullptr) {
     const int lane = lane_id();
@@ -362,8 +364,11 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     }
     STAMP_T(b, 39, false);
     /* ---- inputs: letters, retained peaks, the lane's signature, fixed modifications ---- */
-    const int s = BOTH ? (lane & 31) : lane;
-    const int dir = BOTH ? (lane >> 5) : (cfg->n_fwd > 0 ? 0 : 1);
+    /* BOTH with 33 .. 64 site assignments (r05): a lane per site assignment and the two directions one after the other --
+     * twice the walk, still one kernel instead of score_signatures + localize */
+    const bool two_pass = BOTH && WIDE && N > 32;
+    const int s = (BOTH && !two_pass) ? (lane & 31) : lane;
+    const int dir = BOTH ? (two_pass ? 0 : (lane >> 5)) : (cfg->n_fwd > 0 ? 0 : 1);
     const bool active = s < N;
     const uint32_t letter = lane < L ? (uint32_t)b.pep[pep0 + lane] : (uint32_t)'A';
     const uint64_t bits = active ? order[s] : 0ull;
@@ -438,7 +443,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     if (lane < 16) f.cum_lut[lane] = fused_cum_entry((uint32_t)lane);
     const int Lm1 = L - 1;
     const uint64_t resmask = deposit_sites(bits, site_mask);
-    const int w = !active ? (int)stride - 1 : (BOTH ? (lane >> 5) * N + s : s);   /* this lane's column of the rank lists (last: spare) */
+    const int w = !active ? (int)stride - 1 : (BOTH ? dir * N + s : s);   /* this lane's column of the rank lists (last: spare) */
     /* positive residue masses make every list ascending (what the neighbour-probe pairing needs) */
     const bool presorted = !__any(lane < L && !(m0 > 0.f && m1 > 0.f));
     /* every residue heavier than two tolerances (and a margin for the rounding of the running sums):
@@ -450,7 +455,13 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     STAMP_T(b, 40, false);
     CumCounts cum = walk_record(f.resd, f.cum_lut, tab, L, zmax, resmask, dir, dir ? Ab : Af, dir ? Bb : Bf, Bf == 0. && Bb == 0.,
                                 f.rkl, (int)stride, w);
-    if (BOTH) {                                             /* a signature's two directions: the backward walker's counts to the forward one */
+    if (two_pass) {                                         /* ... and the same lane's backward walk (column N + s) */
+        const CumCounts back = walk_record(f.resd, f.cum_lut, tab, L, zmax, resmask, 1, Ab, Bb, Bf == 0. && Bb == 0., f.rkl, (int)stride,
+                                           active ? N + s : (int)stride - 1);
+        cum.a += back.a;
+        cum.b += back.b;
+        cum.c += back.c;
+    } else if (BOTH) {                                      /* a signature's two directions: the backward walker's counts to the forward one */
         uint32_t *r3 = f.rec + (size_t)s * 3;
         if (active && lane >= 32) {
             r3[0] = cum.a;
@@ -470,7 +481,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
     const uint32_t nfrag = (uint32_t)ndir * (uint32_t)Lm1 * (uint32_t)zmax;     /* <= 255 (host) */
     int fail = 0;
     float ws = 0.f;
-    if (active && (!BOTH || lane < 32)) {
+    if (active && (!BOTH || two_pass || lane < 32)) {
         /* scores from the cumulative counts (Ascore.cpp:123-139) */
         ws = -1.f;
         if (nfrag <= b.lut_n_max) {

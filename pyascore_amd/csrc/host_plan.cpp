@@ -139,7 +139,8 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
      * both directions are scored (one (signature, direction) walker per lane), <= 64 with one */
     const bool both_dirs = h->cfg.n_fwd > 0 && h->cfg.n_fwd < h->cfg.n_types;
     const bool fused_on = plain_on && h->cfg.n_fwd <= 1 && h->cfg.n_types - h->cfg.n_fwd <= 1 && !h->kn.no_fused;
-    const uint32_t fused_max_n = both_dirs ? 32u : 64u;
+    /* (both directions and 33 .. 64 site assignments: the fused kernel walks the directions one after the other) */
+    const uint32_t fused_max_n = 64u;
     p->fused.assign(n, 0);
     /* score_big.hip: one PSM per 8-wave workgroup, fragment tree shared two levels deep */
     const uint64_t big_min_n = (uint64_t)h->kn.big_min_n;
