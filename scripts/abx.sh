@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of in-tree library builds on one box: bash scripts/r05_ab.sh <tag> <cfg> "<lib[:debug switches]> ..."   (2 rounds)
+# A/B of in-tree library builds on one box: bash scripts/abx.sh <tag> <cfg> "<lib[:debug switches]> ..."   (2 rounds)
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 TAG=$1; CFG=$2; LIBS=$3

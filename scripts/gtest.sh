@@ -1,5 +1,5 @@
 #!/bin/bash
-# run selected GPU tests with the full log kept:  bash scripts/r05_t.sh <tag> <pytest args...>
+# run selected GPU tests with the full log kept:  bash scripts/gtest.sh <tag> <pytest args...>
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 TAG=$1; shift

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel durations of one config: bash scripts/r05_kstat.sh <tag> <cfg> [extra bench args]
+# per-kernel durations of one config: bash scripts/kstat.sh <tag> <cfg> [extra bench args]
 cd ${GRAFT_REPO_ROOT:-.}
 ROOT=$PWD; TAG=$1; CFG=$2; shift; shift
 mkdir -p gpurun_out; export TMPDIR=/tmp; rm -rf /tmp/ks; mkdir -p /tmp/ks; cd /tmp

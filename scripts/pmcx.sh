@@ -1,5 +1,5 @@
 #!/bin/bash
-# counters of one config's kernels, per dispatch: bash scripts/r05_pmc.sh <tag> <cfg> [bench args...]
+# counters of one config's kernels, per dispatch: bash scripts/pmcx.sh <tag> <cfg> [bench args...]
 cd ${GRAFT_REPO_ROOT:-.}
 ROOT=$PWD; TAG=$1; CFG=$2; shift; shift
 mkdir -p gpurun_out; export TMPDIR=/tmp; cd /tmp
