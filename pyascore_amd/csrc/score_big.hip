@@ -18,6 +18,7 @@
  * Output as score_signatures: ws, count records, grid, the summary of the scores.
  */
 #include "score_core.hip.h"
+#include "localize_core.hip.h"     /* the one-wavefront std::sort emulation (sort_partition) */
 
 #define BIG_WAVES 8
 #define BIG_SITES1 6
@@ -35,6 +36,9 @@
  * 24 bytes x 3003 signatures x 50 000 PSMs = 3.6 GB per step on cfg5, read back for a dozen signatures per PSM:
  * the localize kernel recounts the few signatures it looks at (localize_core.hip.h: loc_recount). */
 #define BIG_INLINE_AUX 2304
+#ifndef BIG_SPINE_ONE_WAVE
+#define BIG_SPINE_ONE_WAVE 1024       /* the left part at or below which one wavefront finishes the sort's spine */
+#endif
 
 /* (the level-2 table is indexed by the 10-site pattern itself; a dense table -- 638 instead of 1024
  * entries per direction for k = 5, 4 instead of 3 workgroups per CU -- was measured and lost to its
@@ -97,7 +101,7 @@ DEV uint32_t wg_spine_front(const BigSortLds &s, int N, uint32_t kmax, bool *out
     /* three barriers per partition: every thread works out the pivot for itself (the element swapped to the front
      * is only written once everybody has taken its stops), every wavefront scans the chunk counts for itself, and
      * every thread derives the cut for itself from the swap counter (two counters, used alternately) */
-    for (int it = 0; l > 16; it++) {
+    for (int it = 0; l > BIG_SPINE_ONE_WAVE; it++) {
         if (depth == 0) {
             *out_of_depth = true;
             return 0u;
@@ -182,6 +186,35 @@ DEV uint32_t wg_spine_front(const BigSortLds &s, int N, uint32_t kmax, bool *out
         l = cand_l < cand_r ? cand_l : cand_r;
     }
     __syncthreads();
+    /* The rest of the spine by ONE wavefront (localize_core.hip.h: sort_partition<true>, the same emulation, the same arrays:
+     * key f32[N] | idx u16[N], its masks and queues in what this function used for its own): a partition of a thousand
+     * elements is a few dozen wave-steps, where the eight wavefronts spend three workgroup barriers on it (r05: the spine
+     * was a third of score_big's time, most of it waiting at barriers). */
+    if (l > 16) {
+        if (wave == 0) {
+            const SortLds s1 = sort_carve((unsigned char *)s.key, N);
+            int ll = l, d = depth;
+            bool ood = false;
+            while (ll > 16) {
+                if (d == 0) {
+                    ood = true;
+                    break;
+                }
+                d--;
+                ll = sort_partition<true>(s1, 0, ll);
+            }
+            if (lane == 0) {
+                s.misc[5] = (uint32_t)ll;
+                s.misc[6] = ood ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        l = (int)s.misc[5];
+        if (s.misc[6]) {
+            *out_of_depth = true;
+            return 0u;
+        }
+    }
     /* front of the sorted list = left-most maximum of the left-most run */
     if (wave == 0) {
         uint32_t pos = 0xffffffffu;
@@ -237,6 +270,17 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     const uint64_t *order = b.order_tab + b.order_off[psm];
     const int64_t s0 = b.sig_off[psm];
     const int L = res.L;
+    /* the count-node table (walk_core.hip.h) -- its envelopes need the residues only: wavefront 1 runs the recurrence (L - 1
+     * dependent steps) while the others stage the peak table and wavefront 0 builds the grid */
+    const int k = b.n_of_mod[psm];
+    const int n_sites = __popcll(res.site_mask);
+    uint4 *cntP = (uint4 *)l2;                                  /* [2][k + 1][L] prefix sums; behind them [k * n_sites + 1] the per-site table */
+    uint4 *cntG = cntP + (size_t)2 * (k + 1) * L;
+    float2 *envl = (float2 *)((unsigned char *)l2 + 16384);     /* [2][k + 1][pos_cap] */
+    const bool use_cnt = !(b.debug & 0x8000u) && (uint32_t)k + 1u <= kc && k + 1 <= 31 && n_sites <= 32 &&
+                         ((size_t)2 * (k + 1) * L + (size_t)k * n_sites + 1) * sizeof(uint4) <= 16384 &&
+                         (size_t)2 * (k + 1) * pos_cap * sizeof(float2) <= 16384;
+    if (use_cnt && wave == 1) cnt_envelopes(res, k, pos_cap, envl);
     PeakTable tab;
     {
         const int64_t p0 = b.ret_off[psm];
@@ -268,16 +312,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     /* ---- the count-node table (walk_core.hip.h): one lookup per (direction, step, modified residues so far), then the
      * prefix sums over the steps.  The envelopes and the prefix sums go through the level-2 table's LDS, which this route
      * does not use (it needs neither prefix level): P at l2, the envelopes 16 KB behind it. ---- */
-    const int k = b.n_of_mod[psm];
-    const int n_sites = __popcll(res.site_mask);
-    uint4 *cntP = (uint4 *)l2;                                  /* [2][k + 1][L] prefix sums; behind them [k * n_sites + 1] the per-site table */
-    uint4 *cntG = cntP + (size_t)2 * (k + 1) * L;
-    const bool use_cnt = !(b.debug & 0x8000u) && (uint32_t)k + 1u <= kc && k + 1 <= 32 && n_sites <= 32 &&
-                         ((size_t)2 * (k + 1) * L + (size_t)k * n_sites + 1) * sizeof(uint4) <= 16384 &&
-                         (size_t)2 * (k + 1) * pos_cap * sizeof(float2) <= 16384;
     if (use_cnt) {
-        float2 *envl = (float2 *)((unsigned char *)l2 + 16384);  /* [2][k + 1][pos_cap] */
-        if (wave == 0) cnt_envelopes(res, k, pos_cap, envl);
         for (uint32_t i = (uint32_t)tid; i < (uint32_t)score_big_cnt_bytes(pos_cap, kc) / 4u; i += BIG_T) ((uint32_t *)cnt_t)[i] = 0x0f0f0f0fu;
         __syncthreads();
         STAMP_T(b, 15, );
