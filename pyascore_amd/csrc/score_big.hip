@@ -18,7 +18,6 @@
  * Output as score_signatures: ws, count records, grid, the summary of the scores.
  */
 #include "score_core.hip.h"
-#include "localize_core.hip.h"     /* the one-wavefront std::sort emulation (sort_partition) */
 
 #define BIG_WAVES 8
 #define BIG_SITES1 6
@@ -36,9 +35,6 @@
  * 24 bytes x 3003 signatures x 50 000 PSMs = 3.6 GB per step on cfg5, read back for a dozen signatures per PSM:
  * the localize kernel recounts the few signatures it looks at (localize_core.hip.h: loc_recount). */
 #define BIG_INLINE_AUX 2304
-#ifndef BIG_SPINE_ONE_WAVE
-#define BIG_SPINE_ONE_WAVE 1024       /* the left part at or below which one wavefront finishes the sort's spine */
-#endif
 
 /* (the level-2 table is indexed by the 10-site pattern itself; a dense table -- 638 instead of 1024
  * entries per direction for k = 5, 4 instead of 3 workgroups per CU -- was measured and lost to its
@@ -101,7 +97,7 @@ DEV uint32_t wg_spine_front(const BigSortLds &s, int N, uint32_t kmax, bool *out
     /* three barriers per partition: every thread works out the pivot for itself (the element swapped to the front
      * is only written once everybody has taken its stops), every wavefront scans the chunk counts for itself, and
      * every thread derives the cut for itself from the swap counter (two counters, used alternately) */
-    for (int it = 0; l > BIG_SPINE_ONE_WAVE; it++) {
+    for (int it = 0; l > 16; it++) {
         if (depth == 0) {
             *out_of_depth = true;
             return 0u;
@@ -186,35 +182,6 @@ DEV uint32_t wg_spine_front(const BigSortLds &s, int N, uint32_t kmax, bool *out
         l = cand_l < cand_r ? cand_l : cand_r;
     }
     __syncthreads();
-    /* The rest of the spine by ONE wavefront (localize_core.hip.h: sort_partition<true>, the same emulation, the same arrays:
-     * key f32[N] | idx u16[N], its masks and queues in what this function used for its own): a partition of a thousand
-     * elements is a few dozen wave-steps, where the eight wavefronts spend three workgroup barriers on it (r05: the spine
-     * was a third of score_big's time, most of it waiting at barriers). */
-    if (l > 16) {
-        if (wave == 0) {
-            const SortLds s1 = sort_carve((unsigned char *)s.key, N);
-            int ll = l, d = depth;
-            bool ood = false;
-            while (ll > 16) {
-                if (d == 0) {
-                    ood = true;
-                    break;
-                }
-                d--;
-                ll = sort_partition<true>(s1, 0, ll);
-            }
-            if (lane == 0) {
-                s.misc[5] = (uint32_t)ll;
-                s.misc[6] = ood ? 1u : 0u;
-            }
-        }
-        __syncthreads();
-        l = (int)s.misc[5];
-        if (s.misc[6]) {
-            *out_of_depth = true;
-            return 0u;
-        }
-    }
     /* front of the sorted list = left-most maximum of the left-most run */
     if (wave == 0) {
         uint32_t pos = 0xffffffffu;
