@@ -142,45 +142,37 @@ DEV uint32_t lh_ord(float v) {                          /* float -> unsigned wit
  * two lookups per lane with overlapped round trips, and no lookups at all -- PYA_DEBUG=2 -- leave the kernel's
  * time unchanged: it is bound by issue at the occupancy its LDS allows, not by these loads.) */
 #define LH_STAGE 128
+/* The buffer is a ring: `staged` = (entries waiting) | (slot of the oldest << 16).  A flush looks the oldest 64 (or fewer) up
+ * and moves the head; nothing is copied to make room (r04 moved the remainder to the front after every flush). */
 DEV void lh_stage_flush(const LocCtx &c, int &staged) {
     const int lane = lane_id();
     const LocLds &w = c.w;
     float *sv = w.stage_val;
     uint8_t *st = (uint8_t *)(sv + LH_STAGE);
     wave_lds_sync();
-    const int take = staged < 64 ? staged : 64;
+    const int n = staged & 0xffff, head = staged >> 16;
+    const int take = n < 64 ? n : 64;
     if (lane < take) {
-        const uint32_t tg = st[lane];
-        const int r = (c.b->debug & 2u) ? PYA_NO_MATCH : match_rank(c.tab, sv[lane]);     /* (2: ablation, no lookups) */
+        const int slot = (head + lane) & (LH_STAGE - 1);
+        const uint32_t tg = st[slot];
+        const int r = (c.b->debug & 2u) ? PYA_NO_MATCH : match_rank(c.tab, sv[slot]);     /* (2: ablation, no lookups) */
         atomicAdd(&w.c_tr[tg], 1u);
         if (r <= w.c_depth[tg >> 1]) atomicAdd(&w.c_cnt[tg], 1u);
     }
-    wave_lds_sync();
-    const int rem = staged - take;                          /* at most 63 entries move to the front */
-    float mv = 0.f;
-    uint32_t mt = 0;
-    if (lane < rem) {
-        mv = sv[take + lane];
-        mt = st[take + lane];
-    }
-    wave_lds_sync();
-    if (lane < rem) {
-        sv[lane] = mv;
-        st[lane] = (uint8_t)mt;
-    }
-    staged = rem;
+    staged = (n - take) | (((head + take) & (LH_STAGE - 1)) << 16);
     wave_lds_sync();
 }
 DEV void lh_stage_push(const LocCtx &c, bool kept, float val, uint32_t tag, int &staged) {
     const LocLds &w = c.w;
     const uint64_t km = __ballot(kept);
+    const int n = staged & 0xffff, head = staged >> 16;
     if (kept) {
-        const int slot = staged + __popcll(km & lanemask_lt());
+        const int slot = (head + n + __popcll(km & lanemask_lt())) & (LH_STAGE - 1);
         w.stage_val[slot] = val;
         ((uint8_t *)(w.stage_val + LH_STAGE))[slot] = (uint8_t)tag;
     }
-    staged += __popcll(km);
-    if (staged >= 64) lh_stage_flush(c, staged);
+    staged = (n + __popcll(km)) | (head << 16);
+    if ((staged & 0xffff) >= 64) lh_stage_flush(c, staged);
 }
 
 /* what the exact route needs to know about the table in place */
@@ -485,24 +477,33 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
             if (c1 == c0) return true;                        /* one competitor's in-span ions do not fit */
             /* ---- table: values, then the grid ---- */
             for (int i = lane; i < (int)(h.hs / 2); i += 64) h.tab[i] = 0u;
-            for (int i = lane; i < nW; i += 64) {
-                const int pair = (int)fastdiv((uint32_t)i, divZ), z = i - pair * zmax + 1;
+            /* a lane per (prefix, variant) pair, the charges in a wave-uniform inner loop: the pair is decoded and its neutral
+             * m/z formed once, and the charge arithmetic runs the one path its charge needs (lanes with their own charges
+             * ran all of them) */
+            for (int pair = lane; pair < (int)h.cnt[0]; pair += 64) {
                 const uint32_t pz = h.pairs[offW + pair];
                 const int p = (int)(pz & 255u), v = (int)(pz >> 8);
-                h.val[i] = lh_ion(w.run[(size_t)d * c.pos_cap + p], nn ? c.nl.uniq[v] : 0.f, nn, A, B, z);
+                const float run = w.run[(size_t)d * c.pos_cap + p];
+                const float x = nn ? run - c.nl.uniq[v] : run;
+                const double m = ((double)x + A) - B;
+                float *dst = h.val + pair * zmax;
+                for (int z = 1; z <= zmax; z++) dst[z - 1] = charge_mz(m, z);
             }
             {
                 int at = nW;
                 for (int cc = c0; cc < c1; cc++) {
                     const int l = 2 + 2 * (cc - 1);
-                    const int offB = (int)h.off[l], n = (int)h.cnt[l] * zmax;
-                    for (int i = lane; i < n; i += 64) {
-                        const int pair = (int)fastdiv((uint32_t)i, divZ), z = i - pair * zmax + 1;
+                    const int offB = (int)h.off[l], npair = (int)h.cnt[l];
+                    for (int pair = lane; pair < npair; pair += 64) {
                         const uint32_t pz = h.pairs[offB + pair];
                         const int p = (int)(pz & 255u), v = (int)(pz >> 8);
-                        h.val[at + i] = lh_ion(w.run[(size_t)(cc * 2 + d) * c.pos_cap + p], nn ? c.nl.uniq[v] : 0.f, nn, A, B, z);
+                        const float run = w.run[(size_t)(cc * 2 + d) * c.pos_cap + p];
+                        const float x = nn ? run - c.nl.uniq[v] : run;
+                        const double m = ((double)x + A) - B;
+                        float *dst = h.val + at + pair * zmax;
+                        for (int z = 1; z <= zmax; z++) dst[z - 1] = charge_mz(m, z);
                     }
-                    at += n;
+                    at += npair * zmax;
                 }
             }
             wave_lds_sync();
@@ -572,7 +573,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
             c0 = c1;
         }
     }
-    while (staged > 0) lh_stage_flush(c, staged);
+    while ((staged & 0xffff) > 0) lh_stage_flush(c, staged);
     wave_lds_sync();
     STAMP_T(*c.b, 34, false);
     return false;
