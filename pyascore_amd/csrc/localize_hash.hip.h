@@ -527,44 +527,59 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
             q.R = R;
             q.nn = nn;
             q.divZ = divZ;
-            int b_lo = nW;
-            for (int cc = c0; cc < c1; cc++) {
-                const int offA = (int)h.off[1 + 2 * (cc - 1)];
-                const int nA = (int)h.cnt[1 + 2 * (cc - 1)] * zmax, nBc = (int)h.cnt[2 + 2 * (cc - 1)] * zmax;
-                const int b_hi = b_lo + nBc;
-                for (int base = 0; base < nA + nBc; base += 64) {
-                    const int i = base + lane;
-                    const bool on = i < nA + nBc;
-                    bool hit = false;
-                    int id = 0, side = 0;
-                    float x = 0.f;
-                    if (on) {
-                        if (i < nA) {
-                            const int pair = (int)fastdiv((uint32_t)i, divZ);
-                            id = (int)h.pairs[offA + pair] * zmax + (i - pair * zmax);
-                        } else {
-                            side = 1;
-                            id = b_lo + (i - nA);
+            /* the in-span ions of ALL the group's competitors in one item space (a competitor has ~100: two rounds of 64 lanes
+             * with the second one a third full when they go one by one): every lane finds its competitor from the running
+             * totals -- at most PYA_LOC_SB_MAX - 1 of them, wave-uniform values */
+            int n_items = 0;
+            for (int cc = c0; cc < c1; cc++) n_items += ((int)h.cnt[1 + 2 * (cc - 1)] + (int)h.cnt[2 + 2 * (cc - 1)]) * zmax;
+            for (int base = 0; base < n_items; base += 64) {
+                const int i = base + lane;
+                const bool on = i < n_items;
+                int cc = c0, first = 0, b_lo = nW;             /* this lane's competitor, its first item, its B ions' first entry */
+                {
+                    int acc = 0, bl = nW;
+                    for (int q2 = c0; q2 < c1; q2++) {
+                        const int nA_q = (int)h.cnt[1 + 2 * (q2 - 1)] * zmax, nB_q = (int)h.cnt[2 + 2 * (q2 - 1)] * zmax;
+                        if (i >= acc) {
+                            cc = q2;
+                            first = acc;
+                            b_lo = bl;
                         }
-                        x = h.val[id];
-                        const int k0 = lh_cell(x - qr, inv_cw), k1 = lh_cell(x + qr, inv_cw);
-                        hit = lh_probe(h, k0, hshift, id, x, reach, nW, b_lo, b_hi);
-                        if (!hit && k1 != k0) hit = lh_probe(h, k1, hshift, id, x, reach, nW, b_lo, b_hi);
-                        if (c.b->debug & 16384u) hit = true;
-                    }
-                    const uint64_t hm = __ballot(hit);
-                    if (hit) {
-                        const uint32_t slot = nslow + (uint32_t)__popcll(hm & lanemask_lt());
-                        if (slot < LH_SLOW_CAP) h.slow[slot] = (uint32_t)id | ((uint32_t)cc << 16) | ((uint32_t)side << 24);
-                    }
-                    nslow += (uint32_t)__popcll(hm);
-                    lh_stage_push(c, on && !hit, x, (uint32_t)(cc * 2 + side), staged);
-                    if (nslow + 64u > LH_SLOW_CAP && nslow) {           /* (the list could overflow with the next 64 items) */
-                        if (lh_exact(c, h, q, nslow, staged)) return true;
-                        nslow = 0;
+                        acc += nA_q + nB_q;
+                        bl += nB_q;
                     }
                 }
-                b_lo = b_hi;
+                const int offA = (int)h.off[1 + 2 * (cc - 1)];
+                const int nA = (int)h.cnt[1 + 2 * (cc - 1)] * zmax, nBc = (int)h.cnt[2 + 2 * (cc - 1)] * zmax;
+                const int b_hi = b_lo + nBc, li = i - first;
+                bool hit = false;
+                int id = 0, side = 0;
+                float x = 0.f;
+                if (on) {
+                    if (li < nA) {
+                        const int pair = (int)fastdiv((uint32_t)li, divZ);
+                        id = (int)h.pairs[offA + pair] * zmax + (li - pair * zmax);
+                    } else {
+                        side = 1;
+                        id = b_lo + (li - nA);
+                    }
+                    x = h.val[id];
+                    const int k0 = lh_cell(x - qr, inv_cw), k1 = lh_cell(x + qr, inv_cw);
+                    hit = lh_probe(h, k0, hshift, id, x, reach, nW, b_lo, b_hi);
+                    if (!hit && k1 != k0) hit = lh_probe(h, k1, hshift, id, x, reach, nW, b_lo, b_hi);
+                    if (c.b->debug & 16384u) hit = true;
+                }
+                const uint64_t hm = __ballot(hit);
+                if (hit) {
+                    const uint32_t slot = nslow + (uint32_t)__popcll(hm & lanemask_lt());
+                    if (slot < LH_SLOW_CAP) h.slow[slot] = (uint32_t)id | ((uint32_t)cc << 16) | ((uint32_t)side << 24);
+                }
+                nslow += (uint32_t)__popcll(hm);
+                lh_stage_push(c, on && !hit, x, (uint32_t)(cc * 2 + side), staged);
+                if (nslow + 64u > LH_SLOW_CAP && nslow) {               /* (the list could overflow with the next 64 items) */
+                    if (lh_exact(c, h, q, nslow, staged)) return true;
+                    nslow = 0;
+                }
             }
             STAMP_T(*c.b, 32, false);
             if (nslow && lh_exact(c, h, q, nslow, staged)) return true;
