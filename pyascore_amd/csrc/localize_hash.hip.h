@@ -132,6 +132,30 @@ DEV bool lh_probe(const HashLds &h, int cell, int hshift, int self, float x, flo
     return hit;
 }
 
+/* the same over the (one or two) cells an ion's window touches, in one loop: the probe run of the second cell follows the
+ * first's in the same lane (two calls cost the wavefront the longest run of either cell twice) */
+DEV bool lh_probe2(const HashLds &h, int k0, int k1, int hshift, int self, float x, float reach, int nW, int b_lo, int b_hi) {
+    const uint32_t hmask = h.hs - 1u;
+    const uint16_t *t16 = (const uint16_t *)h.tab;
+    uint32_t s = ((uint32_t)k0 * 0x9E3779B1u) >> hshift;
+    bool second = k1 == k0, hit = false;                       /* (nothing more to visit after the first run) */
+    for (;;) {
+        const uint32_t half = t16[s];
+        if (half == 0u) {
+            if (second) break;
+            second = true;
+            s = ((uint32_t)k1 * 0x9E3779B1u) >> hshift;
+            continue;
+        }
+        const int j = (int)half - 1;
+        const float y = h.val[j];
+        const bool mine = j < nW || (j >= b_lo && j < b_hi);
+        hit |= (j != self) && mine && (__builtin_fabsf(y - x) < reach);
+        s = (s + 1u) & hmask;
+    }
+    return hit;
+}
+
 DEV uint32_t lh_ord(float v) {                          /* float -> unsigned with the same order */
     const uint32_t u = __float_as_uint(v);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -490,20 +514,28 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                 for (int z = 1; z <= zmax; z++) dst[z - 1] = charge_mz(m, z);
             }
             {
-                int at = nW;
-                for (int cc = c0; cc < c1; cc++) {
-                    const int l = 2 + 2 * (cc - 1);
-                    const int offB = (int)h.off[l], npair = (int)h.cnt[l];
-                    for (int pair = lane; pair < npair; pair += 64) {
-                        const uint32_t pz = h.pairs[offB + pair];
-                        const int p = (int)(pz & 255u), v = (int)(pz >> 8);
-                        const float run = w.run[(size_t)(cc * 2 + d) * c.pos_cap + p];
-                        const float x = nn ? run - c.nl.uniq[v] : run;
-                        const double m = ((double)x + A) - B;
-                        float *dst = h.val + at + pair * zmax;
-                        for (int z = 1; z <= zmax; z++) dst[z - 1] = charge_mz(m, z);
+                /* ... and the in-span pairs of all the group's competitors in one item space (a dozen pairs each) */
+                int np_all = 0;
+                for (int cc = c0; cc < c1; cc++) np_all += (int)h.cnt[2 + 2 * (cc - 1)];
+                for (int pi = lane; pi < np_all; pi += 64) {
+                    int cc = c0, first = 0;
+                    {
+                        int acc = 0;
+                        for (int q2 = c0; q2 < c1; q2++) {
+                            if (pi >= acc) {
+                                cc = q2;
+                                first = acc;
+                            }
+                            acc += (int)h.cnt[2 + 2 * (q2 - 1)];
+                        }
                     }
-                    at += npair * zmax;
+                    const uint32_t pz = h.pairs[(int)h.off[2 + 2 * (cc - 1)] + (pi - first)];
+                    const int p = (int)(pz & 255u), v = (int)(pz >> 8);
+                    const float run = w.run[(size_t)(cc * 2 + d) * c.pos_cap + p];
+                    const float x = nn ? run - c.nl.uniq[v] : run;
+                    const double m = ((double)x + A) - B;
+                    float *dst = h.val + nW + pi * zmax;               /* (the competitors' lists follow each other in this order) */
+                    for (int z = 1; z <= zmax; z++) dst[z - 1] = charge_mz(m, z);
                 }
             }
             wave_lds_sync();
@@ -565,8 +597,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                     }
                     x = h.val[id];
                     const int k0 = lh_cell(x - qr, inv_cw), k1 = lh_cell(x + qr, inv_cw);
-                    hit = lh_probe(h, k0, hshift, id, x, reach, nW, b_lo, b_hi);
-                    if (!hit && k1 != k0) hit = lh_probe(h, k1, hshift, id, x, reach, nW, b_lo, b_hi);
+                    hit = lh_probe2(h, k0, k1, hshift, id, x, reach, nW, b_lo, b_hi);
                     if (c.b->debug & 16384u) hit = true;
                 }
                 const uint64_t hm = __ballot(hit);
