@@ -20,7 +20,7 @@ extern "C" {
  * switch back to its production default.  pya_reload_env resets all of them.  Unknown names: PYA_ERR_ARG.
  *   flags (any non-NULL value = on): PYA_NO_PLAIN PYA_NO_FUSED PYA_NO_BIG PYA_NO_TINY PYA_NO_PREFIX PYA_NO_CHUNKS
  *     PYA_NO_UPLOAD_THREAD PYA_ONE_PEAK_CLASS PYA_PEAK_CLASSES PYA_ONE_LDS_CLASS PYA_SORT_ROOM PYA_NO_BIG_INLINE
- *     PYA_NO_LOC_HASH PYA_NO_NODES PYA_HOST_TIMING PYA_STAMPS
+ *     PYA_NO_LOC_HASH PYA_NO_NODES PYA_NO_CNT PYA_HOST_TIMING PYA_STAMPS PYA_SLOW_NULL_STREAM
  *   numbers: PYA_DEBUG (bit set, common.h) PYA_PLAIN_MIN PYA_BIG_MIN_N PYA_TINY_MAX PYA_SORT_ROOM_MAX PYA_SB PYA_GTP
  *     PYA_HASH_PP PYA_NODE_CAP PYA_CHUNK_MB PYA_WORKSPACE_MB */
 int pya_set_debug(pya_handle *h, const char *key, const char *value);

@@ -217,6 +217,7 @@ struct Knobs {
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
     bool host_timing = false, stamps = false, sort_room = false, no_big_inline = false;
     bool no_loc_hash = false, no_nodes = false, no_cnt = false;
+    bool slow_null_stream = false;              /* host_one.cpp: widens the window of a (fixed) workspace race for its regression test */
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64;
     uint32_t sort_room_max = 1024;
@@ -270,7 +271,7 @@ struct pya_handle {
     /* pya_score_one: persistent pinned (device-mapped, coherent) host block + one PSM's device workspace */
     struct One {
         unsigned char *host = nullptr, *host_dev = nullptr;    /* the same block as the host / the device sees it */
-        DevBuf<unsigned char> ws;
+        DevBuf<unsigned char> ws, probe;          /* (probe: the PYA_SLOW_NULL_STREAM test switch's 256 MB) */
         uint32_t sig_cap = 0;                      /* signatures the workspace has room for */
         uint32_t seq = 0;
         hipStream_t stream = nullptr;

@@ -29,7 +29,20 @@ int one_prepare(pya_handle *h, uint32_t n_sig) {
         if (o.view && h->kept == o.view) h->kept = nullptr;
         o.last_keep = false;
         HIPCHK(h, o.ws.alloc(bytes));
-        HIPCHK(h, hipMemset(o.ws.p, 0, bytes));
+        if (h->kn.slow_null_stream) {
+            /* (test switch PYA_SLOW_NULL_STREAM: 256 MB of null-stream memset in front, so that anything queued on the null
+             * stream after it starts ~100 us late -- the window of the race described below made wide enough that a
+             * regression is seen at once: tests/test_gpu_handover_stress.py) */
+            if (!o.probe.p) HIPCHK(h, o.probe.alloc((size_t)256 << 20));
+            HIPCHK(h, hipMemset(o.probe.p, 0, (size_t)256 << 20));
+        }
+        /* ON THE KERNEL'S OWN STREAM, and waited for: hipMemset is asynchronous to the host for device memory, it runs on
+         * the null stream, and o.stream is a non-blocking stream -- a null-stream memset could still be zeroing the workspace
+         * while the first kernel launched after it was already reading the scalars its lane 0 had put there (N and the
+         * site count read as 0: an "unambiguous" PSM with no site assignments, status OK -- the empty result seen once in
+         * r04 and once in r05; scripts/handover_repro.py, profiles/r05_handover_race.md) */
+        HIPCHK(h, hipMemsetAsync(o.ws.p, 0, bytes, o.stream));
+        HIPCHK(h, hipStreamSynchronize(o.stream));
         o.sig_cap = cap;
         unsigned char *w = o.ws.p;
         BatchDev &d = o.dev;

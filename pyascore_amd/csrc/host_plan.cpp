@@ -588,6 +588,8 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
                 for (uint32_t t = 0; t < 64; t++) bt[pp * 64 + t] = (uint32_t)std::min<uint64_t>(binom(pp, t), 0xffffffffull);
             HIPCHK(h, h->d_binom.upload(bt.data(), bt.size()));
         }
+        /* (null-stream copies; the kernels that read these tables may run on a non-blocking stream) */
+        HIPCHK(h, hipDeviceSynchronize());
         h->order_uploaded = h->order_tab.size();
     }
     if (io && io->max_k < max_k)
@@ -722,6 +724,8 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
             h->stage.resize(std::max(h->stage.size(), h2d_bytes));
             for (const Up &u : ups) std::memcpy(h->stage.data() + u.off, u.src, u.bytes);
             HIPCHK(h, hipMemcpy(base, h->stage.data(), h2d_bytes, hipMemcpyHostToDevice));
+            /* (a null-stream copy from pageable memory; the plan may run on a non-blocking stream, which does not wait for it) */
+            HIPCHK(h, hipStreamSynchronize(nullptr));
         } else {
             hipStream_t ust = io ? io->stream : nullptr;
             for (const Up &u : ups) HIPCHK(h, hipMemcpyAsync(base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, ust));
@@ -730,7 +734,10 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
         }
     }
     if (n_skipped)      /* bin_spectra never touches these entries, so they keep their code for every run */
+    {
         HIPCHK(h, hipMemcpy(p->d_status.p, p->pre_status.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(h, hipStreamSynchronize(nullptr));
+    }
     lap("arena+upload");
     if (flags & PYA_FLAG_TIMING) {
         p->evring.assign(5 * pya_plan::kEvRing, nullptr);

@@ -1,4 +1,7 @@
-"""The one-PSM hand-over under load (r04: one suite run returned empty pep_scores for a score() PSM, never reproduced).
+"""The one-PSM hand-over under load (r04: one suite run returned empty pep_scores for a score() PSM; r05: this test
+caught it again -- best_sequence '' at the first score() of a PSM that made the one-PSM workspace grow -- and
+scripts/handover_repro.py found the cause: the workspace was zeroed by a null-stream hipMemset that could still be running
+while the kernel, on a non-blocking stream, had already started; profiles/r05_handover_race.md).
 
 PyAscore.score() hands one PSM to a single-launch kernel through a pinned block and polls a sequence word
 (csrc/host_one.cpp); pep_scores replays the PSM lazily (pya_rescore_last_keep); score_batch of one PSM reuses the same
@@ -119,3 +122,24 @@ def test_fifty_thousand_interleaved_calls_with_a_busy_neighbour(tmp_path):
     assert "batches" in out and int(out.split()[-1]) >= 1, out     # the neighbour really ran beside it
     print("%d calls in %.1f s beside %s of a second process: %s" % (done, took, out.strip(), calls))
     assert calls["score"] > 0.6 * n_calls * 0.5 and calls["records"] > 0 and calls["batch_of_one"] > 0
+
+
+def test_the_first_call_after_the_workspace_grows():
+    """The race behind the empty results, with its window made wide (debug switch PYA_SLOW_NULL_STREAM: 256 MB of
+    null-stream memset queued in front of whatever the null stream does next).  Before the fix 9 685 of 9 813 such first
+    calls came back with n_sig 0 / best_score -1; the workspace is now zeroed on the kernel's own stream and waited for."""
+    from pyascore_amd import PyAscore
+    psms, settings = _pool()
+    chk = harness.make_scorer(orc.OracleAscore, settings, kind=checker_kind())
+    picks = [0, 50, 300, 640, 641, 642, 643]
+    want = {}
+    for i in picks:
+        chk.score(**psms[i])
+        want[i] = (chk.best_sequence, np.float32(chk.best_score))
+    for trial in range(60):
+        gpu = harness.make_scorer(PyAscore, settings)
+        gpu.set_debug("PYA_SLOW_NULL_STREAM", "1")
+        # the first call allocates the workspace, a PSM with thousands of site assignments makes it grow
+        for i in (picks[trial % 3], picks[3 + trial % 4], picks[(trial + 1) % 3]):
+            gpu.score(**psms[i])
+            assert (gpu.best_sequence, np.float32(gpu.best_score)) == want[i], (trial, i)
