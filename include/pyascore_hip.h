@@ -53,7 +53,7 @@ extern "C" {
 /* documented limits (DESIGN.md "Limits").  The FAST_* values are what the fast kernels take; a PSM beyond one of
  * them (and inside the limits above it) is scored by the general kernel (csrc/general_psm.hip): same results, the
  * reference's algorithm at a fraction of the speed. */
-#define PYA_MAX_PEPTIDE_LEN 255
+#define PYA_MAX_PEPTIDE_LEN 511               /* (the general kernel; the reference takes any length) */
 #define PYA_MAX_SITES 63                   /* (the reference's own limit: cpp/Ascore.cpp:91-94 keys a signature by a long) */
 #define PYA_MAX_SIGNATURES (1 << 22)       /* C(n_sites, n_of_mod) */
 #define PYA_MAX_FRAGMENTS_PER_TYPE 8192    /* (L - 1) x charges x neutral-loss sums */
@@ -64,7 +64,7 @@ extern "C" {
 #define PYA_FAST_PEAKS 8192
 #define PYA_MAX_FRAGMENT_TYPES 8
 #define PYA_MAX_CHARGE 255                 /* max_fragment_charge (the fragments per ion type above bound it long before) */
-#define PYA_MAX_NL_VALUES 4
+#define PYA_MAX_NL_VALUES 8                /* distinct neutral-loss masses; more than 4: every PSM through the general kernel */
 #define PYA_N_TOP 10                       /* the value everything is built for (the reference's command line passes 10) */
 #define PYA_MAX_N_TOP 16                   /* 11..16: every PSM of the scorer goes through the general kernel            */
 
@@ -224,7 +224,7 @@ int pya_format_peptides(const pya_handle *h, const pya_batch *batch, uint64_t n_
                         const uint64_t *sig_bits, const int32_t *rec_valid, int64_t *str_off, char *buf,
                         uint64_t cap);
 int pya_count_sites(const pya_handle *h, const uint8_t *pep, uint64_t pep_len, int32_t *n_sites,
-                    uint8_t *site_pos /* >= PYA_MAX_PEPTIDE_LEN, 0-based residue of each site */);
+                    uint16_t *site_pos /* >= PYA_MAX_PEPTIDE_LEN, 0-based residue of each site */);
 
 /* test hook: runs the on-device emulation of the reference's std::sort (descending, keyed by
  * weighted score) on arbitrary keys and returns the permutation */

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PYA_LIB") or os.path.join(_HERE, "libpyascore_hip.so"
 
 PYA_OK, PYA_ERR_ARG, PYA_ERR_HIP, PYA_ERR_PSM, PYA_ERR_LIMIT, PYA_ERR_STATE = 0, -1, -2, -3, -4, -5
 PYA_FLAG_KEEP, PYA_FLAG_TIMING, PYA_FLAG_SKIP_INVALID = 1, 2, 4
-PYA_MAX_PEPTIDE_LEN = 255
+PYA_MAX_PEPTIDE_LEN = 511
 
 _vp = C.c_void_p
 

@@ -543,7 +543,7 @@ class PyAscore:
         if pep.size <= 64:
             return [p + 1 for p in range(64) if (m >> p) & 1]
         ns = C.c_int32(0)
-        pos = np.zeros(_lib.PYA_MAX_PEPTIDE_LEN, np.uint8)
+        pos = np.zeros(_lib.PYA_MAX_PEPTIDE_LEN, np.uint16)
         self._lib.pya_count_sites(self._h, _as_ptr(pep), pep.size, C.byref(ns), _as_ptr(pos))
         return [int(pos[j]) + 1 for j in range(min(int(ns.value), 64)) if (m >> j) & 1]
 

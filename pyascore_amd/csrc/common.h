@@ -11,7 +11,10 @@
 #define PYA_TABLE_PAD 4            /* +inf sentinels after the last retained peak of a staged table */
 #define PYA_MAX_L 64
 #define PYA_MAX_TYPES 8
-#define PYA_MAX_NL 4               /* distinct neutral-loss masses                         */
+#define PYA_MAX_NL 8               /* distinct neutral-loss masses (the general kernel)    */
+#define PYA_FAST_NL 4              /* ... the fast kernels take (2 bits each in an 8-bit loss state, <= 16 distinct sums) */
+#define PYA_MAX_UNIQ_WIDE 48       /* distinct sums of <= 2 of eight masses: 1 + 8 + 36    */
+#define PYA_MAX_NL_CANDS 44        /* singles + pairs                                      */
 #define PYA_MAX_UNIQ 16            /* distinct sums of <= 2 neutral losses (incl. 0)       */
 #define PYA_MAX_LIST 2048          /* fragments of one signature and one ion type          */
 #define PYA_MAX_LUT_N 4096         /* largest trial count the score table covers           */
@@ -49,6 +52,12 @@ struct DevConfig {
                                     /*   -> bit set of uniq[] values that exist             */
     float weights[PYA_NTOP];        /* Ascore.cpp:16-18                                     */
     int32_t n_top;                  /* peaks retained per window = depths scored (Ascore.pyx:64-67); 10 unless the general kernel runs everything */
+    /* the same neutral-loss sums as the general kernel reads them (any n_nl <= PYA_MAX_NL; uniq[] / present[] above exist
+     * for n_nl <= PYA_FAST_NL only): candidate i = the loss of class cand_a (cand_b == 255) or the sum of classes cand_a
+     * and cand_b (equal: the class twice), present when the classes occurred that often; it is sum number cand_u */
+    int32_t n_cand;
+    float uniq_w[PYA_MAX_UNIQ_WIDE];
+    uint8_t cand_a[PYA_MAX_NL_CANDS], cand_b[PYA_MAX_NL_CANDS], cand_u[PYA_MAX_NL_CANDS];
 };
 
 /* device pointers + scalars of one launch family; passed by value as kernel argument */

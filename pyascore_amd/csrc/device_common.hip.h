@@ -625,7 +625,7 @@ DEV int nth_set_bit(uint64_t m, int n) {
 }
 
 DEV uint32_t nl_bump(uint32_t state, uint32_t cls) {
-    /* 2 bits per class, saturating at 2; cls in 1..4 */
+    /* 2 bits per class, saturating at 2; cls in 1..4 (the fast kernels: an 8-bit state), 1..8 in the general kernel */
     uint32_t sh = (cls - 1) * 2;
     uint32_t cur = (state >> sh) & 3u;
     return cur < 2u ? state + (1u << sh) : state;

@@ -47,11 +47,11 @@ struct GenLds {
     float *m0, *m1;              /* [l_cap] */
     float *run;                  /* [2][l_cap] running sums of the two signatures being compared, current direction */
     uint32_t *cpre;              /* [2][l_cap] ions (x charges) before the prefix */
-    uint16_t *pm;                /* [2][l_cap] loss sums present */
+    uint64_t *pm;                /* [2][l_cap] loss sums present (bit v = uniq[v]) */
     uint8_t *nl0, *nl1, *sor;    /* [l_cap] loss class unmodified / modified, site index of the residue (255: none) */
     uint8_t *site_pos;           /* [64] residue of the j-th modifiable one */
-    uint16_t *present;           /* [256] */
-    float *uniq;                 /* [PYA_MAX_UNIQ] */
+    float *uniq;                 /* [PYA_MAX_UNIQ_WIDE] the distinct sums of <= 2 neutral losses, [0] = none */
+    uint8_t *cand;               /* [3][PYA_MAX_NL_CANDS] classes a, b (255: a alone) and sum number of every candidate */
     uint32_t *site_max, *site_tie;   /* [64] */
     unsigned long long *site_alt;    /* [64] */
     float *site_asc;             /* [64] */
@@ -62,19 +62,20 @@ struct GenLds {
 };
 __host__ __device__ static inline size_t gen_lds_bytes(uint32_t l_cap, uint32_t list_cap) {
     const size_t lc = (l_cap + 3u) & ~3u;
-    return lc * (4 + 4 + 2 * 4 + 2 * 4 + 2 * 2 + 3) + 64 + 512 + PYA_MAX_UNIQ * 4 + 64 * (4 + 4 + 8 + 4) + 64 + 2 * PYA_NTOP_MAX * 4 + 8 +
-           (size_t)list_cap * (4 * 4 + 2) + 64;
+    return lc * (4 + 4 + 2 * 4 + 2 * 4 + 2 * 8 + 3) + 64 + 3 * PYA_MAX_NL_CANDS + 4 + PYA_MAX_UNIQ_WIDE * 4 + 64 * (4 + 4 + 8 + 4) + 64 +
+           2 * PYA_NTOP_MAX * 4 + 8 + (size_t)list_cap * (4 * 4 + 2) + 64;
 }
 DEV GenLds gen_carve(unsigned char *raw, uint32_t l_cap, uint32_t list_cap) {
     const size_t lc = (l_cap + 3u) & ~3u;
     GenLds g;
     g.site_alt = (unsigned long long *)raw;
-    g.m0 = (float *)(g.site_alt + 64);
+    g.pm = (uint64_t *)(g.site_alt + 64);
+    g.m0 = (float *)(g.pm + 2 * lc);
     g.m1 = g.m0 + lc;
     g.run = g.m1 + lc;
     g.cpre = (uint32_t *)(g.run + 2 * lc);
     g.uniq = (float *)(g.cpre + 2 * lc);
-    g.site_max = (uint32_t *)(g.uniq + PYA_MAX_UNIQ);
+    g.site_max = (uint32_t *)(g.uniq + PYA_MAX_UNIQ_WIDE);
     g.site_tie = g.site_max + 64;
     g.site_asc = (float *)(g.site_tie + 64);
     g.misc = (uint32_t *)(g.site_asc + 64);
@@ -83,13 +84,12 @@ DEV GenLds gen_carve(unsigned char *raw, uint32_t l_cap, uint32_t list_cap) {
     g.lb = g.la + list_cap;
     g.sa = g.lb + list_cap;
     g.sb = g.sa + list_cap;
-    g.pm = (uint16_t *)(g.sb + list_cap);
-    g.present = g.pm + 2 * lc;
-    g.nl0 = (uint8_t *)(g.present + 256);
+    g.nl0 = (uint8_t *)(g.sb + list_cap);
     g.nl1 = g.nl0 + lc;
     g.sor = g.nl1 + lc;
     g.site_pos = g.sor + lc;
-    g.ha = g.site_pos + 64;
+    g.cand = g.site_pos + 64;
+    g.ha = g.cand + 3 * PYA_MAX_NL_CANDS + 4;
     g.hb = g.ha + list_cap;
     return g;
 }
@@ -106,26 +106,43 @@ DEV bool gen_modified(const GenLds &g, uint64_t bits, int ri) {
     return j != 255u && ((bits >> j) & 1ull);
 }
 
+/* which loss sums exist for a fragment whose residues carried the loss classes counted in `st` (2 bits per class,
+ * saturating at 2): none, every class seen, every pair of classes seen, a class twice when it was seen twice --
+ * PowerSetSum(stack, 2), cpp/Util.cpp:95-141, as the set of distinct values (host_tables.cpp: build_dev_config) */
+DEV uint64_t gen_present(const GenLds &g, int n_cand, uint32_t st) {
+    uint64_t m = 1ull;
+    for (int i = 0; i < n_cand; i++) {
+        const uint32_t a = g.cand[i], b2 = g.cand[PYA_MAX_NL_CANDS + i];
+        const uint32_t ca = (st >> (2u * a)) & 3u;
+        const bool ok = b2 == 255u ? ca >= 1u : (b2 == a ? ca >= 2u : (ca >= 1u && ((st >> (2u * b2)) & 3u) >= 1u));
+        if (ok) m |= 1ull << g.cand[2 * PYA_MAX_NL_CANDS + i];
+    }
+    return m;
+}
+
 /* Running sums, loss sums present and ion offsets of one signature along one direction (one lane):
  * ModifiedPeptide.cpp:385-408.  Returns the number of (prefix, loss variant) pairs. */
 DEV uint32_t gen_prefix_table(const GenLds &g, const DevConfig *cfg, uint64_t bits, int L, int dir, int slot, uint32_t lc) {
     float running = 0.f;
     uint32_t st = 0, cnt = 0;
+    uint64_t pm = 1ull;
     for (int step = 0; step + 1 < L; step++) {
         const int ri = dir ? L - 1 - step : step;
         const bool mod = gen_modified(g, bits, ri);
         const float r = mod ? g.m1[ri] : g.m0[ri];
         running = r + running;
-        uint32_t pm = 1u;
         if (cfg->n_nl) {
             const uint32_t cls = mod ? g.nl1[ri] : g.nl0[ri];
-            if (cls) st = nl_bump(st, cls);
-            pm = g.present[st & 255u];
+            if (cls) {
+                const uint32_t st2 = nl_bump(st, cls);
+                if (st2 != st) pm = gen_present(g, cfg->n_cand, st2);
+                st = st2;
+            }
         }
         g.run[slot * lc + step] = running;
-        g.pm[slot * lc + step] = (uint16_t)pm;
+        g.pm[slot * lc + step] = pm;
         g.cpre[slot * lc + step] = cnt;
-        cnt += __popc(pm);
+        cnt += (uint32_t)__popcll(pm);
     }
     return cnt;
 }
@@ -134,10 +151,10 @@ DEV uint32_t gen_prefix_table(const GenLds &g, const DevConfig *cfg, uint64_t bi
 DEV void gen_fill_list(const GenLds &g, const DevConfig *cfg, int L, int zmax, int slot, uint32_t lc, double A, double B, float *out) {
     for (int step = lane_id(); step + 1 < L; step += 64) {
         const float running = g.run[slot * lc + step];
-        uint32_t pm = g.pm[slot * lc + step];
+        uint64_t pm = g.pm[slot * lc + step];
         uint32_t at = g.cpre[slot * lc + step] * (uint32_t)zmax;
         while (pm) {
-            const int v = __builtin_ctz(pm);
+            const int v = __builtin_ctzll(pm);
             pm &= pm - 1;
             const float x = running - (cfg->n_nl ? g.uniq[v] : 0.f);
             const double m = ((double)x + A) - B;
@@ -173,8 +190,12 @@ DEV int gen_setup_residues(const BatchDev &b, const DevConfig *cfg, const GenLds
         g.nl1[i] = modifiable ? cfg->nl_lower[li] : 0;
         g.sor[i] = modifiable ? 0 : 255;
     }
-    for (int i = lane; i < 256; i += 64) g.present[i] = cfg->present[i];
-    if (lane < PYA_MAX_UNIQ) g.uniq[lane] = cfg->uniq[lane];
+    if (lane < PYA_MAX_UNIQ_WIDE) g.uniq[lane] = cfg->uniq_w[lane];
+    if (lane < PYA_MAX_NL_CANDS) {
+        g.cand[lane] = cfg->cand_a[lane];
+        g.cand[PYA_MAX_NL_CANDS + lane] = cfg->cand_b[lane];
+        g.cand[2 * PYA_MAX_NL_CANDS + lane] = cfg->cand_u[lane];
+    }
     if (lane < GEN_MAX_SITES) {
         g.site_max[lane] = 0;
         g.site_tie[lane] = 0;
@@ -353,18 +374,22 @@ __global__ __launch_bounds__(64) void pya_general_psm_kernel(BatchDev b, const u
             if (t0 == t1) continue;
             float running = 0.f;
             uint32_t st = 0;
+            uint64_t pm_now = 1ull;
             for (int step = 0; step + 1 < L; step++) {
                 const int ri = dir ? L - 1 - step : step;
                 const bool mod = gen_modified(g, bits, ri);
                 running = (mod ? g.m1[ri] : g.m0[ri]) + running;
-                uint32_t pm = 1u;
                 if (cfg->n_nl) {
                     const uint32_t cls = mod ? g.nl1[ri] : g.nl0[ri];
-                    if (cls) st = nl_bump(st, cls);
-                    pm = g.present[st & 255u];
+                    if (cls) {
+                        const uint32_t st2 = nl_bump(st, cls);
+                        if (st2 != st) pm_now = gen_present(g, cfg->n_cand, st2);
+                        st = st2;
+                    }
                 }
+                uint64_t pm = pm_now;
                 while (pm) {
-                    const int v = __builtin_ctz(pm);
+                    const int v = __builtin_ctzll(pm);
                     pm &= pm - 1;
                     const float x = running - (cfg->n_nl ? g.uniq[v] : 0.f);
                     for (int t = t0; t < t1; t++) {

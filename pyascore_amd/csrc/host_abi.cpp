@@ -96,12 +96,12 @@ int pya_add_neutral_loss(pya_handle *h, const char *group, float mass) {
     return rc;
 }
 
-int pya_count_sites(const pya_handle *h, const uint8_t *pep, uint64_t L, int32_t *n_sites, uint8_t *site_pos) {
+int pya_count_sites(const pya_handle *h, const uint8_t *pep, uint64_t L, int32_t *n_sites, uint16_t *site_pos) {
     if (!h || !pep || !n_sites) return PYA_ERR_ARG;
     int n = 0;
     for (uint64_t i = 0; i < L; i++)
         if (h->letter_modifiable((char)pep[i], i, L)) {
-            if (site_pos && n < PYA_MAX_PEPTIDE_LEN) site_pos[n] = (uint8_t)i;
+            if (site_pos && n < PYA_MAX_PEPTIDE_LEN) site_pos[n] = (uint16_t)i;
             n++;
         }
     *n_sites = n;
@@ -310,7 +310,7 @@ int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits, cons
      * up to PYA_FAST_PEAKS peaks only; it takes peptides of up to 64 residues and ten depths.  Everything else -- a long
      * peptide, n_top 11..16, a spectrum binned by the global kernel -- goes through the general kernel's own Ascore
      * code (general_psm.hip), which reads the retained table where it lies. */
-    if (L > PYA_FAST_PEPTIDE_LEN || NT != PYA_NTOP || P > PYA_FAST_PEAKS || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) {
+    if (L > PYA_FAST_PEPTIDE_LEN || h->all_general() || P > PYA_FAST_PEAKS || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) {
         if (pya_general_lds_bytes((uint32_t)L, per_type) > kMaxLds)
             return h->fail(PYA_ERR_LIMIT, (int64_t)psm, "calculate_ambiguity: %u fragments per ion type exceed the general kernel's room", per_type);
         e = pya_launch_general_ambiguity(&p->dev, (uint32_t)psm, (uint32_t)L, per_type, ref_bits, other_bits, d_scores.p, NT,

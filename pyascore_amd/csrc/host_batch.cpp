@@ -53,7 +53,7 @@ ChunkCost chunk_costs(pya_handle *h, const pya_batch *b, uint32_t max_k) {
              * spectrum of more than PYA_FAST_PEAKS peaks the global binning kernel's 15 bytes per peak (sized by the largest) */
             double extra = 0.;
             const uint32_t per_type = (uint32_t)std::max<int64_t>(L - 1, 0) * (uint32_t)std::max(1, std::min(b->max_charge[i], PYA_MAX_CHARGE)) * (uint32_t)h->cfg.n_uniq;
-            if (P > PYA_FAST_PEAKS || L > PYA_FAST_PEPTIDE_LEN || sigs > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE || h->n_top != PYA_NTOP) {
+            if (P > PYA_FAST_PEAKS || L > PYA_FAST_PEPTIDE_LEN || sigs > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE || h->all_general()) {
                 const uint32_t ns = c.sites[i] == 255 ? 0u : c.sites[i], kk = (uint32_t)std::max(0, b->n_of_mod[i]);
                 extra += (double)pya_general_scratch_bytes((uint32_t)sigs, kk <= ns ? ((kk * (ns - kk)) + 3u) & ~3u : 0u) + 256.0;
                 if (P > PYA_FAST_PEAKS) extra += 16.0 * (double)PYA_MAX_PEAKS;

@@ -290,6 +290,8 @@ struct pya_handle {
     int64_t err_index = -1;
     std::vector<int32_t> last_status;         /* per-PSM codes of the last pya_score_batch */
     pya_plan *kept = nullptr;                 /* plan of the last PYA_FLAG_KEEP batch */
+    /* settings only the general kernel takes: every PSM of the scorer goes there (cfg is rebuilt by every setter) */
+    bool all_general() const { return n_top != PYA_NTOP || cfg.n_nl > PYA_FAST_NL; }
 
     int fail(int code, int64_t index, const char *fmt, ...) {
         char buf[512];

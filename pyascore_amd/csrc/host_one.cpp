@@ -236,7 +236,7 @@ extern "C" int pya_score_one(pya_handle *h, const double *mz, const double *inte
     if (per_type > PYA_MAX_FRAGMENTS_PER_TYPE)
         return h->fail(PYA_ERR_LIMIT, 0, "PSM 0: %u fragments per ion type exceed %d", per_type, PYA_MAX_FRAGMENTS_PER_TYPE);
     /* (beyond a limit of the fast kernels: the caller takes the batch path, which has the general kernel) */
-    if (h->n_top != PYA_NTOP || n_peaks > PYA_FAST_PEAKS || L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) return PYA_ERR_STATE;
+    if (h->all_general() || n_peaks > PYA_FAST_PEAKS || L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE) return PYA_ERR_STATE;
     if (n_aux > PYA_ONE_MAX_AUX || (uint32_t)n_of_mod > 64u) return PYA_ERR_STATE;     /* (the caller takes the batch path) */
     if (out->max_k < (uint32_t)std::max(n_of_mod, 1)) return h->fail(PYA_ERR_ARG, -1, "results.max_k is smaller than n_of_mod");
     HIPCHK(h, hipSetDevice(h->device));

@@ -291,7 +291,7 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
         if (P <= PYA_FAST_PEAKS) max_P = std::max<uint32_t>(max_P, (uint32_t)P);    /* (sizes the LDS of the fast kernels) */
         lut_need = std::max(lut_need, per_type * n_types);
         if ((uint32_t)k > max_k) max_k = (uint32_t)k;
-        if (P > PYA_FAST_PEAKS || L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE || h->n_top != PYA_NTOP) {
+        if (P > PYA_FAST_PEAKS || L > PYA_FAST_PEPTIDE_LEN || N > PYA_FAST_SIGNATURES || per_type > PYA_FAST_FRAGMENTS_PER_TYPE || h->all_general()) {
             /* beyond a limit of the fast kernels (or n_top > 10): the general kernel takes the PSM whole */
             p->gen[i] = 1;
             p->gen_ids.push_back((uint32_t)i);

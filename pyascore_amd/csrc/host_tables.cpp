@@ -134,10 +134,19 @@ int build_dev_config(pya_handle *h) {
         }
         cand_u[i] = u;
     }
-    if (uniq.size() > PYA_MAX_UNIQ) return h->fail(PYA_ERR_LIMIT, -1, "too many neutral-loss sums");
+    if (uniq.size() > PYA_MAX_UNIQ_WIDE || cands.size() > PYA_MAX_NL_CANDS || (D <= PYA_FAST_NL && uniq.size() > PYA_MAX_UNIQ))
+        return h->fail(PYA_ERR_LIMIT, -1, "too many neutral-loss sums");
     c.n_uniq = (int32_t)uniq.size();
-    for (size_t j = 0; j < uniq.size(); j++) c.uniq[j] = uniq[j];
-    for (int st = 0; st < 256; st++) {
+    c.n_cand = (int32_t)cands.size();
+    for (size_t j = 0; j < uniq.size(); j++) c.uniq_w[j] = uniq[j];
+    for (size_t i = 0; i < cands.size(); i++) {
+        c.cand_a[i] = (uint8_t)cands[i].a;
+        c.cand_b[i] = cands[i].b < 0 ? 255 : (uint8_t)cands[i].b;
+        c.cand_u[i] = (uint8_t)cand_u[i];
+    }
+    /* (more than PYA_FAST_NL masses: every PSM goes through the general kernel, which reads the candidates above) */
+    for (size_t j = 0; j < uniq.size() && j < PYA_MAX_UNIQ; j++) c.uniq[j] = uniq[j];
+    for (int st = 0; st < 256 && D <= PYA_FAST_NL; st++) {
         int cnt[4];
         bool valid = true;
         for (int a = 0; a < 4; a++) {

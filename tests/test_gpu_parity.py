@@ -578,8 +578,8 @@ def test_largest_spectra_and_limits():
     with pytest.raises(ValueError, match="65535"):
         s.score(np.sort(rng.uniform(100.0, 3000.0, 65536)), np.ones(65536), "ASTK", 1)
     with pytest.raises(ValueError, match="length"):
-        s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 256, 0)
-    s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 65, 0)          # (the general kernel: 65 to 255 residues)
+        s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 512, 0)
+    s.score(np.array([100.5, 200.5]), np.ones(2), "A" * 65, 0)          # (the general kernel: 65 to 511 residues)
     assert s.best_sequence == "A" * 65
     with pytest.raises(ValueError, match="site assignments"):
         s.score(np.array([100.5, 200.5]), np.ones(2), "STSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTSTST", 12)
@@ -828,11 +828,12 @@ def _same_psm_by_psm(gpu, chk, batch, records=True):
 
 @pytest.mark.parametrize("L,n_sites,n_mod,over", [
     (65, 4, 2, {}), (100, 6, 2, dict(max_charge=2)), (180, 5, 3, {}), (255, 4, 1, {}),
+    (256, 5, 2, {}), (400, 4, 2, dict(max_charge=2)), (511, 6, 3, {}),
     (90, 5, 2, dict(fragment_types="yb", mz_error=0.5)),
     (70, 4, 2, dict(fragment_types="bycz", max_charge=2, mz_error=0.02, neutral_loss=("sty", 97.9769))),
 ])
 def test_general_kernel_long_peptides(L, n_sites, n_mod, over):
-    """Peptides of 65 to 255 residues (the reference takes any length: cpp/ModifiedPeptide.cpp:24-57) are scored by the
+    """Peptides of 65 to 511 residues (the reference takes any length: cpp/ModifiedPeptide.cpp:24-57) are scored by the
     general kernel (csrc/general_psm.hip), whole: counts, PepScores, the sorted order, Ascores and alternative sites
     equal the reference's."""
     batch, settings = _long_batch(L, n_sites, n_mod, 6, 1000 + L, **over)
@@ -867,6 +868,34 @@ def test_general_kernel_many_site_assignments_and_long_lists():
     st = dict(settings, fragment_types="b", mz_error=0.02, neutral_losses=[["sty", 97.9769], ["ST", 18.01528]])
     lists, _ = synth.make_batch("cfg2", n_psm=4, seed=74, L=60, n_sites=5, n_mod=2, max_charge=8)
     _same_psm_by_psm(_gpu(st), _checker(st), lists)
+
+
+@pytest.mark.parametrize("n_masses", [5, 6, 8])
+def test_more_than_four_neutral_loss_masses(n_masses):
+    """The reference takes any number of neutral-loss entries (cpp/ModifiedPeptide.cpp:99-103); the fast kernels pack the
+    loss state of a fragment into 8 bits = four distinct masses.  With five to eight distinct masses every PSM of the scorer
+    goes through the general kernel (csrc/general_psm.hip: a 16-bit state, up to 45 distinct sums of at most two losses):
+    same results, records and calculate_ambiguity included.  A ninth distinct mass is refused."""
+    from pyascore_amd import PyAscore
+    losses = [["st", 97.9769], ["y", 79.9663], ["ST", 18.01528], ["D", 18.0106], ["E", 17.0265], ["K", 17.0265 + 1.0], ["R", 43.99],
+              ["N", 17.5]][:n_masses]
+    # (the score table covers 4 096 trials = (L - 1) x charges x loss sums x ion types at most: 19 x 2 x 45 x 2, 19 x 1 x 28 x 4)
+    batch, settings = synth.make_batch("cfg2", n_psm=5, seed=600 + n_masses, L=20, n_sites=5, n_mod=2, max_charge=1 if n_masses == 6 else 2)
+    st = dict(settings, fragment_types="bycz" if n_masses == 6 else "by", mz_error=0.02, neutral_losses=losses)
+    gpu, chk = _gpu(st), _checker(st)
+    _same_psm_by_psm(gpu, chk, batch)
+    got = gpu.score_batch(batch)
+    want = chk.score_batch(batch, got["ascores"].shape[1])
+    for key in ("n_sig", "best_sig", "best_score", "alt_mask", "ascores"):
+        assert np.array_equal(got[key], want[key]), key
+    for i in range(2):
+        _ambiguity_agrees(gpu, chk, synth.unpack_psm(batch, i))
+    if n_masses == 8:
+        with pytest.raises(ValueError, match="neutral-loss"):
+            gpu.add_neutral_loss("Q", 1.2345)
+        gpu.score(**synth.unpack_psm(batch, 0))             # (the refused call left the settings as they were)
+        chk.score(**synth.unpack_psm(batch, 0))
+        assert gpu.best_sequence == chk.best_sequence and np.array_equal(gpu.ascores, chk.ascores)
 
 
 def _ambiguity_agrees(gpu, chk, kw, picks=(1, 2, -1)):
@@ -905,7 +934,7 @@ def test_calculate_ambiguity_beyond_the_fast_kernel():
         o = np.argsort(mz, kind="stable")
         _ambiguity_agrees(gpu, chk, dict(kw, mz_arr=mz[o], int_arr=it[o]))
     _ambiguity_agrees(gpu, chk, synth.unpack_psm(small, 3))          # (an ordinary PSM afterwards: the fast kernel again)
-    for L, n_sites, n_mod, over in ((65, 4, 2, {}), (130, 6, 3, dict(max_charge=2)), (255, 5, 2, {}),
+    for L, n_sites, n_mod, over in ((65, 4, 2, {}), (130, 6, 3, dict(max_charge=2)), (255, 5, 2, {}), (511, 4, 2, {}),
                                     (70, 4, 2, dict(fragment_types="bycz", max_charge=2, mz_error=0.02,
                                                     neutral_loss=("sty", 97.9769)))):
         batch, st = _long_batch(L, n_sites, n_mod, 2, 2000 + L, **over)
