@@ -156,6 +156,36 @@ DEV bool lh_probe2(const HashLds &h, int k0, int k1, int hshift, int self, float
     return hit;
 }
 
+/* lh_probe2 that also looks a little further: `hit` = an entry of this task other than `self` within `reach` (as above);
+ * near = the one such entry within `rf` (>= reach), multi = there is more than one.  (An entry can sit in both cells' probe
+ * runs: entries are told apart by their number, not counted.) */
+DEV bool lh_probe_near(const HashLds &h, int k0, int k1, int hshift, int self, float x, float reach, float rf, int nW, int b_lo,
+                       int b_hi, int &near, bool &multi) {
+    const uint32_t hmask = h.hs - 1u;
+    const uint16_t *t16 = (const uint16_t *)h.tab;
+    uint32_t s = ((uint32_t)k0 * 0x9E3779B1u) >> hshift;
+    bool second = k1 == k0, hit = false;
+    for (;;) {
+        const uint32_t half = t16[s];
+        if (half == 0u) {
+            if (second) break;
+            second = true;
+            s = ((uint32_t)k1 * 0x9E3779B1u) >> hshift;
+            continue;
+        }
+        const int j = (int)half - 1;
+        const float dist = __builtin_fabsf(h.val[j] - x);
+        const bool rel = (j != self) && (j < nW || (j >= b_lo && j < b_hi));
+        hit |= rel && dist < reach;
+        if (rel && dist < rf) {
+            multi |= near >= 0 && near != j;
+            near = j;
+        }
+        s = (s + 1u) & hmask;
+    }
+    return hit;
+}
+
 DEV uint32_t lh_ord(float v) {                          /* float -> unsigned with the same order */
     const uint32_t u = __float_as_uint(v);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -165,6 +195,9 @@ DEV uint32_t lh_ord(float v) {                          /* float -> unsigned wit
  * per lane, in the workspace table.  (Staging the table in LDS cost more occupancy than the lookups cost time;
  * two lookups per lane with overlapped round trips, and no lookups at all -- PYA_DEBUG=2 -- leave the kernel's
  * time unchanged: it is bound by issue at the occupancy its LDS allows, not by these loads.) */
+#ifndef LH_CELL_QR
+#define LH_CELL_QR 16.f
+#endif
 #define LH_STAGE 128
 /* The buffer is a ring: `staged` = (entries waiting) | (slot of the oldest << 16).  A flush looks the oldest 64 (or fewer) up
  * and moves the head; nothing is copied to make room (r04 moved the remainder to the front after every flush). */
@@ -467,8 +500,15 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
     const float margin = tau + slop;
     const float reach = err + margin + slop;
     if (!(margin + slop < 0.5f * err)) return true;          /* (huge masses against a tiny tolerance) */
-    const float qr = reach + slop;                           /* cells asked: those of x -+ qr */
-    const float inv_cw = 1.f / (16.f * qr);                 /* (wide cells: an ion's window lies in one cell seven times out of eight, and cells stay almost empty) */
+    const float qr = reach + slop;                           /* (the window of the alone-within-reach test) */
+    /* The commonest collision by far is an in-span ion x next to ONE ion y of the winner outside the span -- which has a twin
+     * y' in the competitor's list (|y - y'| <= margin).  When nothing else of the task lies within rf = 4 err of x, nothing
+     * else can pair with or chain to {x, y, y'} (others are >= rf, their twins >= rf - margin away; the three lie within
+     * reach + margin of x; 3 err - 3 margin - 2 slop >= err under the guard above), and the walk over the three
+     * (ModifiedPeptide.cpp:291-316) has a closed form -- see the query loop.  Everything else takes the exact route. */
+    const float rf = 4.f * err;
+    const float qf = rf + slop;                              /* cells asked: those of x -+ qf */
+    const float inv_cw = 1.f / (LH_CELL_QR * qr);           /* (wide cells: an ion's window lies in one cell most of the time, and cells stay almost empty) */
     const int hshift = 32 - (31 - __builtin_clz(h.hs));
     const float R = 8.f * err;                               /* window of the exact route */
     const FastDiv divZ = fastdiv_make((uint32_t)zmax);
@@ -584,7 +624,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                 const int offA = (int)h.off[1 + 2 * (cc - 1)];
                 const int nA = (int)h.cnt[1 + 2 * (cc - 1)] * zmax, nBc = (int)h.cnt[2 + 2 * (cc - 1)] * zmax;
                 const int b_hi = b_lo + nBc, li = i - first;
-                bool hit = false;
+                bool hit = false, paired_off = false;
                 int id = 0, side = 0;
                 float x = 0.f;
                 if (on) {
@@ -597,7 +637,68 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                     }
                     x = h.val[id];
                     const int k0 = lh_cell(x - qr, inv_cw), k1 = lh_cell(x + qr, inv_cw);
-                    hit = lh_probe2(h, k0, k1, hshift, id, x, reach, nW, b_lo, b_hi);
+                    int near = -1;
+                    bool multi = false;
+                    hit = lh_probe_near(h, k0, k1, hshift, id, x, reach, rf, nW, b_lo, b_hi, near, multi);
+                    if (hit) {
+                        /* (the cells of x -+ qr were visited; those of x -+ qf are one more at most, and only an ion with a
+                         * neighbour asks for it) */
+                        const int w0 = lh_cell(x - qf, inv_cw), w1 = lh_cell(x + qf, inv_cw);
+                        if (w0 != k0 || w1 != k1) {
+                            const int kx = w0 != k0 ? w0 : w1;
+                            (void)lh_probe_near(h, kx, kx, hshift, id, x, reach, rf, nW, b_lo, b_hi, near, multi);
+                        }
+                    }
+                    if (hit && !multi && !(c.b->debug & 0x20000000u)) {
+                        /* one neighbour.  An ion of the winner outside the span has a twin; one in the span, or an ion of the
+                         * competitor (all of those in the table are in the span), has not */
+                        int p = 0, v = 0, z = 1;
+                        bool y_in_span = near >= nW;
+                        if (!y_in_span) {
+                            const int pair = (int)fastdiv((uint32_t)near, divZ);
+                            const uint32_t pz = h.pairs[offW + pair];
+                            z = near - pair * zmax + 1;
+                            p = (int)(pz & 255u);
+                            v = (int)(pz >> 8);
+                            y_in_span = ((h.ispan[cc - 1] >> p) & 1ull) != 0ull;
+                        }
+                        if (y_in_span) {
+                            /* two ions of the span, each an item of this loop: both take the closed form, or both the exact route
+                             * (which accounts for a run as a whole) -- so the neighbour must be as alone as this ion is: nothing
+                             * but this ion within rf of it.  Then the walk over the two pairs them off when they are on opposite
+                             * sides and closer than err, and takes both otherwise. */
+                            const float y = h.val[near];
+                            const int y0 = lh_cell(y - qf, inv_cw), y1 = lh_cell(y + qf, inv_cw);
+                            int near2 = -1;
+                            bool multi2 = false;
+                            (void)lh_probe_near(h, y0, y1, hshift, near, y, reach, rf, nW, b_lo, b_hi, near2, multi2);
+                            if (near2 == id && !multi2) {
+                                const int y_side = near >= nW ? 1 : 0;
+                                paired_off = y_side != side && __builtin_fabsf(x - y) < err;
+                                hit = false;
+                            }
+                        } else {
+                            /* the walk over A = {x, y} / B = {y'} (x the winner's) or A = {y} / B = {x, y'} (x the competitor's):
+                             * with s the pair's ion on x's side and o the other one, x <= s and |x - o| < err pairs x with o and
+                             * leaves s; otherwise x is taken (it is below o, or above the pair, which pairs off) */
+                            const float y = h.val[near];
+                            const float yt = lh_ion(w.run[(size_t)(cc * 2 + d) * c.pos_cap + p], nn ? c.nl.uniq[v] : 0.f, nn, A, B, z);
+                            const float sv = side ? yt : y, ov = side ? y : yt;
+                            if (x <= sv && __builtin_fabsf(x - ov) < err) x = sv;
+                            hit = false;                               /* (staged below like an ion that is alone) */
+                        }
+                    }
+#ifdef PYA_STAMPS
+                    /* (diagnostic build: what the collisions are made of) */
+                    atomicAdd(&c.b->stamps[40], 1ull);
+                    if (near >= 0 && !hit) atomicAdd(&c.b->stamps[41], 1ull);               /* closed form taken (or not a hit at all) */
+                    if (hit) {
+                        atomicAdd(&c.b->stamps[42], 1ull);
+                        if (multi) atomicAdd(&c.b->stamps[43], 1ull);
+                        else if (near >= nW) atomicAdd(&c.b->stamps[44], 1ull);             /* one neighbour: the competitor's in-span ion */
+                        else atomicAdd(&c.b->stamps[45], 1ull);                             /* one neighbour: the winner's in-span ion */
+                    }
+#endif
                     if (c.b->debug & 16384u) hit = true;
                 }
                 const uint64_t hm = __ballot(hit);
@@ -606,7 +707,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                     if (slot < LH_SLOW_CAP) h.slow[slot] = (uint32_t)id | ((uint32_t)cc << 16) | ((uint32_t)side << 24);
                 }
                 nslow += (uint32_t)__popcll(hm);
-                lh_stage_push(c, on && !hit, x, (uint32_t)(cc * 2 + side), staged);
+                lh_stage_push(c, on && !hit && !paired_off, x, (uint32_t)(cc * 2 + side), staged);
                 if (nslow + 64u > LH_SLOW_CAP && nslow) {               /* (the list could overflow with the next 64 items) */
                     if (lh_exact(c, h, q, nslow, staged)) return true;
                     nslow = 0;

@@ -1,6 +1,7 @@
 """Quick parity probe of the hash route of the general localize kernel (through gpurun):
     python scripts/hash_check.py [n] [seed]
 Every case runs under: the default (hash route), PYA_DEBUG=16384 (every in-span ion through the exact run walk),
+PYA_DEBUG=0x20000000 (no closed forms for an ion with one neighbour),
 PYA_DEBUG=8192 (everything declined -> list-based kernel)."""
 import os, sys, time
 import numpy as np
@@ -36,7 +37,7 @@ for cfg, nn, over in cases:
         over["mod_mass"] = mod_mass
     kind = "ref" if orc.available("ref") else "oracle"
     want = None
-    for mode, dbg in (("hash", None), ("exact", "16384"), ("declined", "8192"), ("walkers", "NO_NODES"), ("fewnodes", "NODE_CAP")):
+    for mode, dbg in (("hash", None), ("exact", "16384"), ("noclosed", str(0x20000000)), ("declined", "8192"), ("walkers", "NO_NODES"), ("fewnodes", "NODE_CAP")):
         for v in ("PYA_DEBUG", "PYA_NO_NODES", "PYA_NODE_CAP"):
             os.environ.pop(v, None)
         if dbg == "NO_NODES":

@@ -32,7 +32,7 @@ def test_loaded_library_is_built_from_this_tree():
 
 @pytest.fixture(params=["fused", "lean_localize", "general_localize", "lean_declines", "always_sort", "fused_always_sort",
                         "fused_replay", "general_serial_replay", "big_records", "general_lists", "hash_exact", "hash_declines",
-                        "hash_small_lists", "score_walkers", "score_few_nodes"])
+                        "hash_small_lists", "hash_no_closed_form", "score_walkers", "score_few_nodes"])
 def path(request, monkeypatch):
     """Every batch runs on every route a PSM can take (results stay exact on all of them):
     fused                  plain PSMs (no neutral losses, one ion type per direction) with few site assignments on the
@@ -46,6 +46,9 @@ def path(request, monkeypatch):
     general_serial_replay  the list-based general instantiation with whole-task serial replays (PYA_DEBUG=4096)
     general_lists          the list-based general route the hash route replaced (PYA_NO_LOC_HASH=1)
     hash_exact             the hash route sends every in-span ion through the exact run walk (PYA_DEBUG=16384)
+    hash_no_closed_form    ... sends an ion with one neighbour there too (PYA_DEBUG=0x20000000); by default an ion next to one
+                           ion of the winner outside the span (+ its twin), or next to one other ion of the span that is as
+                           alone, is decided in closed form
     hash_declines          the hash route declines every PSM (PYA_DEBUG=8192: hand-over list, list-based kernel)
     hash_small_lists       room for the pair lists of short spans only (PYA_HASH_PP=2): a share of the PSMs is handed over
     score_walkers          score_signatures under general settings with one walker per signature (PYA_NO_NODES=1)
@@ -69,6 +72,7 @@ def path(request, monkeypatch):
         "general_serial_replay": {"PYA_NO_PLAIN": "1", "PYA_NO_LOC_HASH": "1", "PYA_DEBUG": "4096"},
         "general_lists": {"PYA_NO_PLAIN": "1", "PYA_NO_LOC_HASH": "1"},
         "hash_exact": {"PYA_NO_PLAIN": "1", "PYA_DEBUG": "16384"},
+        "hash_no_closed_form": {"PYA_NO_PLAIN": "1", "PYA_DEBUG": str(0x20000000)},
         "hash_declines": {"PYA_NO_PLAIN": "1", "PYA_DEBUG": "8192"},
         "hash_small_lists": {"PYA_NO_PLAIN": "1", "PYA_HASH_PP": "2"},
         "score_walkers": {"PYA_NO_NODES": "1"},
