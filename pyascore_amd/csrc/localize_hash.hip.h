@@ -99,6 +99,8 @@ DEV int lh_cell(float x, float inv_cw) { return (int)__builtin_floorf(x * inv_cw
 DEV void lh_insert(const HashLds &h, int cell, int id, int hshift) {
     const uint32_t hmask = h.hs - 1u;
     uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> hshift;
+    /* (a loop per lane: the same as one loop for the wavefront with selects -- what the probes below gain from -- measured
+     * 0.19 ms slower on cfg4: a lane that lost a race for a slot holds the others up) */
     for (;;) {
         uint32_t *wp = h.tab + (s >> 1);
         const uint32_t sh = (s & 1u) * 16u;
@@ -113,77 +115,53 @@ DEV void lh_insert(const HashLds &h, int cell, int id, int hshift) {
     }
 }
 
-/* is an entry of this task (the winner's ions, the competitor's in-span ions [b_lo, b_hi)) other than `self`
- * within `reach` of x?  Every entry whose cell is `cell` sits in the probe run that starts at its hash. */
-DEV bool lh_probe(const HashLds &h, int cell, int hshift, int self, float x, float reach, int nW, int b_lo, int b_hi) {
-    const uint32_t hmask = h.hs - 1u;
-    const uint16_t *t16 = (const uint16_t *)h.tab;
-    uint32_t s = ((uint32_t)cell * 0x9E3779B1u) >> hshift;
-    bool hit = false;
-    for (;;) {
-        const uint32_t half = t16[s];
-        if (half == 0u) break;
-        const int j = (int)half - 1;
-        const float y = h.val[j];
-        const bool mine = j < nW || (j >= b_lo && j < b_hi);
-        hit |= (j != self) && mine && (__builtin_fabsf(y - x) < reach);     /* (no early exit: one loop condition) */
-        s = (s + 1u) & hmask;
-    }
-    return hit;
-}
-
-/* the same over the (one or two) cells an ion's window touches, in one loop: the probe run of the second cell follows the
- * first's in the same lane (two calls cost the wavefront the longest run of either cell twice) */
+/* is an entry of this task (the winner's ions, the competitor's in-span ions [b_lo, b_hi)) other than `self` within `reach`
+ * of x?  Every entry whose cell is k sits in the probe run that starts at k's hash; the (one or two) cells an ion's window
+ * touches are visited one after the other by the same loop.  ONE loop for the wavefront, every lane's state advanced by
+ * selects: as a loop with two exits per lane the exec-mask bookkeeping cost as many scalar instructions as the body has
+ * vector ones (cfg4 localize 6.24 -> 6.01 ms). */
 DEV bool lh_probe2(const HashLds &h, int k0, int k1, int hshift, int self, float x, float reach, int nW, int b_lo, int b_hi) {
     const uint32_t hmask = h.hs - 1u;
     const uint16_t *t16 = (const uint16_t *)h.tab;
     uint32_t s = ((uint32_t)k0 * 0x9E3779B1u) >> hshift;
-    bool second = k1 == k0, hit = false;                       /* (nothing more to visit after the first run) */
-    for (;;) {
+    const uint32_t s1 = ((uint32_t)k1 * 0x9E3779B1u) >> hshift;
+    uint32_t left = k1 == k0 ? 1u : 2u;                      /* probe runs still to finish */
+    uint32_t hit = 0u;
+    while (__any(left != 0u)) {
         const uint32_t half = t16[s];
-        if (half == 0u) {
-            if (second) break;
-            second = true;
-            s = ((uint32_t)k1 * 0x9E3779B1u) >> hshift;
-            continue;
-        }
-        const int j = (int)half - 1;
-        const float y = h.val[j];
-        const bool mine = j < nW || (j >= b_lo && j < b_hi);
-        hit |= (j != self) && mine && (__builtin_fabsf(y - x) < reach);
-        s = (s + 1u) & hmask;
+        const bool empty = half == 0u;
+        const int j = (int)(empty ? 1u : half) - 1;
+        const float dist = __builtin_fabsf(h.val[j] - x);
+        const bool rel = left != 0u && !empty && (j != self) && (j < nW || (j >= b_lo && j < b_hi));
+        hit |= (rel && dist < reach) ? 1u : 0u;
+        s = empty ? s1 : ((s + 1u) & hmask);
+        left = (empty && left != 0u) ? left - 1u : left;
     }
-    return hit;
+    return hit != 0u;
 }
 
-/* lh_probe2 that also looks a little further: `hit` = an entry of this task other than `self` within `reach` (as above);
- * near = the one such entry within `rf` (>= reach), multi = there is more than one.  (An entry can sit in both cells' probe
- * runs: entries are told apart by their number, not counted.) */
-DEV bool lh_probe_near(const HashLds &h, int k0, int k1, int hshift, int self, float x, float reach, float rf, int nW, int b_lo,
-                       int b_hi, int &near, bool &multi) {
+/* the same, looking a little further: near = the one such entry within `rf`, multi = there is more than one.  (An entry can
+ * sit in both cells' probe runs: entries are told apart by their number, not counted.) */
+DEV void lh_probe_near(const HashLds &h, int k0, int k1, int hshift, int self, float x, float rf, int nW, int b_lo, int b_hi,
+                       int &near, bool &multi) {
     const uint32_t hmask = h.hs - 1u;
     const uint16_t *t16 = (const uint16_t *)h.tab;
     uint32_t s = ((uint32_t)k0 * 0x9E3779B1u) >> hshift;
-    bool second = k1 == k0, hit = false;
-    for (;;) {
+    const uint32_t s1 = ((uint32_t)k1 * 0x9E3779B1u) >> hshift;
+    uint32_t left = k1 == k0 ? 1u : 2u;
+    uint32_t mul = 0u;
+    while (__any(left != 0u)) {
         const uint32_t half = t16[s];
-        if (half == 0u) {
-            if (second) break;
-            second = true;
-            s = ((uint32_t)k1 * 0x9E3779B1u) >> hshift;
-            continue;
-        }
-        const int j = (int)half - 1;
+        const bool empty = half == 0u;
+        const int j = (int)(empty ? 1u : half) - 1;
         const float dist = __builtin_fabsf(h.val[j] - x);
-        const bool rel = (j != self) && (j < nW || (j >= b_lo && j < b_hi));
-        hit |= rel && dist < reach;
-        if (rel && dist < rf) {
-            multi |= near >= 0 && near != j;
-            near = j;
-        }
-        s = (s + 1u) & hmask;
+        const bool in_f = left != 0u && !empty && (j != self) && (j < nW || (j >= b_lo && j < b_hi)) && dist < rf;
+        mul |= (in_f && near >= 0 && near != j) ? 1u : 0u;
+        near = in_f ? j : near;
+        s = empty ? s1 : ((s + 1u) & hmask);
+        left = (empty && left != 0u) ? left - 1u : left;
     }
-    return hit;
+    multi |= mul != 0u;
 }
 
 DEV uint32_t lh_ord(float v) {                          /* float -> unsigned with the same order */
@@ -234,12 +212,13 @@ DEV void lh_stage_push(const LocCtx &c, bool kept, float val, uint32_t tag, int 
 
 /* what the exact route needs to know about the table in place */
 struct LhPass {
-    int d, zmax, c0, nW, offW, hshift;
+    int d, zmax, c0, c1, nW, offW, hshift;
     double A, B;
-    float err, margin, R;
+    float err, margin, R, rf, qf, inv_cw;
     bool nn;
     FastDiv divZ;
 };
+#define LH_HIT_CAP (LH_SLOW_CAP + 2 * LH_CAND_CAP)      /* the list of ions with a neighbour: h.slow and, until the exact route runs, its candidate arrays behind it */
 
 /* The exact route for the items of h.slow[0, nslow): the run of the merged list around each item is gathered
  * (the winner's ions, the twins of those outside the span computed with the competitor's running sums, the
@@ -385,6 +364,97 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
     return false;
 }
 
+/* The ions the query loop found a neighbour for (h.slow[0, nslow), nslow <= LH_HIT_CAP), one per lane.  Nearly all of them
+ * are one of two simple cases, decided here in closed form; what is left goes through the exact route.
+ *
+ * (a) x next to ONE ion y of the winner outside the span -- which has a twin y' in the competitor's list (|y - y'| <=
+ *     margin).  When nothing else of the task lies within rf = 4 err of x, nothing else can pair with or chain to
+ *     {x, y, y'}: others are >= rf, their twins >= rf - margin away, the three lie within reach + margin of x, and
+ *     3 err - 3 margin - 2 slop >= err under the caller's guard.  The walk (ModifiedPeptide.cpp:291-316) over A = {x, y} /
+ *     B = {y'} (x the winner's) or A = {y} / B = {x, y'} (x the competitor's): with s the pair's ion on x's side and o the
+ *     other one, x <= s and |x - o| < err pairs x with o and leaves s; otherwise x is taken (it is below o, or above the
+ *     pair, which pairs off).
+ * (b) x next to ONE other ion y of the span (the winner's or the competitor's: no twins).  Both are items of the query loop,
+ *     and the exact route accounts for a run as a whole, so both must take the same way: y has to be as alone as x is --
+ *     nothing but x within rf of it (each lane checks both, so both reach the same verdict).  Then the walk pairs them off
+ *     when they are on opposite sides and closer than err, and takes both otherwise.
+ * 58 % / 40 % of cfg4's collisions; the exact route, serial per ion, was 2.05 of the kernel's 7.7 ms. */
+DEV bool lh_resolve(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t nslow, int &staged) {
+    const int lane = lane_id();
+    const LocLds &w = c.w;
+    const int zmax = q.zmax, nW = q.nW;
+    wave_lds_sync();
+    /* (the second half of the list lies where the exact route keeps its candidates: into registers first) */
+    const uint32_t n_lo = nslow < (uint32_t)LH_SLOW_CAP ? nslow : (uint32_t)LH_SLOW_CAP;
+    const uint32_t it_lo = (uint32_t)lane < n_lo ? h.slow[lane] : 0u;
+    const uint32_t it_hi = (uint32_t)(LH_SLOW_CAP + lane) < nslow ? h.slow[LH_SLOW_CAP + lane] : 0u;
+    const bool closed = !(c.b->debug & (0x20000000u | 16384u));
+    for (int chunk = 0; chunk < 2; chunk++) {
+        const uint32_t n = chunk ? nslow - n_lo : n_lo;
+        if (n == 0) break;
+        const uint32_t it = chunk ? it_hi : it_lo;
+        const bool on = (uint32_t)lane < n;
+        const int id = (int)(it & 0xffffu), cc = on ? (int)((it >> 16) & 0xffu) : q.c0, side = (int)(it >> 24);
+        bool unresolved = on, kept = false;
+        float x = 0.f;
+        if (on && closed) {
+            int b_lo = nW;
+            for (int q2 = q.c0; q2 < q.c1; q2++) b_lo += q2 < cc ? (int)h.cnt[2 + 2 * (q2 - 1)] * zmax : 0;
+            const int b_hi = b_lo + (int)h.cnt[2 + 2 * (cc - 1)] * zmax;
+            x = h.val[id];
+            int near = -1;
+            bool multi = false;
+            lh_probe_near(h, lh_cell(x - q.qf, q.inv_cw), lh_cell(x + q.qf, q.inv_cw), q.hshift, id, x, q.rf, nW, b_lo, b_hi, near, multi);
+            if (near >= 0 && !multi) {
+                /* one neighbour.  An ion of the winner outside the span has a twin; one in the span, or an ion of the competitor
+                 * (all of those in the table are in the span), has not */
+                int p = 0, v = 0, z = 1;
+                bool y_in_span = near >= nW;
+                if (!y_in_span) {
+                    const int pair = (int)fastdiv((uint32_t)near, q.divZ);
+                    const uint32_t pz = h.pairs[q.offW + pair];
+                    z = near - pair * zmax + 1;
+                    p = (int)(pz & 255u);
+                    v = (int)(pz >> 8);
+                    y_in_span = ((h.ispan[cc - 1] >> p) & 1ull) != 0ull;
+                }
+                const float y = h.val[near];
+                if (y_in_span) {
+                    int near2 = -1;
+                    bool multi2 = false;
+                    lh_probe_near(h, lh_cell(y - q.qf, q.inv_cw), lh_cell(y + q.qf, q.inv_cw), q.hshift, near, y, q.rf, nW, b_lo, b_hi,
+                                  near2, multi2);
+                    if (near2 == id && !multi2) {
+                        const int y_side = near >= nW ? 1 : 0;
+                        kept = !(y_side != side && __builtin_fabsf(x - y) < q.err);
+                        unresolved = false;
+                    }
+                } else {
+                    const float yt = lh_ion(w.run[(size_t)(cc * 2 + q.d) * c.pos_cap + p], q.nn ? c.nl.uniq[v] : 0.f, q.nn, q.A, q.B, z);
+                    const float sv = side ? yt : y, ov = side ? y : yt;
+                    if (x <= sv && __builtin_fabsf(x - ov) < q.err) x = sv;
+                    kept = true;
+                    unresolved = false;
+                }
+#ifdef PYA_STAMPS
+                if (c.b->stamps) atomicAdd(&c.b->stamps[unresolved ? 44 : (y_in_span ? 42 : 41)], 1ull);   /* (diagnostic build) */
+#endif
+            }
+#ifdef PYA_STAMPS
+            if (c.b->stamps) atomicAdd(&c.b->stamps[40], 1ull);
+            if (c.b->stamps && multi) atomicAdd(&c.b->stamps[43], 1ull);
+#endif
+        }
+        wave_lds_sync();                                         /* (everybody has read its entry) */
+        const uint64_t um = __ballot(unresolved);
+        if (unresolved) h.slow[__popcll(um & lanemask_lt())] = it;
+        lh_stage_push(c, kept, x, (uint32_t)(cc * 2 + side), staged);
+        const uint32_t nleft = (uint32_t)__popcll(um);
+        if (nleft && lh_exact(c, h, q, nleft, staged)) return true;
+    }
+    return false;
+}
+
 /* Pair lists of one direction (built when the ion types change direction: one direction's lists at a time halve
  * the room they need): list 0 = the winner's (prefix | variant << 8) pairs; per competitor cc the in-span prefixes
  * (h.ispan[cc - 1]: loss variants differ, or running sums differ by more than tau), list 1 + 2 (cc - 1) = the
@@ -501,11 +571,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
     const float reach = err + margin + slop;
     if (!(margin + slop < 0.5f * err)) return true;          /* (huge masses against a tiny tolerance) */
     const float qr = reach + slop;                           /* (the window of the alone-within-reach test) */
-    /* The commonest collision by far is an in-span ion x next to ONE ion y of the winner outside the span -- which has a twin
-     * y' in the competitor's list (|y - y'| <= margin).  When nothing else of the task lies within rf = 4 err of x, nothing
-     * else can pair with or chain to {x, y, y'} (others are >= rf, their twins >= rf - margin away; the three lie within
-     * reach + margin of x; 3 err - 3 margin - 2 slop >= err under the guard above), and the walk over the three
-     * (ModifiedPeptide.cpp:291-316) has a closed form -- see the query loop.  Everything else takes the exact route. */
+    /* (the closed forms of lh_resolve ask for nothing else within rf of an ion and its one neighbour) */
     const float rf = 4.f * err;
     const float qf = rf + slop;                              /* cells asked: those of x -+ qf */
     const float inv_cw = 1.f / (LH_CELL_QR * qr);           /* (wide cells: an ion's window lies in one cell most of the time, and cells stay almost empty) */
@@ -589,6 +655,10 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
             q.d = d;
             q.zmax = zmax;
             q.c0 = c0;
+            q.c1 = c1;
+            q.rf = rf;
+            q.qf = qf;
+            q.inv_cw = inv_cw;
             q.nW = nW;
             q.offW = offW;
             q.hshift = hshift;
@@ -624,7 +694,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                 const int offA = (int)h.off[1 + 2 * (cc - 1)];
                 const int nA = (int)h.cnt[1 + 2 * (cc - 1)] * zmax, nBc = (int)h.cnt[2 + 2 * (cc - 1)] * zmax;
                 const int b_hi = b_lo + nBc, li = i - first;
-                bool hit = false, paired_off = false;
+                bool hit = false;
                 int id = 0, side = 0;
                 float x = 0.f;
                 if (on) {
@@ -637,84 +707,23 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                     }
                     x = h.val[id];
                     const int k0 = lh_cell(x - qr, inv_cw), k1 = lh_cell(x + qr, inv_cw);
-                    int near = -1;
-                    bool multi = false;
-                    hit = lh_probe_near(h, k0, k1, hshift, id, x, reach, rf, nW, b_lo, b_hi, near, multi);
-                    if (hit) {
-                        /* (the cells of x -+ qr were visited; those of x -+ qf are one more at most, and only an ion with a
-                         * neighbour asks for it) */
-                        const int w0 = lh_cell(x - qf, inv_cw), w1 = lh_cell(x + qf, inv_cw);
-                        if (w0 != k0 || w1 != k1) {
-                            const int kx = w0 != k0 ? w0 : w1;
-                            (void)lh_probe_near(h, kx, kx, hshift, id, x, reach, rf, nW, b_lo, b_hi, near, multi);
-                        }
-                    }
-                    if (hit && !multi && !(c.b->debug & 0x20000000u)) {
-                        /* one neighbour.  An ion of the winner outside the span has a twin; one in the span, or an ion of the
-                         * competitor (all of those in the table are in the span), has not */
-                        int p = 0, v = 0, z = 1;
-                        bool y_in_span = near >= nW;
-                        if (!y_in_span) {
-                            const int pair = (int)fastdiv((uint32_t)near, divZ);
-                            const uint32_t pz = h.pairs[offW + pair];
-                            z = near - pair * zmax + 1;
-                            p = (int)(pz & 255u);
-                            v = (int)(pz >> 8);
-                            y_in_span = ((h.ispan[cc - 1] >> p) & 1ull) != 0ull;
-                        }
-                        if (y_in_span) {
-                            /* two ions of the span, each an item of this loop: both take the closed form, or both the exact route
-                             * (which accounts for a run as a whole) -- so the neighbour must be as alone as this ion is: nothing
-                             * but this ion within rf of it.  Then the walk over the two pairs them off when they are on opposite
-                             * sides and closer than err, and takes both otherwise. */
-                            const float y = h.val[near];
-                            const int y0 = lh_cell(y - qf, inv_cw), y1 = lh_cell(y + qf, inv_cw);
-                            int near2 = -1;
-                            bool multi2 = false;
-                            (void)lh_probe_near(h, y0, y1, hshift, near, y, reach, rf, nW, b_lo, b_hi, near2, multi2);
-                            if (near2 == id && !multi2) {
-                                const int y_side = near >= nW ? 1 : 0;
-                                paired_off = y_side != side && __builtin_fabsf(x - y) < err;
-                                hit = false;
-                            }
-                        } else {
-                            /* the walk over A = {x, y} / B = {y'} (x the winner's) or A = {y} / B = {x, y'} (x the competitor's):
-                             * with s the pair's ion on x's side and o the other one, x <= s and |x - o| < err pairs x with o and
-                             * leaves s; otherwise x is taken (it is below o, or above the pair, which pairs off) */
-                            const float y = h.val[near];
-                            const float yt = lh_ion(w.run[(size_t)(cc * 2 + d) * c.pos_cap + p], nn ? c.nl.uniq[v] : 0.f, nn, A, B, z);
-                            const float sv = side ? yt : y, ov = side ? y : yt;
-                            if (x <= sv && __builtin_fabsf(x - ov) < err) x = sv;
-                            hit = false;                               /* (staged below like an ion that is alone) */
-                        }
-                    }
-#ifdef PYA_STAMPS
-                    /* (diagnostic build: what the collisions are made of) */
-                    atomicAdd(&c.b->stamps[40], 1ull);
-                    if (near >= 0 && !hit) atomicAdd(&c.b->stamps[41], 1ull);               /* closed form taken (or not a hit at all) */
-                    if (hit) {
-                        atomicAdd(&c.b->stamps[42], 1ull);
-                        if (multi) atomicAdd(&c.b->stamps[43], 1ull);
-                        else if (near >= nW) atomicAdd(&c.b->stamps[44], 1ull);             /* one neighbour: the competitor's in-span ion */
-                        else atomicAdd(&c.b->stamps[45], 1ull);                             /* one neighbour: the winner's in-span ion */
-                    }
-#endif
+                    hit = lh_probe2(h, k0, k1, hshift, id, x, reach, nW, b_lo, b_hi);
                     if (c.b->debug & 16384u) hit = true;
                 }
                 const uint64_t hm = __ballot(hit);
                 if (hit) {
                     const uint32_t slot = nslow + (uint32_t)__popcll(hm & lanemask_lt());
-                    if (slot < LH_SLOW_CAP) h.slow[slot] = (uint32_t)id | ((uint32_t)cc << 16) | ((uint32_t)side << 24);
+                    if (slot < LH_HIT_CAP) h.slow[slot] = (uint32_t)id | ((uint32_t)cc << 16) | ((uint32_t)side << 24);
                 }
                 nslow += (uint32_t)__popcll(hm);
-                lh_stage_push(c, on && !hit && !paired_off, x, (uint32_t)(cc * 2 + side), staged);
-                if (nslow + 64u > LH_SLOW_CAP && nslow) {               /* (the list could overflow with the next 64 items) */
-                    if (lh_exact(c, h, q, nslow, staged)) return true;
+                lh_stage_push(c, on && !hit, x, (uint32_t)(cc * 2 + side), staged);
+                /* (one call site: after the last round, or when the list could overflow with the next 64 items) */
+                if (nslow && (base + 64 >= n_items || nslow + 64u > LH_HIT_CAP)) {
+                    if (lh_resolve(c, h, q, nslow, staged)) return true;
                     nslow = 0;
                 }
             }
             STAMP_T(*c.b, 32, false);
-            if (nslow && lh_exact(c, h, q, nslow, staged)) return true;
             STAMP_T(*c.b, 33, false);
             wave_lds_sync();
             c0 = c1;

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 cd /tmp
 for k in $PTS; do
   rm -rf /tmp/tp_$k
-  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/tp_$k -- python3 $ROOT/scripts/trunc_run.py $CFG $((k << 16)) > /tmp/tp_$k.log 2>&1 || tail -3 /tmp/tp_$k.log
+  timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/tp_$k -- python3 $ROOT/scripts/trunc_run.py $CFG $((k << 16)) > /tmp/tp_$k.log 2>&1 || tail -3 /tmp/tp_$k.log
   python3 - "$k" "$KN" <<'PY'
 import csv, glob, sys, collections
 k, kn = sys.argv[1], sys.argv[2]
