@@ -101,6 +101,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
     if (b.status[psm] != PYA_ST_OK) return;
     const uint32_t N = b.n_sig[psm];
     if (N == 0) return;
+    STAMP_BEGIN();
     const Residues res = load_residues(b, cfg, psm);
     const int zmax = b.max_charge[psm];
     const uint64_t *order = b.order_tab + b.order_off[psm];
@@ -129,6 +130,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
     grid_build(&tab, c.grid);
     wave_lds_sync();
     ((uint64_t *)(b.grid + (size_t)psm * PYA_GRID_CELLS))[lane] = ((const uint64_t *)c.grid)[lane];
+    STAMP_T(b, 25, );
 
     const int n_f = cfg->n_fwd, n_b = cfg->n_types - cfg->n_fwd;
     const int t_max = n_f > n_b ? n_f : n_b;
@@ -138,6 +140,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
     const uint32_t first_nl = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, res.site_mask ? __builtin_ctzll(res.site_mask) : 0);
     const bool uniform = !__any(is_site && res.nl != first_nl) && !(b.debug & 0x40000000u) && k + 1 <= 31 && n_sites <= 32 &&
                          (uint32_t)k <= k_cap && (uint32_t)n_sites <= n_cap;
+    bool tables = false;                                     /* the count tables were built: site assignments read them */
     if (uniform) {
         /* 1. envelopes of the running sums; 2. the loss state of every node, from the chain with the first j sites modified */
         cnt_envelopes(res, k, pos_cap, c.env);
@@ -161,59 +164,66 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
         }
         for (int i = lane; i < rows * (int)pos_cap * 6; i += 64) c.hist[i] = 0u;
         wave_lds_sync();
-        /* 3. one lookup per (node, variant, ion type, charge).  The reachable nodes are listed first (a third of the (row,
-         * step) pairs have fewer modifiable residues than j); a lane takes a (node, ion type) pair, the variants of its node
-         * in a loop, the charges in a wave-uniform inner loop (so that the charge division runs for the charges that need it
-         * only, not for every lane's own). */
-        uint16_t *nlist = (uint16_t *)c.psA;                     /* (the prefix sums' room: not written before step 4) */
-        int n_nodes = 0;
+        STAMP_T(b, 26, );
+        /* 3. one lookup per (node, variant, ion type, charge).  The (reachable node, loss variant) pairs are listed first: a
+         * third of the (row, step) pairs have fewer modifiable residues than j, and a node has one to three variants (more
+         * with more loss masses) -- a lane per node with its variants in a loop ran every wavefront to its longest node.  A lane
+         * takes a (node, variant, ion type) item, the charges in a wave-uniform inner loop (so that the charge division runs
+         * for the charges that need it only, not for every lane's own). */
+        uint16_t *nlist = (uint16_t *)c.psA;                     /* (the prefix sums' and G's room: not written before step 4) */
+        const int n_room = (int)((2u * (k_cap + 1u) * (n_cap + 1u) * 24u + (k_cap * n_cap + 1u) * 24u) / 2u);
+        int n_ent = 0;
         for (int row = 0; row < rows; row++) {
-            bool reach = false;
+            uint32_t pm = 0u;
             if (lane < Lm1) {
-                const float2 lh = c.env[(size_t)row * pos_cap + lane];
-                reach = lh.x <= lh.y;
+                const size_t node = (size_t)row * pos_cap + lane;
+                const float2 lh = c.env[node];
+                if (lh.x <= lh.y) pm = env.n_nl ? (uint32_t)c.nl_present[c.st[node]] : 1u;
             }
-            const uint64_t rm = __ballot(reach);
-            if (reach) nlist[n_nodes + __popcll(rm & lanemask_lt())] = (uint16_t)(row * 64 + lane);
-            n_nodes += __popcll(rm);
+            while (__any(pm != 0u)) {
+                const bool has = pm != 0u;
+                const int v = has ? __builtin_ctz(pm) : 0;
+                pm &= pm - 1u;
+                const uint64_t hm = __ballot(has);
+                const int at = n_ent + __popcll(hm & lanemask_lt());
+                if (has && at < n_room) nlist[at] = (uint16_t)((row * 64 + lane) | (v << 12));
+                n_ent += __popcll(hm);
+            }
         }
+        tables = n_ent <= n_room;                                /* (else: every site assignment is walked) */
         wave_lds_sync();
-        {
+        if (tables) {
             const FastDiv divT = fastdiv_make((uint32_t)t_max);
-            const uint32_t items = (uint32_t)n_nodes * (uint32_t)t_max;
+            const uint32_t items = (uint32_t)n_ent * (uint32_t)t_max;
             for (uint32_t base = 0; base < items; base += 64) {
                 const uint32_t i = base + (uint32_t)lane;
                 const uint32_t ni = fastdiv(i, divT);
                 const int t = (int)(i - ni * (uint32_t)t_max);
                 const uint32_t code = i < items ? (uint32_t)nlist[ni] : 0u;
-                const uint32_t row = code >> 6, s = code & 63u;
+                const uint32_t row = (code >> 6) & 63u, s = code & 63u, v = code >> 12;
                 const int d = row >= (uint32_t)(k + 1) ? 1 : 0;
                 const int my_types = d ? n_b : n_f;
                 const bool on = i < items && t < my_types;
                 const size_t node = (size_t)row * pos_cap + s;
                 const float2 lh = c.env[node];
-                uint32_t pm = on ? (env.n_nl ? (uint32_t)c.nl_present[c.st[node]] : 1u) : 0u;
                 double A, B;
                 type_constants(type_at(types64, (d ? n_f : 0) + (t < my_types ? t : 0)), &A, &B);
                 uint32_t *hn = c.hist + node * 6;
-                if (on && t == 0) atomicAdd(&hn[5], (uint32_t)__popc(pm) * (uint32_t)(my_types * zmax));
-                while (__any(pm != 0u)) {
-                    const bool von = pm != 0u;
-                    const int v = von ? __builtin_ctz(pm) : 0;
-                    pm &= pm - 1u;
-                    const float loss = env.n_nl ? c.nl_uniq[v] : 0.f;
-                    const float x_lo = env.n_nl ? lh.x - loss : lh.x, x_hi = env.n_nl ? lh.y - loss : lh.y;   /* float subtract (:572), monotone */
-                    const double m_lo = ((double)x_lo + A) - B, m_hi = ((double)x_hi + A) - B;
-                    for (int z = 1; z <= zmax; z++) {
-                        const uint32_t ent = cnt_entry_f(tab, charge_mz(m_lo, z), charge_mz(m_hi, z));
-                        const uint32_t rk = ent & 15u;
-                        if (von && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 1], 1u << ((rk & 1u) * 16u));
-                        if (von && (ent & CNT_MARK)) atomicAdd(&hn[5], 1u << 16);
-                    }
+                if (on && t == 0) atomicAdd(&hn[5], (uint32_t)(my_types * zmax));
+                const float loss = env.n_nl ? c.nl_uniq[v] : 0.f;
+                const float x_lo = env.n_nl ? lh.x - loss : lh.x, x_hi = env.n_nl ? lh.y - loss : lh.y;   /* float subtract (:572), monotone */
+                const double m_lo = ((double)x_lo + A) - B, m_hi = ((double)x_hi + A) - B;
+                for (int z = 1; z <= zmax; z++) {
+                    const uint32_t ent = cnt_entry_f(tab, charge_mz(m_lo, z), charge_mz(m_hi, z));
+                    const uint32_t rk = ent & 15u;
+                    if (on && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 1], 1u << ((rk & 1u) * 16u));
+                    if (on && (ent & CNT_MARK)) atomicAdd(&hn[5], 1u << 16);
                 }
             }
         }
         wave_lds_sync();
+        STAMP_T(b, 27, );
+        if (tables) {
         /* 4. prefix sums over the steps of every row, taken at the sites' steps (score_cnt.hip: site_prefix_sums): two rows
          * per scan, one per half of the wavefront, for peptides of up to 33 residues */
         {
@@ -259,6 +269,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
             }
         }
         wave_lds_sync();
+        STAMP_T(b, 28, );
         /* 5. G(t, site) and the constant (walk_core.hip.h) */
         {
             const int W = n_sites + 1;
@@ -283,8 +294,10 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
             }
         }
         wave_lds_sync();
+        }
     }
 
+    STAMP_T(b, 29, );
     /* 6. the site assignments */
     const bool has_f = n_f > 0, has_b = n_b > 0;
     int lut_fail = 0;
@@ -295,7 +308,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
         const uint64_t bits = active ? order[s] : 0ull;
         uint32_t w[6] = {0u, 0u, 0u, 0u, 0u, 0u};
         bool walk = active;                                  /* (no tables: everybody walks) */
-        if (uniform) {
+        if (tables) {
             const uint4 ca = c.gA[k * n_sites];
             const uint2 cb = c.gB[k * n_sites];
             w[0] = ca.x; w[1] = ca.y; w[2] = ca.z; w[3] = ca.w; w[4] = cb.x; w[5] = cb.y;
