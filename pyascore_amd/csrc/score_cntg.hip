@@ -213,11 +213,20 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
                 const float loss = env.n_nl ? c.nl_uniq[v] : 0.f;
                 const float x_lo = env.n_nl ? lh.x - loss : lh.x, x_hi = env.n_nl ? lh.y - loss : lh.y;   /* float subtract (:572), monotone */
                 const double m_lo = ((double)x_lo + A) - B, m_hi = ((double)x_hi + A) - B;
-                for (int z = 1; z <= zmax; z++) {
-                    const uint32_t ent = cnt_entry_f(tab, charge_mz(m_lo, z), charge_mz(m_hi, z));
-                    const uint32_t rk = ent & 15u;
-                    if (on && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 1], 1u << ((rk & 1u) * 16u));
-                    if (on && (ent & CNT_MARK)) atomicAdd(&hn[5], 1u << 16);
+                /* (the items follow the rows, and the rows j = 0 and j = k have one chain per node: whole rounds of point
+                 * envelopes, which need one m/z and no band) */
+                if (__all(!on || lh.x == lh.y)) {
+                    for (int z = 1; z <= zmax; z++) {
+                        const uint32_t rk = cnt_entry_1(tab, charge_mz(m_lo, z));
+                        if (on && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 1], 1u << ((rk & 1u) * 16u));
+                    }
+                } else {
+                    for (int z = 1; z <= zmax; z++) {
+                        const uint32_t ent = cnt_entry_f(tab, charge_mz(m_lo, z), charge_mz(m_hi, z));
+                        const uint32_t rk = ent & 15u;
+                        if (on && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 1], 1u << ((rk & 1u) * 16u));
+                        if (on && (ent & CNT_MARK)) atomicAdd(&hn[5], 1u << 16);
+                    }
                 }
             }
         }

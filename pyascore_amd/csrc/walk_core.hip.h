@@ -460,6 +460,17 @@ DEV uint32_t cnt_entry_f(const PeakTable &t, float f_lo, float f_hi) {
     }
     return (uint32_t)in_best | (band_best < in_best ? CNT_MARK : 0u);
 }
+/* ... when the envelope is a point (f_lo == f_hi: no band, nothing to mark) */
+DEV uint32_t cnt_entry_1(const PeakTable &t, float f) {
+    const float a = f - t.err, b = f + t.err;
+    int best = PYA_NO_MATCH;
+    for (int idx = (int)t.cell[grid_cell(t, a)];; idx++) {
+        const PeakEntry x = t.e[idx];
+        if (!(x.mz < b)) break;
+        if (x.mz > a) best = (int)x.rank < best ? (int)x.rank : best;
+    }
+    return (uint32_t)best;
+}
 /* One node of the plain settings (one ion: charge 1): the envelope [lo, hi] of its running sums (A, B: the ion type's offsets) */
 DEV uint32_t cnt_table_entry(const PeakTable &t, float lo, float hi, double A, double B) {
     if (!(lo <= hi)) return (uint32_t)PYA_NO_MATCH;           /* unreachable: never read */
