@@ -122,15 +122,15 @@ def test_rows_match_per_psm_reference_loop(tmp_path):
 
 @pytest.mark.gpu
 def test_one_unscorable_psm_does_not_cost_the_run_its_output():
-    """A PSM beyond a limit the reference does not have (here: 300 residues) is written as a row
+    """A PSM beyond a limit the reference does not have (here: 600 residues) is written as a row
     without a localisation, with a warning; the other rows are unchanged.  (70 residues -- beyond the fast kernels,
     not beyond the general one -- is scored like any other PSM.)"""
     from pyascore_amd import PyAscore
     spectra, psms = _toy_inputs()
     gpu = PyAscore(100.0, 10, "STY", PHOSPHO, 0.05, "by")
     want = batch_cli.localize(gpu, psms, spectra, "STY", PHOSPHO, hit_depth=2, max_fragment_charge=3)
-    long_psm = dict(psms[0], scan=psms[-1]["scan"] + 1, peptide="A" * 290 + "STSTSTSTSK",
-                    mod_positions=np.array([291], np.int32), mod_masses=np.array([PHOSPHO]))
+    long_psm = dict(psms[0], scan=psms[-1]["scan"] + 1, peptide="A" * 590 + "STSTSTSTSK",
+                    mod_positions=np.array([591], np.int32), mod_masses=np.array([PHOSPHO]))
     spectra2 = dict(spectra)
     spectra2[long_psm["scan"]] = spectra[psms[0]["scan"]]
     said = []
@@ -138,7 +138,7 @@ def test_one_unscorable_psm_does_not_cost_the_run_its_output():
         rows = batch_cli.localize(gpu, psms + [long_psm], spectra2, "STY", PHOSPHO, hit_depth=2, max_fragment_charge=3,
                                   log=said.append)
     # the run's log names how many PSMs were set aside, why, and which scans
-    assert len(said) == 2 and said[0].startswith("1 of ") and "peptide length 300" in said[0]
+    assert len(said) == 2 and said[0].startswith("1 of ") and "peptide length 600" in said[0]
     assert str(long_psm["scan"]) in said[1] and "code" in said[1]
     assert rows[:-1] == want
     assert rows[-1][0] == long_psm["scan"] and rows[-1][1] == "" and np.isnan(rows[-1][2]) and rows[-1][3:] == ["", ""]

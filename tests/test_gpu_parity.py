@@ -770,7 +770,7 @@ def test_skip_invalid_sets_psms_aside():
     mzs = np.sort(rng.uniform(150.0, 1500.0, 200))
     its = rng.lognormal(5, 1, 200)
     odd = [
-        dict(mz=mzs, intensity=its, peptide="A" * 200 + "STY" * 20, n_of_mod=2, max_charge=1),         # 260 residues
+        dict(mz=mzs, intensity=its, peptide="A" * 500 + "STY" * 20, n_of_mod=2, max_charge=1),         # 560 residues
         dict(mz=mzs, intensity=its, peptide="PEPTIXDESK", n_of_mod=1, max_charge=1),                     # unknown residue
         dict(mz=np.zeros(0), intensity=np.zeros(0), peptide="PEPTIDESK", n_of_mod=1, max_charge=1),      # empty spectrum
         dict(mz=mzs, intensity=its, peptide="ST" * 20, n_of_mod=12, max_charge=1),                       # C(40,12) assignments
