@@ -947,6 +947,12 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
                                 bk.gtp(), 1u, sort_room, st);
         if (e) return h->hip_fail((hipError_t)e, "localize launch");
         const uint32_t nnl = (uint32_t)h->cfg.n_nl;
+        if (h->kn.host_timing && !bk.ids.empty() && p->n_runs == 1)    /* diagnostics: what decides the general route's occupancy */
+            std::fprintf(stderr, "[pya plan] localize bucket: %zu PSMs, LDS hash route %zu B (vc %u hs %u pp %u sb %u push %u), list route %zu B\n",
+                         bk.ids.size(), pya_localize_hash_lds_bytes(bk.push_cap(), bk.n_cap, bk.pos_cap, bk.sb(), bk.hash_vc(), bk.hash_hs(),
+                                                                    bk.hash_pp(), p->max_k, nnl),
+                         bk.hash_vc(), bk.hash_hs(), bk.hash_pp(), bk.sb(), bk.push_cap(),
+                         pya_localize_lds_bytes(bk.push_cap(), bk.n_cap, bk.pos_cap, bk.pool_cap(), bk.sb()));
         if (!h->kn.no_loc_hash && bk.hash_ok(p->max_k, nnl))
             e = pya_launch_localize_hash(&d, bk.d_ids.p + bk.n_plain, (uint32_t)bk.ids.size() - bk.n_plain, bk.push_cap(), bk.n_cap,
                                          bk.pos_cap, bk.pool_cap(), bk.sb(), bk.gtp(), bk.hash_vc(), bk.hash_hs(), bk.hash_pp(),
