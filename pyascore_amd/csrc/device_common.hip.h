@@ -109,14 +109,41 @@ DEV double wave_max_f64(double v) {
     return v;
 }
 /* exclusive prefix sum over the wave; *total receives the wave sum */
+/* Inclusive prefix sum of a 32-bit word over the 64 lanes, or over each half of 32 separately (HALVES): the DPP sequence of
+ * wave_excl_scan_i32 below; packed fields add as the integers they are.  Every lane must be active. */
+template <bool HALVES>
+DEV uint32_t wave_incl_scan_u32(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    if (!HALVES) x += __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return (uint32_t)x;
+}
+
+/* Exclusive prefix sum over the 64 lanes (every lane must be active) and the total.  Six DPP additions -- four shifts inside
+ * the rows of 16 lanes, then lane 15 of a row broadcast to the next and lane 31 to the upper half (the sequence LLVM's
+ * atomic optimizer builds for gfx9) -- where six ds_bpermute round trips with their address arithmetic were 40 instructions. */
 DEV int wave_excl_scan_i32(int v, int *total) {
+#ifdef PYA_SCAN_BPERMUTE
     int x = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         int y = __shfl_up(x, o, 64);
         if (lane_id() >= o) x += y;
     }
-    *total = __shfl(x, 63, 64);
+#else
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+#endif
+    *total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
 

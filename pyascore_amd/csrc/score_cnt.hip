@@ -83,15 +83,14 @@ DEV void site_prefix_sums(const CntLds &c, uint32_t pos_cap, uint32_t kc, int L,
             y = inc.y;
             z = inc.z | ((ent >> 7) << 16);
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            if (two && o >= 32) break;
-            const uint32_t ux = (uint32_t)__shfl_up((int)x, o, 64), uy = (uint32_t)__shfl_up((int)y, o, 64), uz = (uint32_t)__shfl_up((int)z, o, 64);
-            if (sl >= o) {
-                x += ux;
-                y += uy;
-                z += uz;
-            }
+        if (two) {
+            x = wave_incl_scan_u32<true>(x);
+            y = wave_incl_scan_u32<true>(y);
+            z = wave_incl_scan_u32<true>(z);
+        } else {
+            x = wave_incl_scan_u32<false>(x);
+            y = wave_incl_scan_u32<false>(y);
+            z = wave_incl_scan_u32<false>(z);
         }
         /* lane i of the row's half: the sum over the steps below e = min(step of site i, L - 1) = the inclusive value of step e - 1 */
         const int st = d ? Lm1 - pos : pos;

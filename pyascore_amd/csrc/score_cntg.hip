@@ -246,14 +246,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
                 uint32_t w[6] = {0u, 0u, 0u, 0u, 0u, 0u};
                 if (sl < Lm1 && row_on) cg_cumulate(c.hist + ((size_t)row * pos_cap + sl) * 6, w);
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    if (two && o >= 32) break;
-#pragma unroll
-                    for (int x = 0; x < 6; x++) {
-                        const uint32_t u = (uint32_t)__shfl_up((int)w[x], o, 64);
-                        if (sl >= o) w[x] += u;
-                    }
-                }
+                for (int x = 0; x < 6; x++) w[x] = two ? wave_incl_scan_u32<true>(w[x]) : wave_incl_scan_u32<false>(w[x]);
                 const int st = d ? Lm1 - pos : pos;
                 const int e = st < Lm1 ? st : Lm1;
                 const int src = hbase + (e > 0 ? e - 1 : 0), last = hbase + (Lm1 > 0 ? Lm1 - 1 : 0);

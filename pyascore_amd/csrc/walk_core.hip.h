@@ -490,17 +490,10 @@ DEV void cnt_prefix_sums(const uint8_t *t, const uint4 *lut, uint32_t pos_cap, u
             v = lut[ent & 15u];
             v.w = ent >> 7;
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t x = (uint32_t)__shfl_up((int)v.x, o, 64), y = (uint32_t)__shfl_up((int)v.y, o, 64);
-            const uint32_t z = (uint32_t)__shfl_up((int)v.z, o, 64), w = (uint32_t)__shfl_up((int)v.w, o, 64);
-            if (lane >= o) {
-                v.x += x;
-                v.y += y;
-                v.z += z;
-                v.w += w;
-            }
-        }
+        v.x = wave_incl_scan_u32<false>(v.x);
+        v.y = wave_incl_scan_u32<false>(v.y);
+        v.z = wave_incl_scan_u32<false>(v.z);
+        v.w = wave_incl_scan_u32<false>(v.w);
         uint4 *out = P + (size_t)row * L;
         if (lane == 0) out[0] = make_uint4(0u, 0u, 0u, 0u);
         if (lane + 1 < L) out[lane + 1] = v;
