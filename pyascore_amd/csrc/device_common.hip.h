@@ -66,26 +66,51 @@ DEV T wave_bcast(T v, int src) {
     return __shfl(v, src, 64);
 }
 
+/* Reductions over the 64 lanes by DPP: the inclusive-scan sequence (four shifts inside the rows of 16 lanes, lane 15 of a row
+ * broadcast into the next, lane 31 into the upper half), the result read from lane 63 -- 13 instructions where six
+ * ds_bpermute exchanges with their address arithmetic were 30 (64-bit: two moves per step).  A lane that is not active
+ * contributes the identity.  The value returned is wave-uniform. */
+#define PYA_DPP_STEP32(x, OP, IDENT, CTRL, ROWS)                                              \
+    {                                                                                         \
+        const int y_ = __builtin_amdgcn_update_dpp((int)(IDENT), (x), (CTRL), (ROWS), 0xf, false); \
+        (x) = OP((x), y_);                                                                    \
+    }
+#define PYA_DPP_REDUCE32(x, OP, IDENT)            \
+    PYA_DPP_STEP32(x, OP, IDENT, 0x111, 0xf)      \
+    PYA_DPP_STEP32(x, OP, IDENT, 0x112, 0xf)      \
+    PYA_DPP_STEP32(x, OP, IDENT, 0x114, 0xf)      \
+    PYA_DPP_STEP32(x, OP, IDENT, 0x118, 0xf)      \
+    PYA_DPP_STEP32(x, OP, IDENT, 0x142, 0xa)      \
+    PYA_DPP_STEP32(x, OP, IDENT, 0x143, 0xc)
+DEV int pya_op_add_i32(int a, int b) { return a + b; }
+DEV int pya_op_max_u32(int a, int b) { return (uint32_t)b > (uint32_t)a ? b : a; }
+DEV int pya_op_min_u32(int a, int b) { return (uint32_t)b < (uint32_t)a ? b : a; }
+DEV int pya_op_max_f32(int a, int b) { return __int_as_float(b) > __int_as_float(a) ? b : a; }
+DEV int pya_op_min_f32(int a, int b) { return __int_as_float(b) < __int_as_float(a) ? b : a; }
 DEV int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    int x = v;
+    PYA_DPP_REDUCE32(x, pya_op_add_i32, 0)
+    return __builtin_amdgcn_readlane(x, 63);
 }
 DEV uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
+    int x = (int)v;
+    PYA_DPP_REDUCE32(x, pya_op_max_u32, 0)
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 DEV uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
-        v = w < v ? w : v;
-    }
-    return v;
+    int x = (int)v;
+    PYA_DPP_REDUCE32(x, pya_op_min_u32, -1)
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+DEV float wave_max_f32(float v) {
+    int x = __float_as_int(v);
+    PYA_DPP_REDUCE32(x, pya_op_max_f32, 0xff800000u)
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+DEV float wave_min_f32(float v) {
+    int x = __float_as_int(v);
+    PYA_DPP_REDUCE32(x, pya_op_min_f32, 0x7f800000u)
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 DEV uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll

@@ -28,22 +28,6 @@
 #define LH_SLOW_CAP 64
 #define LH_LISTS (2 * PYA_LOC_SB_MAX)     /* 1 + 2 per competitor, rounded up to even */
 
-DEV float wave_max_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
-}
-DEV float wave_min_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
-    }
-    return v;
-}
 DEV uint64_t wave_min_u64(uint64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
