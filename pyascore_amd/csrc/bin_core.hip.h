@@ -696,7 +696,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
                     const uint64_t m = __ballot(start);
                     const int here = __popcll(m);
                     if (start) {
-                        const int r = cnt + __popcll(m & lanemask_lt());
+                        const int r = cnt + mask_rank(m);
                         if (r <= 64) run_lo[r] = (uint16_t)i;
                     }
                     if (cnt + here > 64) {
@@ -808,7 +808,7 @@ DEV int bin_exact(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t 
             bool keep = i < P && s_rank[i] < ntop;
             uint64_t m = __ballot(keep);
             if (keep) {
-                int pos = total + __popcll(m & lanemask_lt());
+                int pos = total + mask_rank(m);
                 o_mz[pos] = s_mzf[i];
                 o_rank[pos] = s_rank[i];
             }

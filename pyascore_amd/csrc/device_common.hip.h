@@ -57,6 +57,12 @@ static inline hipError_t pya_set_max_lds(const void *fn, std::atomic<uint32_t> &
 
 DEV int lane_id() { return (int)(threadIdx.x & 63); }
 
+/* how many set bits of a 64-lane mask lie below this lane: v_mbcnt_lo + v_mbcnt_hi (no lane mask held in two registers,
+ * no 64-bit and + two popcounts) */
+DEV int mask_rank(uint64_t m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 DEV uint64_t lanemask_lt() {
     return (1ull << lane_id()) - 1ull;
 }

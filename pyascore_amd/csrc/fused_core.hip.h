@@ -435,7 +435,7 @@ DEV bool fused_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uin
         }
         site_mask = __ballot(modifiable);
         if (in) f.resd[lane] = make_float2(m0, m1);
-        if (modifiable) f.site_pos[__popcll(site_mask & lanemask_lt())] = (uint8_t)lane;
+        if (modifiable) f.site_pos[mask_rank(site_mask)] = (uint8_t)lane;
     }
     STAMP_T(b, 49, false);
     grid_build(&tab, f.grid);

@@ -172,8 +172,8 @@ DEV int sort_partition(const S &s, int f, int l) {
         const float kl = s.key[il < l ? il : l - 1], kr = s.key[ir >= f ? ir : f];
         const bool stop_l = il < l && !(kl > pv), stop_r = ir >= f && !(pv > kr);
         const uint64_t ml = __ballot(stop_l), mr = __ballot(stop_r);
-        if (stop_l) s.lq[__popcll(ml & lanemask_lt())] = (idx_t)il;
-        if (stop_r) s.rq[__popcll(mr & lanemask_lt())] = (idx_t)ir;
+        if (stop_l) s.lq[mask_rank(ml)] = (idx_t)il;
+        if (stop_r) s.rq[mask_rank(mr)] = (idx_t)ir;
         const int nL = __popcll(ml), nR = __popcll(mr);
         s.sync();
         const int np = nL < nR ? nL : nR;
@@ -252,7 +252,7 @@ DEV int sort_partition(const S &s, int f, int l) {
             const uint64_t mv = s.lmask[lc];
             const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mv >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mv);
-            if ((m >> lane) & 1ull) s.lq[(lprod + __popcll(m & lanemask_lt())) & s.qmask] = (idx_t)(f + 1 + lc * 64 + lane);
+            if ((m >> lane) & 1ull) s.lq[(lprod + mask_rank(m)) & s.qmask] = (idx_t)(f + 1 + lc * 64 + lane);
             lprod += __popcll(m);
             lc++;
         }
@@ -262,7 +262,7 @@ DEV int sort_partition(const S &s, int f, int l) {
             const uint64_t mv = s.rmask[rc];
             const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mv >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mv);
-            if ((m >> lane) & 1ull) s.rq[(rprod + __popcll(m & lanemask_lt())) & s.qmask] = (idx_t)(l - 1 - rc * 64 - lane);
+            if ((m >> lane) & 1ull) s.rq[(rprod + mask_rank(m)) & s.qmask] = (idx_t)(l - 1 - rc * 64 - lane);
             rprod += __popcll(m);
             rc++;
         }
@@ -762,7 +762,7 @@ DEV void loc_stage_push(const LocCtx &c, bool kept, float val, uint32_t tag, int
     const LocLds &w = c.w;
     const uint64_t km = __ballot(kept);
     if (kept) {
-        const int slot = staged + __popcll(km & lanemask_lt());
+        const int slot = staged + mask_rank(km);
         w.stage_val[slot] = val;
         w.stage_tag[slot] = tag;
     }

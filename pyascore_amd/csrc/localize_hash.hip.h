@@ -186,7 +186,7 @@ DEV void lh_stage_push(const LocCtx &c, bool kept, float val, uint32_t tag, int 
     const uint64_t km = __ballot(kept);
     const int n = staged & 0xffff, head = staged >> 16;
     if (kept) {
-        const int slot = (head + n + __popcll(km & lanemask_lt())) & (LH_STAGE - 1);
+        const int slot = (head + n + mask_rank(km)) & (LH_STAGE - 1);
         w.stage_val[slot] = val;
         ((uint8_t *)(w.stage_val + LH_STAGE))[slot] = (uint8_t)tag;
     }
@@ -247,7 +247,7 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
             }
             const uint64_t ma = __ballot(a_in);
             if (a_in) {
-                const int slot = ncand + __popcll(ma & lanemask_lt());
+                const int slot = ncand + mask_rank(ma);
                 if (slot < LH_CAND_CAP) {
                     h.cand_val[slot] = av;
                     h.cand_tag[slot] = (uint32_t)j | (isp << 16);
@@ -256,7 +256,7 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
             ncand += __popcll(ma);
             const uint64_t mt = __ballot(t_in);
             if (t_in) {
-                const int slot = ncand + __popcll(mt & lanemask_lt());
+                const int slot = ncand + mask_rank(mt);
                 if (slot < LH_CAND_CAP) {
                     h.cand_val[slot] = tv;
                     h.cand_tag[slot] = (uint32_t)j | (1u << 17);
@@ -274,7 +274,7 @@ DEV bool lh_exact(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t n
             }
             const uint64_t mb = __ballot(b_in);
             if (b_in) {
-                const int slot = ncand + __popcll(mb & lanemask_lt());
+                const int slot = ncand + mask_rank(mb);
                 if (slot < LH_CAND_CAP) {
                     h.cand_val[slot] = bv;
                     h.cand_tag[slot] = (uint32_t)j | (1u << 16) | (1u << 17);
@@ -431,7 +431,7 @@ DEV bool lh_resolve(const LocCtx &c, const HashLds &h, const LhPass &q, uint32_t
         }
         wave_lds_sync();                                         /* (everybody has read its entry) */
         const uint64_t um = __ballot(unresolved);
-        if (unresolved) h.slow[__popcll(um & lanemask_lt())] = it;
+        if (unresolved) h.slow[mask_rank(um)] = it;
         lh_stage_push(c, kept, x, (uint32_t)(cc * 2 + side), staged);
         const uint32_t nleft = (uint32_t)__popcll(um);
         if (nleft && lh_exact(c, h, q, nleft, staged)) return true;
@@ -696,7 +696,7 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                 }
                 const uint64_t hm = __ballot(hit);
                 if (hit) {
-                    const uint32_t slot = nslow + (uint32_t)__popcll(hm & lanemask_lt());
+                    const uint32_t slot = nslow + (uint32_t)mask_rank(hm);
                     if (slot < LH_HIT_CAP) h.slow[slot] = (uint32_t)id | ((uint32_t)cc << 16) | ((uint32_t)side << 24);
                 }
                 nslow += (uint32_t)__popcll(hm);

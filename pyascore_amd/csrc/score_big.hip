@@ -304,7 +304,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         STAMP_T(b, 16, );
         cnt_prefix_sums(cnt_t, cum_lut, pos_cap, kc, L, k, cntP, wave, BIG_WAVES);
         if (wave == 1 && ((res.site_mask >> lane) & 1ull))       /* residue of the j-th modifiable one (first bytes of the envelopes' room) */
-            ((uint8_t *)envl)[__popcll(res.site_mask & lanemask_lt())] = (uint8_t)lane;
+            ((uint8_t *)envl)[mask_rank(res.site_mask)] = (uint8_t)lane;
         __syncthreads();
         cnt_site_table(cntP, (const uint8_t *)envl, L, k, n_sites, cntG, tid, BIG_T);
         __syncthreads();
@@ -364,7 +364,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
                 off += wv < wave ? n_w : 0u;
                 tot += n_w;
             }
-            if (valid) vlist[off + (uint32_t)__popcll(vm & lanemask_lt())] = (uint16_t)c;
+            if (valid) vlist[off + (uint32_t)mask_rank(vm)] = (uint16_t)c;
             before += tot;
             __syncthreads();
         }

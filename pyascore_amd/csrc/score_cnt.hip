@@ -142,7 +142,7 @@ DEV void score_cnt_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw,
     stage_peak_table(b, psm, c.t_e, &tab);
     stage_residues(res, c.resd, nullptr);
     if (lane < 16) c.cum_lut[lane] = fused_cum_entry((uint32_t)lane);
-    if ((res.site_mask >> lane) & 1ull) c.site_pos[__popcll(res.site_mask & lanemask_lt())] = (uint8_t)lane;
+    if ((res.site_mask >> lane) & 1ull) c.site_pos[mask_rank(res.site_mask)] = (uint8_t)lane;
     for (uint32_t i = lane; i < (uint32_t)((2 * pos_cap * kc + 15) & ~15u) / 4u; i += 64) ((uint32_t *)c.T)[i] = 0x0f0f0f0fu;
     wave_lds_sync();
     grid_build(&tab, c.grid);

@@ -125,7 +125,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
     }
     stage_residues(res, c.resd, c.resn);
     const bool is_site = (res.site_mask >> lane) & 1ull;
-    if (is_site) c.site_pos[__popcll(res.site_mask & lanemask_lt())] = (uint8_t)lane;
+    if (is_site) c.site_pos[mask_rank(res.site_mask)] = (uint8_t)lane;
     wave_lds_sync();
     grid_build(&tab, c.grid);
     wave_lds_sync();
@@ -185,7 +185,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
                 const int v = has ? __builtin_ctz(pm) : 0;
                 pm &= pm - 1u;
                 const uint64_t hm = __ballot(has);
-                const int at = n_ent + __popcll(hm & lanemask_lt());
+                const int at = n_ent + mask_rank(hm);
                 if (has && at < n_room) nlist[at] = (uint16_t)((row * 64 + lane) | (v << 12));
                 n_ent += __popcll(hm);
             }
