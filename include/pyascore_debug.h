@@ -25,6 +25,16 @@ extern "C" {
  *     PYA_HASH_PP PYA_NODE_CAP PYA_CHUNK_MB PYA_WORKSPACE_MB */
 int pya_set_debug(pya_handle *h, const char *key, const char *value);
 
+/* The wavefront primitives every kernel leans on (csrc/device_common.hip.h: prefix sums and reductions by DPP, the rank of
+ * a lane in a ballot), run by one full wavefront on 64 values (as every call site does):
+ *   out[0..63]    exclusive prefix sum of in[]
+ *   out[64..127]  inclusive prefix sums within each half of 32 lanes
+ *   out[128..191] inclusive prefix sum over the 64 lanes
+ *   out[192..255] rank of the lane among the lanes whose value is odd
+ *   out[256..262] total, sum, max and min (as unsigned), max and min of the values read as floats, min rank of an odd value's lane
+ * No reference counterpart. */
+int pya_debug_wave_ops(pya_handle *h, const int32_t in[64], int32_t out[263]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,7 @@ SYMBOLS = {
     "pya_add_neutral_loss": (C.c_int, [_vp, C.c_char_p, C.c_float]),
     "pya_reload_env": (C.c_int, [_vp]),
     "pya_set_debug": (C.c_int, [_vp, C.c_char_p, C.c_char_p]),          # include/pyascore_debug.h (test-only)
+    "pya_debug_wave_ops": (C.c_int, [_vp, _vp, _vp]),         # (test-only)
     "pya_score_one": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_int32, C.c_int32, _vp, _vp, C.c_uint64,
                                 C.c_uint32, C.POINTER(Results)]),
     "pya_rescore_last_keep": (C.c_int, [_vp]),

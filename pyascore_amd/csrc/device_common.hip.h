@@ -74,8 +74,8 @@ DEV T wave_bcast(T v, int src) {
 
 /* Reductions over the 64 lanes by DPP: the inclusive-scan sequence (four shifts inside the rows of 16 lanes, lane 15 of a row
  * broadcast into the next, lane 31 into the upper half), the result read from lane 63 -- 13 instructions where six
- * ds_bpermute exchanges with their address arithmetic were 30 (64-bit: two moves per step).  A lane that is not active
- * contributes the identity.  The value returned is wave-uniform. */
+ * ds_bpermute exchanges with their address arithmetic were 30.  Every lane must be active (the scan runs through the lanes:
+ * every call site is in wave-uniform control flow).  The value returned is wave-uniform. */
 #define PYA_DPP_STEP32(x, OP, IDENT, CTRL, ROWS)                                              \
     {                                                                                         \
         const int y_ = __builtin_amdgcn_update_dpp((int)(IDENT), (x), (CTRL), (ROWS), 0xf, false); \

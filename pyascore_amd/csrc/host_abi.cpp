@@ -328,6 +328,19 @@ int pya_calculate_ambiguity(pya_handle *h, uint64_t psm, uint64_t ref_bits, cons
     return PYA_OK;
 }
 
+int pya_debug_wave_ops(pya_handle *h, const int32_t in[64], int32_t out[263]) {
+    if (!h || !in || !out) return PYA_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    DevBuf<int32_t> di, dout;
+    HIPCHK(h, di.upload(in, 64));
+    HIPCHK(h, dout.alloc(263));
+    HIPCHK(h, hipMemset(dout.p, 0, 263 * sizeof(int32_t)));
+    int e = pya_launch_debug_wave_ops(di.p, dout.p, nullptr);
+    if (e) return h->hip_fail((hipError_t)e, "debug wave ops launch");
+    HIPCHK(h, hipMemcpy(out, dout.p, 263 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return PYA_OK;
+}
+
 int pya_debug_sort(pya_handle *h, const float *keys, uint32_t n, uint32_t *perm) {
     if (!h || !keys || !perm) return PYA_ERR_ARG;
     if (n == 0) return PYA_OK;

@@ -71,6 +71,7 @@ int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uin
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
 int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream);
+int pya_launch_debug_wave_ops(const int32_t *d_in, int32_t *d_out, hipStream_t stream);
 size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap, uint32_t kc);
 int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap, uint32_t kc,
                          uint32_t inline_on, hipStream_t stream);

@@ -227,6 +227,34 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     return (int)hipGetLastError();
 }
 
+/* test-only: the wavefront primitives of device_common.hip.h on 64 values (include/pyascore_debug.h: pya_debug_wave_ops) */
+__global__ __launch_bounds__(64) void pya_debug_wave_ops_kernel(const int32_t *in, int32_t *out) {
+    const int lane = lane_id();
+    const int v = in[lane];
+    int total;
+    out[lane] = wave_excl_scan_i32(v, &total);
+    out[64 + lane] = (int32_t)wave_incl_scan_u32<true>((uint32_t)v);
+    out[128 + lane] = (int32_t)wave_incl_scan_u32<false>((uint32_t)v);
+    out[192 + lane] = mask_rank(__ballot(v & 1));
+    const int s = wave_sum_i32(v);
+    const uint32_t mx = wave_max_u32((uint32_t)v), mn = wave_min_u32((uint32_t)v);
+    const float fx = wave_max_f32(__int_as_float(v)), fn = wave_min_f32(__int_as_float(v));
+    const uint32_t first_odd = wave_min_u32((v & 1) ? (uint32_t)lane : 0xffffffffu);
+    if (lane == 17) {                                        /* (the values are wave-uniform: any lane) */
+        out[256] = total;
+        out[257] = s;
+        out[258] = (int32_t)mx;
+        out[259] = (int32_t)mn;
+        out[260] = __float_as_int(fx);
+        out[261] = __float_as_int(fn);
+        out[262] = (int32_t)first_odd;
+    }
+}
+extern "C" int pya_launch_debug_wave_ops(const int32_t *d_in, int32_t *d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(pya_debug_wave_ops_kernel, dim3(1), dim3(64), 0, stream, d_in, d_out);
+    return (int)hipGetLastError();
+}
+
 extern "C" size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
                                               uint32_t hs, uint32_t pp, uint32_t max_k, uint32_t n_nl) {
     return localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, max_k, n_nl);
