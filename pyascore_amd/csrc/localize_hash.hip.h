@@ -465,6 +465,62 @@ DEV bool lh_build_lists(const LocCtx &c, const HashLds &h, int S, int d, float t
         }
         npairs = (uint32_t)tot;
     }
+#ifndef LH_LISTS_PER_COMPETITOR
+    if ((S - 1) * Lm1 <= 64) {
+        /* every competitor's prefixes in ONE pass, a lane per (competitor, prefix) -- cfg4: 3 x 19 lanes where three passes
+         * used 19 each: the two prefix sums run over the whole wavefront, a competitor's share of them is the difference of
+         * the sums at the ends of its lanes (read with a wave-uniform lane index) */
+        const int ci = Lm1 > 0 ? lane / Lm1 : 0, p = lane - ci * Lm1;
+        const bool valid = ci < S - 1 && Lm1 > 0;
+        bool in = false;
+        uint32_t pw = 0, pc = 0;
+        int cw = 0;
+        if (valid) {
+            const size_t iw = (size_t)d * c.pos_cap + p, ic = (size_t)((ci + 1) * 2 + d) * c.pos_cap + p;
+            const float rw = w.run[iw], rc = w.run[ic];
+            pw = nn ? (uint32_t)w.pmk[iw] : 1u;
+            pc = nn ? (uint32_t)w.pmk[ic] : 1u;
+            cw = nn ? (int)w.cpre[iw] : p;
+            in = pw != pc || !(__builtin_fabsf(rc - rw) <= tau);
+        }
+        const uint64_t m_all = __ballot(in);
+        const int nA = in ? __popc(pw) : 0, nB = in ? __popc(pc) : 0;
+        const int sA = (int)wave_incl_scan_u32<false>((uint32_t)nA), sB = (int)wave_incl_scan_u32<false>((uint32_t)nB);
+        int myA0 = 0, myB0 = 0, myOffA = 0, myOffB = 0, prevA = 0, prevB = 0;
+        for (int q = 0; q < S - 1; q++) {
+            const int e = (q + 1) * Lm1 - 1;
+            const int endA = __builtin_amdgcn_readlane(sA, e), endB = __builtin_amdgcn_readlane(sB, e);
+            const int totA = endA - prevA, totB = endB - prevB;
+            if (ci == q) {
+                myA0 = prevA;
+                myB0 = prevB;
+                myOffA = (int)npairs;
+                myOffB = (int)npairs + totA;
+            }
+            if (lane == 0) {
+                h.ispan[q] = (m_all >> (q * Lm1)) & ((1ull << Lm1) - 1ull);
+                h.off[1 + 2 * q] = (uint16_t)npairs;
+                h.cnt[1 + 2 * q] = (uint16_t)totA;
+                h.off[2 + 2 * q] = (uint16_t)(npairs + (uint32_t)totA);
+                h.cnt[2 + 2 * q] = (uint16_t)totB;
+            }
+            npairs += (uint32_t)(totA + totB);
+            prevA = endA;
+            prevB = endB;
+        }
+        if (npairs > h.pp) return true;
+        if (in) {
+            int atA = myOffA + (sA - nA - myA0), atB = myOffB + (sB - nB - myB0);
+            for (int vi = 0; vi < nA; vi++) h.pairs[atA++] = (uint16_t)(cw + vi);
+            while (pc) {
+                const int v = __builtin_ctz(pc);
+                pc &= pc - 1;
+                h.pairs[atB++] = (uint16_t)(p | (v << 8));
+            }
+        }
+        return false;
+    }
+#endif
     for (int cc = 1; cc < S; cc++) {
         bool in = false;
         uint32_t pw = 0, pc = 0;
