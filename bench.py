@@ -70,7 +70,7 @@ def valu_costs():
     return cost, (sum(vals) / len(vals) if vals else 3.7)
 
 
-def profiled_counters(cfg, kern_ms, names, default_size):
+def profiled_counters(cfg, kern_ms, names, default_size, lib_version=None):
     """Per kernel family of the bench line, from the newest committed PMC summary of this config
     (profiles/*_rocprof_<cfg>/pmc_summary.csv, separate --pmc passes, scripts/profile.sh):
       traffic      HBM bytes per step, 2 x FETCH_SIZE + WRITE_SIZE (KB counters; gfx950's FETCH_SIZE tallies
@@ -84,7 +84,12 @@ def profiled_counters(cfg, kern_ms, names, default_size):
       lanes_per_valu  active lanes per vector instruction, of 64 (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU);
       lds_conflict LDS bank-conflict cycles per active LDS cycle.
     Kernel cycles = SQ_BUSY_CYCLES / 32 (the counter sums the 32 shader engines).  None when the run
-    is not the profiled workload."""
+    is not the profiled workload.
+
+    REFUSED (r05 verdict item 3) unless the counters are of the kernels this run executes: scripts/profile.sh writes the
+    library's source digest (pya_version: SHA-256 over csrc/ + include/) into the directory's profile_steps.json, and only
+    the NEWEST *_rocprof_<cfg> directory is considered -- when its digest is missing or differs from the loaded library's,
+    the line carries no traffic, no busy shares, and says why (`traffic_refused`), instead of an older build's numbers."""
     import csv
     import glob
     if not default_size:
@@ -93,6 +98,18 @@ def profiled_counters(cfg, kern_ms, names, default_size):
     if not dirs:
         return None, None
     path = os.path.join(dirs[-1], "pmc_summary.csv")
+    prof_src = None
+    try:
+        with open(os.path.join(dirs[-1], "profile_steps.json")) as f:
+            prof_src = json.load(f).get("src")
+    except (OSError, ValueError):
+        pass
+    if lib_version is not None:
+        lib_src = lib_version.split("src=")[-1].split()[0] if "src=" in lib_version else None
+        if not prof_src or prof_src != lib_src:
+            why = "%s was profiled from source digest %s, this run's library is %s" % (
+                os.path.relpath(dirs[-1], ROOT), (prof_src or "unrecorded")[:12], (lib_src or "unknown")[:12])
+            return {"source": os.path.relpath(path, ROOT), "families": None, "whole_path_traffic": None, "refused": why}, None
     per_kernel = {}
     try:
         with open(path, newline="") as f:
@@ -310,16 +327,28 @@ def timed_blocks(torch, dist, dev, pipe, plan, steps, n_blocks):
 FAMILY_NAMES = ["pya_bin_spectra_kernel", "pya_score_signatures_kernel", "pya_score_localize_kernel", "pya_localize_kernel"]
 
 
-def other_config_leg(torch, dev, local_rank, cfg, steps, warmup, n_blocks):
-    """One of BASELINE's other single-GPU workloads at its full size, timed exactly like the headline (spectra resident,
-    plan pre-built, `n_blocks` blocks of `steps` steps, the median block): value, ms per step, the kernel families'
-    HIP-event times, the dominant family and its algorithmic GB/s against the HBM peak.  cfg3 is quoted on 8 GPUs:
-    its per-GPU share (125 000 PSMs) is what one GPU scores here."""
+# BASELINE's other single-GPU workloads + the dense-spectrum variants of cfg2 (r05 verdict item 4): name -> (config, PSMs,
+# generator options).  cfg3 is quoted on 8 GPUs: its per-GPU share is what one GPU scores here.  `dense*`: cfg2's peptides
+# with ~1 500 / ~4 000 peaks per spectrum, every peak with two isotope satellites (synth._var_shape) -- what current
+# instruments hand over; fewer PSMs so that the spectra (16 bytes per peak) stay in the range of the other legs.
+LEGS = {
+    "cfg3": ("cfg3", 125_000, {}),
+    "cfg4": ("cfg4", 250_000, {}),
+    "cfg5": ("cfg5", 50_000, {}),
+    "dense1500": ("cfg2", 32_768, dict(n_noise=1500, isotopes=True)),
+    "dense4000": ("cfg2", 16_384, dict(n_noise=4000, isotopes=True)),
+}
+
+
+def other_config_leg(torch, dev, local_rank, leg, steps, warmup, n_blocks):
+    """One of LEGS at its full size, timed exactly like the headline (spectra resident, plan pre-built, `n_blocks` blocks of
+    `steps` steps, the median block): value, ms per step, the plan's host pre-pass, the kernel families' HIP-event times,
+    the dominant family and its algorithmic GB/s against the HBM peak, and the same over the whole step."""
     from pyascore_amd import PyAscore, shard, synth
     from pyascore_amd.device import DevicePlan
-    n = synth.CONFIGS[cfg]["n_psm"] // (8 if cfg == "cfg3" else 1)
+    cfg, n, gen = LEGS[leg]
     t_gen = time.perf_counter()
-    desc = synth.describe(cfg, n_psm=n, seed=1000)
+    desc = synth.describe(cfg, n_psm=n, seed=1000, **gen)
     batch = synth.make_slice(desc, 0, n)
     t_gen = time.perf_counter() - t_gen
     st = desc["settings"]
@@ -329,7 +358,13 @@ def other_config_leg(torch, dev, local_rank, cfg, steps, warmup, n_blocks):
         scorer.add_neutral_loss(g, m)
     d_mz = torch.from_numpy(batch["mz"]).to(dev)
     d_int = torch.from_numpy(batch["intensity"]).to(dev)
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
+    DevicePlan(scorer, batch, timing=True).close()           # (the scorer's first plan also builds its score and order tables)
+    t_first = time.perf_counter() - t_first
+    t_plan = time.perf_counter()
     plan = DevicePlan(scorer, batch, timing=True)
+    t_plan = time.perf_counter() - t_plan
     pipe = shard.StepPipeline(lambda: plan.run(d_mz, d_int), None, n, n, shard.record_width(plan.max_k), dev, enabled=False)
     for _ in range(warmup):
         pipe.step()
@@ -341,17 +376,66 @@ def other_config_leg(torch, dev, local_rank, cfg, steps, warmup, n_blocks):
     dom = int(np.argmax(kern_ms))
     alg = algorithmic_bytes(batch, plan.max_k)
     achieved = alg / (kern_ms[dom] * 1e-3) / 1e9 if kern_ms[dom] > 0 else 0.0
-    out = {"workload": "%s: %d PSMs on 1 GPU" % (cfg, n), "value": n * steps / elapsed, "unit": "PSMs/s",
+    peaks = int(batch["peak_off"][-1])
+    out = {"workload": "%s: %d PSMs on 1 GPU%s" % (cfg, n, (", spectra of ~%d peaks with isotope satellites" % gen["n_noise"]) if gen else ""),
+           "value": n * steps / elapsed, "unit": "PSMs/s",
            "ms_per_step": 1e3 * elapsed / max(steps, 1), "steps": steps, "warmup": warmup,
            "blocks_ms_per_step": [1e3 * b[0] / max(steps, 1) for b in blocks],
+           "plan_ms": 1e3 * t_plan, "first_plan_ms": 1e3 * t_first,
            "kernel_ms": {k: float(m) for k, m in zip(FAMILY_NAMES, kern_ms)}, "kernel": FAMILY_NAMES[dom],
            "algorithmic_bytes_per_launch": alg, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+           "whole_step_frac": alg / (float(kern_ms.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms.sum() > 0 else 0.0,
+           "peaks_per_spectrum": peaks / float(n),
+           "bin_ns_per_peak": 1e6 * float(kern_ms[0]) / max(peaks, 1),
            "signatures_total": plan.total_signatures, "mz_error": st["mz_error"], "fragment_types": st["fragment_types"],
            "max_fragment_charge": int(batch["max_charge"].max()), "neutral_losses": st["neutral_losses"],
            "generate_s": t_gen}
     plan.close()
     del plan, d_mz, d_int, scorer
     torch.cuda.empty_cache()
+    return out
+
+
+def leg_child(args):
+    """`bench.py --leg NAME`: one leg in a process of its own, its record as the one JSON line on stdout."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    out = other_config_leg(torch, torch.device("cuda", local_rank), local_rank, args.leg, args.steps, args.warmup, args.other_blocks)
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def run_legs(names, steps, warmup, n_blocks, timeout_s=240.0):
+    """Every leg as a CHILD process (`python bench.py --leg NAME`, a fresh process each, started before this program's first
+    GPU call and waited for one after the other -- the GPU is theirs alone while they run): a fault, an abort or a hang in an
+    extra leg costs that leg's record, never the headline (r05 advisor).  A leg over `timeout_s` is killed with its
+    process group."""
+    import signal
+    import subprocess
+    out = {}
+    for name in names:
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--steps", str(steps), "--warmup", str(warmup),
+               "--other-blocks", str(n_blocks)]
+        t = time.perf_counter()
+        try:
+            p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                so, se = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.communicate()
+                out[name] = {"error": "timed out after %.0f s" % timeout_s}
+                continue
+            if p.returncode != 0:
+                out[name] = {"error": "exit code %d: %s" % (p.returncode, (se or "").strip().splitlines()[-1:] or "")}
+                continue
+            out[name] = json.loads(so.strip().splitlines()[-1])
+            out[name]["leg_wall_s"] = time.perf_counter() - t
+        except Exception as e:
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -446,10 +530,14 @@ def main():
                     help="N = 1, default cfg2 run only: leave out the short timed legs of BASELINE's other configs "
                          "(`other_configs` in the line)")
     ap.add_argument("--other-blocks", type=int, default=2, help="timed blocks per config of `other_configs`")
+    ap.add_argument("--leg", choices=sorted(LEGS), default=None,
+                    help="(internal) run ONE leg of `other_configs` in this process and print its record")
     ap.add_argument("--no-host-api", action="store_true",
                     help="skip the host-array legs (profiling runs: only the timed device-resident steps launch kernels)")
     args = ap.parse_args()
 
+    if args.leg:
+        return leg_child(args)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as written: this process becomes the launcher.  The ranks are CHILDREN
         # (one per GPU under torch.distributed.run), started before anything here touched the GPU; their one
@@ -489,6 +577,13 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(batch, settings)
+    default_size = args.psms is None and args.max_charge is None and args.scaling == "weak" and not args.debug
+    others = None
+    if world == 1 and default_size and args.config == "cfg2" and not args.no_other_configs:
+        # BASELINE's other workloads and the dense-spectrum legs on this GPU, so that the driver's record carries every
+        # config: child processes, one after the other, BEFORE this process touches the GPU.  The headline fields are
+        # cfg2's and only cfg2's.
+        others = run_legs(["cfg3", "cfg4", "cfg5", "dense1500", "dense4000"], args.steps, args.warmup, args.other_blocks)
     # ---- GPU from here on ----
     import torch
     import torch.distributed as dist
@@ -522,7 +617,13 @@ def main():
 
     d_mz = torch.from_numpy(batch["mz"]).to(dev)
     d_int = torch.from_numpy(batch["intensity"]).to(dev)
-    plan = DevicePlan(scorer, batch, timing=True, max_k=job_max_k)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter()
+    DevicePlan(scorer, batch, timing=True, max_k=job_max_k).close()     # the scorer's FIRST plan: + its score and order tables
+    first_plan_ms = 1e3 * (time.perf_counter() - t_plan)
+    t_plan = time.perf_counter()
+    plan = DevicePlan(scorer, batch, timing=True, max_k=job_max_k)      # pya_plan_create: host pre-pass + arena upload
+    plan_ms = 1e3 * (time.perf_counter() - t_plan)
 
     # the step loop lives in pyascore_amd.shard (the gloo test drives the same class on CPU): kernels of
     # this rank's shard, then the step's single RCCL gather of the packed records, asynchronous, waited
@@ -592,8 +693,7 @@ def main():
                             "with planning, kernels and result copies); pcie_only = the same bytes copied up "
                             "and back with nothing else"}
         copy_gbs = achievable_hbm_gbs(torch, dev)
-        default_size = args.psms is None and args.max_charge is None and args.scaling == "weak" and not args.debug
-        counters, fams = profiled_counters(args.config, kern_ms, names, default_size)
+        counters, fams = profiled_counters(args.config, kern_ms, names, default_size, scorer._lib.pya_version().decode())
         dom_c = (fams or {}).get(names[dom], {})
         traffic_path = counters["whole_path_traffic"] if counters else None
         line = {
@@ -603,6 +703,9 @@ def main():
             "blocks": {"n": len(block_ms), "ms_per_step": block_ms, "min": min(block_ms), "max": max(block_ms),
                        "note": "every block is exactly `steps` steps between barrier + synchronize; value / ms_per_step / "
                                "kernel_ms are the median block's"},
+            # what the timed region leaves out (r05 verdict item 3): the plan's host pre-pass (letter scan, routing, tables,
+            # arena upload: pya_plan_create, once per batch) -- and PCIe, which `host_api` prices
+            "plan_ms": plan_ms, "first_plan_ms": first_plan_ms,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32/f64 scalar + i32 counts",
             "data": "synthetic (SURVEY.md 8(d) generator, job seed 1000, spectra per 16k-PSM block)",
             "config": {"workload": "%s: %d PSMs over %d GPU(s), work-balanced contiguous shards" % (args.config, total, world),
@@ -611,13 +714,16 @@ def main():
                        "fragment_types": settings["fragment_types"],
                        "max_fragment_charge": int(batch["max_charge"].max()),
                        "neutral_losses": settings["neutral_losses"],
-                       "timed_region": "spectra resident in HBM, plan pre-built, kernels only%s; results stay on the device "
-                                       "(host arrays in -> host results out is `host_api`)"
+                       "timed_region": "spectra resident in HBM, plan pre-built (`plan_ms`, once per batch, is NOT inside), kernels only%s; "
+                                       "results stay on the device (host arrays in -> host results out is `host_api`)"
                                        % (" + the step's gather of fixed-size records to rank 0" if use_dist else ""),
                        "parallelism": ("psm-shard x%d + 1 gather per step" % world) if use_dist else "1 GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": dom_c.get("traffic"),
-                         "traffic_source": counters["source"] if counters else None,
+                         # the same bytes over ALL the step's kernels (binning reads 98 % of them, not the dominant kernel)
+                         "whole_step_frac": (alg / (float(kern_ms.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms.sum() > 0 else 0.0,
+                         "traffic_source": counters["source"] if counters and counters.get("families") is not None else None,
+                         "traffic_refused": counters.get("refused") if counters else "no committed counters for this config",
                          # HBM bytes the dominant kernel family really moved (counters) over its live duration
                          "hbm_actual": dom_c.get("hbm_actual"),
                          # what actually bounds the kernel: share of SIMD time its vector instructions need at the
@@ -647,15 +753,7 @@ def main():
             line["debug_switches"] = list(args.debug)
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        if world == 1 and default_size and args.config == "cfg2" and not args.no_other_configs:
-            # BASELINE's other workloads on this GPU in the same run, so that the driver's record carries every config
-            # (short legs: a step of the slowest is 14 ms).  The headline fields above are cfg2's and only cfg2's.
-            others = {}
-            for cfg in ("cfg3", "cfg4", "cfg5"):
-                try:
-                    others[cfg] = other_config_leg(torch, dev, local_rank, cfg, args.steps, args.warmup, args.other_blocks)
-                except Exception as e:                       # (never lose the headline line to an extra)
-                    others[cfg] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if others is not None:
             line["other_configs"] = others
         if real_stdout is not None:
             os.write(real_stdout, (json.dumps(line) + "\n").encode())

@@ -182,6 +182,12 @@ int pya_plan_timings(pya_plan *plan, float ms[4]);
  * of more runs than that only the latest 128 count); *n_runs = how many; synchronises with the latest run only,
  * so a caller can enqueue run after run without waiting in between */
 int pya_plan_timings_sum(pya_plan *plan, double ms[4], uint32_t *n_runs);
+/* The multi-GPU path's gather record (north_star: "a single RCCL gather at the end"; no reference counterpart -- the
+ * reference scores on one core and has no collective): packs the device results of `n_psm` PSMs into fixed-size
+ * records of 4 + 3 k int32 words (best_score bits, n_sig, best_sig lo / hi, k Ascore bit patterns, k alternative-site
+ * masks lo / hi; k >= d_res->max_k, the job-wide widest row, columns beyond the results' own are zero) at d_out --
+ * e.g. a rank's slice of its send buffer -- with ONE kernel on `hip_stream`. */
+int pya_pack_records(pya_handle *h, const pya_results *d_res, uint64_t n_psm, uint32_t k, int32_t *d_out, void *hip_stream);
 /* waits for the stream of the last run and reports the first PSM the kernels rejected */
 int pya_plan_check(pya_plan *plan);
 uint64_t pya_plan_workspace_bytes(const pya_plan *plan);

@@ -57,6 +57,7 @@ SYMBOLS = {
     "pya_one_times": (C.c_int, [_vp, C.POINTER(C.c_double * 12)]),
     "pya_plan_timings_sum": (C.c_int, [_vp, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32)]),
     "pya_plan_check": (C.c_int, [_vp]),
+    "pya_pack_records": (C.c_int, [_vp, C.POINTER(Results), C.c_uint64, C.c_uint32, _vp, _vp]),
     "pya_plan_workspace_bytes": (C.c_uint64, [_vp]),
     "pya_plan_total_signatures": (C.c_uint64, [_vp]),
     "pya_plan_destroy": (None, [_vp]),

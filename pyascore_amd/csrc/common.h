@@ -27,6 +27,7 @@
 #define PYA_ST_TOO_MANY_BINS 2
 #define PYA_ST_LUT_RANGE 3         /* trial count outside the uploaded score table          */
 #define PYA_ST_PUSHED_OVERFLOW 4
+#define PYA_ST_ROUTE_CAPS 5        /* a PSM beyond the caps its launch was sized for (a routing bug: never expected)      */
 #define PYA_ST_INVALID 16          /* set aside by the host pre-pass (PYA_FLAG_SKIP_INVALID): invalid PSM    */
 #define PYA_ST_OVER_LIMIT 17       /* ... or one that exceeds a documented limit of this implementation     */
 

@@ -72,6 +72,18 @@ DEV T wave_bcast(T v, int src) {
     return __shfl(v, src, 64);
 }
 
+/* THE WAVE HELPERS BELOW NEED ALL 64 LANES ACTIVE.  The ds_bpermute butterflies they replaced (r05) tolerated a partial EXEC
+ * mask -- an inactive lane read as 0 --; a DPP scan runs THROUGH the lanes, so inside a lane-divergent branch or the tail of a
+ * `for (i = lane; i < n; i += 64)` loop it returns wrong sums without any error.  Every call site is in wave-uniform control
+ * flow; a build with -DPYA_CHECK_EXEC (PYA_DEFS=-DPYA_CHECK_EXEC python -m pyascore_amd.build) traps in any helper entered
+ * with a partial mask -- the GPU suite is run on such a build once per round (profiles/r06_check_exec.txt).  A caller in
+ * divergent flow has to use __shfl_xor / __shfl_up itself (wave_sum_u64, wave_min_f64 below still do). */
+#ifdef PYA_CHECK_EXEC
+#define PYA_FULL_WAVE() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define PYA_FULL_WAVE() do {} while (0)
+#endif
+
 /* Reductions over the 64 lanes by DPP: the inclusive-scan sequence (four shifts inside the rows of 16 lanes, lane 15 of a row
  * broadcast into the next, lane 31 into the upper half), the result read from lane 63 -- 13 instructions where six
  * ds_bpermute exchanges with their address arithmetic were 30.  Every lane must be active (the scan runs through the lanes:
@@ -94,26 +106,31 @@ DEV int pya_op_min_u32(int a, int b) { return (uint32_t)b < (uint32_t)a ? b : a;
 DEV int pya_op_max_f32(int a, int b) { return __int_as_float(b) > __int_as_float(a) ? b : a; }
 DEV int pya_op_min_f32(int a, int b) { return __int_as_float(b) < __int_as_float(a) ? b : a; }
 DEV int wave_sum_i32(int v) {
+    PYA_FULL_WAVE();
     int x = v;
     PYA_DPP_REDUCE32(x, pya_op_add_i32, 0)
     return __builtin_amdgcn_readlane(x, 63);
 }
 DEV uint32_t wave_max_u32(uint32_t v) {
+    PYA_FULL_WAVE();
     int x = (int)v;
     PYA_DPP_REDUCE32(x, pya_op_max_u32, 0)
     return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 DEV uint32_t wave_min_u32(uint32_t v) {
+    PYA_FULL_WAVE();
     int x = (int)v;
     PYA_DPP_REDUCE32(x, pya_op_min_u32, -1)
     return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 DEV float wave_max_f32(float v) {
+    PYA_FULL_WAVE();
     int x = __float_as_int(v);
     PYA_DPP_REDUCE32(x, pya_op_max_f32, 0xff800000u)
     return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 DEV float wave_min_f32(float v) {
+    PYA_FULL_WAVE();
     int x = __float_as_int(v);
     PYA_DPP_REDUCE32(x, pya_op_min_f32, 0x7f800000u)
     return __int_as_float(__builtin_amdgcn_readlane(x, 63));
@@ -144,6 +161,7 @@ DEV double wave_max_f64(double v) {
  * wave_excl_scan_i32 below; packed fields add as the integers they are.  Every lane must be active. */
 template <bool HALVES>
 DEV uint32_t wave_incl_scan_u32(uint32_t v) {
+    PYA_FULL_WAVE();
     int x = (int)v;
     x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
     x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
@@ -158,6 +176,7 @@ DEV uint32_t wave_incl_scan_u32(uint32_t v) {
  * the rows of 16 lanes, then lane 15 of a row broadcast to the next and lane 31 to the upper half (the sequence LLVM's
  * atomic optimizer builds for gfx9) -- where six ds_bpermute round trips with their address arithmetic were 40 instructions. */
 DEV int wave_excl_scan_i32(int v, int *total) {
+    PYA_FULL_WAVE();
 #ifdef PYA_SCAN_BPERMUTE
     int x = v;
 #pragma unroll

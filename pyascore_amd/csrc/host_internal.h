@@ -71,6 +71,8 @@ int pya_launch_ambiguity(const BatchDev *b, uint32_t psm, uint32_t peak_cap, uin
                          uint64_t ref_bits, uint64_t oth_bits, const float *d_scores, float ref_ws,
                          float oth_ws, float *d_out, hipStream_t stream);
 int pya_launch_debug_sort(const float *d_keys, uint32_t n, uint32_t *d_perm, hipStream_t stream);
+int pya_launch_pack_records(const float *best_score, const int32_t *n_sig, const uint64_t *best_sig, const float *ascores,
+                            const uint64_t *alt_mask, uint32_t k, uint32_t res_k, uint64_t n_psm, int32_t *out, hipStream_t stream);
 int pya_launch_debug_wave_ops(const int32_t *d_in, int32_t *d_out, hipStream_t stream);
 size_t pya_score_big_lds_bytes(uint32_t cap, uint32_t pos_cap, uint32_t kc);
 int pya_launch_score_big(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t pos_cap, uint32_t kc,
@@ -227,7 +229,6 @@ struct Knobs {
     double chunk_mb = 0.;                       /* 0: the default chunk size */
     int64_t workspace_mb = 0;                   /* 0: the default budget */
 };
-extern int g_knob_sb, g_knob_gtp, g_knob_hash_pp;     /* (Bucket has no handle: the two A/B overrides are process-wide) */
 
 void read_knobs(Knobs &k);
 bool set_knob(Knobs &k, const char *key, const char *value);
@@ -354,8 +355,16 @@ struct Bucket {
     uint32_t n_cap = 0, list_cap = 1, pos_cap = 1;
     /* Signatures localised together (winner included) -- LDS per wave decides the occupancy of
      * localize, the number of batches its instruction count. */
+    /* the A/B overrides of the handle that owns the plan (PYA_SB, PYA_GTP, PYA_HASH_PP; < 0: the built-in rule), copied in by
+     * take_knobs() when the plan is created: a second scorer in the process does not change them (r05 advisor) */
+    int knob_sb = -1, knob_gtp = -1, knob_hash_pp = -1;
+    void take_knobs(const Knobs &k) {
+        knob_sb = k.sb;
+        knob_gtp = k.gtp;
+        knob_hash_pp = k.hash_pp;
+    }
     uint32_t sb() const {
-        if (g_knob_sb >= 0) return (uint32_t)g_knob_sb;                            /* A/B experiments (PYA_SB) */
+        if (knob_sb >= 0) return (uint32_t)knob_sb;                                /* A/B experiments (PYA_SB) */
         /* one batch holds the winner and one competitor per modified site.  (r01 gave long peptides -- large per-signature
          * tables -- two fewer to keep the LDS, hence the occupancy, up; r05 measured the opposite on cfg3, whose 40-mers then
          * needed two or three batches where one does: 0.465 -> 0.431 ms with the full batch.  These kernels are bound by the
@@ -369,7 +378,7 @@ struct Bucket {
      * so long multi-charge lists (cfg4: 228 per type) go one type at a time and the pool -- hence
      * the LDS per wave, hence the occupancy of localize -- stays small. */
     uint32_t gtp() const {
-        if (g_knob_gtp >= 0) return (uint32_t)g_knob_gtp;                          /* A/B experiments (PYA_GTP) */
+        if (knob_gtp >= 0) return (uint32_t)knob_gtp;                              /* A/B experiments (PYA_GTP) */
         uint32_t g = 0;
         while ((1u << g) < n_types) g++;
         while (g > 0 && (list_cap << g) > 256u) g--;
@@ -402,7 +411,7 @@ struct Bucket {
      * -- room for the worst case, so the hash route never declines for lack of it (PYA_HASH_PP: another multiple of
      * pair_cap, for the tests of the hand-over; 6 instead of 7 measured 4 % slower on cfg4 at the same occupancy: where
      * the arrays behind the lists land in the LDS banks) */
-    uint32_t hash_pp() const { return ((g_knob_hash_pp > 0 ? (uint32_t)g_knob_hash_pp : 1u + 2u * (sb() - 1u)) * pair_cap + 7u) & ~7u; }
+    uint32_t hash_pp() const { return ((knob_hash_pp > 0 ? (uint32_t)knob_hash_pp : 1u + 2u * (sb() - 1u)) * pair_cap + 7u) & ~7u; }
     bool hash_ok(uint32_t max_k, uint32_t n_nl) const {
         return pos_cap <= 64u && hash_vc() <= 8192u &&
                pya_localize_hash_lds_bytes(push_cap(), n_cap, pos_cap, sb(), hash_vc(), hash_hs(), hash_pp(), max_k, n_nl) <= 64u * 1024u;

@@ -108,6 +108,7 @@ int one_run(pya_handle *h, bool keep, uint32_t max_k) {
     d.debug = h->kn.debug & 0xffffu;
     /* caps of this one PSM (the rules of the plan's buckets, for a bucket of one) */
     Bucket bk;
+    bk.take_knobs(h->kn);
     const uint32_t L = m.L, z = (uint32_t)m.max_charge, k = (uint32_t)m.n_of_mod, ns = m.n_sites, N = m.n_sig;
     const uint32_t n_uniq = (uint32_t)h->cfg.n_uniq, n_types = (uint32_t)h->cfg.n_types;
     const uint32_t per_type = (L - 1) * z * n_uniq;

@@ -88,6 +88,9 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
     };
     std::unique_ptr<pya_plan> p(new pya_plan);
     p->h = h;
+    for (Bucket &bk : p->buckets) bk.take_knobs(h->kn);      /* (PYA_SB / PYA_GTP / PYA_HASH_PP of THIS handle) */
+    p->fusedb.take_knobs(h->kn);
+    p->bigloc.take_knobs(h->kn);
     p->flags = flags;
     p->n_psm = n;
     p->peak_off.assign(b->peak_off, b->peak_off + n + 1);
@@ -782,6 +785,7 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     const uint64_t tiny_max = (uint64_t)h->kn.tiny_max;
     bool tiny = !timing && p->n_psm <= tiny_max && p->n_skipped == 0 && !h->kn.no_tiny && p->gen_ids.empty();
     Bucket m;                                               /* caps that cover every PSM of the batch */
+    m.take_knobs(h->kn);
     uint32_t prefix = 0, compact = 0;
     if (tiny) {
         /* (the PSMs the fused kernel would take are accounted in their own bucket: its caps count too --
@@ -1033,6 +1037,9 @@ int check_status(pya_handle *h, const int32_t *st, uint64_t n, bool skip_invalid
                 return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: trial count outside the score table", (unsigned long long)i);
             case PYA_ST_PUSHED_OVERFLOW:
                 return h->fail(PYA_ERR_LIMIT, (int64_t)i, "PSM %llu: more than %d tied competitors", (unsigned long long)i, PYA_MAX_PUSHED);
+            case PYA_ST_ROUTE_CAPS:
+                return h->fail(PYA_ERR_STATE, (int64_t)i, "PSM %llu reached a kernel whose launch was not sized for it (modifications or "
+                               "modifiable residues beyond the launch's caps): a routing error of this library", (unsigned long long)i);
             default:
                 return h->fail(PYA_ERR_HIP, (int64_t)i, "PSM %llu: unexpected kernel status %d", (unsigned long long)i, st[i]);
         }
@@ -1058,6 +1065,20 @@ int pya_plan_check(pya_plan *p) {
     const bool skip = (p->flags & PYA_FLAG_SKIP_INVALID) != 0;
     if (skip) h->last_status = st;
     return check_status(h, st.data(), p->n_psm, skip);
+}
+
+int pya_pack_records(pya_handle *h, const pya_results *d_res, uint64_t n_psm, uint32_t k, int32_t *d_out, void *hip_stream) {
+    if (!h) return PYA_ERR_ARG;
+    if (!d_res || !d_out || !d_res->best_score || !d_res->best_sig || !d_res->n_sig || !d_res->ascores || !d_res->alt_mask)
+        return h->fail(PYA_ERR_ARG, -1, "pya_pack_records: null result array");
+    if (k < d_res->max_k || k > 64 || d_res->max_k == 0)
+        return h->fail(PYA_ERR_ARG, -1, "pya_pack_records: record width k = %u is narrower than the results' rows (%u) or above 64", k,
+                       d_res->max_k);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int e = pya_launch_pack_records(d_res->best_score, d_res->n_sig, d_res->best_sig, d_res->ascores, d_res->alt_mask, k,
+                                          d_res->max_k, n_psm, d_out, (hipStream_t)hip_stream);
+    if (e) return h->fail(PYA_ERR_HIP, -1, "pya_pack_records: launch failed (%d)", e);
+    return PYA_OK;
 }
 
 uint64_t pya_plan_workspace_bytes(const pya_plan *p) { return p ? p->workspace_bytes() : 0; }

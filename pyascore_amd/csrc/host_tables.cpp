@@ -1,8 +1,6 @@
 /* host_tables.cpp -- environment switches, configuration -> DevConfig, score table, pre-sort order tables of the shapes. */
 #include "host_internal.h"
 
-int g_knob_sb = -1, g_knob_gtp = -1, g_knob_hash_pp = -1;     /* (Bucket has no handle: the A/B overrides are process-wide) */
-
 /* The environment reaches the library through FOUR variables, read once per handle (pya_create) and again only when
  * pya_reload_env asks: two sizes a deployment may want to set without touching code, two diagnostics that change no
  * result and no route.  Everything that selects a kernel route or makes a kernel decline work is a DEBUG SWITCH: set
@@ -17,16 +15,9 @@ static void read_env(Knobs &k) {
     k.workspace_mb = w ? (int64_t)std::atoll(w) : 0;
 }
 
-static void publish_process_wide(const Knobs &k) {
-    g_knob_sb = k.sb;
-    g_knob_gtp = k.gtp;
-    g_knob_hash_pp = k.hash_pp;
-}
-
 void read_knobs(Knobs &k) {
     k = Knobs();                 /* every debug switch back to the production default */
     read_env(k);
-    publish_process_wide(k);
 }
 
 /* One debug switch by name (the names the tests have always used); value == nullptr restores its default.
@@ -63,7 +54,6 @@ bool set_knob(Knobs &k, const char *key, const char *value) {
     else if (name == "PYA_NODE_CAP") k.node_cap = (int)num(-1), known = true;
     else if (name == "PYA_CHUNK_MB") k.chunk_mb = on ? std::max(1.0, std::atof(value)) : 0., known = true;
     else if (name == "PYA_WORKSPACE_MB") k.workspace_mb = num(0), known = true;
-    if (known) publish_process_wide(k);
     return known;
 }
 
@@ -144,7 +134,9 @@ int build_dev_config(pya_handle *h) {
         c.cand_b[i] = cands[i].b < 0 ? 255 : (uint8_t)cands[i].b;
         c.cand_u[i] = (uint8_t)cand_u[i];
     }
-    /* (more than PYA_FAST_NL masses: every PSM goes through the general kernel, which reads the candidates above) */
+    /* (more than PYA_FAST_NL masses: every PSM goes through the general kernel, which reads the candidates above; the narrow
+     * tables stay as the memset at the top left them -- present[st] == 0 is "no state is valid", not even the unmodified ion:
+     * a fast kernel routed here by mistake would count nothing instead of reading another configuration's tables) */
     for (size_t j = 0; j < uniq.size() && j < PYA_MAX_UNIQ; j++) c.uniq[j] = uniq[j];
     for (int st = 0; st < 256 && D <= PYA_FAST_NL; st++) {
         int cnt[4];

@@ -255,6 +255,40 @@ extern "C" int pya_launch_debug_wave_ops(const int32_t *d_in, int32_t *d_out, hi
     return (int)hipGetLastError();
 }
 
+/* The gather record of a PSM (pyascore_amd/shard.py: record_width = 4 + 3 k int32 words): best_score bits, n_sig, best_sig
+ * lo / hi, then k Ascore bit patterns and k alternative-site masks lo / hi -- packed straight into the caller's send
+ * buffer, a word per thread, rows read and written coalesced (the widest row is 4 + 3 * 64 words). */
+__global__ __launch_bounds__(256) void pya_pack_records_kernel(const float *best_score, const int32_t *n_sig, const uint32_t *best_sig,
+                                                               const uint32_t *ascores, const uint32_t *alt_mask, uint32_t k,
+                                                               uint32_t res_k, uint64_t n_psm, uint32_t *out) {
+    const uint32_t width = 4u + 3u * k;
+    const uint64_t total = n_psm * width;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t psm = i / width;
+        const uint32_t w = (uint32_t)(i - psm * width);
+        uint32_t v;
+        if (w == 0) v = __float_as_uint(best_score[psm]);
+        else if (w == 1) v = (uint32_t)n_sig[psm];
+        else if (w < 4) v = best_sig[2 * psm + (w - 2)];
+        else if (w < 4 + k) v = (w - 4) < res_k ? ascores[psm * res_k + (w - 4)] : 0u;
+        else {
+            const uint32_t j = w - 4 - k;                    /* word j of the row of k 64-bit masks */
+            v = (j >> 1) < res_k ? alt_mask[2 * (psm * res_k) + j] : 0u;
+        }
+        out[i] = v;
+    }
+}
+extern "C" int pya_launch_pack_records(const float *best_score, const int32_t *n_sig, const uint64_t *best_sig, const float *ascores,
+                                       const uint64_t *alt_mask, uint32_t k, uint32_t res_k, uint64_t n_psm, int32_t *out,
+                                       hipStream_t stream) {
+    if (n_psm == 0) return 0;
+    const uint64_t total = n_psm * (4u + 3u * k);
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pya_pack_records_kernel, dim3(blocks), dim3(256), 0, stream, best_score, n_sig, (const uint32_t *)best_sig,
+                       (const uint32_t *)ascores, (const uint32_t *)alt_mask, k, res_k, n_psm, (uint32_t *)out);
+    return (int)hipGetLastError();
+}
+
 extern "C" size_t pya_localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t sb, uint32_t vc,
                                               uint32_t hs, uint32_t pp, uint32_t max_k, uint32_t n_nl) {
     return localize_hash_lds_bytes(push_cap, n_cap, pos_cap, sb, vc, hs, pp, max_k, n_nl);

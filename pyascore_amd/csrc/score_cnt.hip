@@ -138,6 +138,13 @@ DEV void score_cnt_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw,
     const uint64_t *order = b.order_tab + b.order_off[psm];
     const int64_t s0 = b.sig_off[psm];
     const int L = res.L, k = b.n_of_mod[psm], n_sites = __popcll(res.site_mask);
+    /* the work areas are carved for the launch's caps (host_plan.cpp: the bucket's k_max / ns_max): a PSM beyond them would
+     * overrun the envelopes and the (t, site) table -- the host never lists one here; if a routing change ever does, the PSM
+     * fails loudly instead (r05 advisor) */
+    if ((uint32_t)k > k_cap || (uint32_t)n_sites > n_cap || (uint32_t)(L - 1) > pos_cap || (uint32_t)k + 1u > kc) {
+        if (lane == 0) b.status[psm] = PYA_ST_ROUTE_CAPS;
+        return;
+    }
     PeakTable tab;
     stage_peak_table(b, psm, c.t_e, &tab);
     stage_residues(res, c.resd, nullptr);

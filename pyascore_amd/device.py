@@ -119,16 +119,20 @@ class DevicePlan:
     def packed_summary(self, out=None):
         """Results as one [n_psm, 4 + 3*max_k] int32 device tensor (fixed-size records for the
         gather): best_score bits, n_sig, best_sig lo/hi, then per site ascore bits, alt lo/hi.
-        ``out``: a preallocated [n_psm, width] int32 tensor (e.g. a slice of the send buffer) to pack
-        into with one kernel, instead of a new tensor that is then copied."""
+        ``out``: a preallocated contiguous [n_psm, width] int32 tensor (e.g. a slice of the send buffer).  ONE kernel
+        of the library (pya_pack_records) on torch's current stream writes the records in place: no framework kernel
+        and no intermediate tensor inside the step (r05: torch.cat)."""
         torch = self._torch
-        k = self.max_k
-        cols = [self.best_score.view(torch.int32).unsqueeze(1), self.n_sig.unsqueeze(1),
-                self.best_sig.view(torch.int32).view(-1, 2),
-                self.ascores.view(torch.int32), self.alt_mask.view(torch.int32).view(-1, 2 * k)]
-        if out is not None:
-            return torch.cat(cols, dim=1, out=out)
-        return torch.cat(cols, dim=1).contiguous()
+        width = 4 + 3 * self.max_k
+        if out is None:
+            out = torch.empty((self.n_psm, width), dtype=torch.int32, device=self.device)
+        if out.dtype != torch.int32 or tuple(out.shape) != (self.n_psm, width) or not out.is_contiguous() or not out.is_cuda:
+            raise ValueError("out must be a contiguous int32 device tensor of shape (%d, %d)" % (self.n_psm, width))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.pya_pack_records(self.scorer._h, C.byref(self._res), self.n_psm, self.max_k, out.data_ptr(), stream)
+        if rc:
+            self.scorer._raise(rc)
+        return out
 
 
 def unpack_summary(packed, max_k):

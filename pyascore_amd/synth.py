@@ -153,8 +153,9 @@ def make_batch(config="cfg2", n_psm=None, seed=0, **override):
 BLOCK = 16384
 
 
-def describe(config="cfg2", n_psm=None, seed=0, **override):
-    """Per-PSM shapes of a synthetic job of one BASELINE config (no spectra)."""
+def describe(config="cfg2", n_psm=None, seed=0, n_noise=300, isotopes=False, **override):
+    """Per-PSM shapes of a synthetic job of one BASELINE config (no spectra).  ``n_noise`` / ``isotopes``:
+    denser spectra than section 8(d)'s 300 noise peaks (bench.py's `dense` legs), see _var_shape."""
     cfg = dict(CONFIGS[config])
     cfg.update(override)
     n = int(n_psm if n_psm is not None else cfg["n_psm"])
@@ -172,12 +173,19 @@ def describe(config="cfg2", n_psm=None, seed=0, **override):
                     fragment_types=cfg["fragment_types"],
                     neutral_losses=[list(cfg["neutral_loss"])] if cfg["neutral_loss"] else [])
     return dict(config=config, n_psm=n, seed=int(seed), L=Ls, n_sites=ns, n_mod=ks,
-                max_charge=np.full(n, cfg["max_charge"], np.int64), settings=settings)
+                max_charge=np.full(n, cfg["max_charge"], np.int64), settings=settings,
+                n_noise=int(n_noise), isotopes=bool(isotopes))
 
 
-def _var_shape(rng, Ls, ns, ks, mz_error, n_noise=300, keep_p=0.6):
+ISOTOPE_STEP = 1.00335            # 13C - 12C
+
+
+def _var_shape(rng, Ls, ns, ks, mz_error, n_noise=300, keep_p=0.6, isotopes=False):
     """The generator of _fixed_shape for PSMs of mixed shapes in one vectorised pass (rows padded to
-    the longest peptide and masked): -> (pep uint8 flat, mz flat, intensity flat, peak counts)."""
+    the longest peptide and masked): -> (pep uint8 flat, mz flat, intensity flat, peak counts).
+    ``isotopes``: every peak (fragment or noise) brings two satellites at +1.00335/z and +2.0067/z with
+    0.5x / 0.2x its intensity (z = 1 for the fragments, 1..3 for the noise): ``n_noise`` then counts the
+    noise peaks WITH their satellites (a third of them are drawn)."""
     n, Lmax = Ls.size, int(Ls.max())
     col = np.arange(Lmax)[None, :]
     inside = col < Ls[:, None]
@@ -201,14 +209,24 @@ def _var_shape(rng, Ls, ns, ks, mz_error, n_noise=300, keep_p=0.6):
     keep = (rng.random(sig.shape) < keep_p) & np.concatenate([frag_ok, frag_ok], axis=1)
     sig = sig + rng.uniform(-0.4 * mz_error, 0.4 * mz_error, size=sig.shape)
     sig_int = rng.lognormal(6.0, 1.2, size=sig.shape)
-    noise = rng.uniform(100.0, 2000.0, size=(n, n_noise))
-    noise_int = rng.lognormal(4.5, 1.0, size=(n, n_noise))
-    mz = np.concatenate([np.where(keep, sig, np.inf), noise], axis=1)
-    inten = np.concatenate([sig_int, noise_int], axis=1)
+    if isotopes:
+        n_base = max(1, n_noise // 3)
+        noise = rng.uniform(100.0, 2000.0, size=(n, n_base))
+        noise_int = rng.lognormal(4.5, 1.0, size=(n, n_base))
+        step = ISOTOPE_STEP / rng.integers(1, 4, size=(n, n_base))
+        sig = np.where(keep, sig, np.inf)
+        mz = np.concatenate([sig, sig + ISOTOPE_STEP, sig + 2 * ISOTOPE_STEP, noise, noise + step, noise + 2 * step], axis=1)
+        inten = np.concatenate([sig_int, 0.5 * sig_int, 0.2 * sig_int, noise_int, 0.5 * noise_int, 0.2 * noise_int], axis=1)
+        counts = (3 * keep.sum(axis=1) + 3 * n_base).astype(np.int64)
+    else:
+        noise = rng.uniform(100.0, 2000.0, size=(n, n_noise))
+        noise_int = rng.lognormal(4.5, 1.0, size=(n, n_noise))
+        mz = np.concatenate([np.where(keep, sig, np.inf), noise], axis=1)
+        inten = np.concatenate([sig_int, noise_int], axis=1)
+        counts = (keep.sum(axis=1) + n_noise).astype(np.int64)
     order = np.argsort(mz, axis=1, kind="stable")
     mz = np.take_along_axis(mz, order, axis=1)
     inten = np.take_along_axis(inten, order, axis=1)
-    counts = (keep.sum(axis=1) + n_noise).astype(np.int64)
     valid = np.arange(mz.shape[1])[None, :] < counts[:, None]
     return pep[inside], mz[valid], inten[valid], counts
 
@@ -219,7 +237,8 @@ def _make_block(desc, b):
     n = i1 - i0
     rng = np.random.default_rng([desc["seed"], 0xB10C, b])
     Ls, ns, ks = desc["L"][i0:i1], desc["n_sites"][i0:i1], desc["n_mod"][i0:i1]
-    pep, mz, inten, counts = _var_shape(rng, Ls, ns, ks, desc["settings"]["mz_error"])
+    pep, mz, inten, counts = _var_shape(rng, Ls, ns, ks, desc["settings"]["mz_error"], n_noise=desc.get("n_noise", 300),
+                                        isotopes=desc.get("isotopes", False))
     return dict(n_psm=n, mz=mz, intensity=inten, peak_off=np.concatenate([[0], np.cumsum(counts)]).astype(np.int64),
                 pep=pep, pep_off=np.concatenate([[0], np.cumsum(Ls)]).astype(np.int64),
                 n_of_mod=ks.astype(np.int32), max_charge=desc["max_charge"][i0:i1].astype(np.int32),
@@ -318,3 +337,117 @@ def slice_batch(batch, lo, hi):
         max_charge=batch["max_charge"][lo:hi], aux_pos=batch["aux_pos"][e:f],
         aux_mass=batch["aux_mass"][e:f], aux_off=(batch["aux_off"][lo:hi + 1] - e),
     )
+
+
+# ---------------------------------------------------------------------------------------------
+# Spectra that look like an instrument's (r06): isotope envelopes, doublets inside the tolerance, repeated
+# m/z, count-like intensities, 800-3000 peaks -- the data on which the rare branches of the count-node
+# marking (walk_core.hip.h) and of the site-ion closed forms (localize_hash.hip.h) are NOT rare.
+# ---------------------------------------------------------------------------------------------
+ACETYL = 42.010565
+OXIDATION = 15.994915
+H3PO4 = 97.9769
+H2O = 18.01528
+
+
+def make_realistic(n_psm, seed=0, general=True, mz_error=0.02, fragment_types=None, max_sites=10, max_mod=4,
+                   peaks=(800, 3000)):
+    """PSMs shaped like test/test_ascore.py:10-61's data (a phosphopeptide, fixed oxidation / n-terminal acetyl as
+    auxiliary mods) with spectra that cluster the way centroided MS2 spectra do.
+
+    general=True : phospho on STY, neutral losses ("sty", H3PO4) and ("ST", H2O), fragment charges 1..4,
+                   `fragment_types` "bycz" -- the settings of cfg4's kernels;
+    general=False: no losses, charge 1, "by" -- the plain kernels (fused / count nodes / big).
+    Per PSM: L 8..32, 2..max_sites STY residues, 1..max_mod of them modified; M carries oxidation and the n-terminus
+    acetyl on a share of the peptides (aux mods, never on a modifiable residue: the reference reads out of bounds there).
+    Signal: b / y (+ c / z when asked) fragments of the true assignment at every charge, loss variants on a third, each kept
+    with p = 0.6, with an isotope envelope (+1.00335/z, +2.0067/z at 0.5x / 0.2x); a tenth of the signal peaks get a doublet
+    partner 0.2..1.5 mz_error away, 2 % of all peaks an exact repeat of their m/z.  Noise: envelopes at charge 1..3 up to
+    the target peak count.  Intensities are integer counts (ties everywhere among the weak peaks)."""
+    rng = np.random.default_rng([int(seed), 0x4EA1])
+    ftypes = fragment_types or ("bycz" if general else "by")
+    base = list(BASE_ALPHABET)
+    psms = []
+    for _ in range(int(n_psm)):
+        L = int(rng.integers(8, 33))
+        n_sites = int(rng.integers(2, min(max_sites, L - 1) + 1))
+        k = int(rng.integers(1, min(max_mod, n_sites - 1) + 1))
+        pep = [base[i] for i in rng.integers(0, len(base), size=L)]
+        site_pos = np.sort(rng.choice(L, size=n_sites, replace=False))
+        for p in site_pos:
+            pep[p] = "STY"[int(rng.choice(3, p=(0.5, 0.35, 0.15)))]
+        truth = set(int(p) for p in rng.choice(site_pos, size=k, replace=False))
+        mass = np.array([RESIDUE_MASS[c] for c in pep])
+        aux_pos, aux_mass = [], []
+        for i, c in enumerate(pep):
+            if c == "M" and rng.random() < 0.7:
+                aux_pos.append(i + 1)
+                aux_mass.append(OXIDATION)
+                mass[i] += OXIDATION
+        if rng.random() < 0.3 and 0 not in site_pos:
+            aux_pos.append(0)
+            aux_mass.append(ACETYL)
+            mass[0] += ACETYL
+        for p in truth:
+            mass[p] += PHOSPHO
+        zmax = int(rng.integers(1, 5)) if general else 1
+        is_p = np.array([i in truth for i in range(L)])
+        is_st = np.array([(c in "ST") and (i not in truth) for i, c in enumerate(pep)])
+        sig_mz, sig_z = [], []
+        for direction in (0, 1):
+            order = np.arange(L) if direction == 0 else np.arange(L)[::-1]
+            m1 = np.cumsum(mass[order])[:-1]
+            has_p = np.cumsum(is_p[order])[:-1] > 0
+            has_st = np.cumsum(is_st[order])[:-1] > 0
+            offs = []
+            if direction == 0:
+                if "b" in ftypes:
+                    offs.append(0.0)
+                if "c" in ftypes:
+                    offs.append(17.026549)
+            else:
+                if "y" in ftypes:
+                    offs.append(WATER)
+                if "z" in ftypes or "Z" in ftypes:
+                    offs.append(WATER - 17.026549 + (1.007825 if "Z" in ftypes else 0.0))
+            for off in offs:
+                neutral = m1 + off
+                variants = [neutral]
+                if general:
+                    variants.append(np.where(has_p & (rng.random(m1.size) < 0.35), neutral - H3PO4, np.nan))
+                    variants.append(np.where(has_st & (rng.random(m1.size) < 0.2), neutral - H2O, np.nan))
+                for v in variants:
+                    for z in range(1, zmax + 1):
+                        x = (v + z * PROTON) / z
+                        keep = np.isfinite(x) & (rng.random(x.size) < (0.6 if z == 1 else 0.3))
+                        sig_mz.append(x[keep])
+                        sig_z.append(np.full(int(keep.sum()), z))
+        s_mz = np.concatenate(sig_mz) if sig_mz else np.zeros(0)
+        s_z = np.concatenate(sig_z) if sig_z else np.zeros(0, np.int64)
+        s_mz = s_mz + rng.uniform(-0.4 * mz_error, 0.4 * mz_error, size=s_mz.size)
+        s_int = rng.lognormal(6.0, 1.2, size=s_mz.size)
+        # doublets: a partner 0.2 .. 1.5 tolerances away from a tenth of the signal peaks
+        dbl = rng.random(s_mz.size) < 0.1
+        d_mz = s_mz[dbl] + rng.choice([-1.0, 1.0], size=int(dbl.sum())) * rng.uniform(0.2, 1.5, size=int(dbl.sum())) * mz_error
+        d_int = rng.lognormal(5.5, 1.2, size=d_mz.size)
+        target = int(rng.integers(peaks[0], peaks[1] + 1))
+        n_noise = max(0, (target - 3 * (s_mz.size + d_mz.size)) // 3)
+        n_mz = rng.uniform(100.0, 2200.0, size=n_noise)
+        n_z = rng.integers(1, 4, size=n_noise)
+        n_int = rng.lognormal(4.0, 1.0, size=n_noise)
+        b_mz = np.concatenate([s_mz, d_mz, n_mz])
+        b_z = np.concatenate([s_z, np.ones(d_mz.size, np.int64), n_z]).astype(np.float64)
+        b_int = np.concatenate([s_int, d_int, n_int])
+        mz = np.concatenate([b_mz, b_mz + ISOTOPE_STEP / b_z, b_mz + 2 * ISOTOPE_STEP / b_z])
+        it = np.concatenate([b_int, 0.5 * b_int, 0.2 * b_int])
+        rep = rng.random(mz.size) < 0.02                        # the same m/z twice
+        mz = np.concatenate([mz, mz[rep]])
+        it = np.concatenate([it, rng.lognormal(4.5, 1.0, size=int(rep.sum()))])
+        it = np.floor(it / 8.0) + 1.0                           # counts
+        order = np.argsort(mz, kind="stable")
+        psms.append(dict(mz=mz[order], intensity=it[order], peptide="".join(pep), n_of_mod=k, max_charge=zmax,
+                         aux_pos=np.asarray(aux_pos, np.uint32), aux_mass=np.asarray(aux_mass, np.float32)))
+    settings = dict(bin_size=100.0, n_top=10, mod_group="STY", mod_mass=PHOSPHO, mz_error=float(mz_error),
+                    fragment_types=ftypes,
+                    neutral_losses=[["sty", H3PO4], ["ST", H2O]] if general else [])
+    return pack_batch(psms), settings

@@ -21,7 +21,8 @@ for PCFG in $PCFGS; do
   rm -rf $P /tmp/prof && mkdir -p $P /tmp/prof
   cd /tmp
   STEPS=10; WARM=2; PSTEPS=3; PWARM=1
-  echo "{\"stats_steps\": $((STEPS+WARM)), \"pmc_steps\": $((PSTEPS+PWARM))}" > $P/profile_steps.json
+  SRC=$(PYTHONPATH=$ROOT python3 -c "from pyascore_amd import _lib; print(_lib.load().pya_version().decode().split('src=')[-1])")
+  echo "{\"stats_steps\": $((STEPS+WARM)), \"pmc_steps\": $((PSTEPS+PWARM)), \"src\": \"$SRC\"}" > $P/profile_steps.json
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -- python3 $ROOT/bench.py --config $PCFG --steps $STEPS --warmup $WARM --blocks 1 --no-cpu-baseline --no-host-api --no-other-configs > /tmp/prof/stats.log 2>&1
   f=$(find /tmp/prof/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/kernel_stats.csv
   i=0

@@ -52,7 +52,7 @@ def test_the_environment_reaches_the_library_through_four_variables():
                 names.add((f, m.group(1)))
     assert {f for f, _ in names} <= {"host_tables.cpp"}, names
     text = open(os.path.join(csrc, "host_tables.cpp")).read()
-    body = text[text.index("static void read_env"): text.index("static void publish_process_wide")]
+    body = text[text.index("static void read_env"): text.index("void read_knobs")]
     env = set(re.findall(r'"(PYA_[A-Z_]+)"', body))
     assert env == {"PYA_WORKSPACE_MB", "PYA_CHUNK_MB", "PYA_HOST_TIMING", "PYA_STAMPS"}
     assert len(re.findall(r"getenv", text)) - len(re.findall(r"getenv", body)) == 0

@@ -714,6 +714,32 @@ def test_timing_events_of_runs_enqueued_back_to_back():
     plan.close()
 
 
+def test_gather_records_are_packed_by_the_library():
+    """pya_pack_records (the step's one pack kernel, straight into a slice of the send buffer) writes what the framework's
+    concatenation of the result arrays wrote before -- for a plan at its own width, for a job-wide width wider than the batch
+    needs (cfg3: 1..4 modifications packed at 6), into the middle of a larger buffer, and refuses a narrower one."""
+    import torch
+    from pyascore_amd.device import DevicePlan
+    dev = torch.device("cuda", 0)
+    for cfg, n, wide in (("cfg2", 1000, None), ("cfg3", 3000, 6), ("cfg5", 64, None)):
+        batch, settings = synth.make_batch(cfg, n_psm=n, seed=88)
+        gpu = _gpu(settings)
+        mz, it = torch.from_numpy(batch["mz"]).to(dev), torch.from_numpy(batch["intensity"]).to(dev)
+        plan = DevicePlan(gpu, batch, max_k=wide)
+        plan.run(mz, it)
+        k = plan.max_k
+        cat = torch.cat([plan.best_score.view(torch.int32).unsqueeze(1), plan.n_sig.unsqueeze(1), plan.best_sig.view(torch.int32).view(-1, 2),
+                         plan.ascores.view(torch.int32), plan.alt_mask.view(torch.int32).view(-1, 2 * k)], dim=1)
+        assert torch.equal(plan.packed_summary(), cat)
+        send = torch.full((n + 100, 4 + 3 * k), -7, dtype=torch.int32, device=dev)
+        plan.packed_summary(out=send[50:50 + n])
+        assert torch.equal(send[50:50 + n], cat) and bool((send[:50] == -7).all()) and bool((send[50 + n:] == -7).all())
+        with pytest.raises(ValueError):
+            plan.packed_summary(out=torch.empty((n, 3 + 3 * k), dtype=torch.int32, device=dev))
+        plan.check()
+        plan.close()
+
+
 def test_hand_over_counts_between_the_runs_of_a_plan(monkeypatch):
     """A plan's runs alternate between two sets of hand-over counters, and the binning kernel of a run zeroes the set
     of the next (host_plan.cpp, bin_spectra.hip) -- no memset in between.  Ten runs of one plan whose every spectrum
