@@ -15,6 +15,7 @@
  * resolve them.  The rare paths stay out of the hot kernel's register budget that way.
  */
 #include "bin_core.hip.h"
+#include "bin_select.hip.h"
 
 #ifndef BIN_WAVES
 #define BIN_WAVES 4     /* independent spectra per workgroup when LDS allows (no cross-wave sync) */
@@ -45,7 +46,28 @@ __global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_spectra_kernel(BatchDe
     if (R < 0) bin_store(b, psm, R, status, r_mz, r_rank);                        /* (no windows: the status only) */
 }
 
-/* the spectra the kernel above declined, one per wavefront, a fixed grid striding over the list */
+/* Dense spectra (the host sends the peak classes above pya_handle.kn.bin_select_min here): selection by per-window
+ * histograms, then bin_fast's ranking over the survivors only (bin_select.hip.h) -- O(peaks), LDS independent of the peak
+ * count.  What it declines goes to the same list. */
+__global__ __launch_bounds__(64 * BIN_WAVES) void pya_bin_select_kernel(BatchDev b, const uint32_t *psm_ids, uint32_t n_ids,
+                                                                        uint32_t scap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t slot = xcd_slot(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave;
+    if (blockIdx.x == 0 && threadIdx.x < 3 && b.zero_next) b.zero_next[threadIdx.x] = 0u;      /* (as pya_bin_spectra_kernel) */
+    if (slot >= n_ids) return;
+    unsigned char *lds_raw = lds_all + (size_t)wave * PYA_BIN_SEL_BYTES(scap);
+    const uint32_t psm = psm_ids[slot];
+    int status;
+    const int R = bin_select(b, psm, lds_raw, scap, &status);
+    if (R == PYA_BIN_REDO) {
+        if (lane_id() == 0) b.redo_ids[atomicAdd(b.redo_count, 1u)] = psm;
+        return;
+    }
+    if (R < 0) bin_store(b, psm, R, status, nullptr, nullptr);
+}
+
+/* the spectra the kernels above declined, one per wavefront, a fixed grid striding over the list */
 __global__ __launch_bounds__(64) void pya_bin_exact_kernel(BatchDev b, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
     const uint32_t n = *b.redo_count;
@@ -96,6 +118,19 @@ extern "C" int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_bin_spectra_kernel, dim3((n_ids + nw - 1) / nw), dim3(64 * nw), lds, stream, *b, d_ids,
                        n_ids, cap);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t pya_bin_select_lds_bytes(uint32_t scap) { return PYA_BIN_SEL_BYTES(scap); }
+
+/* scap: survivor slots per spectrum (a multiple of 32) */
+extern "C" int pya_launch_bin_select(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t scap, hipStream_t stream) {
+    if (n_ids == 0) return 0;
+    const size_t per_wave = PYA_BIN_SEL_BYTES(scap);
+    const uint32_t nw = per_wave * BIN_WAVES <= 64 * 1024 ? BIN_WAVES : 1;
+    hipError_t e = PYA_ENSURE_MAX_LDS(pya_bin_select_kernel);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pya_bin_select_kernel, dim3((n_ids + nw - 1) / nw), dim3(64 * nw), nw * per_wave, stream, *b, d_ids, n_ids, scap);
     return (int)hipGetLastError();
 }
 

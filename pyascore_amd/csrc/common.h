@@ -130,7 +130,9 @@ struct BatchDev {
      * 256 score_signatures walks every signature under general settings (no shared tree nodes), 0x8000 no
      * count-node table (walk_core.hip.h: every walker looks every fragment up itself), 0x40000000 every node of that
      * table marked (the table is read, then every walker looks up itself), 0x20000000 the hash route sends an ion with a lone
-     * neighbour through the exact run walk too (no closed form for {ion, winner's ion outside the span, its twin}).  Ablation: 2 the hash route looks no surviving ion up.
+     * neighbour through the exact run walk too (no closed form for {ion, winner's ion outside the span, its twin}), 0x10000000
+     * score_big leaves no candidate records (the PepScores of all site assignments go to the workspace, the finishing kernel
+     * ranks, gathers and recounts: the r05 route).  Ablation: 2 the hash route looks no surviving ion up.
      * Bits 16..31: truncation point of the diagnostic build (device_common.hip.h, STAMP_T). */
     uint32_t debug;
     unsigned long long *stamps;     /* per-phase cycle sums (diagnostic build -DPYA_STAMPS)  */

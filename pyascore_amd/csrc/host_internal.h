@@ -46,6 +46,8 @@ size_t pya_bin_lds_bytes(uint32_t cap);
 size_t pya_score_lds_bytes(uint32_t cap, uint32_t prefix, uint32_t with_nl, uint32_t compact);
 size_t pya_localize_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb);
 int pya_launch_bin(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, hipStream_t stream);
+int pya_launch_bin_select(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t scap, hipStream_t stream);
+size_t pya_bin_select_lds_bytes(uint32_t scap);
 int pya_launch_bin_exact(const BatchDev *b, uint32_t n_total, uint32_t cap, hipStream_t stream);
 int pya_launch_score(const BatchDev *b, const uint32_t *d_ids, uint32_t n_ids, uint32_t cap, uint32_t prefix,
                      uint32_t with_nl, uint32_t compact, uint32_t node_cap, uint32_t node_cols, uint32_t node_words,
@@ -223,6 +225,8 @@ struct Knobs {
     bool slow_null_stream = false;              /* host_one.cpp: widens the window of a (fixed) workspace race for its regression test */
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64;
+    int64_t bin_select_min = 640;               /* peak classes above this many peaks are binned by selection (bin_select.hip.h); tests: 0 = all, huge = none */
+    int64_t bin_select_scap = 768;              /* survivor slots per spectrum there */
     uint32_t sort_room_max = 1024;
     int sb = -1, gtp = -1, hash_pp = -1;        /* < 0: the built-in rule */
     int node_cap = -1;                          /* >= 0: room for that many shared nodes per direction (tests: small values force the walkers) */

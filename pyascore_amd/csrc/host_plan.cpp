@@ -851,7 +851,13 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     p->n_runs++;
     int e = 0;
     for (const pya_plan::IdList &l : p->bin_lists) {
-        e = pya_launch_bin(&d, p->d_bin_ids.p + l.off, l.n, l.cap, st);
+        /* dense classes: selection first (bin_select.hip.h); the all-pairs ranking of bin_fast is O(window^2) and holds 13 bytes
+         * of LDS per raw peak */
+        const uint32_t scap = (uint32_t)std::min<int64_t>(std::max<int64_t>(h->kn.bin_select_scap, 64), 4096) & ~31u;
+        if ((int64_t)l.cap > h->kn.bin_select_min)
+            e = pya_launch_bin_select(&d, p->d_bin_ids.p + l.off, l.n, scap, st);
+        else
+            e = pya_launch_bin(&d, p->d_bin_ids.p + l.off, l.n, l.cap, st);
         if (e) return h->hip_fail((hipError_t)e, "bin_spectra launch");
     }
     e = pya_launch_bin_exact(&d, (uint32_t)p->n_psm, p->peak_cap, st);

@@ -46,6 +46,8 @@ bool set_knob(Knobs &k, const char *key, const char *value) {
     if (name == "PYA_DEBUG") k.debug = (uint32_t)num(0), known = true;
     else if (name == "PYA_PLAIN_MIN") k.plain_min = num(dflt.plain_min), known = true;
     else if (name == "PYA_BIG_MIN_N") k.big_min_n = num(dflt.big_min_n), known = true;
+    else if (name == "PYA_BIN_SELECT_MIN") k.bin_select_min = num(dflt.bin_select_min), known = true;
+    else if (name == "PYA_BIN_SELECT_SCAP") k.bin_select_scap = num(dflt.bin_select_scap), known = true;
     else if (name == "PYA_TINY_MAX") k.tiny_max = num(dflt.tiny_max), known = true;
     else if (name == "PYA_SORT_ROOM_MAX") k.sort_room_max = (uint32_t)num(dflt.sort_room_max), known = true;
     else if (name == "PYA_SB") k.sb = (int)num(-1), known = true;

@@ -70,7 +70,11 @@ struct InlineSrc {
     uint32_t *rec_batch;      /* [sb][PYA_REC_WORDS] */
     uint32_t *hist;           /* [sb][PYA_NTOP] */
     bool valid;               /* false (the default): nothing handed in */
+    bool cand;                /* r06: `ws` holds the PepScores of the winner's k (n - k) single-move competitors in the body's own
+                               * item order and the winner's behind them, count records from word PYA_CAND_REC on (score_big's
+                               * candidate mode): no combination ranks, no gather, no recount */
 };
+#define PYA_CAND_REC 128
 
 /* HASH (general instantiation only): the site-determining ions come from loc_site_ions_hash; pool_cap is then the
  * number of 4-byte words of its work area (loc_hash_words(vc, hs, pp)), and a PSM it declines returns true. */
@@ -260,14 +264,17 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
                 const int fb = e - a * n_free;
                 const int pos_a = nth_set_bit(best_bits, a), pos_b = nth_set_bit(free_bits, fb);
                 const uint64_t c = (best_bits & ~(1ull << pos_a)) | (1ull << pos_b);
-                uint32_t rank = 0;
-                uint64_t m = c;
-                for (int t = 1; m; t++) {                      /* colexicographic rank of the combination */
-                    const int pos = __builtin_ctzll(m);
-                    m &= m - 1;
-                    rank += b.binom[pos * 64 + t];
+                uint32_t idx = (uint32_t)e;                    /* (candidate records: the item number is the index) */
+                if (!in.cand) {
+                    uint32_t rank = 0;
+                    uint64_t m = c;
+                    for (int t = 1; m; t++) {                  /* colexicographic rank of the combination */
+                        const int pos = __builtin_ctzll(m);
+                        m &= m - 1;
+                        rank += b.binom[pos * 64 + t];
+                    }
+                    idx = inv[rank];
                 }
-                const uint32_t idx = inv[rank];
                 const uint32_t u = __float_as_uint(ws[idx]);
                 atomicMax(&lds.site_max[a], u);
                 c_r[r] = c;
@@ -329,9 +336,11 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     uint64_t my_alt = 0ull;
     HashLds hl;
     if (HASH) hl = hash_carve(w.pool, vc, hs, pp, sb);
-    const bool declined = loc_ascore_all<PLAIN, HASH>(ctx, lds.pushed, np, lds.site_alt, b.rec + s0 * PYA_REC_WORDS,
-                   best_bits, best_ws, best_i, res.site_mask,
-                   &my_asc, &my_alt, &fail, use_in ? in.rec_batch : nullptr, use_in ? in.hist : nullptr, HASH ? &hl : nullptr);
+    const bool cand = use_in && in.cand;
+    const bool declined = loc_ascore_all<PLAIN, HASH>(ctx, lds.pushed, np, lds.site_alt,
+                   cand ? (const uint32_t *)ws + PYA_CAND_REC : b.rec + s0 * PYA_REC_WORDS,
+                   best_bits, best_ws, cand ? (uint32_t)(k * (n_sites - k)) : best_i, res.site_mask,
+                   &my_asc, &my_alt, &fail, (use_in && !cand) ? in.rec_batch : nullptr, (use_in && !cand) ? in.hist : nullptr, HASH ? &hl : nullptr);
     if ((PLAIN || HASH) && declined) return true;
     STAMP_T(b, 36, false);
     if (lane < k && lds.site_tie[lane]) my_asc = 0.f < my_asc ? 0.f : my_asc;

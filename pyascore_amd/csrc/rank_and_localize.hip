@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64, 4) void pya_localize_recount_kernel(
     in.rec_batch = rec_batch;
     in.hist = hist;
     in.valid = ok;
+    in.cand = top[3] == 0xC0DE0001u;                       /* (score_big.hip: BIG_CAND_FLAG) */
     in.tab = PeakTable();
     if (!ok || top[1] == 1u) {
         if (ok && !cap) {

@@ -35,6 +35,9 @@
  * 24 bytes x 3003 signatures x 50 000 PSMs = 3.6 GB per step on cfg5, read back for a dozen signatures per PSM:
  * the localize kernel recounts the few signatures it looks at (localize_core.hip.h: loc_recount). */
 #define BIG_INLINE_AUX 2304
+#define BIG_SORT_AUX 1600          /* what the spine really uses: two stop masks and two counts per chunk, five words */
+#define BIG_CAND_REC 128           /* candidate mode: PepScores at words [0, items] of the PSM's score area, count records from this word on */
+#define BIG_CAND_FLAG 0xC0DE0001u  /* fourth word of the score summary: the area holds candidate records, not N PepScores */
 
 /* (the level-2 table is indexed by the 10-site pattern itself; a dense table -- 638 instead of 1024
  * entries per direction for k = 5, 4 instead of 3 workgroups per CU -- was measured and lost to its
@@ -45,7 +48,7 @@
  * the level-1 table and the list of valid level-2 patterns while the tables are built, then the score-table row of the
  * PSM (38.1 KB + 8 B per retained peak for a 30-mer: four workgroups per CU up to 358 retained peaks) */
 __host__ __device__ static inline size_t score_big_resd_bytes(uint32_t pos_cap) { return (((size_t)pos_cap + 1) * 8 + 15) & ~(size_t)15; }
-static inline size_t score_big_tail_bytes(uint32_t pos_cap) {
+__host__ __device__ static inline size_t score_big_tail_bytes(uint32_t pos_cap) {
     const size_t build = 2 * 64 * sizeof(PrefixCompact) + 1024 * sizeof(uint16_t), row = (size_t)PYA_NTOP * (2 * pos_cap + 1) * 4;
     return (build > row ? build : row) + 64;
 }
@@ -82,7 +85,7 @@ struct BigSortLds {
     float *key;
     uint16_t *idx, *lq, *rq;
     unsigned long long *ml, *mr;       /* [64] stop masks per chunk of 64 positions */
-    uint32_t *cl, *cr, *ol, *orr;      /* [64] stops per chunk, and before the chunk in cursor order */
+    uint32_t *cl, *cr;                 /* [64] stops per chunk */
     uint32_t *misc;                    /* [8]: nL, nR, swaps, cut, front */
 };
 DEV uint32_t wg_spine_front(const BigSortLds &s, int N, uint32_t kmax, bool *out_of_depth) {
@@ -241,12 +244,27 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
      * dependent steps) while the others stage the peak table and wavefront 0 builds the grid */
     const int k = b.n_of_mod[psm];
     const int n_sites = __popcll(res.site_mask);
-    uint4 *cntP = (uint4 *)l2;                                  /* [2][k + 1][L] prefix sums; behind them [k * n_sites + 1] the per-site table */
-    uint4 *cntG = cntP + (size_t)2 * (k + 1) * L;
+    uint4 *cntG = (uint4 *)l2;                                  /* [k * n_sites + 1] the per-site table (first: it outlives the prefix sums) */
+    uint4 *cntP = cntG + (size_t)k * n_sites + 1;               /* [2][k + 1][L] prefix sums */
     float2 *envl = (float2 *)((unsigned char *)l2 + 16384);     /* [2][k + 1][pos_cap] */
     const bool use_cnt = !(b.debug & 0x8000u) && (uint32_t)k + 1u <= kc && k + 1 <= 31 && n_sites <= 32 &&
                          ((size_t)2 * (k + 1) * L + (size_t)k * n_sites + 1) * sizeof(uint4) <= 16384 &&
                          (size_t)2 * (k + 1) * pos_cap * sizeof(float2) <= 16384;
+    /* r06 -- candidate mode (inline + count nodes): the PepScores never leave the workgroup.  They are kept at the END of the
+     * level-2 table's room (dead on this route), the sort's queues lie between the per-site table and them, its chunk masks in
+     * what the score-table row leaves of the tail -- so that the per-site table, the count nodes and the row all survive the
+     * sort -- and once the winner is named, wavefront 0 scores its k (n - k) single-move competitors from the table again and
+     * leaves their PepScores and count records (and the winner's) where the PepScores used to go: the finishing kernel reads
+     * those and neither ranks combinations, gathers scores nor recounts (Ascore.cpp:212-254 needs nothing else). */
+    const uint32_t N4 = (N + 3u) & ~3u, N8 = (N + 7u) & ~7u;
+    const int n_free = n_sites - k, items = k * n_free;
+    const size_t g_bytes = (((size_t)k * n_sites + 1) * sizeof(uint4) + 15) & ~(size_t)15;
+    const size_t row_bytes = ((size_t)PYA_NTOP * (2u * (uint32_t)(L - 1) + 1u) * 4 + 15) & ~(size_t)15;
+    const bool aux_in_tail = row_bytes + BIG_SORT_AUX <= score_big_tail_bytes(pos_cap) - 64;
+    const bool cand = inl && use_cnt && items >= 1 && items <= 126 && (uint32_t)(BIG_CAND_REC + (items + 1) * PYA_REC_WORDS) <= N &&
+                      g_bytes + (size_t)6 * N8 + (aux_in_tail ? 0 : BIG_SORT_AUX) + (size_t)4 * N4 <= 2 * 1024 * sizeof(PrefixCompact) &&
+                      !(b.debug & 0x10000000u);
+    float *wsl = (float *)((unsigned char *)l2 + 2 * 1024 * sizeof(PrefixCompact) - (size_t)4 * N4);
     if (use_cnt && wave == 1) cnt_envelopes(res, k, pos_cap, envl);
     PeakTable tab;
     {
@@ -454,7 +472,8 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
             } else {
                 lut_fail = 1;
             }
-            b.ws[s0 + s] = ws;
+            if (cand) wsl[s] = ws;
+            else b.ws[s0 + s] = ws;
             const uint32_t u = __float_as_uint(ws);
             if (ws >= 0.f && (top_n == 0 || u > top_u)) {
                 top_u = u;
@@ -508,44 +527,103 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         t[1] = n_max;
         t[2] = first;
         if (failed) b.status[psm] = PYA_ST_LUT_RANGE;
-        tops[BIG_WAVES * 4 + 0] = kmax;                      /* (lutl's row is dead: its first words carry the summary on) */
-        tops[BIG_WAVES * 4 + 1] = n_max;
-        tops[BIG_WAVES * 4 + 2] = first;
-        tops[BIG_WAVES * 4 + 3] = failed;
+        tops[0] = kmax;                                      /* (every wavefront's entry has been read: the first one carries the summary on) */
+        tops[1] = n_max;
+        tops[2] = first;
+        tops[3] = failed;
     }
+    if (tid == 0) b.ws_top[(size_t)psm * 4 + 3] = 0u;            /* (candidate records: said below, once they exist) */
     if (!inl) return;
     /* ---------------- the winner, right here (see the note at the top) ---------------- */
     __syncthreads();
-    const uint32_t kmax = tops[BIG_WAVES * 4 + 0], n_max = tops[BIG_WAVES * 4 + 1];
-    if (tops[BIG_WAVES * 4 + 3] || n_max == 0) return;           /* (trial count outside the score table: localize writes "no result") */
-    if (n_max == 1 && !(b.debug & 1024u)) return;                /* a unique best PepScore: nothing to resolve */
-    /* a tie for the best PepScore: the front of std::sort decides (cpp/Ascore.cpp:141-146) */
-    BigSortLds srt;
-    srt.key = (float *)l2;                                       /* l2 | cum_lut: nothing reads them any more */
-    srt.idx = (uint16_t *)(srt.key + N);
-    srt.lq = srt.idx + N;
-    srt.rq = srt.lq + N;
-    unsigned char *aux = (unsigned char *)(((uintptr_t)(srt.rq + N) + 15) & ~(uintptr_t)15);
-    srt.ml = (unsigned long long *)aux;
-    srt.mr = srt.ml + 64;
-    srt.cl = (uint32_t *)(srt.mr + 64);
-    srt.cr = srt.cl + 64;
-    srt.ol = srt.cr + 64;
-    srt.orr = srt.ol + 64;
-    srt.misc = srt.orr + 64;
-    for (uint32_t i = (uint32_t)tid; i < N; i += BIG_T) {
-        srt.key[i] = b.ws[s0 + i];
-        srt.idx[i] = (uint16_t)i;
+    const uint32_t kmax = tops[0], n_max = tops[1];
+    if (tops[3] || n_max == 0) return;           /* (trial count outside the score table: localize writes "no result") */
+    uint32_t best_i = tops[2];
+    if (n_max != 1 || (b.debug & 1024u)) {
+        /* a tie for the best PepScore: the front of std::sort decides (cpp/Ascore.cpp:141-146) */
+        BigSortLds srt;
+        unsigned char *aux;
+        if (cand) {
+            srt.key = wsl;                                       /* in place */
+            srt.idx = (uint16_t *)((unsigned char *)l2 + g_bytes);
+            srt.lq = srt.idx + N8;
+            srt.rq = srt.lq + N8;
+            aux = aux_in_tail ? (unsigned char *)lutl + row_bytes : (unsigned char *)(srt.rq + N8);
+        } else {
+            srt.key = (float *)l2;                               /* l2 | cum_lut: nothing reads them any more */
+            srt.idx = (uint16_t *)(srt.key + N);
+            srt.lq = srt.idx + N;
+            srt.rq = srt.lq + N;
+            aux = (unsigned char *)(((uintptr_t)(srt.rq + N) + 15) & ~(uintptr_t)15);
+        }
+        srt.ml = (unsigned long long *)aux;
+        srt.mr = srt.ml + 64;
+        srt.cl = (uint32_t *)(srt.mr + 64);
+        srt.cr = srt.cl + 64;
+        srt.misc = srt.cr + 64;
+        for (uint32_t i = (uint32_t)tid; i < N; i += BIG_T) {
+            if (!cand) srt.key[i] = b.ws[s0 + i];
+            srt.idx[i] = (uint16_t)i;
+        }
+        __syncthreads();
+        if (b.debug & 8u) return;
+        bool ood;
+        best_i = wg_spine_front(srt, (int)N, kmax, &ood);
+        STAMP_T(b, 12, );
+        if (ood) return;                                         /* (out of depth: the count stays, the localize kernel hands the PSM over) */
+        if (tid == 0) {
+            uint32_t *t = b.ws_top + (size_t)psm * 4;
+            t[1] = 1u;
+            t[2] = best_i;
+        }
     }
-    __syncthreads();
-    if (b.debug & 8u) return;
-    bool ood;
-    const uint32_t best_i = wg_spine_front(srt, (int)N, kmax, &ood);
-    STAMP_T(b, 12, );
-    if (tid == 0 && !ood) {                                      /* (out of depth: the count stays, the localize kernel hands the PSM over) */
-        uint32_t *t = b.ws_top + (size_t)psm * 4;
-        t[1] = 1u;
-        t[2] = best_i;
+    if (!cand || wave != 0) return;
+    /* ---- the winner's single-move competitors (cpp/Ascore.cpp:212-254: item e = a * n_free + f moves the winner's a-th
+     * modification to its f-th free site, the enumeration of localize_body) and, as item k (n - k), the winner itself:
+     * counts from the per-site table, PepScore from the row, both left for the finishing kernel ---- */
+    {
+        const uint64_t best_bits = order[best_i];
+        const uint64_t all_sites = (1ull << n_sites) - 1ull;     /* (n_sites <= 32 here) */
+        const uint64_t free_bits = all_sites & ~best_bits;
+        const FastDiv divF = fastdiv_make((uint32_t)n_free);
+        float *out_ws = b.ws + s0;
+        uint32_t *out_rec = (uint32_t *)out_ws + BIG_CAND_REC;
+        for (int base = 0; base <= items; base += 64) {
+            const int e = base + lane;
+            const bool on = e <= items;
+            uint64_t c = best_bits;
+            if (on && e < items) {
+                const int a = (int)fastdiv((uint32_t)e, divF), fb = e - a * n_free;
+                c = (best_bits & ~(1ull << nth_set_bit(best_bits, a))) | (1ull << nth_set_bit(free_bits, fb));
+            }
+            uint32_t marked = 0;
+            CumCounts cc = {0u, 0u, 0u};
+            if (on) cc = cnt_eval_sites(cntG, (uint32_t)c, k, n_sites, &marked);
+            if (__any(marked != 0)) {
+                float run0 = 0.f, run1 = 0.f;
+                CumCounts cw = {0u, 0u, 0u};
+                walk_cnt_both(env, tab, cum_lut, cnt_t, pos_cap, kc, deposit_sites(c, res.site_mask), 0, L - 1, run0, 0u, 0, L - 1, run1, 0u, cw);
+                if (marked != 0) cc = cw;
+            }
+            if (on) {
+                uint32_t cum[PYA_NTOP];
+#pragma unroll
+                for (int d = 0; d < PYA_NTOP; d++) cum[d] = cc.at(d);
+                double sum = 0.;
+#pragma unroll
+                for (int d = 0; d < PYA_NTOP; d++) {
+                    const float sc = lutl[(uint32_t)d * (nfrag + 1) + cum[d]];
+                    const float prod = cfg->weights[d] * sc;
+                    sum = sum + (double)prod;
+                }
+                out_ws[e] = (float)sum;
+                uint32_t *rec = out_rec + (size_t)e * PYA_REC_WORDS;
+#pragma unroll
+                for (int d = 0; d < PYA_NTOP; d += 2) rec[d >> 1] = cum[d] | (cum[d + 1] << 16);
+                rec[5] = nfrag;
+            }
+        }
+        if (lane == 0) b.ws_top[(size_t)psm * 4 + 3] = BIG_CAND_FLAG;
     }
 }
 
