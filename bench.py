@@ -340,7 +340,7 @@ LEGS = {
 }
 
 
-def other_config_leg(torch, dev, local_rank, leg, steps, warmup, n_blocks):
+def other_config_leg(torch, dev, local_rank, leg, steps, warmup, n_blocks, debug=()):
     """One of LEGS at its full size, timed exactly like the headline (spectra resident, plan pre-built, `n_blocks` blocks of
     `steps` steps, the median block): value, ms per step, the plan's host pre-pass, the kernel families' HIP-event times,
     the dominant family and its algorithmic GB/s against the HBM peak, and the same over the whole step."""
@@ -356,6 +356,8 @@ def other_config_leg(torch, dev, local_rank, leg, steps, warmup, n_blocks):
                       device=local_rank)
     for g, m in st["neutral_losses"]:
         scorer.add_neutral_loss(g, m)
+    for kv in debug:                                         # (A/B runs of one leg: `bench.py --leg NAME --debug KEY=VALUE`)
+        scorer.set_debug(*kv.split("=", 1))
     d_mz = torch.from_numpy(batch["mz"]).to(dev)
     d_int = torch.from_numpy(batch["intensity"]).to(dev)
     torch.cuda.synchronize()
@@ -403,7 +405,10 @@ def leg_child(args):
         raise SystemExit("bench.py needs a HIP device; there is no CPU path")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    out = other_config_leg(torch, torch.device("cuda", local_rank), local_rank, args.leg, args.steps, args.warmup, args.other_blocks)
+    out = other_config_leg(torch, torch.device("cuda", local_rank), local_rank, args.leg, args.steps, args.warmup, args.other_blocks,
+                           debug=args.debug)
+    if args.debug:
+        out["debug_switches"] = list(args.debug)
     print(json.dumps(out), flush=True)
     return 0
 

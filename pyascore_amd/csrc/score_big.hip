@@ -225,7 +225,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     uint4 *cum_lut = (uint4 *)(l2 + 2 * 1024);                   /* [16] rank -> increments of the cumulative counts */
     uint32_t *tops = (uint32_t *)(cum_lut + 16);                 /* [BIG_WAVES][4] */
     uint8_t *cnt_t = (uint8_t *)(tops + BIG_WAVES * 4);          /* [2][pos_cap][kc] the count-node table */
-    float *lutl = (float *)(cnt_t + score_big_cnt_bytes(pos_cap, kc));   /* [10][nfrag + 1], once the tables are built; until then: */
+    float *lutl = (float *)(cnt_t + score_big_cnt_bytes(pos_cap, kc));   /* [nfrag + 1][10], once the tables are built; until then: */
     PrefixCompact *l1 = (PrefixCompact *)lutl;                   /* [2][64]   */
     uint16_t *vlist = (uint16_t *)(l1 + 2 * 64);                 /* [1024] the level-2 patterns a signature can have */
 
@@ -412,20 +412,26 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         const uint32_t nf = 2u * (uint32_t)(L - 1);
         if (nf <= b.lut_n_max) {
             const float *src = b.lut + lut_row(nf);
-            for (uint32_t i = (uint32_t)tid; i < PYA_NTOP * (nf + 1); i += 64 * BIG_WAVES) lutl[i] = src[i];
+            /* (transposed -- [count][depth] -- so that a site assignment's ten reads share ONE base register and differ in the
+             * instruction's offset field: with [depth][count] the compiler kept ten row bases in scalar registers, spilled them
+             * into a vector register's lanes and paid a v_readlane + wait per read) */
+            const FastDiv divR = fastdiv_make(nf + 1u);
+            for (uint32_t i = (uint32_t)tid; i < PYA_NTOP * (nf + 1); i += 64 * BIG_WAVES) {
+                const uint32_t d = fastdiv(i, divR), c = i - d * (nf + 1u);
+                lutl[c * PYA_NTOP + d] = src[i];
+            }
         }
     }
     __syncthreads();
     STAMP_T(b, 10, );
     /* ---- the signatures: resume from the level-2 patterns, walk the rest of both directions ---- */
     int lut_fail = 0;
-    uint32_t top_u = 0, top_n = 0, top_i = 0xffffffffu;
+    uint32_t top_u = 0, top_n = 0, top_i = 0xffffffffu, top_b = 0;     /* (top_b: the low word of that site assignment) */
     const uint32_t nfrag = 2u * (uint32_t)(L - 1);
     for (uint32_t sbase = 0; sbase < N; sbase += 64 * BIG_WAVES) {
         const uint32_t s = sbase + (uint32_t)tid;
         const bool active = s < N;
         const uint64_t bits = active ? order[s] : 0ull;
-        const uint64_t resmask = deposit_sites(bits, res.site_mask);
         CumCounts cc = {0u, 0u, 0u};
         if (use_cnt) {
             /* the counts from the prefix sums: k + 1 differences per direction; a site assignment whose path crosses a
@@ -441,12 +447,16 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
             }
 #endif
             if (__any(marked != 0)) {
+                /* (the residue mask only here: deposit_sites is a loop over the sites, 120 instructions a round that the
+                 * table route needs once in a thousand rounds -- r06: it was computed ahead of the branch) */
+                const uint64_t resmask = deposit_sites(bits, res.site_mask);
                 float run0 = 0.f, run1 = 0.f;
                 CumCounts cw = {0u, 0u, 0u};
                 walk_cnt_both(env, tab, cum_lut, cnt_t, pos_cap, kc, resmask, 0, L - 1, run0, 0u, 0, L - 1, run1, 0u, cw);
                 if (marked != 0) cc = cw;
             }
         } else {
+            const uint64_t resmask = deposit_sites(bits, res.site_mask);
             const PrefixCompact p0 = l2[(uint32_t)(bits & 1023ull)];
             const PrefixCompact p1 = l2[1024u + (uint32_t)((__brevll(bits) >> (64 - n_sites)) & 1023ull)];
             float run0 = p0.running, run1 = p1.running;
@@ -464,7 +474,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
                 double sum = 0.;
 #pragma unroll
                 for (int d = 0; d < PYA_NTOP; d++) {
-                    const float sc = lutl[(uint32_t)d * (nfrag + 1) + cum[d]];
+                    const float sc = lutl[cum[d] * PYA_NTOP + (uint32_t)d];
                     const float prod = cfg->weights[d] * sc;              /* float product ...   */
                     sum = sum + (double)prod;                             /* ... double sum      */
                 }
@@ -479,6 +489,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
                 top_u = u;
                 top_n = 1;
                 top_i = s;
+                top_b = (uint32_t)bits;
             } else if (ws >= 0.f && u == top_u) {
                 top_n++;
             }
@@ -499,26 +510,30 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         const bool mine = top_n && top_u == kmax;
         const int n_max = wave_sum_i32(mine ? (int)top_n : 0);
         const uint32_t first = wave_min_u32(mine ? top_i : 0xffffffffu);
+        const uint32_t first_b = wave_max_u32(mine && top_i == first ? top_b : 0u);
+        const uint32_t failed_w = __any(lut_fail) ? 0x80000000u : 0u;
         if (lane == 0) {
             tops[wave * 4 + 0] = kmax;
-            tops[wave * 4 + 1] = (uint32_t)n_max;
+            tops[wave * 4 + 1] = (uint32_t)n_max | failed_w;
             tops[wave * 4 + 2] = first;
-            tops[wave * 4 + 3] = (uint32_t)(__any(lut_fail) ? 1 : 0);
+            tops[wave * 4 + 3] = first_b;
         }
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t kmax = 0, n_max = 0, first = 0xffffffffu, failed = 0;
+        uint32_t kmax = 0, n_max = 0, first = 0xffffffffu, first_b = 0, failed = 0;
         for (int wv = 0; wv < BIG_WAVES; wv++) {
-            const uint32_t ku = tops[wv * 4], kn = tops[wv * 4 + 1], kf = tops[wv * 4 + 2];
-            failed |= tops[wv * 4 + 3];
+            const uint32_t ku = tops[wv * 4], kn = tops[wv * 4 + 1] & 0x7fffffffu, kf = tops[wv * 4 + 2], kb = tops[wv * 4 + 3];
+            failed |= tops[wv * 4 + 1] >> 31;
             if (kn == 0) continue;
             if (n_max == 0 || ku > kmax) {
                 kmax = ku;
                 n_max = kn;
                 first = kf;
+                first_b = kb;
             } else if (ku == kmax) {
                 n_max += kn;
+                first_b = kf < first ? kb : first_b;
                 first = kf < first ? kf : first;
             }
         }
@@ -531,6 +546,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         tops[1] = n_max;
         tops[2] = first;
         tops[3] = failed;
+        tops[4] = first_b;
     }
     if (tid == 0) b.ws_top[(size_t)psm * 4 + 3] = 0u;            /* (candidate records: said below, once they exist) */
     if (!inl) return;
@@ -582,7 +598,8 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
      * modification to its f-th free site, the enumeration of localize_body) and, as item k (n - k), the winner itself:
      * counts from the per-site table, PepScore from the row, both left for the finishing kernel ---- */
     {
-        const uint64_t best_bits = order[best_i];
+        /* (a unique best score: its thread kept the site assignment -- no dependent load from the order table) */
+        const uint64_t best_bits = (n_max != 1 || (b.debug & 1024u)) ? order[best_i] : (uint64_t)tops[4];
         const uint64_t all_sites = (1ull << n_sites) - 1ull;     /* (n_sites <= 32 here) */
         const uint64_t free_bits = all_sites & ~best_bits;
         const FastDiv divF = fastdiv_make((uint32_t)n_free);
@@ -612,7 +629,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
                 double sum = 0.;
 #pragma unroll
                 for (int d = 0; d < PYA_NTOP; d++) {
-                    const float sc = lutl[(uint32_t)d * (nfrag + 1) + cum[d]];
+                    const float sc = lutl[cum[d] * PYA_NTOP + (uint32_t)d];
                     const float prod = cfg->weights[d] * sc;
                     sum = sum + (double)prod;
                 }
