@@ -122,6 +122,24 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     }
 
     STAMP_BEGIN();
+    /* r06: the binomials the competitor enumeration ranks combinations with -- C(site, t), t = 1 .. k -- requested here, while
+     * the tables below are staged, and parked in LDS before the enumeration: its rank loop made k global loads one after the
+     * other (a per-lane trip count: each load waited for), then the dependent loads of the order table and the PepScore --
+     * six round trips where three remain (r06 stamps: the enumeration was a fifth of the lean kernel's wave time on cfg3) */
+    const int nk = n_sites * k;
+    const bool binom_lds = !(use_in && in.cand) && nk <= 128;
+    uint32_t bin_pre[2] = {0u, 0u};
+    if (binom_lds) {
+        const FastDiv divS = fastdiv_make((uint32_t)n_sites);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int i = r * 64 + lane;
+            if (i < nk) {
+                const int t1 = (int)fastdiv((uint32_t)i, divS);       /* t - 1 */
+                bin_pre[r] = b.binom[(i - t1 * n_sites) * 64 + t1 + 1];
+            }
+        }
+    }
     /* only a handful of ions are matched here, so the retained-peak table is not staged in LDS:
      * that keeps this kernel's LDS small (occupancy) and saves the staging + grid build */
     /* (the hash route looks up ~1 300 ions per PSM on cfg4-like settings; staging the table for it was measured
@@ -250,6 +268,13 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
         const int n_free = n_sites - k, items = k * n_free;
         const uint32_t *inv = b.inv_tab + b.order_off[psm];
         const FastDiv divF = fastdiv_make((uint32_t)(n_free > 0 ? n_free : 1));
+        uint32_t *bl = (uint32_t *)lds.scratch;              /* [k][n_sites] (the sort is over, the batch tables not yet carved) */
+        if (binom_lds) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (r * 64 + lane < nk) bl[r * 64 + lane] = bin_pre[r];
+            wave_lds_sync();
+        }
         /* items <= 126 (PYA_MAX_PUSHED): two per lane at most, both kept in registers between the passes */
         uint64_t c_r[2] = {0ull, 0ull};
         int a_r[2] = {0, 0};
@@ -271,7 +296,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
                     for (int t = 1; m; t++) {                  /* colexicographic rank of the combination */
                         const int pos = __builtin_ctzll(m);
                         m &= m - 1;
-                        rank += b.binom[pos * 64 + t];
+                        rank += binom_lds ? bl[(t - 1) * n_sites + pos] : b.binom[pos * 64 + t];
                     }
                     idx = inv[rank];
                 }

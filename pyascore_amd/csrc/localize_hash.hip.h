@@ -175,8 +175,11 @@ DEV void lh_stage_flush(const LocCtx &c, int &staged) {
         const int slot = (head + lane) & (LH_STAGE - 1);
         const uint32_t tg = st[slot];
         const int r = (c.b->debug & 2u) ? PYA_NO_MATCH : match_rank(c.tab, sv[slot]);     /* (2: ablation, no lookups) */
-        atomicAdd(&w.c_tr[tg], 1u);
-        if (r <= w.c_depth[tg >> 1]) atomicAdd(&w.c_cnt[tg], 1u);
+        /* ONE atomic per ion: trials in the low half of c_tr[tag], matches in its high half (loc_site_ions_hash unpacks them at
+         * its end; a competitor has < 2^16 site-determining ions: <= 8 ion types x 2 048 fragments).  64 lanes add to a handful
+         * of words here, and LDS atomics on one address take their turns (r05 counters: SQ_LDS_ADDR_CONFLICT = 16 % of the
+         * kernel's LDS cycles with two atomics per ion) */
+        atomicAdd(&w.c_tr[tg], 1u | (r <= w.c_depth[tg >> 1] ? 0x10000u : 0u));
     }
     staged = (n - take) | (((head + take) & (LH_STAGE - 1)) << 16);
     wave_lds_sync();
@@ -746,6 +749,9 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
                         id = b_lo + (li - nA);
                     }
                     x = h.val[id];
+#ifdef PYA_STAMPS
+                    if (c.b->stamps) atomicAdd(&c.b->stamps[62], 1ull);      /* (diagnostic build: in-span ions asked) */
+#endif
                     const int k0 = lh_cell(x - qr, inv_cw), k1 = lh_cell(x + qr, inv_cw);
                     hit = lh_probe2(h, k0, k1, hshift, id, x, reach, nW, b_lo, b_hi);
                     if (c.b->debug & 16384u) hit = true;
@@ -770,6 +776,12 @@ DEV bool loc_site_ions_hash(const LocCtx &c, const HashLds &h, int S) {
         }
     }
     while ((staged & 0xffff) > 0) lh_stage_flush(c, staged);
+    wave_lds_sync();
+    if (lane < S * 2) {                                      /* (the packed counts of lh_stage_flush) */
+        const uint32_t v = w.c_tr[lane];
+        w.c_tr[lane] = v & 0xffffu;
+        w.c_cnt[lane] = v >> 16;
+    }
     wave_lds_sync();
     STAMP_T(*c.b, 34, false);
     return false;

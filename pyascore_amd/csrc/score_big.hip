@@ -206,6 +206,21 @@ extern "C" uint32_t pya_big_inline_max(void) {
     return pya_big_inline_max_dev();
 }
 
+/* the one row of the score table every site assignment of a PSM reads: 10 x (nfrag + 1) floats into LDS, TRANSPOSED --
+ * [count][depth] -- so that a site assignment's ten reads share ONE base register and differ in the instruction's offset
+ * field: with [depth][count] the compiler kept ten row bases in scalar registers, spilled them into a vector register's
+ * lanes and paid a v_readlane + wait per read.  Threads t = 0 .. nt - 1 of the caller's choice. */
+DEV void stage_score_row(const BatchDev &b, float *lutl, int L, int t, int nt) {
+    const uint32_t nf = 2u * (uint32_t)(L - 1);
+    if (nf > b.lut_n_max) return;
+    const float *src = b.lut + lut_row(nf);
+    const FastDiv divR = fastdiv_make(nf + 1u);
+    for (uint32_t i = (uint32_t)t; i < PYA_NTOP * (nf + 1); i += (uint32_t)nt) {
+        const uint32_t d = fastdiv(i, divR), c = i - d * (nf + 1u);
+        lutl[c * PYA_NTOP + d] = src[i];
+    }
+}
+
 struct BigLoc {
     uint32_t inline_on;              /* summary results only: no count records, ties for the best score resolved here */
 };
@@ -280,6 +295,12 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     }
     if (wave == 0) stage_residues(res, resd, nullptr);
     if (tid < 16) cum_lut[tid] = fused_cum_entry((uint32_t)tid);
+    if (use_cnt) {
+        /* r06: what does not depend on the envelopes is done while wavefront 1 runs their recurrence (L - 1 dependent steps: the
+         * others waited for it at the barrier below, then filled the table and staged the score row behind two more barriers) */
+        for (uint32_t i = (uint32_t)tid; i < (uint32_t)score_big_cnt_bytes(pos_cap, kc) / 4u; i += BIG_T) ((uint32_t *)cnt_t)[i] = 0x0f0f0f0fu;
+        if (wave >= 2) stage_score_row(b, lutl, L, tid - 128, BIG_T - 128);
+    }
     __syncthreads();
     STAMP_T(b, 13, );
     /* the grid: cell geometry in every wavefront's registers, cells written by wavefront 0 */
@@ -298,8 +319,6 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
      * prefix sums over the steps.  The envelopes and the prefix sums go through the level-2 table's LDS, which this route
      * does not use (it needs neither prefix level): P at l2, the envelopes 16 KB behind it. ---- */
     if (use_cnt) {
-        for (uint32_t i = (uint32_t)tid; i < (uint32_t)score_big_cnt_bytes(pos_cap, kc) / 4u; i += BIG_T) ((uint32_t *)cnt_t)[i] = 0x0f0f0f0fu;
-        __syncthreads();
         STAMP_T(b, 15, );
         double A0 = 0., B0 = 0., A1 = 0., B1 = 0.;
         type_constants(cfg->types[0], &A0, &B0);
@@ -358,7 +377,7 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, 0, stop1[dir], run, cum);
         l1[dir * 64 + lane] = make_entry(run, cum);
     }
-    __syncthreads();
+    if (!use_cnt) __syncthreads();                               /* (use_cnt is uniform over the workgroup) */
     STAMP_T(b, 9, );
     /* ---- level 2: the patterns of the first 10 sites that a signature can have (at most k modified,
      * enough sites left for the rest), resumed from level 1.  Which patterns those are depends on their number of
@@ -406,32 +425,22 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
         walk_cum_range(env, tab, cum_lut, deposit_sites(pbits, res.site_mask), dir, stop1[dir], stop2[dir], run, cum);
         if (valid) l2[item] = make_entry(run, cum);
     }
-    __syncthreads();
-    {
-        /* the one row of the score table every signature of this PSM reads: 10 x (nfrag + 1) floats (over the list) */
-        const uint32_t nf = 2u * (uint32_t)(L - 1);
-        if (nf <= b.lut_n_max) {
-            const float *src = b.lut + lut_row(nf);
-            /* (transposed -- [count][depth] -- so that a site assignment's ten reads share ONE base register and differ in the
-             * instruction's offset field: with [depth][count] the compiler kept ten row bases in scalar registers, spilled them
-             * into a vector register's lanes and paid a v_readlane + wait per read) */
-            const FastDiv divR = fastdiv_make(nf + 1u);
-            for (uint32_t i = (uint32_t)tid; i < PYA_NTOP * (nf + 1); i += 64 * BIG_WAVES) {
-                const uint32_t d = fastdiv(i, divR), c = i - d * (nf + 1u);
-                lutl[c * PYA_NTOP + d] = src[i];
-            }
-        }
+    if (!use_cnt) {
+        __syncthreads();                                         /* (the list of patterns is dead: the row takes its place) */
+        stage_score_row(b, lutl, L, tid, BIG_T);
+        __syncthreads();
     }
-    __syncthreads();
     STAMP_T(b, 10, );
     /* ---- the signatures: resume from the level-2 patterns, walk the rest of both directions ---- */
     int lut_fail = 0;
     uint32_t top_u = 0, top_n = 0, top_i = 0xffffffffu, top_b = 0;     /* (top_b: the low word of that site assignment) */
     const uint32_t nfrag = 2u * (uint32_t)(L - 1);
+    uint64_t bits_next = (uint32_t)tid < N ? order[tid] : 0ull;  /* (one round ahead: the load of a round travels during the round before) */
     for (uint32_t sbase = 0; sbase < N; sbase += 64 * BIG_WAVES) {
         const uint32_t s = sbase + (uint32_t)tid;
         const bool active = s < N;
-        const uint64_t bits = active ? order[s] : 0ull;
+        const uint64_t bits = bits_next;
+        bits_next = s + BIG_T < N ? order[s + BIG_T] : 0ull;
         CumCounts cc = {0u, 0u, 0u};
         if (use_cnt) {
             /* the counts from the prefix sums: k + 1 differences per direction; a site assignment whose path crosses a

@@ -171,6 +171,12 @@ DEV void score_cnt_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw,
             uint32_t ent = cnt_table_entry(tab, lh.x, lh.y, d ? A1 : A0, d ? B1 : B0);
             if ((b.debug & 0x40000000u) && lh.x <= lh.y) ent |= CNT_MARK;
             c.T[((size_t)d * pos_cap + st) * kc + j] = (uint8_t)ent;
+#ifdef PYA_STAMPS                                              /* diagnostic build: reachable nodes looked up / marked (slots 56, 57) */
+            if (b.stamps && lh.x <= lh.y) {
+                atomicAdd(&b.stamps[56], 1ull);
+                if (ent & CNT_MARK) atomicAdd(&b.stamps[57], 1ull);
+            }
+#endif
         }
     }
     wave_lds_sync();
@@ -215,6 +221,12 @@ DEV void score_cnt_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw,
         }
         CumCounts cc = {ax, ay, az & 0xffffu};
         const bool marked = active && (az >> 16) != 0u;
+#ifdef PYA_STAMPS                                              /* ... site assignments / those through a marked node (58, 59) */
+        if (b.stamps && active) {
+            atomicAdd(&b.stamps[58], 1ull);
+            if (marked) atomicAdd(&b.stamps[59], 1ull);
+        }
+#endif
         if (__any(marked)) {                                 /* (rare: a peak within a few ulps of some window end) */
             float run0 = 0.f, run1 = 0.f;
             CumCounts cw = {0u, 0u, 0u};

@@ -226,6 +226,12 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
                         const uint32_t rk = ent & 15u;
                         if (on && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 1], 1u << ((rk & 1u) * 16u));
                         if (on && (ent & CNT_MARK)) atomicAdd(&hn[5], 1u << 16);
+#ifdef PYA_STAMPS                                              /* diagnostic build: ions of nodes with an interval envelope looked up / marked (56, 57) */
+                        if (b.stamps && on) {
+                            atomicAdd(&b.stamps[56], 1ull);
+                            if (ent & CNT_MARK) atomicAdd(&b.stamps[57], 1ull);
+                        }
+#endif
                     }
                 }
             }
@@ -324,6 +330,12 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
             }
             walk = active && (w[5] >> 16) != 0u;
         }
+#ifdef PYA_STAMPS                                              /* ... site assignments / walked ones (58, 59) */
+        if (b.stamps && active) {
+            atomicAdd(&b.stamps[58], 1ull);
+            if (walk) atomicAdd(&b.stamps[59], 1ull);
+        }
+#endif
         uint32_t cum[PYA_NTOP];
 #pragma unroll
         for (int d = 0; d < PYA_NTOP; d++) cum[d] = (w[d >> 1] >> ((d & 1) * 16)) & 0xffffu;
