@@ -22,7 +22,9 @@ extern "C" {
  *     PYA_NO_UPLOAD_THREAD PYA_ONE_PEAK_CLASS PYA_PEAK_CLASSES PYA_ONE_LDS_CLASS PYA_SORT_ROOM PYA_NO_BIG_INLINE
  *     PYA_NO_LOC_HASH PYA_NO_NODES PYA_NO_CNT PYA_HOST_TIMING PYA_STAMPS PYA_SLOW_NULL_STREAM
  *   numbers: PYA_DEBUG (bit set, common.h) PYA_PLAIN_MIN PYA_BIG_MIN_N PYA_TINY_MAX PYA_SORT_ROOM_MAX PYA_SB PYA_GTP
- *     PYA_HASH_PP PYA_NODE_CAP PYA_CHUNK_MB PYA_WORKSPACE_MB */
+ *     PYA_HASH_PP PYA_NODE_CAP PYA_CHUNK_MB PYA_WORKSPACE_MB
+ *     PYA_BIN_SELECT_MIN (r06: peak classes above this many peaks are binned by selection, csrc/bin_select.hip.h; default 640,
+ *     0 = every class, a huge value = none) PYA_BIN_SELECT_SCAP (survivor slots per spectrum there; default 768) */
 int pya_set_debug(pya_handle *h, const char *key, const char *value);
 
 /* The wavefront primitives every kernel leans on (csrc/device_common.hip.h: prefix sums and reductions by DPP, the rank of

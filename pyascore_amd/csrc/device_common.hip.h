@@ -366,6 +366,15 @@ DEV void copy_peak_table(const PeakEntry *src, int R, PeakEntry *dst, int tid, i
 }
 
 /* copies the retained peaks of `psm` (written by bin_spectra) into LDS and appends sentinels */
+DEV void stage_peak_table_at(const BatchDev &b, int64_t p0, int R, PeakEntry *dst, PeakTable *t) {
+    copy_peak_table(b.ret + p0, R, dst, lane_id(), 64);
+    t->e = dst;
+    t->g_cell = nullptr;
+    t->g_e = b.ret + p0;
+    t->n = R;
+    t->err = b.cfg->mz_error;
+    t->half_check = b.cfg->mz_error > 0.49f;
+}
 DEV void stage_peak_table(const BatchDev &b, uint32_t psm, PeakEntry *dst, PeakTable *t) {
     const int64_t p0 = b.ret_off[psm];
     const int R = (int)b.ret_n[psm];
@@ -455,13 +464,17 @@ DEV void grid_build(PeakTable *t, uint16_t *cell_lds) {
  * are fetched at once (the sentinels make this safe) and reduced with selects; only when the
  * window is not closed by the fourth entry does a lane continue with the scalar scan. */
 /* the table of `psm` left in global memory (for kernels that make only a handful of lookups) */
+DEV void global_peak_table_at(const BatchDev &b, uint32_t psm, int64_t p0, int R, PeakTable *t);
 DEV void global_peak_table(const BatchDev &b, uint32_t psm, PeakTable *t) {
-    const int64_t p0 = b.ret_off[psm];
+    global_peak_table_at(b, psm, b.ret_off[psm], (int)b.ret_n[psm], t);
+}
+/* (offset and count already known: the packed descriptor, ret_n fetched beside it) */
+DEV void global_peak_table_at(const BatchDev &b, uint32_t psm, int64_t p0, int R, PeakTable *t) {
     t->e = nullptr;
     t->cell = nullptr;
     t->g_cell = b.grid + (size_t)psm * PYA_GRID_CELLS;
     t->g_e = b.ret + p0;
-    t->n = (int)b.ret_n[psm];
+    t->n = R;
     t->err = b.cfg->mz_error;
     t->half_check = b.cfg->mz_error > 0.49f;
     t->base = 0.f;
@@ -666,6 +679,87 @@ DEV Residues load_residues(const BatchDev &b, const DevConfig *cfg, int64_t psm)
                 m0 += am;
                 m1 += am;
                 if (cfg->nl_lower[li]) nl0 = cfg->nl_lower[li];
+            }
+        }
+    }
+    r.m0 = m0;
+    r.m1 = m1;
+    r.nl = nl0 | (nl1 << 4);
+    r.site_mask = __ballot(modifiable);
+    return r;
+}
+
+/* r06 -- the same from the PSM's packed descriptor (BatchDev.desc: one cache line, common.h) and with the per-letter tables
+ * of the configuration taken into registers up front: a PSM's prologue is then TWO rounds of loads -- {descriptor, status,
+ * the 32 table entries, one per lane} and {letters, fixed modifications, whatever the caller fetches at the descriptor's
+ * offsets} -- where load_residues behind the callers' status / count tests made five or six, one after the other (offsets,
+ * letters, a gather from the tables by letter: r06 stamps, a fifth of score_big's and of the lean localize kernel's wave
+ * time went by before the first useful instruction). */
+struct PsmDesc {
+    int64_t ret0, pep0, sig0, aux0;     /* offsets of the retained table, the letters, the site assignments' arrays, the fixed modifications */
+    int L, n_aux, k, n_sites, zmax;
+    uint32_t N, order_off;
+};
+DEV PsmDesc load_desc(const BatchDev &b, uint32_t psm) {
+    const uint64_t *dw = b.desc + (size_t)psm * PYA_DESC_WORDS;
+    const uint64_t w4 = dw[4], w5 = dw[5];
+    PsmDesc d;
+    d.ret0 = (int64_t)dw[0];
+    d.pep0 = (int64_t)dw[1];
+    d.sig0 = (int64_t)dw[2];
+    d.aux0 = (int64_t)dw[3];
+    d.L = (int)(w4 & 0xffffu);
+    d.n_aux = (int)((w4 >> 16) & 0xffffu);
+    d.k = (int)((w4 >> 32) & 0xffffu);
+    d.n_sites = (int)((w4 >> 48) & 0xffu);
+    d.zmax = (int)(w4 >> 56);
+    d.N = (uint32_t)w5;
+    d.order_off = (uint32_t)(w5 >> 32);
+    return d;
+}
+/* the configuration's per-letter tables, entry (lane & 31) in every lane: issue before anything is waited for */
+struct LetterRegs {
+    float mass;
+    uint32_t flags;                     /* modifiable | nl_upper << 8 | nl_lower << 16 */
+};
+DEV LetterRegs load_letter_regs(const DevConfig *cfg) {
+    const int l = lane_id() & 31;
+    LetterRegs t;
+    t.mass = cfg->res_mass[l];
+    t.flags = (uint32_t)cfg->res_modifiable[l] | ((uint32_t)cfg->nl_upper[l] << 8) | ((uint32_t)cfg->nl_lower[l] << 16);
+    return t;
+}
+DEV Residues load_residues_desc(const BatchDev &b, const DevConfig *cfg, const PsmDesc &d, const LetterRegs &t) {
+    Residues r;
+    r.L = d.L;
+    const int i = lane_id();
+    const bool in = i < r.L;
+    const uint32_t c = in ? (uint32_t)b.pep[d.pep0 + i] : (uint32_t)'A';
+    const uint32_t li = (c - 'A') & 31u;
+    float m0 = __shfl(t.mass, (int)li, 64);                       /* (lanes 0 .. 31 hold the table) */
+    const uint32_t fl = (uint32_t)__shfl((int)t.flags, (int)li, 64);
+    const uint32_t nl_lower = (fl >> 16) & 0xffu;
+    const bool modifiable = in && ((fl & 0xffu) || (cfg->allow_n && i == 0) || (cfg->allow_c && i == r.L - 1));
+    float m1 = m0 + cfg->mod_mass;
+    uint32_t nl0 = (fl >> 8) & 0xffu;
+    const uint32_t nl1 = modifiable ? nl_lower : 0u;
+    /* fixed modifications (ModifiedPeptide.cpp:59-79), as load_residues applies them */
+    for (int base = 0; base < d.n_aux; base += 64) {
+        const int n = d.n_aux - base < 64 ? d.n_aux - base : 64;
+        uint32_t my_pos = 0;
+        float my_am = 0.f;
+        if (i < n) {
+            my_pos = b.aux_pos[d.aux0 + base + i];
+            my_am = b.aux_mass[d.aux0 + base + i];
+        }
+        for (int j = 0; j < n; j++) {
+            const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)my_pos, j);
+            const float am = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_am), j));
+            const int idx = pos > 0 ? (int)pos - 1 : 0;
+            if (idx == i) {
+                m0 += am;
+                m1 += am;
+                if (nl_lower) nl0 = nl_lower;
             }
         }
     }

@@ -84,7 +84,13 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
                        uint32_t vc = 0, uint32_t hs = 0, uint32_t pp = 0) {
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
-    const int k = b.n_of_mod[psm];
+    /* (r06: the prologue's loads in two rounds -- device_common.hip.h: load_desc) */
+    LetterRegs letters = {0.f, 0u};
+    if (!HASH) letters = load_letter_regs(cfg);             /* (the hash route is short of registers: two more live ones cost it ten spilled -- it keeps load_residues) */
+    const PsmDesc dsc = load_desc(b, psm);
+    const int status0 = b.status[psm];
+    const int R0 = (int)b.ret_n[psm];
+    const int k = dsc.k;
     const uint32_t max_k = b.max_k;
     float *out_asc = b.ascores + (size_t)psm * max_k;
     uint64_t *out_alt = b.alt_mask + (size_t)psm * max_k;
@@ -93,7 +99,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
         out_asc[a] = 0.f;
         out_alt[a] = 0ull;
     }
-    if (b.status[psm] != PYA_ST_OK) {
+    if (status0 != PYA_ST_OK) {
         if (lane == 0) {
             b.best_score[psm] = -1.f;
             b.best_sig[psm] = 0ull;
@@ -102,10 +108,10 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
         return false;
     }
 
-    const int N = (int)b.n_sig[psm];
-    const int n_sites = (int)b.n_sites[psm];
-    const uint64_t *order = b.order_tab + b.order_off[psm];
-    const int64_t s0 = b.sig_off[psm];
+    const int N = (int)dsc.N;
+    const int n_sites = dsc.n_sites;
+    const uint64_t *order = b.order_tab + dsc.order_off;
+    const int64_t s0 = dsc.sig0;
     const bool use_in = in.valid;
     const float *ws = use_in ? in.ws : b.ws + s0;
 
@@ -149,12 +155,12 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
-    stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, false);
+    stage_tables(b, cfg, lds, psm, &ctx.tab, &ctx.nl, false, dsc.ret0, R0);
     if (use_in) ctx.tab = in.tab;                               /* (the caller's table in LDS: lookups stay on chip) */
-    const Residues res = load_residues(b, cfg, psm);
+    const Residues res = HASH ? load_residues(b, cfg, psm) : load_residues_desc(b, cfg, dsc, letters);
     const uint64_t site_mask_u = res.site_mask;
     /* positive residue masses make the float32 running sum, hence every m/z list, ascending */
-    const int zmax = b.max_charge[psm];
+    const int zmax = dsc.zmax;
     const bool presorted = zmax == 1 && cfg->n_nl == 0 &&
                            !__any(lane < res.L && !(res.m0 > 0.f && res.m1 > 0.f));
     const float wide_min = 2.f * cfg->mz_error + 0.02f;
@@ -266,7 +272,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
         const uint64_t all_sites = n_sites >= 64 ? ~0ull : ((1ull << n_sites) - 1ull);
         const uint64_t free_bits = all_sites & ~best_bits;
         const int n_free = n_sites - k, items = k * n_free;
-        const uint32_t *inv = b.inv_tab + b.order_off[psm];
+        const uint32_t *inv = b.inv_tab + dsc.order_off;
         const FastDiv divF = fastdiv_make((uint32_t)(n_free > 0 ? n_free : 1));
         uint32_t *bl = (uint32_t *)lds.scratch;              /* [k][n_sites] (the sort is over, the batch tables not yet carved) */
         if (binom_lds) {

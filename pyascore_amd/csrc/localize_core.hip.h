@@ -623,11 +623,18 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, ui
     return w;
 }
 
+/* p0 >= 0: the retained table's offset and count are known already (the packed descriptor; ret_n fetched beside it) */
 DEV void stage_tables(const BatchDev &b, const DevConfig *cfg, const K3Lds &k, uint32_t psm,
-                      PeakTable *tab, NlTables *nl, bool with_table = true) {
+                      PeakTable *tab, NlTables *nl, bool with_table = true, int64_t p0 = -1, int R = 0) {
     const int lane = lane_id();
-    if (with_table) stage_peak_table(b, psm, k.t_e, tab);
-    else global_peak_table(b, psm, tab);
+    if (with_table) {
+        if (p0 >= 0) stage_peak_table_at(b, p0, R, k.t_e, tab);
+        else stage_peak_table(b, psm, k.t_e, tab);
+    } else if (p0 >= 0) {
+        global_peak_table_at(b, psm, p0, R, tab);
+    } else {
+        global_peak_table(b, psm, tab);
+    }
     nl->n_nl = cfg->n_nl;
     if (nl->n_nl) {
         for (int i = lane; i < (int)k.nl_cap; i += 64) k.nl_present[i] = cfg->present[i];

@@ -245,19 +245,24 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     uint16_t *vlist = (uint16_t *)(l1 + 2 * 64);                 /* [1024] the level-2 patterns a signature can have */
 
     STAMP_BEGIN();
-    if (b.status[psm] != PYA_ST_OK) return;                      /* (uniform over the workgroup) */
-    const uint32_t N = b.n_sig[psm];
+    /* (r06: the prologue's loads in two rounds -- device_common.hip.h: load_desc) */
+    const LetterRegs letters = load_letter_regs(cfg);
+    const PsmDesc dsc = load_desc(b, psm);
+    const int status0 = b.status[psm];
+    const int R0 = (int)b.ret_n[psm];
+    if (status0 != PYA_ST_OK) return;                            /* (uniform over the workgroup) */
+    const uint32_t N = dsc.N;
     if (N == 0) return;
     const bool inl = loc.inline_on && !b.keep && N <= pya_big_inline_max_dev();
     /* every wavefront reads the peptide for itself (registers: site mask, length); wavefront 0 stages
      * what is shared */
-    const Residues res = load_residues(b, cfg, psm);
-    const uint64_t *order = b.order_tab + b.order_off[psm];
-    const int64_t s0 = b.sig_off[psm];
+    const Residues res = load_residues_desc(b, cfg, dsc, letters);
+    const uint64_t *order = b.order_tab + dsc.order_off;
+    const int64_t s0 = dsc.sig0;
     const int L = res.L;
     /* the count-node table (walk_core.hip.h) -- its envelopes need the residues only: wavefront 1 runs the recurrence (L - 1
      * dependent steps) while the others stage the peak table and wavefront 0 builds the grid */
-    const int k = b.n_of_mod[psm];
+    const int k = dsc.k;
     const int n_sites = __popcll(res.site_mask);
     uint4 *cntG = (uint4 *)l2;                                  /* [k * n_sites + 1] the per-site table (first: it outlives the prefix sums) */
     uint4 *cntP = cntG + (size_t)k * n_sites + 1;               /* [2][k + 1][L] prefix sums */
@@ -283,8 +288,8 @@ DEV void big_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint3
     if (use_cnt && wave == 1) cnt_envelopes(res, k, pos_cap, envl);
     PeakTable tab;
     {
-        const int64_t p0 = b.ret_off[psm];
-        const int R = (int)b.ret_n[psm];
+        const int64_t p0 = dsc.ret0;
+        const int R = R0;
         copy_peak_table(b.ret + p0, R, t_e, tid, 64 * BIG_WAVES);
         tab.e = t_e;
         tab.g_cell = nullptr;

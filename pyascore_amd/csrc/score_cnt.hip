@@ -131,13 +131,18 @@ DEV void score_cnt_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw,
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const CntLds c = cnt_carve(lds_raw, cap, pos_cap, kc, k_cap, n_cap);
-    if (b.status[psm] != PYA_ST_OK) return;
-    const uint32_t N = b.n_sig[psm];
+    /* (r06: the prologue's loads in two rounds -- device_common.hip.h: load_desc) */
+    const LetterRegs letters = load_letter_regs(cfg);
+    const PsmDesc dsc = load_desc(b, psm);
+    const int status0 = b.status[psm];
+    const int R0 = (int)b.ret_n[psm];
+    if (status0 != PYA_ST_OK) return;
+    const uint32_t N = dsc.N;
     if (N == 0) return;
-    const Residues res = load_residues(b, cfg, psm);
-    const uint64_t *order = b.order_tab + b.order_off[psm];
-    const int64_t s0 = b.sig_off[psm];
-    const int L = res.L, k = b.n_of_mod[psm], n_sites = __popcll(res.site_mask);
+    const Residues res = load_residues_desc(b, cfg, dsc, letters);
+    const uint64_t *order = b.order_tab + dsc.order_off;
+    const int64_t s0 = dsc.sig0;
+    const int L = res.L, k = dsc.k, n_sites = __popcll(res.site_mask);
     /* the work areas are carved for the launch's caps (host_plan.cpp: the bucket's k_max / ns_max): a PSM beyond them would
      * overrun the envelopes and the (t, site) table -- the host never lists one here; if a routing change ever does, the PSM
      * fails loudly instead (r05 advisor) */
@@ -146,7 +151,7 @@ DEV void score_cnt_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw,
         return;
     }
     PeakTable tab;
-    stage_peak_table(b, psm, c.t_e, &tab);
+    stage_peak_table_at(b, dsc.ret0, R0, c.t_e, &tab);
     stage_residues(res, c.resd, nullptr);
     if (lane < 16) c.cum_lut[lane] = fused_cum_entry((uint32_t)lane);
     if ((res.site_mask >> lane) & 1ull) c.site_pos[mask_rank(res.site_mask)] = (uint8_t)lane;

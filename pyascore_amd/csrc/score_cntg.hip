@@ -98,17 +98,22 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
     const int lane = lane_id();
     const DevConfig *cfg = b.cfg;
     const CgLds c = cg_carve(lds_raw, cap, pos_cap, k_cap, n_cap, nl_cap);
-    if (b.status[psm] != PYA_ST_OK) return;
-    const uint32_t N = b.n_sig[psm];
+    /* (r06: the prologue's loads in two rounds -- device_common.hip.h: load_desc) */
+    const LetterRegs letters = load_letter_regs(cfg);
+    const PsmDesc dsc = load_desc(b, psm);
+    const int status0 = b.status[psm];
+    const int R0 = (int)b.ret_n[psm];
+    if (status0 != PYA_ST_OK) return;
+    const uint32_t N = dsc.N;
     if (N == 0) return;
     STAMP_BEGIN();
-    const Residues res = load_residues(b, cfg, psm);
-    const int zmax = b.max_charge[psm];
-    const uint64_t *order = b.order_tab + b.order_off[psm];
-    const int64_t s0 = b.sig_off[psm];
-    const int L = res.L, Lm1 = L - 1, k = b.n_of_mod[psm], n_sites = __popcll(res.site_mask);
+    const Residues res = load_residues_desc(b, cfg, dsc, letters);
+    const int zmax = dsc.zmax;
+    const uint64_t *order = b.order_tab + dsc.order_off;
+    const int64_t s0 = dsc.sig0;
+    const int L = res.L, Lm1 = L - 1, k = dsc.k, n_sites = __popcll(res.site_mask);
     PeakTable tab;
-    stage_peak_table(b, psm, c.t_e, &tab);
+    stage_peak_table_at(b, dsc.ret0, R0, c.t_e, &tab);
     WalkEnv env;
     env.cfg = cfg;
     env.n_nl = cfg->n_nl;
