@@ -90,6 +90,9 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
     const PsmDesc dsc = load_desc(b, psm);
     const int status0 = b.status[psm];
     const int R0 = (int)b.ret_n[psm];
+    /* (the score summary beside them: read further down, it was a round trip of its own behind the status test) */
+    uint4 top4 = make_uint4(0u, 0u, 0u, 0u);
+    if (!in.valid) top4 = *(const uint4 *)(b.ws_top + (size_t)psm * 4);
     const int k = dsc.k;
     const uint32_t max_k = b.max_k;
     float *out_asc = b.ascores + (size_t)psm * max_k;
@@ -186,10 +189,9 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
         n_max = 1;
         first_max = in.best_i;
     } else {
-        const uint32_t *top = b.ws_top + (size_t)psm * 4;  /* score_signatures' summary (0 signatures = none) */
-        kmax = top[0];
-        n_max = (int)top[1];
-        first_max = top[2];
+        kmax = top4.x;                                      /* score_signatures' summary (0 signatures = none) */
+        n_max = (int)top4.y;
+        first_max = top4.z;
     }
     if (n_max == 0) {
         kmax = 0;

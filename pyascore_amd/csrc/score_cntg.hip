@@ -39,11 +39,23 @@ struct CgLds {
     uint2 *gB;
 };
 __host__ __device__ static inline size_t cg_al16(size_t v) { return (v + 15) & ~(size_t)15; }
+/* r06: three work areas that take turns -- X: the nodes' rank counts (steps 3-4), then the walkers' rank histogram (step 6);
+ * Y: envelopes and loss states (steps 1-3), then the per-site table G (steps 5-6); Z: the list of (node, variant) pairs (step
+ * 3), then the prefix sums at the sites (steps 4-5).  Side by side they were 11.9 KB on cfg4's launch (13 wavefronts per CU);
+ * taking turns 10.2 KB (15). */
+__host__ __device__ static inline size_t cg_x_bytes(uint32_t pos_cap, uint32_t k_cap) {
+    const size_t rows = 2 * ((size_t)k_cap + 1), h = rows * pos_cap * 24, c = PYA_NTOP / 2 * 64 * 4;
+    return h > c ? h : c;
+}
+__host__ __device__ static inline size_t cg_y_bytes(uint32_t pos_cap, uint32_t k_cap, uint32_t n_cap) {
+    const size_t rows = 2 * ((size_t)k_cap + 1), e = rows * pos_cap * 8 + cg_al16(rows * pos_cap), g = cg_al16(((size_t)k_cap * n_cap + 1) * 24);
+    return e > g ? e : g;
+}
+__host__ __device__ static inline size_t cg_z_bytes(uint32_t k_cap, uint32_t n_cap) { return 2 * ((size_t)k_cap + 1) * (n_cap + 1) * 24; }
 __host__ __device__ static inline size_t score_cntg_lds_bytes(uint32_t cap, uint32_t pos_cap, uint32_t k_cap, uint32_t n_cap, uint32_t nl_cap) {
-    const size_t rows = 2 * ((size_t)k_cap + 1);
-    return PYA_GRID_CELLS * 2 + PYA_NTOP / 2 * 64 * 4 + cg_al16(((size_t)pos_cap + 1) * 8) + ((size_t)cap + PYA_TABLE_PAD) * 8 +
-           cg_al16(2 * (size_t)nl_cap) + PYA_MAX_UNIQ * 4 + 64 + 64 + rows * pos_cap * 8 + cg_al16(rows * pos_cap) + rows * pos_cap * 24 +
-           rows * (n_cap + 1) * 24 + ((size_t)k_cap * n_cap + 1) * 24 + 64;
+    return PYA_GRID_CELLS * 2 + cg_al16(((size_t)pos_cap + 1) * 8) + ((size_t)cap + PYA_TABLE_PAD) * 8 +
+           cg_al16(2 * (size_t)nl_cap) + PYA_MAX_UNIQ * 4 + 64 + 64 + cg_x_bytes(pos_cap, k_cap) + cg_y_bytes(pos_cap, k_cap, n_cap) +
+           cg_z_bytes(k_cap, n_cap) + 64;
 }
 DEV CgLds cg_carve(unsigned char *raw, uint32_t cap, uint32_t pos_cap, uint32_t k_cap, uint32_t n_cap, uint32_t nl_cap) {
     const size_t rows = 2 * ((size_t)k_cap + 1);
@@ -51,8 +63,6 @@ DEV CgLds cg_carve(unsigned char *raw, uint32_t cap, uint32_t pos_cap, uint32_t 
     size_t o = 0;
     c.grid = (uint16_t *)raw;
     o += PYA_GRID_CELLS * 2;
-    c.cnt = (uint32_t *)(raw + o);
-    o += PYA_NTOP / 2 * 64 * 4;
     c.resd = (float2 *)(raw + o);
     o += cg_al16(((size_t)pos_cap + 1) * 8);
     c.t_e = (PeakEntry *)(raw + o);
@@ -65,19 +75,17 @@ DEV CgLds cg_carve(unsigned char *raw, uint32_t cap, uint32_t pos_cap, uint32_t 
     o += 64;
     c.site_pos = raw + o;
     o += 64;
-    c.env = (float2 *)(raw + o);
-    o += rows * pos_cap * 8;
-    c.st = raw + o;
-    o += cg_al16(rows * pos_cap);
-    c.hist = (uint32_t *)(raw + o);
-    o += rows * pos_cap * 24;
-    c.psA = (uint4 *)(raw + o);
+    c.env = (float2 *)(raw + o);                             /* Y */
+    c.st = raw + o + rows * pos_cap * 8;
+    c.gA = (uint4 *)(raw + o);
+    c.gB = (uint2 *)(raw + o + ((size_t)k_cap * n_cap + 1) * 16);
+    o += cg_y_bytes(pos_cap, k_cap, n_cap);
+    c.hist = (uint32_t *)(raw + o);                          /* X */
+    c.cnt = (uint32_t *)(raw + o);
+    o += cg_x_bytes(pos_cap, k_cap);
+    c.psA = (uint4 *)(raw + o);                              /* Z */
     o += rows * (n_cap + 1) * 16;
     c.psB = (uint2 *)(raw + o);
-    o += rows * (n_cap + 1) * 8;
-    c.gA = (uint4 *)(raw + o);
-    o += ((size_t)k_cap * n_cap + 1) * 16;
-    c.gB = (uint2 *)(raw + o);
     return c;
 }
 
@@ -176,7 +184,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
          * takes a (node, variant, ion type) item, the charges in a wave-uniform inner loop (so that the charge division runs
          * for the charges that need it only, not for every lane's own). */
         uint16_t *nlist = (uint16_t *)c.psA;                     /* (the prefix sums' and G's room: not written before step 4) */
-        const int n_room = (int)((2u * (k_cap + 1u) * (n_cap + 1u) * 24u + (k_cap * n_cap + 1u) * 24u) / 2u);
+        const int n_room = (int)(cg_z_bytes(k_cap, n_cap) / 2u);
         int n_ent = 0;
         for (int row = 0; row < rows; row++) {
             uint32_t pm = 0u;

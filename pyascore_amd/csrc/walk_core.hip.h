@@ -446,6 +446,45 @@ DEV void cnt_envelopes(const Residues &res, int k, uint32_t pos_cap, float2 *env
 /* One fragment ion of a node: its smallest and largest m/z over the chains through the node (f_lo <= f_hi) against the
  * staged peak table: the rank every walker finds, | CNT_MARK when a peak between the windows could make walkers differ.
  * (mz_error <= 0.49: no half check) */
+#ifndef PYA_CNT_SCAN_LOOP
+/* r06: the first four entries from the cell's (even) start as two 16-byte reads and a straight line of selects -- what
+ * look4 does for a walker's lookup -- and the scan loop only for a window that reaches past them (rare: a cell holds less than
+ * one retained peak on average).  As a per-lane loop every wavefront ran to its longest lane, with the exec-mask
+ * bookkeeping of two exits per step.  (a0 <= a and b0 <= b1 -- float subtraction and addition are monotone -- so "inside
+ * every walker's window" implies "inside the widest one".) */
+DEV uint32_t cnt_entry_f(const PeakTable &t, float f_lo, float f_hi) {
+    const float a0 = f_lo - t.err, a = f_hi - t.err, b0 = f_lo + t.err, b1 = f_hi + t.err;
+    PeakEntry e4[4];
+    int idx = entries4(t, (uint32_t)t.cell[grid_cell(t, a0)], e4);
+    int in_best = PYA_NO_MATCH, band_best = PYA_NO_MATCH;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const PeakEntry x = e4[j];
+        const int rw = (x.mz > a0 && x.mz < b1) ? (int)x.rank : PYA_NO_MATCH;
+        const bool core = x.mz > a && x.mz < b0;
+        const int ri = core ? rw : PYA_NO_MATCH, rb = core ? PYA_NO_MATCH : rw;
+        in_best = ri < in_best ? ri : in_best;
+        band_best = rb < band_best ? rb : band_best;
+    }
+    if (e4[3].mz < b1) {
+        for (;; idx++) {
+            const PeakEntry x = t.e[idx];
+            if (!(x.mz < b1)) break;
+            if (x.mz > a0) {
+                const int r = (int)x.rank;
+                if (x.mz > a && x.mz < b0) in_best = r < in_best ? r : in_best;
+                else band_best = r < band_best ? r : band_best;
+            }
+        }
+    }
+    return (uint32_t)in_best | (band_best < in_best ? CNT_MARK : 0u);
+}
+/* ... when the envelope is a point (f_lo == f_hi: no band, nothing to mark) */
+DEV uint32_t cnt_entry_1(const PeakTable &t, float f) {
+    const Look k = look4(t, f);
+    return (uint32_t)(k.more() ? look_rest(t, k) : k.best);
+}
+#else
 DEV uint32_t cnt_entry_f(const PeakTable &t, float f_lo, float f_hi) {
     const float a0 = f_lo - t.err, a = f_hi - t.err, b0 = f_lo + t.err, b1 = f_hi + t.err;
     int in_best = PYA_NO_MATCH, band_best = PYA_NO_MATCH;
@@ -471,6 +510,7 @@ DEV uint32_t cnt_entry_1(const PeakTable &t, float f) {
     }
     return (uint32_t)best;
 }
+#endif
 /* One node of the plain settings (one ion: charge 1): the envelope [lo, hi] of its running sums (A, B: the ion type's offsets) */
 DEV uint32_t cnt_table_entry(const PeakTable &t, float lo, float hi, double A, double B) {
     if (!(lo <= hi)) return (uint32_t)PYA_NO_MATCH;           /* unreachable: never read */
