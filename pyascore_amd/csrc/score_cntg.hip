@@ -21,6 +21,8 @@
  */
 #include "score_core.hip.h"
 
+#define CG_NODE_WORDS 4            /* LDS words per count node (cg_cumulate) */
+
 struct CgLds {
     uint16_t *grid;
     uint32_t *cnt;       /* [PYA_NTOP / 2][64] rank histogram of the walkers (marked site assignments) */
@@ -32,7 +34,7 @@ struct CgLds {
     uint8_t *site_pos;
     float2 *env;         /* [rows][pos_cap] */
     uint8_t *st;         /* [rows][pos_cap] loss state of the node */
-    uint32_t *hist;      /* [rows][pos_cap][6]: ranks 0-9 as 16-bit counts, word 5 = fragments | marked ions << 16 */
+    uint32_t *hist;      /* [rows][pos_cap][4]: ranks 0-9 as byte counts, word 3 = fragments | marked ions << 16 */
     uint4 *psA;          /* [rows][n_cap + 1] prefix sums at the sites' steps: cumulative counts of depths 0-7 */
     uint2 *psB;          /* ... depths 8-9, fragments | marked << 16 */
     uint4 *gA;           /* [k_cap * n_cap + 1] */
@@ -44,7 +46,7 @@ __host__ __device__ static inline size_t cg_al16(size_t v) { return (v + 15) & ~
  * 3), then the prefix sums at the sites (steps 4-5).  Side by side they were 11.9 KB on cfg4's launch (13 wavefronts per CU);
  * taking turns 10.2 KB (15). */
 __host__ __device__ static inline size_t cg_x_bytes(uint32_t pos_cap, uint32_t k_cap) {
-    const size_t rows = 2 * ((size_t)k_cap + 1), h = rows * pos_cap * 24, c = PYA_NTOP / 2 * 64 * 4;
+    const size_t rows = 2 * ((size_t)k_cap + 1), h = rows * pos_cap * CG_NODE_WORDS * 4, c = PYA_NTOP / 2 * 64 * 4;
     return h > c ? h : c;
 }
 __host__ __device__ static inline size_t cg_y_bytes(uint32_t pos_cap, uint32_t k_cap, uint32_t n_cap) {
@@ -89,16 +91,20 @@ DEV CgLds cg_carve(unsigned char *raw, uint32_t cap, uint32_t pos_cap, uint32_t 
     return c;
 }
 
-/* the node's rank counts (16-bit fields, ranks 0-9 in words 0-4) -> cumulative counts over the ranks, same packing */
+/* the node's rank counts (BYTE fields, ranks 0-9 in words 0-2; word 3 = fragments | marked ions << 16) -> cumulative counts
+ * over the ranks as 16-bit fields in words 0-4, word 5 = word 3.  (r06: 16 bytes per node instead of 24 -- a node has at most
+ * ion types x charges x loss variants ions, and a launch whose bound exceeds 255 walks instead: the kernel's LDS decides how
+ * many wavefronts a CU holds, and its time follows that.) */
 DEV void cg_cumulate(const uint32_t *h, uint32_t out[6]) {
     uint32_t acc = 0;
 #pragma unroll
     for (int w = 0; w < 5; w++) {
-        const uint32_t lo = acc + (h[w] & 0xffffu), hi = lo + (h[w] >> 16);
+        const int r0 = 2 * w, r1 = 2 * w + 1;
+        const uint32_t lo = acc + ((h[r0 >> 2] >> ((r0 & 3) * 8)) & 0xffu), hi = lo + ((h[r1 >> 2] >> ((r1 & 3) * 8)) & 0xffu);
         out[w] = lo | (hi << 16);
         acc = hi;
     }
-    out[5] = h[5];
+    out[5] = h[3];
 }
 
 DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, uint32_t cap, uint32_t pos_cap, uint32_t k_cap,
@@ -152,7 +158,8 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
     /* every modifiable residue the same pair of loss classes?  (else: every site assignment is walked) */
     const uint32_t first_nl = (uint32_t)__builtin_amdgcn_readlane((int)res.nl, res.site_mask ? __builtin_ctzll(res.site_mask) : 0);
     const bool uniform = !__any(is_site && res.nl != first_nl) && !(b.debug & 0x40000000u) && k + 1 <= 31 && n_sites <= 32 &&
-                         (uint32_t)k <= k_cap && (uint32_t)n_sites <= n_cap;
+                         (uint32_t)k <= k_cap && (uint32_t)n_sites <= n_cap &&
+                         (uint32_t)t_max * (uint32_t)zmax * (env.n_nl ? (uint32_t)PYA_MAX_UNIQ : 1u) <= 255u;   /* (byte counts per node) */
     bool tables = false;                                     /* the count tables were built: site assignments read them */
     if (uniform) {
         /* 1. envelopes of the running sums; 2. the loss state of every node, from the chain with the first j sites modified */
@@ -175,7 +182,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
                 }
             }
         }
-        for (int i = lane; i < rows * (int)pos_cap * 6; i += 64) c.hist[i] = 0u;
+        for (int i = lane; i < rows * (int)pos_cap * CG_NODE_WORDS; i += 64) c.hist[i] = 0u;
         wave_lds_sync();
         STAMP_T(b, 26, );
         /* 3. one lookup per (node, variant, ion type, charge).  The (reachable node, loss variant) pairs are listed first: a
@@ -221,8 +228,8 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
                 const float2 lh = c.env[node];
                 double A, B;
                 type_constants(type_at(types64, (d ? n_f : 0) + (t < my_types ? t : 0)), &A, &B);
-                uint32_t *hn = c.hist + node * 6;
-                if (on && t == 0) atomicAdd(&hn[5], (uint32_t)(my_types * zmax));
+                uint32_t *hn = c.hist + node * CG_NODE_WORDS;
+                if (on && t == 0) atomicAdd(&hn[3], (uint32_t)(my_types * zmax));
                 const float loss = env.n_nl ? c.nl_uniq[v] : 0.f;
                 const float x_lo = env.n_nl ? lh.x - loss : lh.x, x_hi = env.n_nl ? lh.y - loss : lh.y;   /* float subtract (:572), monotone */
                 const double m_lo = ((double)x_lo + A) - B, m_hi = ((double)x_hi + A) - B;
@@ -231,14 +238,14 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
                 if (__all(!on || lh.x == lh.y)) {
                     for (int z = 1; z <= zmax; z++) {
                         const uint32_t rk = cnt_entry_1(tab, charge_mz(m_lo, z));
-                        if (on && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 1], 1u << ((rk & 1u) * 16u));
+                        if (on && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 2], 1u << ((rk & 3u) * 8u));
                     }
                 } else {
                     for (int z = 1; z <= zmax; z++) {
                         const uint32_t ent = cnt_entry_f(tab, charge_mz(m_lo, z), charge_mz(m_hi, z));
                         const uint32_t rk = ent & 15u;
-                        if (on && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 1], 1u << ((rk & 1u) * 16u));
-                        if (on && (ent & CNT_MARK)) atomicAdd(&hn[5], 1u << 16);
+                        if (on && rk < (uint32_t)PYA_NTOP) atomicAdd(&hn[rk >> 2], 1u << ((rk & 3u) * 8u));
+                        if (on && (ent & CNT_MARK)) atomicAdd(&hn[3], 1u << 16);
 #ifdef PYA_STAMPS                                              /* diagnostic build: ions of nodes with an interval envelope looked up / marked (56, 57) */
                         if (b.stamps && on) {
                             atomicAdd(&b.stamps[56], 1ull);
@@ -263,7 +270,7 @@ DEV void score_cntg_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw
                 const bool row_on = row < rows;
                 const int d = row >= k + 1 ? 1 : 0;
                 uint32_t w[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-                if (sl < Lm1 && row_on) cg_cumulate(c.hist + ((size_t)row * pos_cap + sl) * 6, w);
+                if (sl < Lm1 && row_on) cg_cumulate(c.hist + ((size_t)row * pos_cap + sl) * CG_NODE_WORDS, w);
 #pragma unroll
                 for (int x = 0; x < 6; x++) w[x] = two ? wave_incl_scan_u32<true>(w[x]) : wave_incl_scan_u32<false>(w[x]);
                 const int st = d ? Lm1 - pos : pos;
