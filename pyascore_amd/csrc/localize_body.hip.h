@@ -38,6 +38,19 @@ static inline size_t localize_hash_lds_bytes(uint32_t push_cap, uint32_t n_cap, 
     return fixed + (srt > lst ? srt : lst) + 64;
 }
 
+/* r06: the lean instantiation's own size -- what it never touches is left out: the loss-variant tables of the run tables
+ * (a quarter of their bytes), the staged loss-state table (512 B), per-site and per-residue arrays beyond the launch's
+ * largest k and longest peptide.  10.6 -> 7.6 KB on cfg5's finishing launch, 15 -> 21 wavefronts per CU: these kernels wait
+ * for memory (valu_busy 0.36), residency is what hides it. */
+static inline size_t localize_lean_lds_bytes(uint32_t push_cap, uint32_t n_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb,
+                                             uint32_t max_k) {
+    const uint32_t site_cap = hash_site_cap(max_k), res_cap = hash_res_cap(pos_cap);
+    size_t fixed = 2 * (size_t)hash_nl_cap(0) + PYA_MAX_UNIQ * 4 + (size_t)push_cap * 16 + (size_t)site_cap * 16 + 16;
+    size_t srt = n_cap ? sort_lds_bytes(n_cap) + 64 : 64;
+    size_t lst = pya_loc_lds_bytes(pos_cap, pool_cap, sb) - (64 - res_cap) * 8 - (size_t)sb * 2 * pos_cap * 4;
+    return fixed + (srt > lst ? srt : lst) + 64;
+}
+
 /* (five wavefronts per SIMD -- 96 registers, ~60 spilled -- and the LDS trimmed to 8 KB to match were measured:
  * 10.8-11.7 ms on cfg4 against 10.4 with four and no spills) */
 #ifndef LOC_WAVES_HASH
@@ -153,8 +166,8 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
      * that keeps this kernel's LDS small (occupancy) and saves the staging + grid build */
     /* (the hash route looks up ~1 300 ions per PSM on cfg4-like settings; staging the table for it was measured
      * slower -- occupancy -- and is gone: DESIGN.md section 10) */
-    const uint32_t site_cap = HASH ? hash_site_cap(max_k) : 64u, res_cap = HASH ? hash_res_cap(pos_cap) : 64u;
-    K3Lds lds = carve(lds_raw, 0, false, push_cap, site_cap, HASH ? hash_nl_cap((uint32_t)cfg->n_nl) : 256u);
+    const uint32_t site_cap = (HASH || PLAIN) ? hash_site_cap(max_k) : 64u, res_cap = (HASH || PLAIN) ? hash_res_cap(pos_cap) : 64u;
+    K3Lds lds = carve(lds_raw, 0, false, push_cap, site_cap, HASH ? hash_nl_cap((uint32_t)cfg->n_nl) : (PLAIN ? hash_nl_cap(0u) : 256u));
     LocCtx ctx;
     ctx.b = &b;
     ctx.cfg = cfg;
@@ -346,7 +359,7 @@ DEV bool localize_body(const BatchDev &b, uint32_t psm, unsigned char *lds_raw, 
 
     STAMP_T(b, 24, false);
     /* ---- Ascores, sb-1 competitors at a time ---- */
-    ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap, sb, res_cap, !HASH);
+    ctx.w = loc_carve(lds.scratch, pos_cap, pool_cap, sb, res_cap, !HASH, !PLAIN);
     ctx.sb = (int)sb;
     ctx.gtp = (int)gtp;
     ctx.L = res.L;

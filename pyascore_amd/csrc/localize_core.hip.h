@@ -597,8 +597,10 @@ struct LocLds {
 
 /* res_cap: entries of the residue arrays (64, or the launch's longest peptide rounded up to a multiple of 4);
  * lean_tables = false leaves the span tables of the lean pairing out (the hash route: LDS decides its occupancy) */
+/* nl_tables = false (the lean instantiation, r06): no room for the loss-variant tables pmk / cpre, which only the general
+ * settings read -- a quarter of the run tables' bytes */
 DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, uint32_t LOC_SB, uint32_t res_cap = 64,
-                     bool lean_tables = true) {
+                     bool lean_tables = true, bool nl_tables = true) {
     LocLds w;
     w.sig_mask = (uint64_t *)raw;
     w.m0 = (float *)(w.sig_mask + LOC_SB);
@@ -617,8 +619,8 @@ DEV LocLds loc_carve(unsigned char *raw, uint32_t pos_cap, uint32_t pool_cap, ui
     w.c_cnt = (uint32_t *)(w.c_depth + LOC_SB);
     w.c_tr = w.c_cnt + LOC_SB * 2;
     w.pmk = (uint16_t *)(w.c_tr + LOC_SB * 2);
-    w.cpre = w.pmk + (size_t)LOC_SB * 2 * pos_cap;
-    w.nlp = (uint8_t *)(w.cpre + (size_t)LOC_SB * 2 * pos_cap);
+    w.cpre = w.pmk + (nl_tables ? (size_t)LOC_SB * 2 * pos_cap : 0);
+    w.nlp = (uint8_t *)(w.cpre + (nl_tables ? (size_t)LOC_SB * 2 * pos_cap : 0));
     w.keep = w.nlp + 64;
     return w;
 }

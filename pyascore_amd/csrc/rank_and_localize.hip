@@ -204,7 +204,7 @@ extern "C" int pya_launch_localize(const BatchDev *b, const uint32_t *d_ids, uin
     if (e != hipSuccess) return (int)e;
     /* sort_room = 0 (the host's choice for thousands of signatures): the lean launch without room for the sort
      * emulation; PSMs with a tie at the top go through the hand-over list to a second lean pass that has it */
-    const size_t lds_lean = sort_room ? lds : pya_localize_lds_bytes(push_cap, 0, pos_cap, pool_cap, sb);
+    const size_t lds_lean = localize_lean_lds_bytes(push_cap, sort_room ? n_cap : 0u, pos_cap, pool_cap, sb, b->max_k);   /* (r06: its own, smaller layout) */
     hipLaunchKernelGGL(pya_localize_kernel<true>, dim3(n_ids), dim3(64), lds_lean, stream, *b, d_ids, n_ids, push_cap,
                        pos_cap, pool_cap, sb, gtp, sort_room);
     e = hipGetLastError();
@@ -327,7 +327,9 @@ extern "C" int pya_launch_localize_recount(const BatchDev *b, const uint32_t *d_
                                            uint32_t push_cap, uint32_t pos_cap, uint32_t pool_cap, uint32_t sb, uint32_t gtp,
                                            uint32_t *d_redo_count, uint32_t *d_redo_ids, hipStream_t stream) {
     if (n_ids == 0) return 0;
-    const size_t lds = pya_localize_recount_lds_bytes(cap, push_cap, pos_cap, pool_cap, sb);
+    /* (the lean layout; pya_localize_recount_lds_bytes -- what the host's feasibility test asks -- is an upper bound of it) */
+    const size_t lds = (cap ? ((size_t)cap + PYA_TABLE_PAD) * 8 + PYA_GRID_CELLS * 2 : 0) + PYA_LOC_SB_MAX * (PYA_REC_WORDS + PYA_NTOP) * 4 +
+                       localize_lean_lds_bytes(push_cap, 0, pos_cap, pool_cap, sb, b->max_k) + 64;
     hipError_t e = PYA_ENSURE_MAX_LDS(pya_localize_recount_kernel);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pya_localize_recount_kernel, dim3(n_ids), dim3(64), lds, stream, *b, d_ids, n_ids, cap, push_cap, pos_cap,
