@@ -87,3 +87,43 @@ def test_traffic_is_the_named_profiles_counter(line):
     assert r["traffic"] == pytest.approx((2.0 * fetch + write) * 1024.0, rel=1e-6)
     # wasted re-reads would show here first: the whole path moves less than twice its algorithmic bytes on cfg2
     assert r["traffic_over_algorithmic"] < 2.0
+
+
+def test_design_quotes_the_newest_counters():
+    """DESIGN.md section 8 quotes, per config, the HBM traffic of the whole step over its algorithmic bytes ("= N.NN×" in the
+    row's last cell).  The figure must be the one the NEWEST committed counters of that config give (r05 verdict: the text
+    quoted one profile while bench.py read the next): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the kernels of
+    profiles/<tag>_rocprof_<cfg>/pmc_summary.csv over roofline.algorithmic_bytes_per_launch of <tag>_bench_<cfg>.json."""
+    import re
+    with open(os.path.join(ROOT, "DESIGN.md")) as f:
+        text = f.read()
+    sec = text[text.index("## 8. Measurements"):text.index("## 9. Multi-GPU")]
+    checked = 0
+    for cfg in ("cfg2", "cfg3", "cfg4", "cfg5"):
+        dirs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_" + cfg)))
+        if not dirs:
+            continue
+        newest = dirs[-1]
+        tag = os.path.basename(newest)[: -len("_rocprof_" + cfg)]
+        bench_json = os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (tag, cfg))
+        if not os.path.exists(bench_json):
+            continue
+        with open(bench_json) as f:
+            alg = json.loads(f.read().strip().splitlines()[-1])["roofline"]["algorithmic_bytes_per_launch"]
+        fetch = write = 0.0
+        with open(os.path.join(newest, "pmc_summary.csv"), newline="") as f:
+            for row in csv.DictReader(f):
+                v = float(row.get("per_step") or row["mean_value"])
+                fetch += v if row["counter"] == "FETCH_SIZE" else 0.0
+                write += v if row["counter"] == "WRITE_SIZE" else 0.0
+        ratio = (2.0 * fetch + write) * 1024.0 / alg
+        rows = [ln for ln in sec.splitlines() if ln.startswith("| " + cfg + " ")]
+        assert rows, "DESIGN.md section 8 has no row for " + cfg
+        quoted = re.findall(r"=\s*([0-9]+\.[0-9]+)\s*×", rows[0].rstrip().rstrip("|").split("|")[-1])
+        assert quoted, "the %s row of DESIGN.md section 8 quotes no traffic ratio" % cfg
+        assert abs(float(quoted[-1]) - ratio) <= 0.02 * ratio + 0.005, \
+            "%s: DESIGN.md quotes %s x, the newest counters (%s) give %.3f x" % (cfg, quoted[-1], os.path.basename(newest), ratio)
+        assert tag in sec, "DESIGN.md section 8 does not name the profile it quotes (%s)" % tag
+        checked += 1
+    if not checked:
+        pytest.skip("no committed counters")
