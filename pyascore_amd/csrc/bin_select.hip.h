@@ -10,13 +10,18 @@
  *   thresholds  per window the highest bucket b with  #{peaks of the window in buckets >= b} >= n_top  (0 when the window has
  *           fewer peaks): every peak of the window's top n_top lies in a bucket >= b, and so does every peak MORE INTENSE
  *           than any such peak -- the survivors are closed upwards;
+ *   pass 1b only when the survivors so chosen would not fit their slots (intensities packed into few buckets: a flat noise
+ *           floor, a narrow dynamic range): a second histogram, over the NEXT 6 bits, of the peaks in their window's threshold
+ *           bucket, and per window the highest sub-bucket that still leaves n_top peaks at or above (bucket, sub-bucket):
+ *           the survivors are the peaks whose top 12 key bits are >= that pair -- still closed upwards, still at least n_top
+ *           per window, now about one percent of intensity wide at the threshold instead of a factor of 1.4;
  *   pass 2  the survivors (bucket >= threshold of their window: n_top plus what shares the threshold bucket, ~ 15 per window)
  *           compacted in m/z order into LDS: composite key, float m/z, index of the raw peak;
  *   ranks   bin_fast's sweep over the survivors only.  A survivor's rank among the survivors of its window IS its rank in the
  *           window (everything more intense survived), equal keys share a bucket (all of them survive or none), so the
  *           deficit test, the second sweep by whole intensities and the hand-over of truly equal intensities carry over
  *           unchanged.
- * The raw spectrum is read three times (twice from L2) and never staged: LDS is max(8 KB, 14 B per survivor slot) per
+ * The raw spectrum is read three times (four with pass 1b; all but the first from L2 / the Infinity Cache) and never staged: LDS is max(8 KB, 14 B per survivor slot) per
  * wavefront whatever the peak count.  More survivors than slots (flat intensities: everything in one bucket), peaks out of
  * order, more than 64 windows, bad intensities, equal intensities inside a top n_top: PYA_BIN_REDO, as bin_fast answers.
  * Results are stored straight to the workspace table (the batch kernel's DIRECT way). */
@@ -25,7 +30,7 @@
 #include "bin_core.hip.h"
 
 #define PYA_BIN_SEL_HIST_BYTES (PYA_BIN_FAST_WINDOWS * 32 * 4)      /* [window][32 words of two 16-bit buckets] */
-#define PYA_BIN_SEL_TAIL 512                                           /* thresholds, window table, chunk maxima */
+#define PYA_BIN_SEL_TAIL 640                                           /* thresholds (two levels), window table, chunk maxima */
 __host__ __device__ static inline size_t pya_bin_sel_area(uint32_t scap) {
     const size_t s = (((size_t)scap * 14 + 63) & ~(size_t)63);
     return s > PYA_BIN_SEL_HIST_BYTES ? s : PYA_BIN_SEL_HIST_BYTES;
@@ -43,6 +48,8 @@ DEV int bin_select(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t
     uint16_t *w_last = (uint16_t *)(tail + 64);              /* [64] + the slot of "window 64" */
     uint16_t *w_first = w_last + PYA_BIN_FAST_WINDOWS + 1;
     uint32_t *cmax = (uint32_t *)(tail + 64 + 264);          /* [15] */
+    uint8_t *thr2 = tail + 448;                              /* [64] threshold sub-bucket per window (0: no second level) */
+    uint8_t *need = tail + 512;                              /* [64] peaks still wanted from the window's threshold bucket */
 
     STAMP_BEGIN();
     STAMP_T(b, 1, -1);
@@ -151,15 +158,66 @@ DEV int bin_select(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t
     }
     wave_lds_sync();
     /* ---- thresholds: a window at a time, a bucket per lane ---- */
+    uint32_t s_est = 0;                                                  /* survivors the first level would leave */
     for (int w = 0; w <= last_win; w++) {
         const uint32_t c = (hist[(uint32_t)w * 32u + ((uint32_t)lane >> 1)] >> (((uint32_t)lane & 1u) * 16u)) & 0xffffu;
         const uint32_t incl = wave_incl_scan_u32<false>(c);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t suffix = tot - incl + c;                          /* peaks of the window in buckets >= lane */
         const uint64_t m = __ballot(suffix >= (uint32_t)ntop);
-        if (lane == 0) thr[w] = (uint8_t)(m ? 63 - __builtin_clzll(m) : 0);
+        const int t = m ? 63 - __builtin_clzll(m) : 0;
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)suffix, t);          /* ... in buckets >= t */
+        const uint32_t in_t = (uint32_t)__builtin_amdgcn_readlane((int)c, t);
+        s_est += at;
+        if (lane == 0) {
+            thr[w] = (uint8_t)t;
+            thr2[w] = 0;
+            /* peaks above the threshold bucket: at - in_t < n_top (or the window has fewer than n_top peaks: all survive) */
+            const uint32_t above = at - in_t;
+            need[w] = (uint8_t)(above < (uint32_t)ntop ? (uint32_t)ntop - above : 0u);
+        }
     }
-    wave_lds_sync();                                                    /* (the histograms are dead: the survivors take their place) */
+    wave_lds_sync();
+    if (s_est > scap) {
+        /* ---- pass 1b: the threshold buckets, six bits finer ---- */
+        constexpr uint32_t DSHIFT2 = DSHIFT - 6;
+        for (uint32_t i = (uint32_t)lane; i < PYA_BIN_SEL_HIST_BYTES / 4; i += 64) hist[i] = 0u;
+        wave_lds_sync();
+        for (uint32_t base = 0; base < P; base += 64 * U) {
+            double v[U];
+            uint32_t hw[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t i = base + u * 64 + (uint32_t)lane;
+                const uint32_t ic = i < P ? i : P - 1;
+                v[u] = mz[ic];
+                hw[u] = inten_hi[2 * ic];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t i = base + u * 64 + (uint32_t)lane;
+                if (base + u * 64 < P) {
+                    const uint32_t w = window_of(v[u]);
+                    const uint32_t k = (hw[u] > keybase ? hw[u] : keybase) - keybase;
+                    const uint32_t sub = (k >> DSHIFT2) & 63u;
+                    if (i < P && (k >> DSHIFT) == (uint32_t)thr[w]) atomicAdd(&hist[w * 32u + (sub >> 1)], 1u << ((sub & 1u) * 16u));
+                }
+            }
+        }
+        wave_lds_sync();
+        for (int w = 0; w <= last_win; w++) {
+            const uint32_t c = (hist[(uint32_t)w * 32u + ((uint32_t)lane >> 1)] >> (((uint32_t)lane & 1u) * 16u)) & 0xffffu;
+            const uint32_t incl = wave_incl_scan_u32<false>(c);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t suffix = tot - incl + c;                      /* peaks of the threshold bucket in sub-buckets >= lane */
+            const uint32_t nd = (uint32_t)need[w];
+            const uint64_t m = __ballot(nd != 0u && suffix >= nd);
+            if (lane == 0) thr2[w] = (uint8_t)(m ? 63 - __builtin_clzll(m) : 0);
+        }
+        wave_lds_sync();
+    }
+    /* (the histograms are dead: the survivors take their place) */
     STAMP_T(b, 3, -1);
 
     /* ---- pass 2: the survivors, compacted in m/z order ---- */
@@ -181,7 +239,8 @@ DEV int bin_select(const BatchDev &b, uint32_t psm, unsigned char *lds, uint32_t
             if (base + u * 64 < P) {
                 const uint32_t w = window_of(v[u]);
                 const uint32_t k = (hw[u] > keybase ? hw[u] : keybase) - keybase;
-                const bool sv = i < P && (k >> DSHIFT) >= (uint32_t)thr[w];
+                /* the top 12 key bits against (threshold bucket, threshold sub-bucket): one compare */
+                const bool sv = i < P && (k >> (DSHIFT - 6)) >= (((uint32_t)thr[w] << 6) | (uint32_t)thr2[w]);
                 const uint64_t m = __ballot(sv);
                 const uint32_t pos = S + lanes_below(m);
                 if (sv && pos < scap) {
