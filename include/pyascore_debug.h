@@ -20,7 +20,8 @@ extern "C" {
  * switch back to its production default.  pya_reload_env resets all of them.  Unknown names: PYA_ERR_ARG.
  *   flags (any non-NULL value = on): PYA_NO_PLAIN PYA_NO_FUSED PYA_NO_BIG PYA_NO_TINY PYA_NO_PREFIX PYA_NO_CHUNKS
  *     PYA_NO_UPLOAD_THREAD PYA_ONE_PEAK_CLASS PYA_PEAK_CLASSES PYA_ONE_LDS_CLASS PYA_SORT_ROOM PYA_NO_BIG_INLINE
- *     PYA_NO_LOC_HASH PYA_NO_NODES PYA_NO_CNT PYA_HOST_TIMING PYA_STAMPS PYA_SLOW_NULL_STREAM
+ *     PYA_NO_LOC_HASH PYA_NO_NODES PYA_NO_CNT PYA_HOST_TIMING PYA_STAMPS PYA_SLOW_NULL_STREAM PYA_NO_FORK (r06: the
+ *     fused family behind the scoring kernels on the caller's stream instead of beside them on the plan's side stream)
  *   numbers: PYA_DEBUG (bit set, common.h) PYA_PLAIN_MIN PYA_BIG_MIN_N PYA_TINY_MAX PYA_SORT_ROOM_MAX PYA_SB PYA_GTP
  *     PYA_HASH_PP PYA_NODE_CAP PYA_CHUNK_MB PYA_WORKSPACE_MB
  *     PYA_BIN_SELECT_MIN (r06: peak classes above this many peaks are binned by selection, csrc/bin_select.hip.h; default 640,

@@ -222,6 +222,7 @@ struct Knobs {
     bool no_upload_thread = false, one_peak_class = false, peak_classes = false, one_lds_class = false;
     bool host_timing = false, stamps = false, sort_room = false, no_big_inline = false;
     bool no_loc_hash = false, no_nodes = false, no_cnt = false;
+    bool no_fork = false;                       /* r06: the fused family on the plan's stream behind the scoring kernels instead of beside them */
     bool slow_null_stream = false;              /* host_one.cpp: widens the window of a (fixed) workspace race for its regression test */
     uint32_t debug = 0;
     int64_t plain_min = 512, big_min_n = 1024, tiny_max = 64;
@@ -526,12 +527,22 @@ struct pya_plan {
     /* PYA_FLAG_TIMING: five events per run, in a ring so that a caller can enqueue run after run and read the
      * timings of all of them afterwards (pya_plan_timings_sum) instead of waiting for every run */
     static constexpr uint32_t kEvRing = 128;
-    std::vector<hipEvent_t> evring;      /* [kEvRing][5] */
-    std::vector<uint8_t> evalias;        /* [kEvRing][5] the event that marks boundary i of the run: a family that launched
-                                          * nothing records no event of its own (a record costs microseconds of stream time) */
+    static constexpr uint32_t kEvPerRun = 7;      /* boundaries 0 .. 4 of the caller's stream; 5, 6: begin and end of the fused family on the side stream */
+    std::vector<hipEvent_t> evring;      /* [kEvRing][kEvPerRun] */
+    std::vector<uint8_t> evalias;        /* [kEvRing][kEvPerRun] the event that marks boundary i of the run: a family that launched
+                                          * nothing records no event of its own (a record costs microseconds of stream time);
+                                          * entry 5 != 0: the run's fused family ran on the side stream, between events 5 and 6 */
     uint64_t ev_runs = 0, ev_read = 0;   /* runs recorded, runs already summed */
-    hipEvent_t *ev_set(uint64_t run) { return evring.data() + 5 * (run % kEvRing); }
-    uint8_t *ev_alias(uint64_t run) { return evalias.data() + 5 * (run % kEvRing); }
+    hipEvent_t *ev_set(uint64_t run) { return evring.data() + kEvPerRun * (run % kEvRing); }
+    uint8_t *ev_alias(uint64_t run) { return evalias.data() + kEvPerRun * (run % kEvRing); }
+    /* r06 -- a batch of mixed shapes has two independent chains behind the binning: the fused score + localize kernels (few
+     * site assignments) and the scoring + localize kernels of everything else.  They run BESIDE each other: the fused family
+     * on a stream of the plan's own, forked after the binning and joined at the end of the run (two events); the latency-bound
+     * localize kernels and the issue-bound fused kernels fill each other's idle slots, and no launch waits for another
+     * family's tail. */
+    bool fork = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t last_stream = nullptr;
     uint64_t n_runs = 0;                 /* pya_plan_run calls so far (which set of hand-over counts is in use) */
     bool ran = false;
@@ -540,6 +551,9 @@ struct pya_plan {
     ~pya_plan() {
         for (auto &e : evring)
             if (e) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
     }
     uint64_t workspace_bytes() const { return arena.bytes(); }
 };

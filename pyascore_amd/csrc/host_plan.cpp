@@ -742,9 +742,21 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
         HIPCHK(h, hipStreamSynchronize(nullptr));
     }
     lap("arena+upload");
+    {
+        /* the fused family beside the others (host_internal.h: pya_plan::fork) when the batch has both */
+        bool others = !p->gen_ids.empty();
+        for (const pya_plan::IdList &l : p->score_lists) others = others || l.n != 0;
+        for (const pya_plan::IdList &l : p->big_lists) others = others || l.n != 0;
+        p->fork = !h->kn.no_fork && p->n_fused_total != 0 && others;
+        if (p->fork) {
+            HIPCHK(h, hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        }
+    }
     if (flags & PYA_FLAG_TIMING) {
-        p->evring.assign(5 * pya_plan::kEvRing, nullptr);
-        p->evalias.assign(5 * pya_plan::kEvRing, 0);
+        p->evring.assign(pya_plan::kEvPerRun * pya_plan::kEvRing, nullptr);
+        p->evalias.assign(pya_plan::kEvPerRun * pya_plan::kEvRing, 0);
         /* (timing only: nothing synchronises-with the work through these events, so no system-scope fence per record) */
         for (auto &e : p->evring) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     }
@@ -865,6 +877,34 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
     e = pya_launch_bin_global(&d, p->d_bigbin_ids.p, (uint32_t)p->bigbin_ids.size(), p->d_bigbin_scratch.p, p->bigbin_stride, p->bigbin_cap, st);
     if (e) return h->hip_fail((hipError_t)e, "bin_spectra (global) launch");
     if (mark(1, true)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
+    /* the fused family: few site assignments, plain settings, scored and localised in one pass (score_localize.hip), one PSM
+     * per wavefront; what it hands over goes through the general localize instantiation.  On `fs`: the plan's side stream when
+     * the run forks (everything below is independent of it: other PSMs, other hand-over lists), else the caller's. */
+    auto fused_family = [&](hipStream_t fs) -> int {
+        const Bucket &fb = p->fusedb;
+        for (const pya_plan::FusedLaunch &l : p->fused_launches) {
+            int fe = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, l.n_cap, l.stride, l.pos_cap, l.ent_cap, l.push_cap,
+                                      p->fused_both, l.multi_z, d.redo4_count, d.redo4_ids, fs);
+            if (fe) return h->hip_fail((hipError_t)fe, "score_localize launch");
+        }
+        int fe = pya_launch_localize_redo(&d, d.redo4_count, d.redo4_ids, p->n_fused_total, fb.push_cap(), fb.n_cap,
+                                          fb.pos_cap, fb.pool_cap(), fb.sb(), fb.gtp(), fs);
+        if (fe) return h->hip_fail((hipError_t)fe, "localize (hand-over) launch");
+        return 0;
+    };
+    if (timing) alias[5] = 0;
+    if (p->fork) {
+        HIPCHK(h, hipEventRecord(p->ev_fork, st));
+        HIPCHK(h, hipStreamWaitEvent(p->side, p->ev_fork, 0));
+        if (timing) {
+            alias[5] = 1;
+            HIPCHK(h, hipEventRecord(ev[5], p->side));
+        }
+        const int fe = fused_family(p->side);
+        if (fe) return fe;
+        if (timing) HIPCHK(h, hipEventRecord(ev[6], p->side));
+        HIPCHK(h, hipEventRecord(p->ev_join, p->side));
+    }
     for (const pya_plan::IdList &l : p->score_lists) {
         /* classes with C(n,k) > 64 share the walk over the first sites between signatures */
         const uint32_t prefix = (p->buckets[l.ncls].n_cap >= 128 && !h->kn.no_prefix) ? 1u : 0u;
@@ -922,20 +962,11 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         for (const pya_plan::IdList &l : p->big_lists) any = any || l.n != 0;
         if (mark(2, any)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
     }
-    if (p->n_fused_total) {
-        /* few site assignments, plain settings: scored and localised in one pass (score_localize.hip), one PSM per
-         * wavefront; what it hands over goes through the general localize instantiation */
-        const Bucket &fb = p->fusedb;
-        for (const pya_plan::FusedLaunch &l : p->fused_launches) {
-            e = pya_launch_fused(&d, p->d_fused_ids.p + l.off, l.n, l.cap, l.n_cap, l.stride, l.pos_cap, l.ent_cap, l.push_cap,
-                                 p->fused_both, l.multi_z, d.redo4_count, d.redo4_ids, st);
-            if (e) return h->hip_fail((hipError_t)e, "score_localize launch");
-        }
-        e = pya_launch_localize_redo(&d, d.redo4_count, d.redo4_ids, p->n_fused_total, fb.push_cap(), fb.n_cap,
-                                     fb.pos_cap, fb.pool_cap(), fb.sb(), fb.gtp(), st);
-        if (e) return h->hip_fail((hipError_t)e, "localize (hand-over) launch");
+    if (p->n_fused_total && !p->fork) {
+        e = fused_family(st);
+        if (e) return e;
     }
-    if (mark(3, p->n_fused_total != 0)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
+    if (mark(3, p->n_fused_total != 0 && !p->fork)) return h->hip_fail(hipGetLastError(), "hipEventRecord");
     if (p->big_inline && !p->bigloc.ids.empty()) {
         /* what score_big scored in its summary mode: the lean body with recounted signatures and the winner score_big
          * named; what that declines is scored again with count records and goes to the general localize body */
@@ -984,6 +1015,9 @@ int pya_plan_run(pya_plan *p, const double *d_mz, const double *d_inten, void *h
         p->ev_runs++;
         if (p->ev_runs - p->ev_read > pya_plan::kEvRing) p->ev_read = p->ev_runs - pya_plan::kEvRing;   /* (overwritten) */
     }
+    /* the join: whatever the caller enqueues behind this run waits for the side stream too (after boundary 4, so that the
+     * localize family's interval does not include the wait) */
+    if (p->fork) HIPCHK(h, hipStreamWaitEvent(st, p->ev_join, 0));
     p->last_stream = st;
     p->ran = true;
     p->dev = d;
@@ -997,10 +1031,12 @@ int pya_plan_timings(pya_plan *p, float ms[4]) {
     hipEvent_t *ev = p->ev_set(p->ev_runs - 1);
     const uint8_t *al = p->ev_alias(p->ev_runs - 1);
     HIPCHK(h, hipEventSynchronize(ev[al[4]]));
+    if (al[5]) HIPCHK(h, hipEventSynchronize(ev[6]));
     for (int i = 0; i < 4; i++) {
         ms[i] = 0.f;
         if (al[i] != al[i + 1]) HIPCHK(h, hipEventElapsedTime(&ms[i], ev[al[i]], ev[al[i + 1]]));
     }
+    if (al[5]) HIPCHK(h, hipEventElapsedTime(&ms[2], ev[5], ev[6]));      /* (the fused family on the side stream) */
     return PYA_OK;
 }
 
@@ -1012,6 +1048,7 @@ int pya_plan_timings_sum(pya_plan *p, double ms[4], uint32_t *n_runs) {
     *n_runs = (uint32_t)(p->ev_runs - p->ev_read);
     if (*n_runs == 0) return PYA_OK;
     HIPCHK(h, hipEventSynchronize(p->ev_set(p->ev_runs - 1)[p->ev_alias(p->ev_runs - 1)[4]]));
+    if (p->ev_alias(p->ev_runs - 1)[5]) HIPCHK(h, hipEventSynchronize(p->ev_set(p->ev_runs - 1)[6]));
     for (uint64_t r = p->ev_read; r < p->ev_runs; r++) {
         hipEvent_t *ev = p->ev_set(r);
         const uint8_t *al = p->ev_alias(r);
@@ -1019,6 +1056,11 @@ int pya_plan_timings_sum(pya_plan *p, double ms[4], uint32_t *n_runs) {
             float t = 0.f;
             if (al[i] != al[i + 1]) HIPCHK(h, hipEventElapsedTime(&t, ev[al[i]], ev[al[i + 1]]));
             ms[i] += (double)t;
+        }
+        if (al[5]) {                                          /* (the fused family on the side stream) */
+            float t = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&t, ev[5], ev[6]));
+            ms[2] += (double)t;
         }
     }
     p->ev_read = p->ev_runs;

@@ -35,7 +35,7 @@ bool set_knob(Knobs &k, const char *key, const char *value) {
         {"PYA_SORT_ROOM", &Knobs::sort_room}, {"PYA_NO_BIG_INLINE", &Knobs::no_big_inline},
         {"PYA_NO_LOC_HASH", &Knobs::no_loc_hash}, {"PYA_NO_CNT", &Knobs::no_cnt}, {"PYA_NO_NODES", &Knobs::no_nodes},
         {"PYA_HOST_TIMING", &Knobs::host_timing}, {"PYA_STAMPS", &Knobs::stamps},
-        {"PYA_SLOW_NULL_STREAM", &Knobs::slow_null_stream},
+        {"PYA_SLOW_NULL_STREAM", &Knobs::slow_null_stream}, {"PYA_NO_FORK", &Knobs::no_fork},
     };
     bool known = false;
     for (auto &f : flags)

@@ -11,7 +11,7 @@ SWITCHES = ("PYA_NO_PLAIN", "PYA_NO_FUSED", "PYA_NO_BIG", "PYA_NO_TINY", "PYA_NO
             "PYA_NO_UPLOAD_THREAD", "PYA_ONE_PEAK_CLASS", "PYA_PEAK_CLASSES", "PYA_ONE_LDS_CLASS", "PYA_SORT_ROOM",
             "PYA_NO_BIG_INLINE", "PYA_NO_LOC_HASH", "PYA_NO_NODES", "PYA_DEBUG", "PYA_PLAIN_MIN", "PYA_BIG_MIN_N",
             "PYA_TINY_MAX", "PYA_SORT_ROOM_MAX", "PYA_SB", "PYA_GTP", "PYA_HASH_PP", "PYA_NODE_CAP", "PYA_NO_CNT",
-            "PYA_SLOW_NULL_STREAM", "PYA_BIN_SELECT_MIN", "PYA_BIN_SELECT_SCAP")
+            "PYA_SLOW_NULL_STREAM", "PYA_BIN_SELECT_MIN", "PYA_BIN_SELECT_SCAP", "PYA_NO_FORK")
 # (PYA_WORKSPACE_MB, PYA_CHUNK_MB, PYA_HOST_TIMING, PYA_STAMPS are the four variables the library reads itself)
 
 

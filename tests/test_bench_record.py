@@ -58,7 +58,10 @@ def test_value_and_roofline_follow_from_the_measured_times(line):
     kern = r["kernel_ms"]
     dom = max(kern, key=kern.get)
     assert r["kernel"] == dom
-    assert sum(kern.values()) <= line["ms_per_step"] * 1.001               # the families are inside the step
+    # the families are inside the step -- unless the line says they overlap (a batch of mixed shapes: the fused family runs
+    # beside the others on the plan's side stream; never the case for cfg2, which has only that family)
+    assert sum(kern.values()) <= line["ms_per_step"] * 1.001 or r.get("families_overlap")
+    assert not r.get("families_overlap")
     # the algorithmic bytes of the workload, from the same seeded generator bench.py uses
     desc = synth.describe("cfg2", seed=1000)
     batch = synth.make_slice(desc)
