@@ -62,6 +62,7 @@ void pya_destroy(pya_handle *h) {
         if (ps) (void)hipHostFree(ps);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->run_stream) (void)hipStreamDestroy(h->run_stream);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     delete h;
 }
 

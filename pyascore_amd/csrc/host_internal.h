@@ -241,6 +241,7 @@ bool set_knob(Knobs &k, const char *key, const char *value);
 struct pya_handle {
     Knobs kn;
     int device = 0;
+    hipStream_t side_stream = nullptr;        /* r06: where the plans' forked fused families run (pya_plan::fork) */
     float bin_size = 100.f, mod_mass = 0.f, mz_error = 0.5f;
     uint32_t n_top = PYA_NTOP;                /* 10: the fast kernels; 11..16: every PSM through the general kernel */
     uint32_t rec_words() const { return (n_top + 1u) / 2u + 1u; }   /* count record: n_top 16-bit counts + the fragment total */
@@ -541,7 +542,7 @@ struct pya_plan {
      * localize kernels and the issue-bound fused kernels fill each other's idle slots, and no launch waits for another
      * family's tail. */
     bool fork = false;
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;          /* the handle's (pya_handle::side_stream: created once, plans share it) */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t last_stream = nullptr;
     uint64_t n_runs = 0;                 /* pya_plan_run calls so far (which set of hand-over counts is in use) */
@@ -553,7 +554,6 @@ struct pya_plan {
             if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
     }
     uint64_t workspace_bytes() const { return arena.bytes(); }
 };

@@ -749,7 +749,8 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
         for (const pya_plan::IdList &l : p->big_lists) others = others || l.n != 0;
         p->fork = !h->kn.no_fork && p->n_fused_total != 0 && others;
         if (p->fork) {
-            HIPCHK(h, hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+            if (!h->side_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            p->side = h->side_stream;
             HIPCHK(h, hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
