@@ -434,14 +434,25 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
          * rounded up to 32 (one class for small batches) */
         std::vector<uint32_t> caps;
         if (n >= 2048 && !h->kn.one_peak_class) {
-            std::vector<uint32_t> pk(n);
-            for (uint64_t i = 0; i < n; i++)
-                pk[i] = p->pre_status[i] ? 1u : (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
-            for (uint32_t id : p->bigbin_ids) pk[id] = 1u;         /* (binned by their own kernel) */
+            /* (the order statistics from a histogram of the counts -- they are at most PYA_FAST_PEAKS here --: one pass
+             * instead of three std::nth_element over the batch) */
+            std::vector<uint32_t> hist(PYA_FAST_PEAKS + 2, 0);
+            std::vector<uint8_t> global_bin(p->bigbin_ids.empty() ? 0 : n, 0);
+            for (uint32_t id : p->bigbin_ids) global_bin[id] = 1;      /* (binned by their own kernel) */
+            for (uint64_t i = 0; i < n; i++) {
+                uint32_t v = p->pre_status[i] ? 1u : (uint32_t)(p->peak_off[i + 1] - p->peak_off[i]);
+                if (!global_bin.empty() && global_bin[i]) v = 1u;
+                hist[v > PYA_FAST_PEAKS ? PYA_FAST_PEAKS + 1 : v]++;
+            }
             for (double q : {0.5, 0.9, 0.99}) {
                 const size_t at = (size_t)(q * (double)(n - 1));
-                std::nth_element(pk.begin(), pk.begin() + at, pk.end());
-                caps.push_back((pk[at] + 31u) & ~31u);
+                size_t acc = 0;
+                uint32_t v = 0;
+                for (; v < hist.size(); v++) {
+                    acc += hist[v];
+                    if (acc > at) break;
+                }
+                caps.push_back((v + 31u) & ~31u);
             }
         }
         /* classes only pay when the tail is long: every extra launch has its own ramp-up and tail */
@@ -526,9 +537,40 @@ int plan_create_impl(pya_handle *h, const pya_batch *b, uint32_t flags, const Io
                 it.need = pya_fused_lds_bytes(caps[pcls[i]], it.n_cap, ndir * it.n_cap + 4, it.pos, it.ent, it.push, p->fused_both, z > 1 ? 1u : 0u);
                 items.push_back(it);
             }
-            std::sort(items.begin(), items.end(), [](const Item &a, const Item &b2) {
-                return a.group != b2.group ? a.group < b2.group : (a.need != b2.need ? a.need < b2.need : a.id < b2.id);
-            });
+            /* order: (group, LDS need, id).  The items come in id order and (group, need) takes a few hundred values at most, so
+             * a stable counting sort over the distinct pairs (kept sorted, found by bisection) does it in O(n log pairs) with
+             * eight-byte keys -- r06: std::sort over 100 000 forty-byte items was 3 of the 7 ms of a cfg2 batch's pre-pass */
+            {
+                std::vector<std::pair<uint64_t, uint32_t>> keys;     /* (group << 40 | need, class id), sorted by key */
+                keys.reserve(256);
+                std::vector<uint32_t> cls(items.size());
+                std::vector<size_t> cnt;
+                uint64_t last_key = ~0ull;
+                uint32_t last_cls = 0;
+                for (size_t t = 0; t < items.size(); t++) {
+                    const uint64_t key = ((uint64_t)items[t].group << 40) | (uint64_t)items[t].need;
+                    if (key != last_key) {
+                        auto it = std::lower_bound(keys.begin(), keys.end(), std::make_pair(key, 0u));
+                        if (it == keys.end() || it->first != key) {
+                            it = keys.insert(it, std::make_pair(key, (uint32_t)cnt.size()));
+                            cnt.push_back(0);
+                        }
+                        last_key = key;
+                        last_cls = it->second;
+                    }
+                    cls[t] = last_cls;
+                    cnt[last_cls]++;
+                }
+                std::vector<size_t> at(cnt.size());
+                size_t acc = 0;
+                for (const auto &kc : keys) {                        /* ascending (group, need) */
+                    at[kc.second] = acc;
+                    acc += cnt[kc.second];
+                }
+                std::vector<Item> sorted(items.size());
+                for (size_t t = 0; t < items.size(); t++) sorted[at[cls[t]]++] = items[t];     /* (stable: ids stay ascending) */
+                items.swap(sorted);
+            }
             p->fused_ids.resize(items.size());
             size_t g0 = 0;
             while (g0 < items.size()) {
